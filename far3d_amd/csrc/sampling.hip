@@ -1,0 +1,300 @@
+// Deformable sampling kernels for the Far3D cross-attention.
+//
+//  * far3d_msda_forward      -- drop-in for mmcv's ms_deform_attn_forward as called at
+//                               reference detr3d_transformer.py:561-563 (operator boundary).
+//  * far3d_aggregate_forward -- the fused perspective-aware aggregation: everything in
+//                               DeformableFeatureAggregationCuda.feature_sampling + _get_weights'
+//                               softmax (detr3d_transformer.py:535-569) in ONE launch:
+//                               projection of the 13 key points into the 7 cameras, visibility
+//                               culling, 364-way softmax per group, bilinear gather over 4 levels,
+//                               weighting, and the cross-camera sum.  No (B*N,A,8,4,13,2) replicated
+//                               location tensor, no (B*N,A,8,52) permuted weight tensor, no
+//                               (B*N,A,256) per-camera output ever reaches HBM.
+//
+// Layout facts the kernels are built around (gfx950, wave = 64 lanes):
+//   value maps are token-major (camera, token, 256 channels); one token row is 1 KiB fp32 / 512 B
+//   bf16, so ONE wave-wide 16 B(8 B)-per-lane load fetches a whole token row for all 8 groups:
+//   lane = group*8 + chunk, 4 channels per lane.  All 8 groups sample the same pixel (the reference
+//   replicates locations over groups, :555), so a bilinear sample is 4 fully-coalesced row loads.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Generic MSDA (mmcv contract).  value (bs,S,H,Dh) TV; shapes (L,2) i64 (h,w); lsi (L) i64;
+// loc (bs,Q,H,L,P,2) f32 in [0,1] (x,y); attn (bs,Q,H,L,P) f32; out (bs,Q,H*Dh) f32.
+// One thread owns 4 consecutive channels of one (b,q,h): neighbouring lanes read neighbouring
+// 16-B pieces of the same token row -> coalesced.
+// ------------------------------------------------------------------------------------------
+template <typename TV>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const TV* __restrict__ value,
+                                                       const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lsi,
+                                                       const float* __restrict__ loc,
+                                                       const float* __restrict__ attn,
+                                                       float* __restrict__ out, int bs, int S, int H,
+                                                       int Dh, int L, int Q, int P) {
+  const int c4n = Dh >> 2;
+  const long total = (long)bs * Q * H * c4n;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    long t = idx / c4n;
+    const int h = (int)(t % H);
+    t /= H;
+    const int q = (int)(t % Q);
+    const int b = (int)(t / Q);
+    const long bqh = ((long)b * Q + q) * H + h;
+    const float* locp = loc + bqh * L * P * 2;
+    const float* wp = attn + bqh * L * P;
+    const TV* vb = value + (long)b * S * H * Dh + h * Dh + c4 * 4;
+    const long row = (long)H * Dh;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < L; ++l) {
+      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+      const TV* vl = vb + lsi[l] * row;
+      for (int p = 0; p < P; ++p) {
+        const float lx = locp[(l * P + p) * 2], ly = locp[(l * P + p) * 2 + 1];
+        const float aw = wp[l * P + p];
+        const float h_im = ly * Hl - 0.5f, w_im = lx * Wl - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < Hl && w_im < Wl) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const float lh = h_im - h_low, lw = w_im - w_low;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          float4 v1 = make_float4(0, 0, 0, 0), v2 = v1, v3 = v1, v4 = v1;
+          if (h_low >= 0 && w_low >= 0) v1 = load4(vl + ((long)h_low * Wl + w_low) * row);
+          if (h_low >= 0 && w_high <= Wl - 1) v2 = load4(vl + ((long)h_low * Wl + w_high) * row);
+          if (h_high <= Hl - 1 && w_low >= 0) v3 = load4(vl + ((long)h_high * Wl + w_low) * row);
+          if (h_high <= Hl - 1 && w_high <= Wl - 1) v4 = load4(vl + ((long)h_high * Wl + w_high) * row);
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          acc.x += aw * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x);
+          acc.y += aw * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y);
+          acc.z += aw * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z);
+          acc.w += aw * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(out + bqh * Dh + c4 * 4) = acc;
+  }
+}
+
+extern "C" int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* sampling_loc,
+                                  const float* attn_weight, float* out, int bs, int S, int H, int Dh,
+                                  int L, int Q, int P, void* stream) {
+  FAR3D_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+                  "far3d_msda_forward: null pointer argument");
+  FAR3D_CHECK_ARG(bs >= 0 && S > 0 && H > 0 && Dh > 0 && L > 0 && Q >= 0 && P > 0,
+                  "far3d_msda_forward: bad sizes bs=%d S=%d H=%d Dh=%d L=%d Q=%d P=%d", bs, S, H, Dh, L, Q, P);
+  FAR3D_CHECK_ARG((Dh & 3) == 0, "far3d_msda_forward: head dim %d must be a multiple of 4", Dh);
+  FAR3D_CHECK_ARG(value_dtype == FAR3D_DT_F32 || value_dtype == FAR3D_DT_BF16,
+                  "far3d_msda_forward: unsupported value dtype %d", value_dtype);
+  const long total = (long)bs * Q * H * (Dh / 4);
+  if (total == 0) return FAR3D_OK;
+  long blocks = (total + 255) / 256;
+  if (blocks > 256L * 16) blocks = 256L * 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == FAR3D_DT_F32)
+    hipLaunchKernelGGL(msda_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, bs, S, H, Dh, L, Q, P);
+  else
+    hipLaunchKernelGGL(msda_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, bs, S, H, Dh, L, Q, P);
+  FAR3D_CHECK_LAUNCH("far3d_msda_forward");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused perspective-aware aggregation.  One 256-thread workgroup (4 waves) per query.
+//   phase 1: 91 (camera, point) projections -> LDS (u,v) + per-level in-range bit mask
+//   phase 2: 364-way softmax for the 8 groups (logit = U[a] + Vc[n]; see aggregate.py) -> LDS
+//   phase 3: each wave walks the visible (camera,point) pairs; per level 4 coalesced row loads
+//   phase 4: 4-wave LDS reduction, 1 KiB coalesced store
+// ------------------------------------------------------------------------------------------
+#define AGG_MAX_L 4
+#define AGG_MAX_NLP 384  // 12 softmax items per thread
+struct AggParams {
+  int A, N, S, P, L;
+  int H[AGG_MAX_L], W[AGG_MAX_L], start[AGG_MAX_L];
+  float pc_lo[3], pc_span[3];
+  float pad_w, pad_h;
+  int q_per_xcd;
+};
+
+template <typename TV>
+__global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict__ feat,
+                                                            const float* __restrict__ ref,
+                                                            const float* __restrict__ offs,
+                                                            const float* __restrict__ l2i,
+                                                            const float* __restrict__ U,
+                                                            const float* __restrict__ Vc,
+                                                            float* __restrict__ out, AggParams prm) {
+  // XCD-aware query mapping: workgroup b lands on XCD b%8 (observed dispatch order); give each XCD a
+  // contiguous query range so that camera-major adaptive queries share an L2.  Speed only.
+  const int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  if (a >= prm.A) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NP = prm.N * prm.P;
+  const int NLP = NP * prm.L;
+  const int J = prm.L * prm.P;            // logits per camera per group
+  float* w_s = reinterpret_cast<float*>(smem);                 // [NLP][8]
+  float* red_s = w_s + NLP * 8;                                 // [4][256]
+  float* uv_s = red_s + 1024;                                   // [NP][2]
+  float* stat_s = uv_s + 2 * NP;                                // [2][4][8]
+  int* mask_s = reinterpret_cast<int*>(stat_s + 64);            // [NP]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+  // ---- phase 1: projection (detr3d_transformer.py:524-525,547-552)
+  if (t < NP) {
+    const int n = t / prm.P, p = t - n * prm.P;
+    float k[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      k[d] = (ref[a * 3 + d] * prm.pc_span[d] + prm.pc_lo[d]) + offs[(long)a * prm.P * 3 + p * 3 + d];
+    const float* m = l2i + n * 16;
+    const float x = m[0] * k[0] + m[1] * k[1] + m[2] * k[2] + m[3];
+    const float y = m[4] * k[0] + m[5] * k[1] + m[6] * k[2] + m[7];
+    const float z = m[8] * k[0] + m[9] * k[1] + m[10] * k[2] + m[11];
+    const float zc = fmaxf(z, 1e-5f);
+    const float u = (x / zc) / prm.pad_w, v = (y / zc) / prm.pad_h;
+    int mask = 0;
+#pragma unroll
+    for (int l = 0; l < AGG_MAX_L; ++l) {
+      if (l < prm.L) {
+        const float h_im = v * prm.H[l] - 0.5f, w_im = u * prm.W[l] - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < prm.H[l] && w_im < prm.W[l]) mask |= 1 << l;
+      }
+    }
+    uv_s[2 * t] = u;
+    uv_s[2 * t + 1] = v;
+    mask_s[t] = mask;
+  }
+
+  // ---- phase 2: softmax over cams x levels x points per group (detr3d_transformer.py:539-540)
+  {
+    const int g = t & 7, r = t >> 3;
+    float lg[AGG_MAX_NLP / 32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
+      const int idx = r + 32 * i;
+      lg[i] = -INFINITY;
+      if (idx < NLP) {
+        const int n = idx / J, j = idx - n * J;
+        lg[i] = U[(long)a * J * 8 + j * 8 + g] + Vc[n * J * 8 + j * 8 + g];
+      }
+      mx = fmaxf(mx, lg[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lane < 8) stat_s[wv * 8 + lane] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(stat_s[g], stat_s[8 + g]), fmaxf(stat_s[16 + g], stat_s[24 + g]));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
+      lg[i] = (r + 32 * i < NLP) ? expf(lg[i] - mx) : 0.f;
+      sum += lg[i];
+    }
+    sum += __shfl_xor(sum, 8);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (lane < 8) stat_s[32 + wv * 8 + lane] = sum;
+    __syncthreads();
+    sum = (stat_s[32 + g] + stat_s[40 + g]) + (stat_s[48 + g] + stat_s[56 + g]);
+#pragma unroll
+    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
+      const int idx = r + 32 * i;
+      if (idx < NLP) w_s[idx * 8 + g] = lg[i] / sum;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: gather (mmcv ms_deform_attn bilinear semantics; zeros outside)
+  const int g = lane >> 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const TV* fbase = feat + lane * 4;
+  for (int pair = wv; pair < NP; pair += 4) {
+    const int mask = mask_s[pair];
+    if (mask == 0) continue;  // wave-uniform
+    const int n = pair / prm.P, p = pair - n * prm.P;
+    const float u = uv_s[2 * pair], v = uv_s[2 * pair + 1];
+#pragma unroll
+    for (int l = 0; l < AGG_MAX_L; ++l) {
+      if (l >= prm.L || !((mask >> l) & 1)) continue;
+      const int Hl = prm.H[l], Wl = prm.W[l];
+      const float h_im = v * Hl - 0.5f, w_im = u * Wl - 0.5f;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const float lh = h_im - h_low, lw = w_im - w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= Hl - 1;
+      const bool l_ok = w_low >= 0, r_ok = w_low + 1 <= Wl - 1;
+      const int hl_c = t_ok ? h_low : 0, hh_c = b_ok ? h_low + 1 : Hl - 1;
+      const int wl_c = l_ok ? w_low : 0, wh_c = r_ok ? w_low + 1 : Wl - 1;
+      const TV* lvl = fbase + ((long)n * prm.S + prm.start[l]) * 256;
+      float4 v1 = load4(lvl + (long)(hl_c * Wl + wl_c) * 256);
+      float4 v2 = load4(lvl + (long)(hl_c * Wl + wh_c) * 256);
+      float4 v3 = load4(lvl + (long)(hh_c * Wl + wl_c) * 256);
+      float4 v4 = load4(lvl + (long)(hh_c * Wl + wh_c) * 256);
+      const float aw = w_s[((n * prm.L + l) * prm.P + p) * 8 + g];
+      const float w1 = (t_ok && l_ok) ? hh * hw : 0.f;
+      const float w2 = (t_ok && r_ok) ? hh * lw : 0.f;
+      const float w3 = (b_ok && l_ok) ? lh * hw : 0.f;
+      const float w4 = (b_ok && r_ok) ? lh * lw : 0.f;
+      if (!(t_ok && l_ok)) v1 = make_float4(0, 0, 0, 0);
+      if (!(t_ok && r_ok)) v2 = make_float4(0, 0, 0, 0);
+      if (!(b_ok && l_ok)) v3 = make_float4(0, 0, 0, 0);
+      if (!(b_ok && r_ok)) v4 = make_float4(0, 0, 0, 0);
+      acc.x += aw * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x);
+      acc.y += aw * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y);
+      acc.z += aw * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z);
+      acc.w += aw * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+    }
+  }
+
+  // ---- phase 4: cross-wave (= cross-camera/point) reduction, coalesced store
+  *reinterpret_cast<float4*>(red_s + wv * 256 + lane * 4) = acc;
+  __syncthreads();
+  out[(long)a * 256 + t] = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
+}
+
+extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref,
+                                       const float* offsets, const float* lidar2img, const float* U,
+                                       const float* Vc, float* out, int A, int N, int S, int C, int G,
+                                       int P, int L, const int32_t* level_hw, const int32_t* level_start,
+                                       const float* pc_range, float pad_h, float pad_w, void* stream) {
+  FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && Vc && out && level_hw && level_start && pc_range,
+                  "far3d_aggregate_forward: null pointer argument");
+  FAR3D_CHECK_ARG(C == 256 && G == 8, "far3d_aggregate_forward: fused kernel is built for C=256,G=8 (got C=%d G=%d)", C, G);
+  FAR3D_CHECK_ARG(L >= 1 && L <= AGG_MAX_L, "far3d_aggregate_forward: L=%d out of range [1,%d]", L, AGG_MAX_L);
+  FAR3D_CHECK_ARG(N >= 1 && P >= 1 && N * P <= 256 && N * P * L <= AGG_MAX_NLP,
+                  "far3d_aggregate_forward: N*P=%d (<=256) or N*P*L=%d (<=%d) too large", N * P, N * P * L, AGG_MAX_NLP);
+  FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
+                  "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
+  FAR3D_CHECK_ARG(A >= 0 && S > 0, "far3d_aggregate_forward: bad sizes A=%d S=%d", A, S);
+  if (A == 0) return FAR3D_OK;
+  AggParams prm;
+  prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
+  for (int l = 0; l < AGG_MAX_L; ++l) {
+    prm.H[l] = l < L ? level_hw[2 * l] : 1;
+    prm.W[l] = l < L ? level_hw[2 * l + 1] : 1;
+    prm.start[l] = l < L ? level_start[l] : 0;
+    if (l < L)
+      FAR3D_CHECK_ARG(prm.H[l] > 0 && prm.W[l] > 0 && prm.start[l] >= 0 && prm.start[l] + prm.H[l] * prm.W[l] <= S,
+                      "far3d_aggregate_forward: level %d (%dx%d @%d) exceeds S=%d", l, prm.H[l], prm.W[l], prm.start[l], S);
+  }
+  for (int d = 0; d < 3; ++d) { prm.pc_lo[d] = pc_range[d]; prm.pc_span[d] = pc_range[3 + d] - pc_range[d]; }
+  prm.pad_w = pad_w; prm.pad_h = pad_h;
+  prm.q_per_xcd = cdiv(A, 8);
+  const size_t lds = (size_t)(N * P * L * 8 + 1024 + 2 * N * P + 64) * 4 + (size_t)N * P * 4;
+  dim3 grid(8 * prm.q_per_xcd), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (feat_dtype == FAR3D_DT_F32)
+    hipLaunchKernelGGL(aggregate_fwd_kernel<float>, grid, block, lds, st, (const float*)feat, ref, offsets,
+                       lidar2img, U, Vc, out, prm);
+  else
+    hipLaunchKernelGGL(aggregate_fwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)feat, ref, offsets,
+                       lidar2img, U, Vc, out, prm);
+  FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
+  return FAR3D_OK;
+}

@@ -1,0 +1,62 @@
+"""ctypes binding of libfar3d_hip.so (the C-ABI declared in include/far3d_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or a kernel is asked to run
+without a HIP device, this raises.  PyTorch is only used for device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfar3d_hip.so")
+
+c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
+_p = c_void_p
+
+# name -> (restype, argtypes).  Must list every symbol of include/far3d_hip.h (tests check it).
+SIGNATURES = {
+    "far3d_last_error": (c_char_p, []),
+    "far3d_abi_version": (c_int, []),
+    "far3d_device_count": (c_int, []),
+    "far3d_device_arch": (c_int, [c_int, c_char_p, c_int]),
+    "far3d_msda_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p] + [c_int] * 7 + [_p]),
+    "far3d_aggregate_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p] + [c_int] * 7 +
+                                [_p, _p, _p, c_float, c_float, _p]),
+}
+
+_lib = None
+
+
+class Far3dHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Far3dHipError(
+            "libfar3d_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python far3d_amd/build.py`). There is no CPU fallback for the Far3D hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().far3d_last_error()
+        raise Far3dHipError("%s failed (code %d): %s" % (what, status, msg.decode() if msg else "?"))
+
+
+def require_device():
+    lib = load()
+    if lib.far3d_device_count() <= 0:
+        raise Far3dHipError("far3d_amd needs a HIP device (MI355X / gfx950); none is visible and there is "
+                            "no CPU fallback. The CPU restatement lives in oracle/ and is test-only.")
+    return lib

@@ -1,0 +1,69 @@
+/* far3d_hip.h -- C ABI of libfar3d_hip.so: the MI355X (gfx950) kernels of the Far3D inference hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every `const void*` / `float*` tensor argument is a DEVICE pointer
+ *     to a contiguous buffer unless the parameter comment says "host";
+ *   - `stream` is a hipStream_t (NULL = default stream); kernels are enqueued, never synchronised;
+ *   - return 0 on success, negative FAR3D_ERR_* otherwise; far3d_last_error() gives the reason
+ *     (thread-local, valid until the next failing call on the same thread);
+ *   - dtype codes: FAR3D_DT_F32 = 0, FAR3D_DT_BF16 = 1 (raw bfloat16 bits).
+ * Citations `ref:` are file:line under the reference checkout (projects/mmdet3d_plugin/...).
+ */
+#ifndef FAR3D_HIP_H
+#define FAR3D_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAR3D_DT_F32 0
+#define FAR3D_DT_BF16 1
+
+#define FAR3D_OK 0
+#define FAR3D_ERR_ARG (-1)
+#define FAR3D_ERR_LAUNCH (-2)
+#define FAR3D_ERR_UNSUPPORTED (-3)
+
+const char* far3d_last_error(void);
+int far3d_abi_version(void);
+int far3d_device_count(void);
+int far3d_device_arch(int dev, char* buf, int buflen);
+
+/* Multi-scale deformable attention, forward.
+ * Replaces: mmcv-full 1.6.2 `ms_deform_attn_forward` as reached through
+ *   MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index,
+ *                                          sampling_locations, attention_weights, im2col_step)
+ *   ref: models/utils/detr3d_transformer.py:561-563 (and models/utils/sparse_blocks.py:334-336).
+ * value (bs,S,H,Dh) f32|bf16; spatial_shapes (L,2) int64 (h,w) DEVICE; level_start_index (L) int64 DEVICE;
+ * sampling_loc (bs,Q,H,L,P,2) f32, (x,y) in [0,1]; attn_weight (bs,Q,H,L,P) f32; out (bs,Q,H*Dh) f32.
+ * Semantics: out[b,q,h,:] = sum_l sum_p w * bilinear(value_l[b,:,h,:], x*W_l-0.5, y*H_l-0.5), zeros outside
+ * (== grid_sample(align_corners=False, padding_mode='zeros')).  Dh must be a multiple of 4. */
+int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, float* out, int bs, int S, int H, int Dh, int L, int Q,
+                       int P, void* stream);
+
+/* Fused perspective-aware aggregation (3D deformable cross-attention sampling), forward, one sample.
+ * Replaces, in one launch: DeformableFeatureAggregationCuda.feature_sampling
+ *   ref: models/utils/detr3d_transformer.py:544-569 (projection :547-552, replication :555, MSDA :561,
+ *   cross-camera sum :565-569), the key-point construction :524-525, and the softmax/permute of
+ *   _get_weights :540-542.  Operator shape family follows the reference's own (unused) fused op
+ *   ref: models/utils/deformable_aggregation.py:17-29.
+ * feat (N,S,C=256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
+ * offsets (A,P,3) f32 = learnable_fc(x); lidar2img (N,4,4) f32 row-major;
+ * U (A,L*P*G) f32 and Vc (N,L*P*G) f32 with logits[a,n,(l*P+p)*G+g] = U[a,.] + Vc[n,.]
+ *   ( = weights_fc((x+pos)[a] + cam_embed[n]) split by linearity; bias lives in Vc );
+ * level_hw (L,2) int32 HOST (h,w); level_start (L) int32 HOST; pc_range 6 floats HOST;
+ * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) f32.  Requires C=256, G=8, L<=4,
+ * N*P<=256, N*P*L<=384. */
+int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
+                            const float* lidar2img, const float* U, const float* Vc, float* out, int A,
+                            int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
+                            const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAR3D_HIP_H */

@@ -1,0 +1,67 @@
+"""Per-kernel micro-benchmarks on one MI355X (HIP events on the launch stream).  Writes JSON lines.
+
+  python tools/bench_kernels.py [--iters 200] [--out gpurun_out/kernels.jsonl]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from far3d_amd import ops  # noqa: E402
+from tests import cases  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters, warmup=20):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def agg_bytes(N, S, C, A, P, G, L, ev):
+    # value maps once + unreplicated points + attention weights + fused output
+    return N * S * C * ev + A * P * N * 2 * 4 + N * A * G * L * P * 4 + A * C * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    dev = "cuda:0"
+    rows = []
+    c = cases.config2_aggregate_case(seed=0)
+    N, S, C = c["feat"].shape
+    A = c["ref"].shape[0]
+    for dt, ev in ((torch.bfloat16, 2), (torch.float32, 4)):
+        d = lambda t: t.to(dev).contiguous()
+        feat = d(c["feat"].to(dt))
+        args = [d(c[k]) for k in ("ref", "offsets", "lidar2img", "U", "Vc")]
+        out = torch.empty(A, C, device=dev)
+        fn = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], out=out)
+        t = timeit(fn, a.iters)
+        by = agg_bytes(N, S, C, A, 13, 8, 4, ev)
+        rows.append(dict(kernel="aggregate_fwd", dtype=str(dt).split(".")[-1], us=t * 1e6, algorithmic_bytes=by,
+                         achieved_GBps=by / t / 1e9, frac_hbm_peak=by / t / HBM_PEAK))
+    for r in rows:
+        print(json.dumps(r))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
+
+
+if __name__ == "__main__":
+    main()
