@@ -1,0 +1,335 @@
+// Implicit-GEMM convolution / linear layer on the CDNA4 matrix cores.
+//
+//   Out[m][p] = epilogue( sum_k W[m][k] * X[p][k] )      m: output channel, p: output pixel (n,oy,ox),
+//                                                        k: (tap, input channel), tap-major.
+// One kernel serves the VoVNet 3x3 / 1x1 convolutions (folded BN + ReLU), the FPN, the YOLOX towers and
+// every nn.Linear of the decoder (a Linear is a 1x1 "conv" over rows).  Activations are NHWC so that a
+// K-slice of one pixel is contiguous; reading / writing through (pointer, pixel-stride) pairs lets an OSA
+// block's five 3x3 convs write straight into their channel slice of the concat buffer (no torch.cat).
+//
+// gfx950 mapping: 256 threads = 4 waves in a 2x2 grid; each wave owns WM x WN tiles of 32x32 computed with
+// v_mfma_f32_32x32x16_bf16 (TC = bf16) or the exact-fp32 v_mfma_f32_32x32x2_f32 (TC = float, parity mode).
+// The weight tile is the MFMA A operand (rows -> output channels) so every lane ends up holding 4
+// consecutive channels of one pixel per accumulator quad -> 8/16-byte stores.  BK = 32; LDS rows are padded
+// by 16 B which makes the 16-lane ds_read_b128 groups conflict-free (row stride 80 B / 144 B).
+// Global -> register -> LDS staging with the next tile's loads in flight during the MFMAs, two LDS buffers,
+// one barrier per K step.
+#include "common.hpp"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_SWISH 2
+
+struct IgemmParams {
+  const void* x;        // input activations (TIn), NHWC with pixel stride ldx, channel offset pre-applied
+  const void* w;        // packed weights (TC) [Cout_pad][taps][cin_pad]
+  const float* bias;    // [Cout_pad] or null
+  void* y;              // output, dtype y_dt, pixel stride ldy
+  void* y2;             // optional second output: y2 = scale[n][m]*v + shift[n][m]  (camera-aware MLN)
+  const float* y2_scale;
+  const float* y2_shift;
+  const void* res;      // optional residual, NHWC (Hr x Wr, nearest-neighbour upsampled to Ho x Wo)
+  long x_img_stride, y_img_stride, y2_img_stride, res_img_stride;  // elements between images
+  int N, H, W, Cin, ldx;
+  int Ho, Wo, Cout, ldy;
+  int KH, KW, stride, pad;
+  int cin_pad, nsteps;
+  int act, y_dt, y2_dt, ldy2;
+  int res_dt, ldr, Hr, Wr;
+  int x_vec, y_vec, y2_vec, res_vec;
+};
+
+template <typename TC> struct Cfg;
+template <> struct Cfg<bf16_t> { static constexpr int E = 8, ROWB = 80, KSUB = 2; };
+template <> struct Cfg<float> { static constexpr int E = 4, ROWB = 144, KSUB = 4; };
+
+// Load E consecutive input channels (E = elements per 16-B LDS chunk) converting TIn -> TC.
+template <typename TIn, typename TC>
+__device__ __forceinline__ u32x4_t load_chunk(const TIn* src, int nvalid, bool vec) {
+  constexpr int E = Cfg<TC>::E;
+  u32x4_t r = {0u, 0u, 0u, 0u};
+  if (nvalid <= 0) return r;
+  if (vec && nvalid >= E) {
+    if constexpr (sizeof(TIn) == sizeof(TC)) {
+      r = *reinterpret_cast<const u32x4_t*>(src);
+    } else {  // float -> bf16
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 b = *reinterpret_cast<const float4*>(src + 4);
+      r.x = pack_bf16x2(a.x, a.y); r.y = pack_bf16x2(a.z, a.w);
+      r.z = pack_bf16x2(b.x, b.y); r.w = pack_bf16x2(b.z, b.w);
+    }
+    return r;
+  }
+  float v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = e < nvalid ? LoadCvt<TIn>::ld(src + e) : 0.f;
+  if constexpr (sizeof(TC) == 4) {
+    r.x = __float_as_uint(v[0]); r.y = __float_as_uint(v[1]); r.z = __float_as_uint(v[2]); r.w = __float_as_uint(v[3]);
+  } else {
+    r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+  }
+  return r;
+}
+
+template <typename TC>
+__device__ __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  if constexpr (sizeof(TC) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void store4(void* base, int dt, long off, const float* v, int nv, bool vec) {
+  if (dt == FAR3D_DT_F32) {
+    float* p = reinterpret_cast<float*>(base) + off;
+    if (vec && nv == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) p[e] = v[e];
+    }
+  } else {
+    bf16_t* p = reinterpret_cast<bf16_t*>(base) + off;
+    if (vec && nv == 4) *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) p[e] = f32_to_bf16(v[e]);
+    }
+  }
+}
+
+template <typename TIn, typename TC, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
+  constexpr int E = Cfg<TC>::E, ROWB = Cfg<TC>::ROWB, KSUB = Cfg<TC>::KSUB;
+  constexpr int BM = 64 * WM, BP = 64 * WN;
+  constexpr int CPR = 32 / E;                 // 16-B chunks per tile row
+  constexpr int A_CH = BM * CPR / 256;        // weight chunks per thread
+  constexpr int B_CH = BP * CPR / 256;        // pixel chunks per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                               // [2][BM][ROWB]
+  unsigned char* Bs = smem + 2 * BM * ROWB;               // [2][BP][ROWB]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, hi = lane >> 5;
+  const int p0 = blockIdx.x * BP, m0 = blockIdx.y * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int Ktot = P.KH * P.KW * P.cin_pad;
+
+  // ---- per-thread staging coordinates (fixed for the whole K loop)
+  const TC* wsrc[A_CH];
+  int arow[A_CH], acol[A_CH];
+#pragma unroll
+  for (int c = 0; c < A_CH; ++c) {
+    const int id = t + c * 256;
+    arow[c] = id / CPR; acol[c] = id % CPR;
+    wsrc[c] = reinterpret_cast<const TC*>(P.w) + (long)(m0 + arow[c]) * Ktot + acol[c] * E;
+  }
+  int brow[B_CH], bcol[B_CH], bn[B_CH], boy[B_CH], box[B_CH];
+#pragma unroll
+  for (int c = 0; c < B_CH; ++c) {
+    const int id = t + c * 256;
+    brow[c] = id / CPR; bcol[c] = id % CPR;
+    const long p = (long)p0 + brow[c];
+    if (p < Npix) {
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      bn[c] = n; boy[c] = (rem / P.Wo) * P.stride - P.pad; box[c] = (rem % P.Wo) * P.stride - P.pad;
+    } else {
+      bn[c] = -1; boy[c] = 0; box[c] = 0;
+    }
+  }
+  u32x4_t areg[A_CH], breg[B_CH];
+  auto gload = [&](int step) __attribute__((always_inline)) {
+    const int kb = step * 32;
+    const int tap = kb / P.cin_pad, c0 = kb - tap * P.cin_pad;
+    const int ky = tap / P.KW, kx = tap - ky * P.KW;
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) areg[c] = *reinterpret_cast<const u32x4_t*>(wsrc[c] + kb);
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int iy = boy[c] + ky, ix = box[c] + kx, ch = c0 + bcol[c] * E;
+      const bool ok = bn[c] >= 0 && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const TIn* src = reinterpret_cast<const TIn*>(P.x) + (long)bn[c] * P.x_img_stride + ((long)iy * P.W + ix) * P.ldx + ch;
+      breg[c] = load_chunk<TIn, TC>(src, ok ? P.Cin - ch : 0, P.x_vec != 0);
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c)
+      *reinterpret_cast<u32x4_t*>(As + (buf * BM + arow[c]) * ROWB + acol[c] * 16) = areg[c];
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c)
+      *reinterpret_cast<u32x4_t*>(Bs + (buf * BP + brow[c]) * ROWB + bcol[c] * 16) = breg[c];
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int step = 0; step < P.nsteps; ++step) {
+    const bool more = step + 1 < P.nsteps;
+    if (more) gload(step + 1);
+    const unsigned char* Ab = As + (buf * BM + wm * WM * 32 + l31) * ROWB + hi * 16;
+    const unsigned char* Bb = Bs + (buf * BP + wn * WN * 32 + l31) * ROWB + hi * 16;
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk) {
+      u32x4_t af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(Ab + i * 32 * ROWB + kk * 32);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 32 * ROWB + kk * 32);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma<TC>(acc[i][j], af[i], bf[j]);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: bias -> activation -> residual -> store (+ optional modulated second output)
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const long p = (long)p0 + (wn * WN + j) * 32 + l31;
+    if (p >= Npix) continue;
+    const int n = (int)(p / HoWo), pix = (int)(p - (long)n * HoWo);
+    long roff = 0;
+    if (P.res) {
+      const int oy = pix / P.Wo, ox = pix - oy * P.Wo;
+      const int ry = (P.Hr == P.Ho) ? oy : min((int)floorf(oy * ((float)P.Hr / P.Ho)), P.Hr - 1);
+      const int rx = (P.Wr == P.Wo) ? ox : min((int)floorf(ox * ((float)P.Wr / P.Wo)), P.Wr - 1);
+      roff = (long)n * P.res_img_stride + ((long)ry * P.Wr + rx) * P.ldr;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (wm * WM + i) * 32 + 8 * q + 4 * hi;
+        if (m >= P.Cout) continue;
+        const int nv = min(4, P.Cout - m);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        if (P.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += P.bias[m + e];
+        }
+        if (P.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (P.act == ACT_SWISH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
+        }
+        if (P.res) {
+          if (P.res_dt == FAR3D_DT_F32) {
+            const float* rp = reinterpret_cast<const float*>(P.res) + roff + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += rp[e];
+          } else {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(P.res) + roff + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf16_to_f32(rp[e]);
+          }
+        }
+        store4(P.y, P.y_dt, (long)n * P.y_img_stride + (long)pix * P.ldy + m, v, nv, P.y_vec != 0);
+        if (P.y2) {
+          float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) u[e] = P.y2_scale[(long)n * P.Cout + m + e] * v[e] + P.y2_shift[(long)n * P.Cout + m + e];
+          store4(P.y2, P.y2_dt, (long)n * P.y2_img_stride + (long)pix * P.ldy2 + m, u, nv, P.y2_vec != 0);
+        }
+      }
+    }
+  }
+}
+
+template <typename TIn, typename TC, int WM, int WN>
+static int launch_igemm(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 64 * WM, BP = 64 * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
+  const size_t lds = (size_t)2 * (BM + BP) * Cfg<TC>::ROWB;
+  hipLaunchKernelGGL((igemm_kernel<TIn, TC, WM, WN>), grid, dim3(256), lds, st, P);
+  return 0;
+}
+
+// See include/far3d_hip.h for the argument contract.
+extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y,
+                                 int y_dt, int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho,
+                                 int Wo, int Cout, int ldy, long y_img_stride, int KH, int KW, int stride,
+                                 int pad, int act, const void* res, int res_dt, int ldr, long res_img_stride,
+                                 int Hr, int Wr, void* y2, int y2_dt, int ldy2, long y2_img_stride,
+                                 const float* y2_scale, const float* y2_shift, int tile, void* stream) {
+  FAR3D_CHECK_ARG(x && w && y, "far3d_conv2d_nhwc: null x/w/y");
+  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0,
+                  "far3d_conv2d_nhwc: bad sizes N=%d H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d", N, H, W, Cin, Ho, Wo, Cout);
+  FAR3D_CHECK_ARG(KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "far3d_conv2d_nhwc: bad kernel geometry");
+  FAR3D_CHECK_ARG((Ho - 1) * stride - pad + KH - 1 < H + pad + stride && (Wo - 1) * stride - pad + KW - 1 < W + pad + stride,
+                  "far3d_conv2d_nhwc: output size %dx%d inconsistent with input %dx%d k=%d s=%d p=%d", Ho, Wo, H, W, KH, stride, pad);
+  FAR3D_CHECK_ARG(ldx >= Cin && ldy >= Cout, "far3d_conv2d_nhwc: pixel strides smaller than channel counts");
+  FAR3D_CHECK_ARG((x_dt == FAR3D_DT_F32 || x_dt == FAR3D_DT_BF16) && (w_dt == FAR3D_DT_F32 || w_dt == FAR3D_DT_BF16) &&
+                  (y_dt == FAR3D_DT_F32 || y_dt == FAR3D_DT_BF16), "far3d_conv2d_nhwc: unsupported dtype");
+  FAR3D_CHECK_ARG(!(x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_F32),
+                  "far3d_conv2d_nhwc: bf16 activations with fp32 weights is not a supported combination");
+  FAR3D_CHECK_ARG(act >= 0 && act <= 2, "far3d_conv2d_nhwc: unknown activation %d", act);
+  FAR3D_CHECK_ARG(!y2 || (y2_scale && y2_shift), "far3d_conv2d_nhwc: y2 needs scale and shift");
+  IgemmParams P;
+  memset(&P, 0, sizeof(P));
+  P.x = x; P.w = w; P.bias = bias; P.y = y; P.y2 = y2; P.y2_scale = y2_scale; P.y2_shift = y2_shift; P.res = res;
+  P.x_img_stride = x_img_stride; P.y_img_stride = y_img_stride; P.y2_img_stride = y2_img_stride;
+  P.res_img_stride = res_img_stride;
+  P.N = N; P.H = H; P.W = W; P.Cin = Cin; P.ldx = ldx; P.Ho = Ho; P.Wo = Wo; P.Cout = Cout; P.ldy = ldy;
+  P.KH = KH; P.KW = KW; P.stride = stride; P.pad = pad;
+  P.cin_pad = (Cin + 31) / 32 * 32;
+  P.nsteps = KH * KW * P.cin_pad / 32;
+  P.act = act; P.y_dt = y_dt; P.y2_dt = y2_dt; P.ldy2 = ldy2;
+  P.res_dt = res_dt; P.ldr = ldr; P.Hr = res ? Hr : Ho; P.Wr = res ? Wr : Wo;
+  const int xe = x_dt == FAR3D_DT_F32 ? 4 : 2;
+  const int ve = w_dt == FAR3D_DT_F32 ? 4 : 8;  // elements per LDS chunk of the compute type
+  auto aligned = [](const void* p, long a) { return ((uintptr_t)p % a) == 0; };
+  P.x_vec = aligned(x, 16) && (ldx % ve == 0) && (x_img_stride % ve == 0) && (long)ve * xe % 16 == 0;
+  P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
+  P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const long Npix = (long)N * Ho * Wo;
+  // tile: 0 = auto.  1 = 128(ch) x 128(px), 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64
+  if (tile == 0) {
+    const long big = ((Npix + 127) / 128) * ((Cout + 127) / 128);
+    if (Cout <= 64) tile = (Npix >= 128 * 512) ? 2 : 3;
+    else if (big >= 512) tile = 1;
+    else if (((Npix + 63) / 64) * ((Cout + 127) / 128) >= 512) tile = 4;
+    else tile = 3;
+  }
+#define LAUNCH(TIN, TCC)                                                        \
+  switch (tile) {                                                               \
+    case 1: launch_igemm<TIN, TCC, 2, 2>(P, st); break;                         \
+    case 2: launch_igemm<TIN, TCC, 1, 2>(P, st); break;                         \
+    case 3: launch_igemm<TIN, TCC, 1, 1>(P, st); break;                         \
+    case 4: launch_igemm<TIN, TCC, 2, 1>(P, st); break;                         \
+    default: far3d_set_error("far3d_conv2d_nhwc: unknown tile %d", tile); return FAR3D_ERR_ARG; \
+  }
+  if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32) { LAUNCH(float, float) }
+  else if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_BF16) { LAUNCH(float, bf16_t) }
+  else { LAUNCH(bf16_t, bf16_t) }
+#undef LAUNCH
+  FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
+  return FAR3D_OK;
+}

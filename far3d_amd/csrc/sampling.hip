@@ -81,15 +81,15 @@ extern "C" int far3d_msda_forward(const void* value, int value_dtype, const int6
                                   const int64_t* level_start_index, const float* sampling_loc,
                                   const float* attn_weight, float* out, int bs, int S, int H, int Dh,
                                   int L, int Q, int P, void* stream) {
-  FAR3D_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
-                  "far3d_msda_forward: null pointer argument");
   FAR3D_CHECK_ARG(bs >= 0 && S > 0 && H > 0 && Dh > 0 && L > 0 && Q >= 0 && P > 0,
                   "far3d_msda_forward: bad sizes bs=%d S=%d H=%d Dh=%d L=%d Q=%d P=%d", bs, S, H, Dh, L, Q, P);
   FAR3D_CHECK_ARG((Dh & 3) == 0, "far3d_msda_forward: head dim %d must be a multiple of 4", Dh);
   FAR3D_CHECK_ARG(value_dtype == FAR3D_DT_F32 || value_dtype == FAR3D_DT_BF16,
                   "far3d_msda_forward: unsupported value dtype %d", value_dtype);
   const long total = (long)bs * Q * H * (Dh / 4);
-  if (total == 0) return FAR3D_OK;
+  if (total == 0) return FAR3D_OK;  // empty query set: nothing to write (pointers may be null)
+  FAR3D_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+                  "far3d_msda_forward: null pointer argument");
   long blocks = (total + 255) / 256;
   if (blocks > 256L * 16) blocks = 256L * 16;
   hipStream_t st = (hipStream_t)stream;

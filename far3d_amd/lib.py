@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfar3d_hip.so")
 
 c_int, c_float, c_void_p, c_char_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
+c_long = ctypes.c_long
 _p = c_void_p
 
 # name -> (restype, argtypes).  Must list every symbol of include/far3d_hip.h (tests check it).
@@ -21,6 +22,9 @@ SIGNATURES = {
     "far3d_msda_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p] + [c_int] * 7 + [_p]),
     "far3d_aggregate_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p] + [c_int] * 7 +
                                 [_p, _p, _p, c_float, c_float, _p]),
+    "far3d_conv2d_nhwc": (c_int, [_p, c_int, _p, c_int, _p, _p, c_int] + [c_int] * 5 + [c_long] + [c_int] * 4 +
+                          [c_long] + [c_int] * 5 + [_p, c_int, c_int, c_long, c_int, c_int] +
+                          [_p, c_int, c_int, c_long, _p, _p, c_int, _p]),
 }
 
 _lib = None

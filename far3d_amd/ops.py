@@ -120,3 +120,98 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
                                            float(pad_hw[0]), float(pad_hw[1]), _stream(feat)),
                "far3d_aggregate_forward")
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# implicit-GEMM convolution / linear
+# --------------------------------------------------------------------------------------------------
+ACT = {None: 0, "none": 0, "relu": 1, "swish": 2}
+
+
+class PackedConv:
+    """Weights of one conv / linear layer in the kernel's layout (built once at model-prepare time).
+
+    w (rows=ceil(Cout/128)*128, taps*cin_pad) in the compute dtype (bf16 -> bf16 MFMA, fp32 -> exact fp32
+    MFMA), tap-major K; bias (rows,) f32 or None.
+    """
+
+    def __init__(self, weight, bias=None, stride=1, pad=0, dtype=torch.bfloat16, device=None):
+        if weight.dim() == 2:
+            weight = weight[:, :, None, None]
+        Cout, Cin, KH, KW = weight.shape
+        device = device if device is not None else weight.device
+        cin_pad = (Cin + 31) // 32 * 32
+        rows = (Cout + 127) // 128 * 128
+        w = torch.zeros(rows, KH * KW, cin_pad, dtype=torch.float32, device=weight.device)
+        w[:Cout, :, :Cin] = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin)
+        self.w = w.reshape(rows, KH * KW * cin_pad).to(dtype).to(device).contiguous()
+        self.bias = None
+        if bias is not None:
+            b = torch.zeros(rows, dtype=torch.float32, device=weight.device)
+            b[:Cout] = bias.detach().float()
+            self.bias = b.to(device)
+        self.Cout, self.Cin, self.KH, self.KW, self.stride, self.pad = Cout, Cin, KH, KW, stride, pad
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+
+def _nhwc_view(t, name):
+    """(N,H,W,C) view with unit channel stride and dense rows: returns (ld, img_stride)."""
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(1) != t.shape[2] * t.stride(2):
+        raise ValueError("%s must be an NHWC view with unit channel stride and dense rows, got shape %s stride %s" %
+                         (name, tuple(t.shape), t.stride()))
+    if not t.is_cuda:
+        raise _lib.Far3dHipError("%s must live on a HIP device; there is no CPU path" % name)
+    return t.stride(2), t.stride(0)
+
+
+def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0):
+    """x: (N,H,W,Cin) NHWC view (f32|bf16).  pc: PackedConv.  out: optional (N,Ho,Wo,Cout) NHWC view to write
+    into (e.g. a channel slice of an OSA concat buffer).  Returns out."""
+    lib = _lib.require_device()
+    N, H, W, Cin = x.shape
+    if Cin != pc.Cin:
+        raise ValueError("conv2d_nhwc: input has %d channels, layer expects %d" % (Cin, pc.Cin))
+    ldx, xs = _nhwc_view(x, "x")
+    Ho, Wo = pc.out_hw(H, W)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, pc.Cout), dtype=out_dtype or x.dtype, device=x.device)
+    if tuple(out.shape) != (N, Ho, Wo, pc.Cout):
+        raise ValueError("conv2d_nhwc: out shape %s != %s" % (tuple(out.shape), (N, Ho, Wo, pc.Cout)))
+    ldy, ys = _nhwc_view(out, "out")
+    rp, rdt, ldr, rs, Hr, Wr = None, 0, 0, 0, Ho, Wo
+    if res is not None:
+        ldr, rs = _nhwc_view(res, "res")
+        if res.shape[0] != N or res.shape[3] != pc.Cout:
+            raise ValueError("conv2d_nhwc: residual shape %s incompatible" % (tuple(res.shape),))
+        rp, rdt, Hr, Wr = _ptr(res), _dt(res), res.shape[1], res.shape[2]
+    y2p, y2dt, ldy2, y2s, sp, hp = None, 0, 0, 0, None, None
+    if y2 is not None:
+        ldy2, y2s = _nhwc_view(y2, "y2")
+        _chk(y2_scale, "y2_scale", torch.float32)
+        _chk(y2_shift, "y2_shift", torch.float32)
+        if y2_scale.numel() != N * pc.Cout or y2_shift.numel() != N * pc.Cout or tuple(y2.shape) != tuple(out.shape):
+            raise ValueError("conv2d_nhwc: y2/scale/shift shapes inconsistent")
+        y2p, y2dt, sp, hp = _ptr(y2), _dt(y2), _ptr(y2_scale), _ptr(y2_shift)
+    _lib.check(lib.far3d_conv2d_nhwc(
+        _ptr(x), _dt(x), _ptr(pc.w), _dt(pc.w), _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
+        N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],
+        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, tile, _stream(x)), "far3d_conv2d_nhwc")
+    return out
+
+
+def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0):
+    """y = act(x @ W^T + b) (+ res).  x (M,K) with unit inner stride (row stride free); returns (M,Cout)."""
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("linear: x must be (M,K) with unit inner stride")
+    M = x.shape[0]
+    xv = x.as_strided((1, 1, M, x.shape[1]), (M * x.stride(0), M * x.stride(0), x.stride(0), 1))
+    if out is None:
+        out = torch.empty((M, pc.Cout), dtype=out_dtype, device=x.device)
+    ov = out.as_strided((1, 1, M, pc.Cout), (M * out.stride(0), M * out.stride(0), out.stride(0), 1))
+    rv = None
+    if res is not None:
+        rv = res.as_strided((1, 1, M, pc.Cout), (M * res.stride(0), M * res.stride(0), res.stride(0), 1))
+    conv2d_nhwc(xv, pc, out=ov, act=act, res=rv, tile=tile)
+    return out

@@ -63,6 +63,29 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
                             void* stream);
 
+/* Implicit-GEMM convolution / linear layer on the matrix cores (bf16 MFMA, or exact-fp32 MFMA when w_dt = F32).
+ * Replaces the torch/cuDNN convolutions and nn.Linear GEMMs of the path:
+ *   VoVNet conv+BN(eval)+ReLU  ref: models/backbones/vovnet.py:114-139,218-238 (BN folded into w/bias by the host),
+ *   mmdet FPN laterals/outputs (ref cfg projects/configs/far3d.py:50-57; in-tree cousin models/necks/cp_fpn.py:156-208),
+ *   YOLOX towers conv+BN+Swish ref: models/dense_heads/yolox_head.py:197-258, depth head convs
+ *   ref: models/depth_predictor/depth_predictor.py:41-86, and every Linear of FarHead / the decoder
+ *   (ref: models/dense_heads/farhead.py:228-282, models/utils/detr3d_transformer.py:503-512,525-540).
+ * x: NHWC activations (x_dt), pixel stride ldx elements, image stride x_img_stride elements; the pointer is
+ *    pre-offset to the first input channel (channel slices of a wider buffer are fine).
+ * w: packed weights (w_dt) [ceil(Cout/128)*128][KH*KW][ceil(Cin/32)*32], zero padded; bias [same rows] f32 or NULL.
+ * y: NHWC output (y_dt), pixel stride ldy, image stride y_img_stride.  v = act(conv + bias) + res.
+ * act: 0 none, 1 ReLU, 2 Swish.  res (optional, res_dt): NHWC Hr x Wr map added with nearest-neighbour upsampling
+ *    (FPN top-down path); Hr=Ho, Wr=Wo gives a plain residual.
+ * y2 (optional, y2_dt): second output y2 = y2_scale[n][m] * v + y2_shift[n][m] (FarHead's camera-aware MLN,
+ *    ref: models/utils/misc.py:182-190, models/dense_heads/farhead.py:553-563) so that the FPN output conv writes
+ *    the modulated token-major value maps directly.
+ * tile: 0 auto, 1 = 128ch x 128px, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 per workgroup. */
+int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y, int y_dt,
+                      int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
+                      long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,
+                      int ldr, long res_img_stride, int Hr, int Wr, void* y2, int y2_dt, int ldy2,
+                      long y2_img_stride, const float* y2_scale, const float* y2_shift, int tile, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
