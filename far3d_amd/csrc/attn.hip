@@ -1,0 +1,230 @@
+// Decoder self-attention core: softmax(q k^T / sqrt(32)) v for 8 heads of dim 32,
+// 1544 queries x 2312 keys, flash-style (the 1544 x 2312 x 8 score tensor never exists).
+// Replaces the bmm/softmax/bmm inside torch.nn.MultiheadAttention as wrapped by mmcv MultiheadAttention
+// (reference cfg projects/configs/far3d.py:112-116; in-tree statement models/utils/petr_transformer.py:286-326).
+//
+// gfx950 mapping.  Workgroup = 4 waves = 128 queries of one head; a wave owns 32 queries.  Scores are computed
+// TRANSPOSED, S^T = K Q^T, so the MFMA C layout puts one query per lane column: lane (q = lane&31, hi = lane>>5)
+// holds 16 of the 32 keys of a tile for ITS query, the partner lane q+32 the other 16 -> the row max / row sum
+// are 15 in-register ops + one cross-half shuffle, and the running max / rescale are per-lane scalars.
+// O^T = V^T P^T accumulates with the same column = query mapping.  K/V tiles of 64 keys go through LDS once per
+// workgroup (K row-major, padded rows; V transposed with the key order permuted inside 16-key groups so that the
+// bf16 MFMA A-fragment is ONE ds_read_b128); the next tile's global loads are in flight during the MFMAs.
+// T = bf16: v_mfma_f32_32x32x16_bf16.  T = float: exact-fp32 v_mfma_f32_32x32x2_f32 (parity mode).
+#include "common.hpp"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+#define ATT_D 32
+#define ATT_KT 64
+
+template <typename T> struct ACfg;
+template <> struct ACfg<bf16_t> { static constexpr int KROW = 80, VROW = 144, KSUB = 2, CH = 1; };   // bytes
+template <> struct ACfg<float> { static constexpr int KROW = 144, VROW = 144, KSUB = 4, CH = 2; };
+
+template <typename T>
+__device__ __forceinline__ void mma_att(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  if constexpr (sizeof(T) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+}
+
+// position of key k inside a permuted 16-key group: quads 1 and 2 swapped (matches the S^T register order)
+__device__ __forceinline__ int vt_pos(int key) {
+  const int quad = (key >> 2) & 3;
+  const int sw = (quad == 1) ? 2 : ((quad == 2) ? 1 : quad);
+  return (key & ~15) | (sw << 2) | (key & 3);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                       const T* __restrict__ V, float* __restrict__ O, int Aq,
+                                                       int Nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+  constexpr int KROW = ACfg<T>::KROW, VROW = ACfg<T>::VROW, KSUB = ACfg<T>::KSUB, CH = ACfg<T>::CH;
+  constexpr int E = 16 / sizeof(T);
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_KT * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[(sizeof(T) == 2 ? ATT_D : ATT_KT) * VROW];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y;
+  const int q = blockIdx.x * 128 + wv * 32 + l31;
+  const bool q_ok = q < Aq;
+
+  // Q fragments (B operand: column = query), held in registers for the whole key loop
+  u32x4_t qf[KSUB];
+#pragma unroll
+  for (int kk = 0; kk < KSUB; ++kk) {
+    qf[kk] = u32x4_t{0u, 0u, 0u, 0u};
+    if (q_ok) {
+      const T* src = Q + (long)q * ldq + head * ATT_D + kk * 2 * E + hi * E;
+      qf[kk] = *reinterpret_cast<const u32x4_t*>(src);
+      if constexpr (sizeof(T) == 4) {  // torch scales q before the product (F.multi_head_attention_forward)
+        qf[kk].x = __float_as_uint(__uint_as_float(qf[kk].x) * scale);
+        qf[kk].y = __float_as_uint(__uint_as_float(qf[kk].y) * scale);
+        qf[kk].z = __float_as_uint(__uint_as_float(qf[kk].z) * scale);
+        qf[kk].w = __float_as_uint(__uint_as_float(qf[kk].w) * scale);
+      }
+    }
+  }
+
+  // cooperative K/V tile staging: chunk id -> (key, 16-B piece of the 32-dim head slice)
+  constexpr int CPK = ATT_D * sizeof(T) / 16;  // 16-B chunks per key row: 4 (bf16) / 8 (f32)
+  u32x4_t kreg[CH], vreg[CH];
+  auto gload = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int id = t + c * 256, key = id / CPK, ck = id % CPK;
+      const int gk = tile * ATT_KT + key;
+      kreg[c] = u32x4_t{0u, 0u, 0u, 0u};
+      vreg[c] = u32x4_t{0u, 0u, 0u, 0u};
+      if (gk < Nk) {
+        kreg[c] = *reinterpret_cast<const u32x4_t*>(K + (long)gk * ldk + head * ATT_D + ck * E);
+        vreg[c] = *reinterpret_cast<const u32x4_t*>(V + (long)gk * ldv + head * ATT_D + ck * E);
+      }
+    }
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int id = t + c * 256, key = id / CPK, ck = id % CPK;
+      *reinterpret_cast<u32x4_t*>(Ks + key * KROW + ck * 16) = kreg[c];
+      if constexpr (sizeof(T) == 2) {
+        const int pos = vt_pos(key);
+        const uint32_t w[4] = {vreg[c].x, vreg[c].y, vreg[c].z, vreg[c].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint16_t val = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+          *reinterpret_cast<uint16_t*>(Vs + (ck * 8 + e) * VROW + pos * 2) = val;
+        }
+      } else {
+        *reinterpret_cast<u32x4_t*>(Vs + key * VROW + ck * 16) = vreg[c];
+      }
+    }
+  };
+
+  f32x16_t o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (Nk + ATT_KT - 1) / ATT_KT;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const bool more = tile + 1 < ntiles;
+    if (more) gload(tile + 1);
+
+    // ---- S^T = K Q^T for the two 32-key sub-tiles
+    f32x16_t s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Ks + (u * 32 + l31) * KROW + kk * 32 + hi * 16);
+        mma_att<T>(s[u], a, qf[kk]);
+      }
+    }
+    // ---- online softmax (per-lane query)
+    const int kbase = tile * ATT_KT + 4 * hi;
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[u][r];
+        if constexpr (sizeof(T) == 2) v *= scale;
+        const int key = kbase + u * 32 + (r & 3) + 8 * (r >> 2);
+        v = key < Nk ? v : -INFINITY;
+        s[u][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = expf(m_run - m_use);   // m_run = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(s[u][r] - m_use);
+        s[u][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+
+    // ---- O^T += V^T P^T
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          u32x4_t b;
+          b.x = pack_bf16x2(s[u][8 * g + 0], s[u][8 * g + 1]);
+          b.y = pack_bf16x2(s[u][8 * g + 2], s[u][8 * g + 3]);
+          b.z = pack_bf16x2(s[u][8 * g + 4], s[u][8 * g + 5]);
+          b.w = pack_bf16x2(s[u][8 * g + 6], s[u][8 * g + 7]);
+          const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Vs + l31 * VROW + ((u * 32 + 16 * g) + hi * 8) * 2);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), o, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float a = *reinterpret_cast<const float*>(Vs + key * VROW + l31 * 4);
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[u][r], o, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) lstore();
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane (q,hi) holds d = (r&3) + 8*(r>>2) + 4*hi
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (q_ok) {
+    const float inv = 1.f / l_tot;
+    float* dst = O + (long)q * ldo + head * ATT_D + 4 * hi;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      *reinterpret_cast<float4*>(dst + 8 * qd) =
+          make_float4(o[4 * qd] * inv, o[4 * qd + 1] * inv, o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+  }
+}
+
+extern "C" int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, float* out, int Aq,
+                                       int Nk, int heads, int head_dim, int ldq, int ldk, int ldv, int ldo,
+                                       float scale, void* stream) {
+  FAR3D_CHECK_ARG(q && k && v && out, "far3d_attention_forward: null pointer argument");
+  FAR3D_CHECK_ARG(head_dim == ATT_D, "far3d_attention_forward: head_dim must be %d (got %d)", ATT_D, head_dim);
+  FAR3D_CHECK_ARG(Aq > 0 && Nk > 0 && heads > 0, "far3d_attention_forward: bad sizes Aq=%d Nk=%d heads=%d", Aq, Nk, heads);
+  FAR3D_CHECK_ARG(dtype == FAR3D_DT_F32 || dtype == FAR3D_DT_BF16, "far3d_attention_forward: unsupported dtype %d", dtype);
+  const int es = dtype == FAR3D_DT_F32 ? 4 : 2;
+  FAR3D_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                  (ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && ldo % 4 == 0,
+                  "far3d_attention_forward: pointers / row strides must be 16-byte aligned");
+  dim3 grid((Aq + 127) / 128, heads), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FAR3D_DT_F32)
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v, out,
+                       Aq, Nk, ldq, ldk, ldv, ldo, scale);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       out, Aq, Nk, ldq, ldk, ldv, ldo, scale);
+  FAR3D_CHECK_LAUNCH("far3d_attention_forward");
+  return FAR3D_OK;
+}

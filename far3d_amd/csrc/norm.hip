@@ -1,0 +1,307 @@
+// Row-wise normalisations and reductions of the path (HBM-bound; one wave per row, 16-B accesses).
+//   far3d_layernorm        -- nn.LayerNorm(C) (+ optional ReLU) (+ optional second output y2 = y + add, used to
+//                             hand the next GEMM "query + query_pos" without another pass).  Decoder norms
+//                             (ref models/utils/detr3d_transformer.py:304-307,398-400), cls branch LN
+//                             (ref models/dense_heads/farhead.py:230-239), cam_embed LN (:506-512), time_embedding LN.
+//   far3d_groupnorm_nhwc   -- GroupNorm(32, C) + ReLU on NHWC maps (ref models/depth_predictor/depth_predictor.py:43-45).
+//   far3d_ese_nhwc         -- VoVNet eSE: x * hsigmoid(fc(avgpool(x))) (+ identity) (ref models/backbones/vovnet.py:173-185,232-236).
+//   far3d_maxpool3x3s2_nhwc-- MaxPool2d(3, 2, ceil_mode=True) (ref models/backbones/vovnet.py:249-250).
+#include "common.hpp"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------- LayerNorm
+template <int MAXV>  // float4 per lane; C <= 256 * MAXV
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, int rows,
+                                                        int C, int ldx, int ldy, float eps, int act,
+                                                        const float* __restrict__ add, int lda, float* __restrict__ y2,
+                                                        int ldy2) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    v[i] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (d * d + e * e);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      float4 g = make_float4(1, 1, 1, 1), b = make_float4(0, 0, 0, 0);
+      if (gamma) g = *reinterpret_cast<const float4*>(gamma + c);
+      if (beta) b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(y + (long)row * ldy + c) = o;
+      if (y2) {
+        const float4 a = *reinterpret_cast<const float4*>(add + (long)row * lda + c);
+        *reinterpret_cast<float4*>(y2 + (long)row * ldy2 + c) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+      }
+    }
+  }
+}
+
+extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
+                               int ldx, int ldy, float eps, int act, const float* add, int lda, float* y2, int ldy2,
+                               void* stream) {
+  FAR3D_CHECK_ARG(x && y, "far3d_layernorm: null x/y");
+  FAR3D_CHECK_ARG(rows >= 0 && C > 0 && (C % 4) == 0 && C <= 1024, "far3d_layernorm: C=%d must be a multiple of 4, <= 1024", C);
+  FAR3D_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && (!y2 || (add && lda % 4 == 0 && ldy2 % 4 == 0)),
+                  "far3d_layernorm: row strides must be multiples of 4 floats; y2 needs add");
+  if (rows == 0) return FAR3D_OK;
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 256)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2);
+  FAR3D_CHECK_LAUNCH("far3d_layernorm");
+  return FAR3D_OK;
+}
+
+// ---------------------------------------------------------------- per-(image, channel-group) sums over H*W
+// Used by eSE (group size 1 -> channel means) and GroupNorm (sum and sum of squares per group).
+// x NHWC (T), C channels, `cpg` channels per group.  Partial sums accumulate with one atomicAdd per
+// (workgroup, channel) into sums[n][C][2] (zeroed by the caller on the same stream).
+template <typename T>
+__global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C,
+                                                        int ldx, long img_stride, int rows_per_block) {
+  // thread -> 4 consecutive channels; threads of a block cover (256*4/C) rows at a time
+  const int n = blockIdx.y;
+  const int cq = C / 4;                       // float4 groups per row
+  const int tcol = threadIdx.x % cq, trow = threadIdx.x / cq;
+  const int rstep = 256 / cq;
+  if (trow >= rstep) return;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(HW, r0 + rows_per_block);
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  const T* base = x + (long)n * img_stride + tcol * 4;
+  for (int r = r0 + trow; r < r1; r += rstep) {
+    const float4 v = load4(base + (long)r * ldx);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  float* dst = sums + ((long)n * C + tcol * 4) * 2;
+  atomicAdd(dst + 0, s.x); atomicAdd(dst + 1, q.x);
+  atomicAdd(dst + 2, s.y); atomicAdd(dst + 3, q.y);
+  atomicAdd(dst + 4, s.z); atomicAdd(dst + 5, q.z);
+  atomicAdd(dst + 6, s.w); atomicAdd(dst + 7, q.w);
+}
+
+static int launch_chan_sums(const void* x, int dt, float* sums, int N, int HW, int C, int ldx, long img_stride, hipStream_t st) {
+  const int rows_per_block = 256;
+  dim3 grid((HW + rows_per_block - 1) / rows_per_block, N), block(256);
+  if (dt == FAR3D_DT_F32)
+    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, sums, HW, C, ldx, img_stride, rows_per_block);
+  else
+    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, sums, HW, C, ldx, img_stride, rows_per_block);
+  return 0;
+}
+
+// ---------------------------------------------------------------- eSE
+// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ); one wave per output channel.
+__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ sums, const float* __restrict__ fcw,
+                                                       const float* __restrict__ fcb, float* __restrict__ gate, int C,
+                                                       float inv_hw) {
+  const int n = blockIdx.y, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int k = lane; k < C; k += 64) acc += fcw[(long)c * C + k] * (sums[((long)n * C + k) * 2] * inv_hw);
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float z = acc + fcb[c];
+    gate[(long)n * C + c] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x, const float* __restrict__ gate,
+                                                        const T* __restrict__ idn, T* __restrict__ y, long total4, int C,
+                                                        int HW, int ldx, long xs, int ldi, long is, int ldy, long ys) {
+  const int cq = C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    const long pr = i / cq;
+    const int n = (int)(pr / HW);
+    const long pix = pr - (long)n * HW;
+    float4 v = load4(x + n * xs + pix * ldx + c);
+    const float4 g = *reinterpret_cast<const float4*>(gate + (long)n * C + c);
+    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+    if (idn) {
+      const float4 d = load4(idn + n * is + pix * ldi + c);
+      v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+    }
+    T* dst = y + n * ys + pix * ldy + c;
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
+    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  }
+}
+
+extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
+                              float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
+                              long i_img_stride, int ldy, long y_img_stride, void* stream) {
+  FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
+                  "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4 and <= 1024)", C);
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
+  hipStream_t st = (hipStream_t)stream;
+  // scratch: [N][C][2] sums followed by [N][C] gates
+  float* sums = scratch;
+  float* gate = scratch + (long)N * C * 2;
+  hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
+  if (e != hipSuccess) { far3d_set_error("far3d_ese_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
+  launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW);
+  const long total4 = (long)N * HW * (C / 4);
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dt == FAR3D_DT_F32)
+    hipLaunchKernelGGL(ese_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, gate,
+                       (const float*)identity, (float*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
+  else
+    hipLaunchKernelGGL(ese_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, gate,
+                       (const bf16_t*)identity, (bf16_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
+  FAR3D_CHECK_LAUNCH("far3d_ese_nhwc");
+  return FAR3D_OK;
+}
+
+// ---------------------------------------------------------------- GroupNorm + ReLU (NHWC)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ sums, float* __restrict__ stat, int C,
+                                                       int groups, float inv_cnt, float eps, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
+  if (i >= total) return;
+  const int n = i / groups, g = i % groups, cpg = C / groups;
+  float s = 0.f, q = 0.f;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += sums[((long)n * C + c) * 2]; q += sums[((long)n * C + c) * 2 + 1]; }
+  const float mean = s * inv_cnt;
+  const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
+  stat[2 * i] = mean;
+  stat[2 * i + 1] = 1.f / sqrtf(var + eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stat,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, long total4, int C, int groups, int HW, int relu) {
+  const int cq = C / 4, cpg = C / groups;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    const long pr = i / cq;
+    const int n = (int)(pr / HW);
+    float4 v = load4(x + pr * C + c);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int g = (c + e) / cpg;
+      const float mean = stat[((long)n * groups + g) * 2], rstd = stat[((long)n * groups + g) * 2 + 1];
+      o[e] = (o[e] - mean) * rstd * gamma[c + e] + beta[c + e];
+      if (relu) o[e] = fmaxf(o[e], 0.f);
+    }
+    T* dst = y + pr * C + c;
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+  }
+}
+
+extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch,
+                                    int N, int HW, int C, int groups, float eps, int relu, void* stream) {
+  FAR3D_CHECK_ARG(x && gamma && beta && y && scratch, "far3d_groupnorm_nhwc: null pointer argument");
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_groupnorm_nhwc: unsupported dtype");
+  hipStream_t st = (hipStream_t)stream;
+  float* sums = scratch;                         // [N][C][2]
+  float* stat = scratch + (long)N * C * 2;       // [N][groups][2]
+  hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
+  if (e != hipSuccess) { far3d_set_error("far3d_groupnorm_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
+  launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
+  const int tot = N * groups;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, sums, stat, C, groups,
+                     1.f / ((float)HW * (C / groups)), eps, tot);
+  const long total4 = (long)N * HW * (C / 4);
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dt == FAR3D_DT_F32)
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, stat, gamma, beta,
+                       (float*)y, total4, C, groups, HW, relu);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, stat, gamma, beta,
+                       (bf16_t*)y, total4, C, groups, HW, relu);
+  FAR3D_CHECK_LAUNCH("far3d_groupnorm_nhwc");
+  return FAR3D_OK;
+}
+
+// ---------------------------------------------------------------- MaxPool 3x3 stride 2, ceil_mode (NHWC)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, long total4, int C, int H,
+                                                      int W, int Ho, int Wo) {
+  const int cq = C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    long pr = i / cq;
+    const int ox = (int)(pr % Wo); pr /= Wo;
+    const int oy = (int)(pr % Ho);
+    const int n = (int)(pr / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 + ky;
+      if (iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 + kx;
+        if (ix >= W) continue;
+        const float4 v = load4(x + (((long)n * H + iy) * W + ix) * C + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    T* dst = y + (((long)n * Ho + oy) * Wo + ox) * C + c;
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = m;
+    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w));
+  }
+}
+
+extern "C" int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  FAR3D_CHECK_ARG(x && y, "far3d_maxpool3x3s2_nhwc: null pointer argument");
+  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0, "far3d_maxpool3x3s2_nhwc: bad sizes");
+  // ceil_mode output size: ceil((H-3)/2)+1, last window must start inside the input
+  int eh = (H - 3 + 1) / 2 + 1; if ((eh - 1) * 2 >= H) --eh;
+  int ew = (W - 3 + 1) / 2 + 1; if ((ew - 1) * 2 >= W) --ew;
+  FAR3D_CHECK_ARG(Ho == eh && Wo == ew, "far3d_maxpool3x3s2_nhwc: output %dx%d != ceil-mode size %dx%d", Ho, Wo, eh, ew);
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_maxpool3x3s2_nhwc: unsupported dtype");
+  const long total4 = (long)N * Ho * Wo * (C / 4);
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == FAR3D_DT_F32)
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, total4, C, H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, total4, C, H, W, Ho, Wo);
+  FAR3D_CHECK_LAUNCH("far3d_maxpool3x3s2_nhwc");
+  return FAR3D_OK;
+}

@@ -215,3 +215,90 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
         rv = res.as_strided((1, 1, M, pc.Cout), (M * res.stride(0), M * res.stride(0), res.stride(0), 1))
     conv2d_nhwc(xv, pc, out=ov, act=act, res=rv, tile=tile)
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# attention / normalisation / pooling
+# --------------------------------------------------------------------------------------------------
+def attention_forward(q, k, v, num_heads=8, out=None):
+    """softmax(q k^T / sqrt(d)) v per head.  q (Aq,E), k/v (Nk,E) f32|bf16 with unit inner stride; out (Aq,E) f32."""
+    lib = _lib.require_device()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+            raise ValueError("attention_forward: %s must be a 2-D device tensor with unit inner stride" % n)
+    if not (q.dtype == k.dtype == v.dtype):
+        raise TypeError("attention_forward: q/k/v dtypes differ")
+    Aq, E = q.shape
+    Nk = k.shape[0]
+    hd = E // num_heads
+    if out is None:
+        out = torch.empty((Aq, E), dtype=torch.float32, device=q.device)
+    _lib.check(lib.far3d_attention_forward(_ptr(q), _ptr(k), _ptr(v), _dt(q), _ptr(out), Aq, Nk, num_heads, hd,
+                                           q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                           float(hd) ** -0.5, _stream(q)), "far3d_attention_forward")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None):
+    """Returns LN(x) (and LN(x)+add when `add` is given)."""
+    lib = _lib.require_device()
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
+        raise ValueError("layernorm: x must be (rows,C) f32 with unit inner stride")
+    rows, C = x.shape
+    y = out if out is not None else torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    y2 = torch.empty_like(y) if add is not None else None
+    _lib.check(lib.far3d_layernorm(_ptr(x), _ptr(gamma) if gamma is not None else None,
+                                   _ptr(beta) if beta is not None else None, _ptr(y), rows, C, x.stride(0), y.stride(0),
+                                   float(eps), 1 if act == "relu" else 0,
+                                   _ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
+                                   _ptr(y2) if y2 is not None else None, y2.stride(0) if y2 is not None else 0,
+                                   _stream(x)), "far3d_layernorm")
+    return (y, y2) if add is not None else y
+
+
+def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
+    """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride)."""
+    lib = _lib.require_device()
+    N, H, W, C = x.shape
+    ldx, xs = _nhwc_view(x, "x")
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    ldy, ys = _nhwc_view(out, "out")
+    ldi, isd, ip = 0, 0, None
+    if identity is not None:
+        ldi, isd = _nhwc_view(identity, "identity")
+        ip = _ptr(identity)
+    if scratch is None:
+        scratch = torch.empty(N * C * 3, dtype=torch.float32, device=x.device)
+    _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
+                                  ldx, xs, ldi, isd, ldy, ys, _stream(x)), "far3d_ese_nhwc")
+    return out
+
+
+def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scratch=None):
+    lib = _lib.require_device()
+    _chk(x, "x", ndim=4)
+    N, H, W, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    if scratch is None:
+        scratch = torch.empty(N * C * 2 + N * groups * 2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.far3d_groupnorm_nhwc(_ptr(x), _dt(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), N, H * W, C,
+                                        groups, float(eps), 1 if relu else 0, _stream(x)), "far3d_groupnorm_nhwc")
+    return out
+
+
+def maxpool3x3s2_nhwc(x, out=None):
+    lib = _lib.require_device()
+    _chk(x, "x", ndim=4)
+    N, H, W, C = x.shape
+    Ho, Wo = -(-(H - 3) // 2) + 1, -(-(W - 3) // 2) + 1
+    if (Ho - 1) * 2 >= H:
+        Ho -= 1
+    if (Wo - 1) * 2 >= W:
+        Wo -= 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    _lib.check(lib.far3d_maxpool3x3s2_nhwc(_ptr(x), _dt(x), _ptr(out), N, H, W, C, Ho, Wo, _stream(x)),
+               "far3d_maxpool3x3s2_nhwc")
+    return out

@@ -86,6 +86,39 @@ int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const fl
                       int ldr, long res_img_stride, int Hr, int Wr, void* y2, int y2_dt, int ldy2,
                       long y2_img_stride, const float* y2_scale, const float* y2_shift, int tile, void* stream);
 
+/* Multi-head self-attention core: out = softmax(q k^T * scale) v per head (flash-style, no score tensor in HBM).
+ * Replaces the bmm/softmax/bmm inside torch.nn.MultiheadAttention as wrapped by mmcv's MultiheadAttention
+ *   (ref cfg projects/configs/far3d.py:112-116; call site models/utils/detr3d_transformer.py:385-394; in-tree
+ *   statement of the wrapper models/utils/petr_transformer.py:286-326).  The in/out projections are
+ *   far3d_conv2d_nhwc calls.
+ * q (Aq, heads*32), k/v (Nk, heads*32) of `dtype` (F32 -> exact fp32 MFMA, BF16 -> bf16 MFMA), row strides
+ * ldq/ldk/ldv elements; out (Aq, heads*32) f32, row stride ldo.  head_dim must be 32.  No masks (inference). */
+int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, float* out, int Aq, int Nk,
+                            int heads, int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+
+/* y = act(LayerNorm_C(x) * gamma + beta); optional y2 = y + add (next GEMM's "query + query_pos").
+ * Replaces nn.LayerNorm at ref models/utils/detr3d_transformer.py:304-307,398-400,506-512 and
+ * models/dense_heads/farhead.py:230-239,274-277.  x,y,add,y2: f32 rows with strides ldx,ldy,lda,ldy2 (multiples of 4);
+ * gamma/beta may be NULL (no affine).  act: 0 none, 1 ReLU.  C multiple of 4, <= 1024. */
+int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int ldx,
+                    int ldy, float eps, int act, const float* add, int lda, float* y2, int ldy2, void* stream);
+
+/* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
+ * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
+ * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
+ * scratch: N*C*3 floats of device workspace. */
+int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
+                   float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
+                   int ldy, long y_img_stride, void* stream);
+
+/* GroupNorm(groups, C) (+ReLU) on dense NHWC maps.  Replaces nn.GroupNorm(32, 256)+ReLU of the depth head,
+ * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: N*C*2 + N*groups*2 floats. */
+int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch, int N,
+                         int HW, int C, int groups, float eps, int relu, void* stream);
+
+/* MaxPool2d(kernel 3, stride 2, ceil_mode=True) on dense NHWC maps (ref models/backbones/vovnet.py:249-250). */
+int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
