@@ -1,0 +1,67 @@
+"""CPU: the oracle reproduces the golden vectors the reference's own files produced (tools/gen_golden.py), and the
+state-dict schema matches the reference's (manifest fixture)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from far3d_amd import synth, weights
+from oracle import far3d_oracle
+from tests.conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load_small():
+    z = np.load(os.path.join(GOLD, "far3d_small_3frames.npz"))
+    recipe = json.loads(bytes(z["recipe"]).decode())
+    return z, recipe
+
+
+def small_oracle(recipe):
+    spec = weights.detector_spec(recipe["backbone"], num_query=recipe["num_query"], num_propagated=recipe["num_propagated"])
+    sd = weights.init_state_dict(spec, seed=recipe["weight_seed"])
+    cfg = far3d_oracle.default_cfg(num_cams=recipe["num_cams"], num_query=recipe["num_query"],
+                                   num_propagated=recipe["num_propagated"], memory_len=recipe["memory_len"],
+                                   topk_proposals=recipe["topk_proposals"])
+    return far3d_oracle.Far3DOracle(sd, cfg), sd
+
+
+def test_schema_matches_reference_manifest():
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))
+    spec = weights.detector_spec("V-99-eSE")
+    assert {k: list(v) for k, v in spec.items()} == man
+    assert len(spec) == 870
+    assert weights.canonical_key("pts_bbox_head.cls_branches.4.6.weight") == "pts_bbox_head.cls_branches.0.6.weight"
+    assert weights.canonical_key("img_backbone.stem.stem_1/norm.num_batches_tracked") is None
+    assert "img_backbone.stem.stem_1/conv.weight" in spec   # '/'-containing names are kept
+
+
+def test_oracle_reproduces_reference_golden_sequence():
+    z, rc = load_small()
+    orc, _ = small_oracle(rc)
+    with torch.no_grad():
+        for fi in range(rc["frames"]):
+            data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
+            o = orc.simple_test(data, metas)
+            for key, got in (("all_cls_scores", o["all_cls_scores"]), ("all_bbox_preds", o["all_bbox_preds"]),
+                             ("boxes_3d", o["result"]["boxes_3d"]), ("scores_3d", o["result"]["scores_3d"]),
+                             ("bbox2d", torch.cat(o["roi"]["bbox_list"])), ("bbox2d_scores", o["roi"]["bbox2d_scores"])):
+                want = torch.from_numpy(z["f%d_%s" % (fi, key)])
+                assert got.shape == want.shape, (fi, key)
+                assert (got - want).abs().max().item() < 2e-4, (fi, key)   # logits tolerance: 1e-3 per north_star
+            assert np.array_equal(o["result"]["labels_3d"].numpy(), z["f%d_labels_3d" % fi])
+            assert np.array_equal(o["roi"]["valid_indices"].nonzero().numpy(), z["f%d_valid_idx" % fi])
+            assert np.array_equal(o["roi"]["pred_depth"].argmax(1).numpy(), z["f%d_depth_argmax" % fi])
+
+
+def test_closed_form_known_answers():
+    orc = far3d_oracle.Far3DOracle({}, far3d_oracle.default_cfg())
+    # depth bin 0 -> depth_min (farhead.py:521-527); bins are monotone and end near depth_max
+    d = orc._bin_to_depth(torch.arange(51, dtype=torch.float32))
+    assert abs(d[0].item() - 0.1) < 1e-6 and (d[1:] > d[:-1]).all() and abs(d[50].item() - 114.353) < 0.01
+    e = far3d_oracle.pos2posemb3d(torch.zeros(1, 3))
+    assert e.shape == (1, 384) and torch.equal(e[0, 0::2], torch.zeros(192)) and torch.equal(e[0, 1::2], torch.ones(192))
+    x = torch.tensor([0.0, 0.25, 1.0])
+    assert torch.allclose(far3d_oracle.inverse_sigmoid(x).sigmoid(), torch.tensor([1e-5, 0.25, 1 - 1e-5]), atol=1e-6)
