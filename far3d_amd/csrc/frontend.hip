@@ -1,0 +1,344 @@
+// Per-camera front-end glue kernels (HBM-bound, byte/index work -- no MFMA):
+//   far3d_stem_im2col      NCHW fp32 image -> NHWC 32-channel im2col of the 3x3/s2 stem conv (27 taps + 5 zeros) so the
+//                          first VoVNet conv (ref models/backbones/vovnet.py:306-311) runs as a K=32 1x1 implicit GEMM.
+//   far3d_proposal_scores  sigma(obj)*sigma(max cls) and the 3x3 peak test of YOLOXHeadCustom.get_bboxes
+//                          (ref models/dense_heads/yolox_head.py:426-438).
+//   far3d_proposal_select  ordered, fixed-capacity selection (score > thr, or the K best per camera) -- replaces the
+//                          boolean-mask indexing that forces host syncs in the reference (:435-458).
+//   far3d_proposal_gather  2D box decode (:491-501), depth-bin lookup + LID un-binning, un-projection to normalised 3D
+//                          reference points and the 257-wide context vector (ref models/dense_heads/farhead.py:571-610,
+//                          710-827, 521-531).
+//   far3d_row_affine_ln    out = gamma[row] * LN_noaffine(x[row]) + beta[row] (+ add[row]): the MLN(180) modulation of
+//                          queries / memory (ref models/utils/misc.py:153-190; farhead.py:292-303).
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------ stem im2col
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int N, int H,
+                                                          int W, int Ho, int Wo) {
+  // one thread per (n, oy, ox, tap); writes 3 channels; the 5 pad channels are written by tap 8's thread
+  const long total = (long)N * Ho * Wo * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    long p = i / 9;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = img[(((long)n * 3 + c) * H + iy) * W + ix];
+    }
+    T* dst = out + (((long)n * Ho + oy) * Wo + ox) * 32 + tap * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if constexpr (sizeof(T) == 4) dst[c] = v[c]; else dst[c] = f32_to_bf16(v[c]);
+    }
+    if (tap == 8) {
+#pragma unroll
+      for (int c = 3; c < 8; ++c) {
+        if constexpr (sizeof(T) == 4) dst[c] = 0.f; else dst[c] = 0;
+      }
+    }
+  }
+}
+
+extern "C" int far3d_stem_im2col(const float* img, void* out, int out_dt, int N, int H, int W, void* stream) {
+  FAR3D_CHECK_ARG(img && out && N > 0 && H > 0 && W > 0, "far3d_stem_im2col: bad arguments");
+  FAR3D_CHECK_ARG(out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16, "far3d_stem_im2col: unsupported dtype");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * 9;
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dt == FAR3D_DT_F32)
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, img, (float*)out, N, H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, img, (bf16_t*)out, N, H, W, Ho, Wo);
+  FAR3D_CHECK_LAUNCH("far3d_stem_im2col");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ 2D proposal scores
+#define PROP_MAX_L 4
+struct PropLevels {
+  int L, S;
+  int H[PROP_MAX_L], W[PROP_MAX_L], start[PROP_MAX_L], stride[PROP_MAX_L];
+  const float* cls[PROP_MAX_L];   // (N, h, w, ncls) f32
+  const float* reg[PROP_MAX_L];   // (N, h, w, nreg>=5) f32: 4 box deltas + objectness
+  int ncls, nreg;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void prop_score_kernel(PropLevels lv, float* __restrict__ sw, int N) {
+  const long total = (long)N * lv.S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / lv.S), s = (int)(i - (long)n * lv.S);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < PROP_MAX_L; ++k) if (k < lv.L && s >= lv.start[k]) l = k;
+    const long pix = (long)n * lv.H[l] * lv.W[l] + (s - lv.start[l]);
+    const float* c = lv.cls[l] + pix * lv.ncls;
+    float m = c[0];
+    for (int k = 1; k < lv.ncls; ++k) m = fmaxf(m, c[k]);
+    sw[i] = sigmoidf_(lv.reg[l][pix * lv.nreg + 4]) * sigmoidf_(m);
+  }
+}
+
+__global__ __launch_bounds__(256) void prop_peak_kernel(PropLevels lv, const float* __restrict__ sw, float* __restrict__ wgt, int N) {
+  const long total = (long)N * lv.S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / lv.S), s = (int)(i - (long)n * lv.S);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < PROP_MAX_L; ++k) if (k < lv.L && s >= lv.start[k]) l = k;
+    const int H = lv.H[l], W = lv.W[l], r = s - lv.start[l], y = r / W, x = r - y * W;
+    const float* base = sw + (long)n * lv.S + lv.start[l];
+    const float v = base[r];
+    float m = v;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, base[yy * W + xx]);
+      }
+    wgt[i] = (v == m) ? v : 0.f;   // sample_weight * (sample_weight == maxpool3x3(sample_weight))
+  }
+}
+
+// One workgroup per camera.  mode 0: keep w > thr (count <= cap, extra entries dropped in index order);
+// mode 1: keep the K (= cap) largest, ties resolved towards the lower index.  Output indices ascending.
+__global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restrict__ wgt, int* __restrict__ sel_idx,
+                                                           int* __restrict__ sel_cnt, int S, int cap, float thr, int mode) {
+  const int n = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const float* w = wgt + (long)n * S;
+  __shared__ int s_cnt[1024 / 64];
+  __shared__ int s_tot;
+  __shared__ unsigned s_key;
+  // --- mode 1: find the K-th largest value by bisection on the (monotone, w >= 0) float bit pattern
+  unsigned kth = __float_as_uint(thr);   // mode 0: strict threshold
+  if (mode == 1) {
+    unsigned lo = 0u, hi = 0x7f800000u;   // invariant: count(w >= lo) >= K, count(w >= hi) < K
+    while (hi - lo > 1u) {
+      const unsigned mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+      for (int i = t; i < S; i += nt) c += (__float_as_uint(w[i]) >= mid) ? 1 : 0;
+      for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+      if ((t & 63) == 0) s_cnt[t >> 6] = c;
+      __syncthreads();
+      if (t == 0) { int tot = 0; for (int k = 0; k < nt / 64; ++k) tot += s_cnt[k]; s_tot = tot; }
+      __syncthreads();
+      if (s_tot >= cap) lo = mid; else hi = mid;
+      __syncthreads();
+    }
+    kth = lo;   // value of the K-th largest element
+  }
+  // --- ordered compaction, chunk by chunk (chunk = workgroup size)
+  // mode 0 keeps w > thr.  mode 1 keeps w > kth first-come AND as many w == kth (in index order) as needed.
+  int n_gt = 0;
+  if (mode == 1) {
+    int c = 0;
+    for (int i = t; i < S; i += nt) c += (__float_as_uint(w[i]) > kth) ? 1 : 0;
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((t & 63) == 0) s_cnt[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) { int tot = 0; for (int k = 0; k < nt / 64; ++k) tot += s_cnt[k]; s_tot = tot; }
+    __syncthreads();
+    n_gt = s_tot;
+    __syncthreads();
+  }
+  int base = 0, eq_left = (mode == 1) ? cap - n_gt : 0;
+  for (int c0 = 0; c0 < S; c0 += nt) {
+    const int i = c0 + t;
+    const unsigned bits = i < S ? __float_as_uint(w[i]) : 0u;
+    bool gt = i < S && ((mode == 0) ? (w[i] > thr) : (bits > kth));
+    bool eq = (mode == 1) && i < S && bits == kth;
+    // rank of equal-valued entries inside this chunk (needed to cut ties in index order)
+    const unsigned long long eqm = __ballot(eq);
+    int eq_before = __popcll(eqm & ((1ull << (t & 63)) - 1ull));
+    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(eqm);
+    __syncthreads();
+    int eq_wave_off = 0, eq_chunk = 0;
+    for (int k = 0; k < nt / 64; ++k) { if (k < (t >> 6)) eq_wave_off += s_cnt[k]; eq_chunk += s_cnt[k]; }
+    __syncthreads();
+    const bool keep = gt || (eq && (eq_wave_off + eq_before) < eq_left);
+    const unsigned long long km = __ballot(keep);
+    const int k_before = __popcll(km & ((1ull << (t & 63)) - 1ull));
+    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(km);
+    __syncthreads();
+    int wave_off = 0, chunk = 0;
+    for (int k = 0; k < nt / 64; ++k) { if (k < (t >> 6)) wave_off += s_cnt[k]; chunk += s_cnt[k]; }
+    const int pos = base + wave_off + k_before;
+    if (keep && pos < cap) sel_idx[(long)n * cap + pos] = i;
+    base += chunk;
+    eq_left -= min(eq_left, eq_chunk);
+    __syncthreads();
+  }
+  if (t == 0) sel_cnt[n] = min(base, cap);
+  (void)s_key;
+}
+
+struct GatherParams {
+  PropLevels lv;
+  const int* sel_idx; const int* sel_cnt;    // (N,cap), (N)
+  const int* row_off;                         // (N) exclusive prefix of sel_cnt (device) -> output row of camera n
+  const float* wgt;                           // (N,S) peak weights
+  const float* depth_logit;                   // (N, hd, wd, nd) f32
+  const float* img2lidar;                     // (N,4,4)
+  const void* feat; int feat_dt;              // (N,S,C) token-major (post-MLN) value maps
+  float* ref2d;                               // (Mcap,3) normalised reference points
+  float* ctx;                                 // (Mcap, C+1) context: feature || log-odds
+  float* box2d;                               // (Mcap,4) cx,cy,w,h (pixels)
+  float* score;                               // (Mcap)
+  int cap, C, hd, wd, nd, ds;
+  float depth_min, bin_size, pc_lo[3], pc_span[3], thr_logodds;
+};
+
+__global__ __launch_bounds__(64) void prop_gather_kernel(GatherParams g) {
+  const int n = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
+  if (j >= g.sel_cnt[n]) return;
+  const int s = g.sel_idx[(long)n * g.cap + j];
+  const int row = g.row_off[n] + j;
+  const PropLevels& lv = g.lv;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < PROP_MAX_L; ++k) if (k < lv.L && s >= lv.start[k]) l = k;
+  const int W = lv.W[l], r = s - lv.start[l], y = r / W, x = r - y * W;
+  const float st = (float)lv.stride[l];
+  const float* rp = lv.reg[l] + ((long)n * lv.H[l] * W + r) * lv.nreg;
+  const float cx = rp[0] * st + x * st, cy = rp[1] * st + y * st;   // xys = pred * stride + prior
+  const float bw = expf(rp[2]) * st, bh = expf(rp[3]) * st;
+  const float tlx = cx - bw / 2, tly = cy - bh / 2, brx = cx + bw / 2, bry = cy + bh / 2;
+  const float bcx = (tlx + brx) / 2, bcy = (tly + bry) / 2;          // xyxy -> cxcywh exactly as the reference chains them
+  const float sc = g.wgt[(long)n * lv.S + s];
+  // depth bin at round(centre / ds), clamped (farhead.py:736-747); torch.round = half-to-even = rintf
+  int u = (int)rintf(bcx / g.ds), v = (int)rintf(bcy / g.ds);
+  u = min(max(u, 0), g.wd - 1); v = min(max(v, 0), g.hd - 1);
+  const float* dl = g.depth_logit + (((long)n * g.hd + v) * g.wd + u) * g.nd;
+  int best = 0; float bv = dl[0];
+  for (int k = 1; k < g.nd; ++k) if (dl[k] > bv) { bv = dl[k]; best = k; }   // first maximum, like argmax
+  const float q = (float)best / 0.5f + 1.f;
+  const float d = g.depth_min + g.bin_size / 8.f * (q * q - 1.f);
+  const float dm = fmaxf(d, 1e-5f);
+  const float px = bcx * dm, py = bcy * dm;
+  const float* m = g.img2lidar + n * 16;
+  float c3[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = m[4 * k] * px + m[4 * k + 1] * py + m[4 * k + 2] * d + m[4 * k + 3];
+    c3[k] = (w - g.pc_lo[k]) / g.pc_span[k];
+  }
+  if (lane == 0) {
+    g.ref2d[row * 3 + 0] = c3[0]; g.ref2d[row * 3 + 1] = c3[1]; g.ref2d[row * 3 + 2] = c3[2];
+    g.box2d[row * 4 + 0] = bcx; g.box2d[row * 4 + 1] = bcy; g.box2d[row * 4 + 2] = brx - tlx; g.box2d[row * 4 + 3] = bry - tly;
+    g.score[row] = sc;
+    g.ctx[(long)row * (g.C + 1) + g.C] = logf(sc / (1.f - sc)) - g.thr_logodds;
+  }
+  for (int c = lane; c < g.C; c += 64) {
+    float fv;
+    if (g.feat_dt == FAR3D_DT_F32) fv = reinterpret_cast<const float*>(g.feat)[((long)n * lv.S + s) * g.C + c];
+    else fv = bf16_to_f32(reinterpret_cast<const bf16_t*>(g.feat)[((long)n * lv.S + s) * g.C + c]);
+    g.ctx[(long)row * (g.C + 1) + c] = fv;
+  }
+}
+
+static int fill_levels(PropLevels& lv, int L, const int32_t* hw, const int32_t* strides, const float* const* cls,
+                       const float* const* reg, int ncls, int nreg) {
+  lv.L = L; lv.ncls = ncls; lv.nreg = nreg;
+  int acc = 0;
+  for (int l = 0; l < PROP_MAX_L; ++l) {
+    lv.H[l] = l < L ? hw[2 * l] : 1; lv.W[l] = l < L ? hw[2 * l + 1] : 1; lv.stride[l] = l < L ? strides[l] : 1;
+    lv.start[l] = acc; lv.cls[l] = l < L ? cls[l] : nullptr; lv.reg[l] = l < L ? reg[l] : nullptr;
+    if (l < L) acc += lv.H[l] * lv.W[l];
+  }
+  lv.S = acc;
+  return acc;
+}
+
+// cls[l]: (N,h_l,w_l,ncls) f32; reg[l]: (N,h_l,w_l,nreg) f32 with channels (dx,dy,log w,log h,objectness).
+// scratch_sw, weights: (N,S) f32.  mode 0 threshold / 1 top-K.  sel_idx (N,cap) i32, sel_cnt (N) i32.
+extern "C" int far3d_proposal_select(const float* const* cls, const float* const* reg, int ncls, int nreg, int N, int L,
+                                     const int32_t* level_hw, const int32_t* strides, float* scratch_sw, float* weights,
+                                     int* sel_idx, int* sel_cnt, int cap, float thr, int mode, void* stream) {
+  FAR3D_CHECK_ARG(cls && reg && level_hw && strides && scratch_sw && weights && sel_idx && sel_cnt, "far3d_proposal_select: null argument");
+  FAR3D_CHECK_ARG(L >= 1 && L <= PROP_MAX_L && N > 0 && cap > 0 && nreg >= 5 && ncls >= 1, "far3d_proposal_select: bad sizes");
+  PropLevels lv;
+  const int S = fill_levels(lv, L, level_hw, strides, cls, reg, ncls, nreg);
+  FAR3D_CHECK_ARG(mode == 0 || (mode == 1 && cap <= S), "far3d_proposal_select: bad mode / K > S");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)N * S;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(prop_score_kernel, dim3(blocks), dim3(256), 0, st, lv, scratch_sw, N);
+  hipLaunchKernelGGL(prop_peak_kernel, dim3(blocks), dim3(256), 0, st, lv, scratch_sw, weights, N);
+  hipLaunchKernelGGL(prop_select_kernel, dim3(N), dim3(1024), 0, st, weights, sel_idx, sel_cnt, S, cap, thr, mode);
+  FAR3D_CHECK_LAUNCH("far3d_proposal_select");
+  return FAR3D_OK;
+}
+
+extern "C" int far3d_proposal_gather(const float* const* reg, int nreg, int N, int L, const int32_t* level_hw,
+                                     const int32_t* strides, const int* sel_idx, const int* sel_cnt, const int* row_off,
+                                     int cap, const float* weights, const float* depth_logit, int hd, int wd, int nd,
+                                     int depth_stride, float depth_min, float depth_max, int depth_bins,
+                                     const float* img2lidar, const void* feat, int feat_dt, int C, const float* pc_range,
+                                     float score_thr, float* ref2d, float* ctx, float* box2d, float* score, void* stream) {
+  FAR3D_CHECK_ARG(reg && level_hw && strides && sel_idx && sel_cnt && row_off && weights && depth_logit && img2lidar && feat &&
+                  pc_range && ref2d && ctx && box2d && score, "far3d_proposal_gather: null argument");
+  FAR3D_CHECK_ARG(L >= 1 && L <= PROP_MAX_L && N > 0 && cap > 0, "far3d_proposal_gather: bad sizes");
+  GatherParams g;
+  memset(&g, 0, sizeof(g));
+  const float* none[PROP_MAX_L] = {nullptr, nullptr, nullptr, nullptr};
+  fill_levels(g.lv, L, level_hw, strides, none, reg, 1, nreg);
+  g.sel_idx = sel_idx; g.sel_cnt = sel_cnt; g.row_off = row_off; g.wgt = weights; g.depth_logit = depth_logit;
+  g.img2lidar = img2lidar; g.feat = feat; g.feat_dt = feat_dt; g.ref2d = ref2d; g.ctx = ctx; g.box2d = box2d; g.score = score;
+  g.cap = cap; g.C = C; g.hd = hd; g.wd = wd; g.nd = nd; g.ds = depth_stride;
+  g.depth_min = depth_min;
+  g.bin_size = 2.f * (depth_max - depth_min) / ((float)depth_bins * (1.f + depth_bins));
+  for (int k = 0; k < 3; ++k) { g.pc_lo[k] = pc_range[k]; g.pc_span[k] = pc_range[3 + k] - pc_range[k]; }
+  g.thr_logodds = logf(score_thr / (1.f - score_thr));
+  hipLaunchKernelGGL(prop_gather_kernel, dim3(cap, N), dim3(64), 0, (hipStream_t)stream, g);
+  FAR3D_CHECK_LAUNCH("far3d_proposal_gather");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ row-affine LayerNorm (MLN apply)
+__global__ __launch_bounds__(256) void row_affine_ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ add,
+                                                            float* __restrict__ y, int rows, int C, int ldx, int ldg, int lda,
+                                                            int ldy, float eps, int do_ln) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = lane * 4;   // C == 256
+  float4 v = *reinterpret_cast<const float4*>(x + (long)row * ldx + c);
+  if (do_ln) {
+    float s = (v.x + v.y) + (v.z + v.w);
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    const float a = v.x - mean, b = v.y - mean, d = v.z - mean, e = v.w - mean;
+    float q = (a * a + b * b) + (d * d + e * e);
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / C + eps);
+    v = make_float4(a * rstd, b * rstd, d * rstd, e * rstd);
+  }
+  const float4 g = *reinterpret_cast<const float4*>(gamma + (long)row * ldg + c);
+  const float4 b = *reinterpret_cast<const float4*>(beta + (long)row * ldg + c);
+  float4 o = make_float4(g.x * v.x + b.x, g.y * v.y + b.y, g.z * v.z + b.z, g.w * v.w + b.w);
+  if (add) {
+    const float4 a = *reinterpret_cast<const float4*>(add + (long)row * lda + c);
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+  }
+  *reinterpret_cast<float4*>(y + (long)row * ldy + c) = o;
+}
+
+// gamma/beta rows use stride ldg (0 = one shared row for all rows); add rows stride lda (0 = shared row).
+extern "C" int far3d_row_affine_ln(const float* x, const float* gamma, const float* beta, const float* add, float* y,
+                                   int rows, int C, int ldx, int ldg, int lda, int ldy, float eps, int do_ln, void* stream) {
+  FAR3D_CHECK_ARG(x && gamma && beta && y, "far3d_row_affine_ln: null argument");
+  FAR3D_CHECK_ARG(C == 256 && ldx % 4 == 0 && ldg % 4 == 0 && lda % 4 == 0 && ldy % 4 == 0, "far3d_row_affine_ln: C must be 256, strides multiples of 4");
+  if (rows <= 0) return FAR3D_OK;
+  hipLaunchKernelGGL(row_affine_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, add, y, rows,
+                     C, ldx, ldg, lda, ldy, eps, do_ln);
+  FAR3D_CHECK_LAUNCH("far3d_row_affine_ln");
+  return FAR3D_OK;
+}

@@ -259,7 +259,7 @@ extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, c
 // ---------------------------------------------------------------- MaxPool 3x3 stride 2, ceil_mode (NHWC)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, long total4, int C, int H,
-                                                      int W, int Ho, int Wo) {
+                                                      int W, int Ho, int Wo, int ldy, long ys) {
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cq) * 4;
@@ -280,15 +280,16 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    T* dst = y + (((long)n * Ho + oy) * Wo + ox) * C + c;
+    T* dst = y + (long)n * ys + ((long)oy * Wo + ox) * ldy + c;
     if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = m;
     else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w));
   }
 }
 
-extern "C" int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, int ldy,
+                                       long y_img_stride, void* stream) {
   FAR3D_CHECK_ARG(x && y, "far3d_maxpool3x3s2_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0, "far3d_maxpool3x3s2_nhwc: bad sizes");
+  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldy >= C && ldy % 4 == 0, "far3d_maxpool3x3s2_nhwc: bad sizes");
   // ceil_mode output size: ceil((H-3)/2)+1, last window must start inside the input
   int eh = (H - 3 + 1) / 2 + 1; if ((eh - 1) * 2 >= H) --eh;
   int ew = (W - 3 + 1) / 2 + 1; if ((ew - 1) * 2 >= W) --ew;
@@ -299,9 +300,9 @@ extern "C" int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, in
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
   if (dt == FAR3D_DT_F32)
-    hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, total4, C, H, W, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, total4, C, H, W, Ho, Wo, ldy, y_img_stride);
   else
-    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, total4, C, H, W, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, total4, C, H, W, Ho, Wo, ldy, y_img_stride);
   FAR3D_CHECK_LAUNCH("far3d_maxpool3x3s2_nhwc");
   return FAR3D_OK;
 }

@@ -1,0 +1,477 @@
+"""Far3DEngine: one 7-camera frame through the HIP kernels, batch 1, inference only.
+
+Host-side orchestration only: every heavy step is a C-ABI kernel from libfar3d_hip.so (far3d_amd.ops).  torch is used
+for device memory, the stream, and a handful of O(1k)-element index/glue ops (sin/cos position codes, top-k, 4x4 pose
+products) that SURVEY.md marks negligible; there is NO CPU path -- constructing the engine without a HIP device raises.
+
+Data layout (HBM): all feature maps are NHWC (channels-last) in the activation dtype (bf16 in 'bf16' mode, fp32 in
+'fp32' parity mode); an OSA block's input and its five 3x3 outputs live in ONE (N,H,W,Cin+5*Cs) buffer and every conv
+writes its channel slice in place, so torch.cat never runs; FPN outputs are written twice by the same conv epilogue:
+raw (for the 2D head) and camera-modulated, token-major (N, S, 256), which IS `feat_flatten` of the reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as _lib
+from . import ops, weights
+from .synth import level_shapes, level_starts
+
+PRECISIONS = {
+    # activations/weights of the convs, value maps, decoder GEMM weights, attention operands
+    "bf16": dict(act=torch.bfloat16, value=torch.bfloat16, dec_w=torch.bfloat16, attn=torch.bfloat16),
+    "fp32": dict(act=torch.float32, value=torch.float32, dec_w=torch.float32, attn=torch.float32),
+}
+
+
+def default_cfg(**over):
+    cfg = dict(
+        backbone="V-99-eSE", embed_dims=256, num_classes=26, strides=(8, 16, 32, 64),
+        num_cams=7, num_query=644, num_propagated=256, memory_len=1024, topk_proposals=256,
+        num_layers=6, num_heads=8, num_groups=8, num_levels=4, num_pts=13, ffn_dim=1024,
+        pc_range=[-152.4, -152.4, -5.0, 152.4, 152.4, 5.0], code_size=8, max_num=300,
+        depthnet=dict(num_depth_bins=50, depth_min=0.1, depth_max=110.0, stride=8), score_thr=0.1,
+        proposal_topk=None,      # None = reference (score > thr, dynamic M, one host sync); K = static K best per camera
+        proposal_cap=512,        # per-camera capacity in threshold mode
+    )
+    cfg.update(over)
+    return cfg
+
+
+def pos2posemb(pos, num_pos_feats, temperature=10000):
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=pos.device)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    p = (pos * (2 * math.pi))[..., None] / dim_t
+    return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
+
+
+def pos2posemb3d(pos):   # reference order (y, x, z): models/utils/positional_encoding.py:13-25
+    return torch.cat([pos2posemb(pos[..., 1], 128), pos2posemb(pos[..., 0], 128), pos2posemb(pos[..., 2], 128)], dim=-1)
+
+
+def nerf_encoding(t, n=6):   # positional_encoding.py:38-80
+    out = []
+    for k in range(n):
+        f = float(2.0 ** k)
+        out += [torch.sin(t * f), torch.cos(t * f)]
+    return torch.cat(out, dim=-1)
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+class _Lin:
+    """A Linear layer packed for far3d_conv2d_nhwc."""
+
+    def __init__(self, sd, name, dtype, device, bias=True, rows=None):
+        w = sd[name + ".weight"]
+        b = sd[name + ".bias"] if bias else None
+        if rows is not None:
+            w = w[rows]
+            b = b[rows] if b is not None else None
+        self.pc = ops.PackedConv(w, b, dtype=dtype, device=device)
+
+    def __call__(self, x, act=None, res=None, out=None, out_dtype=torch.float32):
+        return ops.linear(x, self.pc, act=act, res=res, out=out, out_dtype=out_dtype)
+
+
+class Far3DEngine:
+    def __init__(self, state_dict, cfg=None, device="cuda:0", precision="bf16"):
+        _lib.require_device()
+        self.cfg = cfg or default_cfg()
+        self.dev = torch.device(device)
+        self.prec = PRECISIONS[precision]
+        self.precision = precision
+        self.sd = {}
+        for k, v in state_dict.items():
+            ck = weights.canonical_key(k)
+            if ck is not None:
+                self.sd[ck] = v.detach().float()
+        self.spec = weights.VOV_SPECS[self.cfg["backbone"]]
+        self._bufs = {}
+        self.reset_memory()
+        self.prev_scene = None
+        self._prepare()
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _conv_bn(self, prefix, conv="/conv", norm="/norm", eps=1e-5, stride=1, pad=1):
+        sd = self.sd
+        n = prefix + norm + "."
+        w, b = weights.fold_bn(sd[prefix + conv + ".weight"], sd[n + "weight"], sd[n + "bias"], sd[n + "running_mean"],
+                               sd[n + "running_var"], eps)
+        return w, b, stride, pad
+
+    def _pack(self, w, b, stride=1, pad=0):
+        return ops.PackedConv(w, b, stride=stride, pad=pad, dtype=self.prec["act"], device=self.dev)
+
+    def _prepare(self):
+        sd, cfg, dev = self.sd, self.cfg, self.dev
+        f32 = lambda t: t.to(dev).float().contiguous()
+        # ---- backbone (a2)
+        bb = {}
+        w, b, _, _ = self._conv_bn("img_backbone.stem.stem_1")
+        bb["stem1"] = self._pack(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), b)          # 1x1 over the im2col'd image
+        bb["stem2"] = self._pack(*self._conv_bn("img_backbone.stem.stem_2"))
+        bb["stem3"] = self._pack(*self._conv_bn("img_backbone.stem.stem_3", stride=2))
+        stages = []
+        for si in range(4):
+            k = si + 2
+            blocks = []
+            for bi in range(self.spec["block_per_stage"][si]):
+                name = "OSA%d_%d" % (k, bi + 1)
+                p = "img_backbone.stage%d.%s" % (k, name)
+                convs = [self._pack(*self._conv_bn("%s.layers.%d.%s_%d" % (p, i, name, i))) for i in range(self.spec["layer_per_block"])]
+                cw, cb, _, _ = self._conv_bn("%s.concat.%s_concat" % (p, name), pad=0)
+                blocks.append(dict(convs=convs, concat=self._pack(cw, cb), fcw=f32(sd[p + ".ese.fc.weight"].flatten(1)),
+                                   fcb=f32(sd[p + ".ese.fc.bias"])))
+            stages.append(blocks)
+        bb["stages"] = stages
+        self.bb = bb
+        # ---- FPN (a3)
+        nl = len(self.spec["stage_out_ch"]) - 1
+        self.fpn_lat = [self._pack(sd["img_neck.lateral_convs.%d.conv.weight" % i], sd["img_neck.lateral_convs.%d.conv.bias" % i]) for i in range(nl)]
+        self.fpn_out = [self._pack(sd["img_neck.fpn_convs.%d.conv.weight" % i], sd["img_neck.fpn_convs.%d.conv.bias" % i],
+                                   stride=2 if i == nl else 1, pad=1) for i in range(nl + 1)]
+        # ---- 2D head + depth (a4)
+        r = "img_roi_head."
+        self.roi = []
+        for l in range(len(cfg["strides"])):
+            lv = {}
+            for t in ("cls", "reg"):
+                lv[t] = [self._pack(*self._conv_bn(r + "multi_level_%s_convs.%d.%d" % (t, l, i), conv=".conv", norm=".bn", eps=1e-3)) for i in range(2)]
+            lv["cls_head"] = self._pack(sd[r + "multi_level_conv_cls.%d.weight" % l], sd[r + "multi_level_conv_cls.%d.bias" % l])
+            lv["reg_head"] = self._pack(torch.cat([sd[r + "multi_level_conv_reg.%d.weight" % l], sd[r + "multi_level_conv_obj.%d.weight" % l]]),
+                                        torch.cat([sd[r + "multi_level_conv_reg.%d.bias" % l], sd[r + "multi_level_conv_obj.%d.bias" % l]]))
+            self.roi.append(lv)
+        self.depth = dict(
+            convs=[self._pack(sd[r + "depthnet.depth_head.%d.0.weight" % i], sd[r + "depthnet.depth_head.%d.0.bias" % i], pad=1) for i in range(2)],
+            gn=[(f32(sd[r + "depthnet.depth_head.%d.1.weight" % i]), f32(sd[r + "depthnet.depth_head.%d.1.bias" % i])) for i in range(2)],
+            cls=self._pack(sd[r + "depthnet.depth_classifier.weight"], sd[r + "depthnet.depth_classifier.bias"]))
+        # ---- FarHead (a6, a10)
+        h = "pts_bbox_head."
+        dw = self.prec["dec_w"]
+        L = lambda name, **kw: _Lin(sd, h + name, dw, dev, **kw)
+        self.pc_range = f32(sd[h + "pc_range"])
+        self.pc_lo, self.pc_span = self.pc_range[:3], self.pc_range[3:6] - self.pc_range[:3]
+        self.sa = dict(reduce=L("spatial_alignment.reduce.0"), gamma=L("spatial_alignment.gamma"), beta=L("spatial_alignment.beta"))
+        self.qe = (L("query_embedding.0"), L("query_embedding.2"))
+        self.ce = (L("context_embed.0"), L("context_embed.2"))
+        self.te = L("time_embedding.0")
+        self.te_ln = (f32(sd[h + "time_embedding.1.weight"]), f32(sd[h + "time_embedding.1.bias"]))
+        self.mln = {n: dict(reduce=L(n + ".reduce.0"), gamma=L(n + ".gamma"), beta=L(n + ".beta")) for n in ("ego_pose_pe", "ego_pose_memory")}
+        self.cls_b = (L("cls_branches.0.0"), L("cls_branches.0.3"), L("cls_branches.0.6"))
+        self.cls_ln = [(f32(sd[h + "cls_branches.0.%d.weight" % j]), f32(sd[h + "cls_branches.0.%d.bias" % j])) for j in (1, 4)]
+        self.reg_b = (L("reg_branches.0.0"), L("reg_branches.0.2"), L("reg_branches.0.4"))
+        self.ref_fixed = f32(sd[h + "reference_points.weight"])
+        self.pseudo_ref = f32(sd[h + "pseudo_reference_points.weight"]) if cfg["num_propagated"] > 0 else None
+        # ---- decoder layers (a7, a8)
+        E = cfg["embed_dims"]
+        self.layers = []
+        for i in range(cfg["num_layers"]):
+            lp = h + "transformer.decoder.layers.%d." % i
+            a, c = lp + "attentions.0.attn.", lp + "attentions.1."
+            ipw, ipb = sd[a + "in_proj_weight"], sd[a + "in_proj_bias"]
+            pk = lambda w, b: ops.PackedConv(w, b, dtype=dw, device=dev)
+            ly = dict(
+                qk=pk(ipw[:2 * E], ipb[:2 * E]), k=pk(ipw[E:2 * E], ipb[E:2 * E]), v=pk(ipw[2 * E:], ipb[2 * E:]),
+                out=pk(sd[a + "out_proj.weight"], sd[a + "out_proj.bias"]),
+                wfc=pk(sd[c + "weights_fc.weight"], None), wfc_full=pk(sd[c + "weights_fc.weight"], sd[c + "weights_fc.bias"]),
+                lfc=pk(sd[c + "learnable_fc.weight"], sd[c + "learnable_fc.bias"]),
+                oproj=pk(sd[c + "output_proj.weight"], sd[c + "output_proj.bias"]),
+                ce0=pk(sd[c + "cam_embed.0.weight"], sd[c + "cam_embed.0.bias"]), ce2=pk(sd[c + "cam_embed.2.weight"], sd[c + "cam_embed.2.bias"]),
+                ce_ln=(f32(sd[c + "cam_embed.4.weight"]), f32(sd[c + "cam_embed.4.bias"])),
+                ffn1=pk(sd[lp + "ffns.0.layers.0.0.weight"], sd[lp + "ffns.0.layers.0.0.bias"]),
+                ffn2=pk(sd[lp + "ffns.0.layers.1.weight"], sd[lp + "ffns.0.layers.1.bias"]),
+                norms=[(f32(sd[lp + "norms.%d.weight" % j]), f32(sd[lp + "norms.%d.bias" % j])) for j in range(3)])
+            self.layers.append(ly)
+        # ---- frame-invariant pieces of temporal_alignment (farhead.py:284-303): the current frame's ego motion is the
+        # identity, so its MLN(180) codes are constants, and the 644 learned queries never change.
+        eye = torch.eye(4, device=dev)[:3, :].flatten()
+        rec = nerf_encoding(torch.cat([torch.zeros(3, device=dev), eye])[None])              # (1,180)
+        self.rec_code = {}
+        for n in ("ego_pose_pe", "ego_pose_memory"):
+            hh = self.mln[n]["reduce"](rec, act="relu")
+            self.rec_code[n] = (self.mln[n]["gamma"](hh), self.mln[n]["beta"](hh))             # (1,256) each
+        self.time0 = ops.layernorm(self.te(pos2posemb(torch.zeros(1, device=dev), 256)), *self.te_ln)   # (1,256)
+        qp = self._query_pos(self.ref_fixed)
+        self.qpos_fixed = ops.row_affine_ln(qp, *self.rec_code["ego_pose_pe"], add=self.time0)
+        self.tgt_fixed = ops.row_affine_ln(torch.zeros_like(qp), *self.rec_code["ego_pose_memory"])
+        torch.cuda.synchronize(dev)
+
+    def _query_pos(self, ref):
+        return self.qe[1](self.qe[0](pos2posemb3d(ref).contiguous(), act="relu"))
+
+    def _buf(self, key, shape, dtype):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            b = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------------------------------ a2: backbone
+    def backbone(self, img):
+        """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps."""
+        act, spec = self.prec["act"], self.spec
+        N = img.shape[0]
+        Lb = spec["layer_per_block"]
+        x = ops.stem_im2col(img, act)
+        x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
+        x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
+        H, W = self.bb["stem3"].out_hw(x.shape[1], x.shape[2])
+        in_ch = spec["stem"][2]
+        outs = []
+        stage_in = None   # dense input of the stage (stem3 output is written straight into the first concat buffer)
+        for si, blocks in enumerate(self.bb["stages"]):
+            sc, oc = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
+            if si > 0:
+                Hp, Wp = H, W
+                H, W = -(-(Hp - 3) // 2) + 1, -(-(Wp - 3) // 2) + 1
+                if (H - 1) * 2 >= Hp:
+                    H -= 1
+                if (W - 1) * 2 >= Wp:
+                    W -= 1
+            cat = self._buf(("cat", si, 0), (N, H, W, in_ch + Lb * sc), act)
+            if si == 0:
+                ops.conv2d_nhwc(x, self.bb["stem3"], out=cat[..., :in_ch], act="relu")
+            else:
+                ops.maxpool3x3s2_nhwc(stage_in, out=cat[..., :in_ch])
+            cur_in = in_ch
+            for bi, blk in enumerate(blocks):
+                last = bi == len(blocks) - 1
+                src = cat[..., :cur_in]
+                for i, pc in enumerate(blk["convs"]):
+                    dst = cat[..., cur_in + i * sc: cur_in + (i + 1) * sc]
+                    ops.conv2d_nhwc(src, pc, out=dst, act="relu")
+                    src = dst
+                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc), act), act="relu")
+                if last:
+                    out = self._buf(("stage", si), (N, H, W, oc), act)
+                    nxt = None
+                else:
+                    nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, oc + Lb * sc), act)
+                    out = nxt[..., :oc]
+                ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out,
+                             scratch=self._buf(("ese", si), (N * oc * 3,), torch.float32))
+                if not last:
+                    cat, cur_in = nxt, oc
+            stage_in = self._bufs[("stage", si)]
+            outs.append(stage_in)
+            in_ch = oc
+        return outs
+
+    # ------------------------------------------------------------------------------------------ a3 + MLN: FPN
+    def fpn(self, feats, mln_scale, mln_shift):
+        """Returns (raw levels [NHWC act], feat_flatten (N,S,256) value dtype, level_hw, level_start)."""
+        act, val = self.prec["act"], self.prec["value"]
+        ins = feats[1:]
+        N = ins[0].shape[0]
+        n = len(ins)
+        hw = [(f.shape[1], f.shape[2]) for f in ins]
+        hw.append(self.fpn_out[n].out_hw(*hw[-1]))
+        starts, S = level_starts(hw)
+        tokens = self._buf(("tokens",), (N, S, 256), val)
+        lat = [None] * n
+        for i in range(n - 1, -1, -1):   # top-down: laterals[i-1] += nearest_upsample(laterals[i])
+            lat[i] = ops.conv2d_nhwc(ins[i], self.fpn_lat[i], out=self._buf(("lat", i), (N, hw[i][0], hw[i][1], 256), act),
+                                     res=lat[i + 1] if i + 1 < n else None)
+        raw = []
+        for i in range(n + 1):
+            src = lat[i] if i < n else raw[n - 1]
+            y2 = tokens[:, starts[i]: starts[i] + hw[i][0] * hw[i][1]].view(N, hw[i][0], hw[i][1], 256)
+            raw.append(ops.conv2d_nhwc(src, self.fpn_out[i], out=self._buf(("fpn", i), (N, hw[i][0], hw[i][1], 256), act),
+                                       y2=y2, y2_scale=mln_scale, y2_shift=mln_shift))
+        return raw, tokens, hw, starts
+
+    # ------------------------------------------------------------------------------------------ a4: 2D head + depth
+    def roi_head(self, raw):
+        cls, reg = [], []
+        for l, x in enumerate(raw):
+            lv = self.roi[l]
+            cf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["cls"][0], act="swish"), lv["cls"][1], act="swish")
+            rf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["reg"][0], act="swish"), lv["reg"][1], act="swish")
+            cls.append(ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32))
+            reg.append(ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32))
+        d = raw[0]
+        for i in range(2):
+            d = ops.conv2d_nhwc(d, self.depth["convs"][i])
+            d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True)
+        depth_logit = ops.conv2d_nhwc(d, self.depth["cls"], out_dtype=torch.float32)
+        return cls, reg, depth_logit
+
+    # ------------------------------------------------------------------------------------------ memory (a6/a11, tiny)
+    def reset_memory(self):
+        self.mem = None
+
+    def _pre_update_memory(self, data, prev_exists):   # farhead.py:453-477
+        cfg, dev = self.cfg, self.dev
+        Lm, E, P_ = cfg["memory_len"], cfg["embed_dims"], cfg["num_propagated"]
+        x = prev_exists
+        if self.mem is None:
+            self.mem = dict(emb=torch.zeros(1, Lm, E, device=dev), ref=torch.zeros(1, Lm, 3, device=dev),
+                            ts=torch.zeros(1, Lm, 1, device=dev), pose=torch.zeros(1, Lm, 4, 4, device=dev),
+                            velo=torch.zeros(1, Lm, 2, device=dev))
+        else:
+            m = self.mem
+            m["ts"] = m["ts"] + data["timestamp"].unsqueeze(-1).unsqueeze(-1)
+            m["pose"] = data["ego_pose_inv"].unsqueeze(1) @ m["pose"]
+            m["ref"] = self._transform_ref(m["ref"], data["ego_pose_inv"])
+            for k in ("ts", "ref", "emb", "pose", "velo"):
+                m[k] = m[k][:, :Lm] * x.view(-1, *([1] * (m[k].dim() - 1)))
+        if P_ > 0:
+            m = self.mem
+            pseudo = self.pseudo_ref * self.pc_span + self.pc_lo
+            m["ref"] = torch.cat([m["ref"][:, :P_] + (1 - x).view(1, 1, 1) * pseudo, m["ref"][:, P_:]], dim=1)
+            m["pose"] = torch.cat([m["pose"][:, :P_] + (1 - x).view(1, 1, 1, 1) * torch.eye(4, device=dev), m["pose"][:, P_:]], dim=1)
+
+    @staticmethod
+    def _transform_ref(ref, pose):
+        r = torch.cat([ref, torch.ones_like(ref[..., :1])], dim=-1)
+        return (pose.unsqueeze(1) @ r.unsqueeze(-1)).squeeze(-1)[..., :3]
+
+    def _mln_rows(self, x, code, name, add=None):
+        m = self.mln[name]
+        hh = m["reduce"](code, act="relu")
+        return ops.row_affine_ln(x, m["gamma"](hh), m["beta"](hh), add=add)
+
+    # ------------------------------------------------------------------------------------------ a7/a8: decoder
+    def decoder(self, tgt, qpos, tokens, ref, hw, starts, mem, mempos, lidar2img, pad_hw):
+        cfg = self.cfg
+        A, E = tgt.shape
+        Km = mem.shape[0]
+        at = self.prec["attn"]
+        x = tgt
+        xq = x + qpos
+        memk = (mem + mempos).contiguous()
+        l2i = lidar2img[:, :3, :].flatten(1).contiguous()             # (N,12)
+        outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
+        qk = self._buf(("qk",), (A + Km, 2 * E), at)
+        vb = self._buf(("v",), (A + Km, E), at)
+        for li, ly in enumerate(self.layers):
+            # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
+            ops.linear(xq, ly["qk"], out=qk[:A])
+            ops.linear(memk, ly["k"], out=qk[A:, E:])
+            ops.linear(x, ly["v"], out=vb[:A])
+            ops.linear(mem, ly["v"], out=vb[A:])
+            att = ops.attention_forward(qk[:A, :E], qk[:, E:], vb, num_heads=cfg["num_heads"])
+            y = ops.linear(att, ly["out"], res=x)
+            x, xq = ops.layernorm(y, *ly["norms"][0], add=qpos)
+            # cross-attention: fused perspective-aware aggregation (detr3d_transformer.py:522-569)
+            ce = ops.linear(ops.linear(l2i, ly["ce0"], act="relu"), ly["ce2"], act="relu")
+            ce = ops.layernorm(ce, *ly["ce_ln"])
+            Vc = ops.linear(ce, ly["wfc_full"])                         # (N,416) camera part + bias
+            U = ops.linear(xq, ly["wfc"])                               # (A,416) query part
+            offs = ops.linear(x, ly["lfc"])                             # (A,39)
+            agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
+                                        num_groups=cfg["num_groups"])
+            y = ops.linear(agg, ly["oproj"], res=x)
+            x = ops.layernorm(y, *ly["norms"][1])
+            # FFN: x + W2 relu(W1 x), hidden 1024 (SURVEY.md finding 4)
+            hdn = ops.linear(x, ly["ffn1"], act="relu")
+            y = ops.linear(hdn, ly["ffn2"], res=x)
+            x, xq = ops.layernorm(y, *ly["norms"][2], add=qpos, out=outs[li])
+        return outs
+
+    # ------------------------------------------------------------------------------------------ one frame
+    @torch.no_grad()
+    def forward_frame(self, data, img_metas):
+        cfg, dev = self.cfg, self.dev
+        img = data["img"]
+        if img.dim() == 5:
+            assert img.shape[0] == 1, "batch 1 per engine (one scene stream per GPU)"
+            img = img[0]
+        img = img.to(dev, torch.float32).contiguous()
+        N = img.shape[0]
+        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
+        dd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "img"}
+        lidar2img = dd["lidar2img"][0].float().contiguous()
+        # ---- camera-aware MLN codes (farhead.py:553-556)
+        intr = dd["intrinsics"][0].float() / 1e3
+        extr = dd["extrinsics"][0].float()[:, :3, :]
+        c14 = torch.cat([intr[:, 0, 0:1], intr[:, 1, 1:2], extr.flatten(1)], dim=-1).contiguous()
+        hh = self.sa["reduce"](c14, act="relu")
+        mln_scale, mln_shift = self.sa["gamma"](hh), self.sa["beta"](hh)
+        # ---- a2-a4
+        feats = self.backbone(img)
+        raw, tokens, hw, starts = self.fpn(feats, mln_scale, mln_shift)
+        cls, reg, depth_logit = self.roi_head(raw)
+        # ---- a5 + adaptive queries
+        K = cfg["proposal_topk"]
+        cap = K if K is not None else min(cfg["proposal_cap"], tokens.shape[1])
+        wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
+        row_off = (torch.cumsum(sel_cnt, 0) - sel_cnt).to(torch.int32)
+        img2lidar = torch.linalg.inv(lidar2img).contiguous()
+        ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, row_off, wgt, depth_logit,
+                                                         cfg["depthnet"]["stride"], cfg["depthnet"], img2lidar, tokens,
+                                                         cfg["pc_range"], score_thr=0.1)
+        M = N * K if K is not None else int(sel_cnt.sum().item())   # the reference's data-dependent M: one host sync
+        ref2d, ctx = ref2d[:M], ctx[:M]
+        # ---- scene change / memory (detectors/far3d.py:252-257)
+        if img_metas[0]["scene_token"] != self.prev_scene:
+            self.prev_scene = img_metas[0]["scene_token"]
+            prev = torch.zeros(1, device=dev)
+            self.reset_memory()
+        else:
+            prev = torch.ones(1, device=dev)
+        self._pre_update_memory(dd, prev)
+        # ---- a6: queries
+        m = self.mem
+        P_ = cfg["num_propagated"]
+        if M > 0:
+            qpos_a = ops.row_affine_ln(self._query_pos(ref2d), *self.rec_code["ego_pose_pe"], add=self.time0)
+            tgt_a = ops.row_affine_ln(self.ce[1](self.ce[0](ctx, act="relu")), *self.rec_code["ego_pose_memory"])
+        temp_ref = ((m["ref"][0] - self.pc_lo) / self.pc_span).contiguous()
+        mem_code = nerf_encoding(torch.cat([m["velo"][0], m["ts"][0], m["pose"][0][:, :3, :].flatten(1)], dim=-1).float()).contiguous()
+        t_emb = ops.layernorm(self.te(pos2posemb(m["ts"][0, :, 0], 256).float().contiguous()), *self.te_ln)
+        temp_pos = self._mln_rows(self._query_pos(temp_ref), mem_code, "ego_pose_pe", add=t_emb)
+        temp_mem = self._mln_rows(m["emb"][0].contiguous(), mem_code, "ego_pose_memory")
+        parts_t, parts_q, parts_r = [self.tgt_fixed], [self.qpos_fixed], [self.ref_fixed]
+        if M > 0:
+            parts_t.append(tgt_a); parts_q.append(qpos_a); parts_r.append(ref2d)
+        parts_t.append(temp_mem[:P_]); parts_q.append(temp_pos[:P_]); parts_r.append(temp_ref[:P_])
+        tgt, qpos, ref = torch.cat(parts_t).contiguous(), torch.cat(parts_q).contiguous(), torch.cat(parts_r).contiguous()
+        A = tgt.shape[0]
+        outs_dec = self.decoder(tgt, qpos, tokens, ref, hw, starts, temp_mem[P_:].contiguous(), temp_pos[P_:].contiguous(),
+                                lidar2img, pad_hw)
+        outs_dec = torch.nan_to_num(outs_dec)
+        # ---- a10: shared heads over all 6 layers at once
+        flat = outs_dec.view(-1, outs_dec.shape[-1])
+        c1 = ops.layernorm(self.cls_b[0](flat), *self.cls_ln[0], act="relu")
+        c2 = ops.layernorm(self.cls_b[1](c1), *self.cls_ln[1], act="relu")
+        all_cls = self.cls_b[2](c2).view(cfg["num_layers"], 1, A, cfg["num_classes"])
+        rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](flat, act="relu"), act="relu")).view(cfg["num_layers"], 1, A, cfg["code_size"])
+        xyz = (rr[..., 0:3] + inverse_sigmoid(ref)[None, None]).sigmoid() * self.pc_span + self.pc_lo
+        all_box = torch.cat([xyz, rr[..., 3:]], dim=-1)
+        # ---- a11: memory post-update (farhead.py:479-508)
+        sc = all_cls[-1].sigmoid().topk(1, dim=-1).values[..., 0:1]
+        _, idx = torch.topk(sc, cfg["topk_proposals"], dim=1)
+        g = lambda t: torch.gather(t, 1, idx.view(1, -1, *([1] * (t.dim() - 2))).repeat(1, 1, *t.shape[2:]))
+        rec_pose = torch.eye(4, device=dev).view(1, 1, 4, 4).repeat(1, A, 1, 1)
+        m["emb"] = torch.cat([g(outs_dec[-1][None]), m["emb"]], dim=1)
+        m["ts"] = torch.cat([g(torch.zeros_like(sc, dtype=torch.float64)), m["ts"]], dim=1)
+        m["pose"] = torch.cat([g(rec_pose), m["pose"]], dim=1)
+        m["ref"] = torch.cat([g(all_box[-1][..., :3]), m["ref"]], dim=1)
+        m["velo"] = torch.cat([g(all_box[-1][..., -2:]), m["velo"]], dim=1)
+        m["ref"] = self._transform_ref(m["ref"], dd["ego_pose"])
+        m["ts"] = m["ts"] - dd["timestamp"].unsqueeze(-1).unsqueeze(-1)
+        m["pose"] = dd["ego_pose"].unsqueeze(1) @ m["pose"]
+        outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
+                    fpn=raw, depth_logit=depth_logit, bbox2d=box2d[:M], bbox2d_scores=score2d[:M], sel_idx=sel_idx, sel_cnt=sel_cnt,
+                    reference_points=ref)
+        outs["result"] = self.decode(all_cls, all_box)
+        return outs
+
+    # ------------------------------------------------------------------------------------------ a12: NMS-free decode
+    def decode(self, all_cls, all_box):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245
+        cfg = self.cfg
+        cls = all_cls[-1][0].sigmoid()
+        box = all_box[-1][0]
+        scores, idx = cls.view(-1).topk(min(cfg["max_num"], cls.numel()))
+        labels = idx % cfg["num_classes"]
+        b = box[torch.div(idx, cfg["num_classes"], rounding_mode="floor")]
+        b = torch.cat([b[..., 0:3], b[..., 3:6].exp(), torch.atan2(b[..., 6:7], b[..., 7:8])], dim=-1)
+        mask = (b[..., :3] >= self.pc_range[:3]).all(1) & (b[..., :3] <= self.pc_range[3:]).all(1)
+        b = torch.cat([b[:, :2], b[:, 2:3] - b[:, 5:6] * 0.5, b[:, 3:]], dim=-1)
+        return dict(boxes_3d=b, scores_3d=scores, labels_3d=labels, keep=mask)

@@ -30,7 +30,12 @@ SIGNATURES = {
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
                                c_int, c_long, _p]),
     "far3d_groupnorm_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p]),
-    "far3d_maxpool3x3s2_nhwc": (c_int, [_p, c_int, _p] + [c_int] * 6 + [_p]),
+    "far3d_maxpool3x3s2_nhwc": (c_int, [_p, c_int, _p] + [c_int] * 7 + [c_long, _p]),
+    "far3d_stem_im2col": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p]),
+    "far3d_proposal_select": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_float, c_int, _p]),
+    "far3d_proposal_gather": (c_int, [_p, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, _p, _p, c_int, c_int, c_int, c_int,
+                                      c_float, c_float, c_int, _p, _p, c_int, c_int, _p, c_float, _p, _p, _p, _p, _p]),
+    "far3d_row_affine_ln": (c_int, [_p, _p, _p, _p, _p] + [c_int] * 6 + [c_float, c_int, _p]),
 }
 
 _lib = None

@@ -299,6 +299,99 @@ def maxpool3x3s2_nhwc(x, out=None):
         Wo -= 1
     if out is None:
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
-    _lib.check(lib.far3d_maxpool3x3s2_nhwc(_ptr(x), _dt(x), _ptr(out), N, H, W, C, Ho, Wo, _stream(x)),
+    ldy, ys = _nhwc_view(out, "out")
+    _lib.check(lib.far3d_maxpool3x3s2_nhwc(_ptr(x), _dt(x), _ptr(out), N, H, W, C, Ho, Wo, ldy, ys, _stream(x)),
                "far3d_maxpool3x3s2_nhwc")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# front-end glue: stem im2col, 2D proposals, MLN apply
+# --------------------------------------------------------------------------------------------------
+def stem_im2col(img, out_dtype=torch.bfloat16, out=None):
+    """(N,3,H,W) f32 NCHW -> (N,Ho,Wo,32) NHWC im2col of the stride-2 3x3 stem conv."""
+    lib = _lib.require_device()
+    _chk(img, "img", torch.float32, 4)
+    N, C, H, W = img.shape
+    if C != 3:
+        raise ValueError("stem_im2col expects 3 input channels")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, 32), dtype=out_dtype, device=img.device)
+    _lib.check(lib.far3d_stem_im2col(_ptr(img), _ptr(out), _dt(out), N, H, W, _stream(img)), "far3d_stem_im2col")
+    return out
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def proposal_select(cls_maps, reg_maps, strides, cap, thr=0.1, topk=False):
+    """cls_maps[l] (N,h,w,ncls) f32, reg_maps[l] (N,h,w,>=5) f32 (dx,dy,logw,logh,obj).  Returns
+    (weights (N,S) f32, sel_idx (N,cap) i32, sel_cnt (N) i32) -- all on device, no sync."""
+    lib = _lib.require_device()
+    L = len(cls_maps)
+    for t in list(cls_maps) + list(reg_maps):
+        _chk(t, "cls/reg map", torch.float32, 4)
+    N = cls_maps[0].shape[0]
+    hw = [(int(c.shape[1]), int(c.shape[2])) for c in cls_maps]
+    S = sum(h * w for h, w in hw)
+    dev = cls_maps[0].device
+    sw = torch.empty((N, S), dtype=torch.float32, device=dev)
+    wgt = torch.empty((N, S), dtype=torch.float32, device=dev)
+    sel_idx = torch.zeros((N, cap), dtype=torch.int32, device=dev)
+    sel_cnt = torch.zeros((N,), dtype=torch.int32, device=dev)
+    hk, hp = _host_i32([list(x) for x in hw])
+    sk, sp = _host_i32(list(strides))
+    ca, ra = _ptr_array(cls_maps), _ptr_array(reg_maps)
+    _lib.check(lib.far3d_proposal_select(ca, ra, cls_maps[0].shape[3], reg_maps[0].shape[3], N, L, hp, sp, _ptr(sw), _ptr(wgt),
+                                         _ptr(sel_idx), _ptr(sel_cnt), cap, float(thr), 1 if topk else 0, _stream(wgt)),
+               "far3d_proposal_select")
+    return wgt, sel_idx, sel_cnt
+
+
+def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, row_off, weights, depth_logit, depth_stride, depth_cfg, img2lidar,
+                    feat, pc_range, score_thr=0.1):
+    """Returns ref2d (N*cap,3), ctx (N*cap,C+1), box2d (N*cap,4), score (N*cap); rows >= sum(sel_cnt) are untouched zeros."""
+    lib = _lib.require_device()
+    L = len(reg_maps)
+    N, cap = sel_idx.shape
+    hw = [(int(c.shape[1]), int(c.shape[2])) for c in reg_maps]
+    _chk(depth_logit, "depth_logit", torch.float32, 4)
+    _chk(img2lidar, "img2lidar", torch.float32, 3)
+    _chk(feat, "feat", ndim=3)
+    C = feat.shape[2]
+    dev = feat.device
+    M = N * cap
+    ref2d = torch.zeros((M, 3), dtype=torch.float32, device=dev)
+    ctx = torch.zeros((M, C + 1), dtype=torch.float32, device=dev)
+    box2d = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+    score = torch.zeros((M,), dtype=torch.float32, device=dev)
+    hk, hp = _host_i32([list(x) for x in hw])
+    sk, sp = _host_i32(list(strides))
+    pk, pp = _host_f32(list(pc_range))
+    ra = _ptr_array(reg_maps)
+    _, hd, wd, nd = depth_logit.shape
+    _lib.check(lib.far3d_proposal_gather(ra, reg_maps[0].shape[3], N, L, hp, sp, _ptr(sel_idx), _ptr(sel_cnt), _ptr(row_off), cap,
+                                         _ptr(weights), _ptr(depth_logit), hd, wd, nd, int(depth_stride),
+                                         float(depth_cfg["depth_min"]), float(depth_cfg["depth_max"]),
+                                         int(depth_cfg["num_depth_bins"]), _ptr(img2lidar), _ptr(feat), _dt(feat), C, pp,
+                                         float(score_thr), _ptr(ref2d), _ptr(ctx), _ptr(box2d), _ptr(score), _stream(feat)),
+               "far3d_proposal_gather")
+    return ref2d, ctx, box2d, score
+
+
+def row_affine_ln(x, gamma, beta, add=None, do_ln=True, eps=1e-5, out=None):
+    """out[r] = gamma[r] * LN(x[r]) + beta[r] (+ add[r]); gamma/beta/add may be a single row (broadcast).  C = 256."""
+    lib = _lib.require_device()
+    rows, C = x.shape
+    bc = lambda t: 0 if (t.dim() == 1 or t.shape[0] == 1) else t.stride(0)
+    if out is None:
+        out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    if bc(gamma) != bc(beta):
+        raise ValueError("row_affine_ln: gamma and beta must broadcast alike")
+    _lib.check(lib.far3d_row_affine_ln(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(add) if add is not None else None, _ptr(out),
+                                       rows, C, x.stride(0), bc(gamma), bc(add) if add is not None else 0, out.stride(0),
+                                       float(eps), 1 if do_ln else 0, _stream(x)), "far3d_row_affine_ln")
     return out

@@ -116,8 +116,45 @@ int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, co
 int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch, int N,
                          int HW, int C, int groups, float eps, int relu, void* stream);
 
-/* MaxPool2d(kernel 3, stride 2, ceil_mode=True) on dense NHWC maps (ref models/backbones/vovnet.py:249-250). */
-int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* MaxPool2d(kernel 3, stride 2, ceil_mode=True), dense NHWC input, output with pixel stride ldy / image stride
+ * y_img_stride (so it can land in the first C channels of the next OSA concat buffer)
+ * (ref models/backbones/vovnet.py:249-250). */
+int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, int ldy,
+                            long y_img_stride, void* stream);
+
+/* NCHW fp32 image (N,3,H,W) -> NHWC (N,Ho,Wo,32) im2col of the stride-2 3x3 stem conv: channel = (ky*3+kx)*3 + c for the
+ * 27 taps, 5 zero channels; Ho = (H-1)/2+1.  The first VoVNet conv (ref models/backbones/vovnet.py:306-311) then runs as
+ * a K=32 far3d_conv2d_nhwc 1x1. */
+int far3d_stem_im2col(const float* img, void* out, int out_dt, int N, int H, int W, void* stream);
+
+/* 2D proposal scoring + ordered fixed-capacity selection (no host sync).
+ * Replaces YOLOXHeadCustom.get_bboxes' score / 3x3-peak / threshold steps, ref models/dense_heads/yolox_head.py:426-438,
+ * and its boolean-mask indexing :452-467.  cls[l] (N,h,w,ncls) f32 logits, reg[l] (N,h,w,nreg) f32 with channels
+ * (dx,dy,log w,log h,objectness) -- HOST arrays of L device pointers.  level_hw (L,2), strides (L) int32 HOST.
+ * scratch_sw, weights: (N,S) f32 device; weights receives sample_weight*(sample_weight==maxpool3x3).
+ * mode 0: keep weights > thr (first `cap` in flat-index order); mode 1: the cap largest per camera (ties -> lower index).
+ * sel_idx (N,cap) int32 ascending flat indices (camera-local, level-major), sel_cnt (N) int32. */
+int far3d_proposal_select(const float* const* cls, const float* const* reg, int ncls, int nreg, int N, int L,
+                          const int32_t* level_hw, const int32_t* strides, float* scratch_sw, float* weights, int* sel_idx,
+                          int* sel_cnt, int cap, float thr, int mode, void* stream);
+
+/* Adaptive-query construction from the selected 2D peaks: 2D box decode (ref yolox_head.py:491-501 + xyxy->cxcywh :457),
+ * depth bin argmax at round(centre/stride) (ref models/dense_heads/farhead.py:736-747), LID un-binning (:521-527),
+ * un-projection with img2lidar = inverse(lidar2img) and pc_range normalisation (:792-811), context = value-map token ||
+ * log-odds(score) - log-odds(thr) (:576-581,773-784).  row_off (N) int32 device = exclusive prefix of sel_cnt.
+ * Outputs: ref2d (M,3), ctx (M,C+1), box2d (M,4 cxcywh), score (M). */
+int far3d_proposal_gather(const float* const* reg, int nreg, int N, int L, const int32_t* level_hw, const int32_t* strides,
+                          const int* sel_idx, const int* sel_cnt, const int* row_off, int cap, const float* weights,
+                          const float* depth_logit, int hd, int wd, int nd, int depth_stride, float depth_min,
+                          float depth_max, int depth_bins, const float* img2lidar, const void* feat, int feat_dt, int C,
+                          const float* pc_range, float score_thr, float* ref2d, float* ctx, float* box2d, float* score,
+                          void* stream);
+
+/* y[r] = gamma[r] * LN_noaffine(x[r]) + beta[r] (+ add[r]);  C = 256.  ldg / lda = 0 broadcast one row.  do_ln = 0 skips
+ * the normalisation (MLN with use_ln=False).  Replaces MLN.forward, ref models/utils/misc.py:182-190, at
+ * models/dense_heads/farhead.py:292-303. */
+int far3d_row_affine_ln(const float* x, const float* gamma, const float* beta, const float* add, float* y, int rows, int C,
+                        int ldx, int ldg, int lda, int ldy, float eps, int do_ln, void* stream);
 
 #ifdef __cplusplus
 }

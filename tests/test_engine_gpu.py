@@ -1,0 +1,67 @@
+"""GPU: the whole frame through the HIP engine vs the golden vectors produced by the REFERENCE's own files
+(tests/golden/far3d_small_3frames.npz, 3 streaming frames) -- north_star tolerance 1e-3 on logits in fp32 mode."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from far3d_amd import synth, weights
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _small_engine(precision):
+    from far3d_amd import engine
+    z = np.load(os.path.join(GOLD, "far3d_small_3frames.npz"))
+    rc = json.loads(bytes(z["recipe"]).decode())
+    spec = weights.detector_spec(rc["backbone"], num_query=rc["num_query"], num_propagated=rc["num_propagated"])
+    sd = weights.init_state_dict(spec, seed=rc["weight_seed"])
+    cfg = engine.default_cfg(backbone=rc["backbone"], num_cams=rc["num_cams"], num_query=rc["num_query"],
+                             num_propagated=rc["num_propagated"], memory_len=rc["memory_len"], topk_proposals=rc["topk_proposals"])
+    return engine.Far3DEngine(sd, cfg, device=DEV, precision=precision), z, rc
+
+
+def test_engine_fp32_matches_reference_golden_sequence(hip_lib):
+    eng, z, rc = _small_engine("fp32")
+    for fi in range(rc["frames"]):
+        data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
+        o = eng.forward_frame(data, metas)
+        # 2D proposals: same peaks, same order
+        want_idx = z["f%d_valid_idx" % fi]          # rows (camera, flat index, 0)
+        cnt = o["sel_cnt"].cpu().numpy()
+        got = [(n, int(i)) for n in range(rc["num_cams"]) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()]
+        assert got == [(int(r[0]), int(r[1])) for r in want_idx], "frame %d: proposal set differs" % fi
+        assert np.abs(o["bbox2d"].cpu().numpy() - z["f%d_bbox2d" % fi]).max() < 1e-3
+        assert np.abs(o["bbox2d_scores"].cpu().numpy() - z["f%d_bbox2d_scores" % fi][:, 0]).max() < 1e-5
+        for key in ("all_cls_scores", "all_bbox_preds"):
+            want = z["f%d_%s" % (fi, key)]
+            g = o[key].cpu().numpy()
+            assert g.shape == want.shape, (fi, key, g.shape, want.shape)
+            err = np.abs(g - want).max()
+            assert err < 1e-3, "frame %d %s: max abs err %.3e" % (fi, key, err)
+        r = o["result"]
+        keep = r["keep"].cpu().numpy()
+        assert np.array_equal(r["labels_3d"].cpu().numpy()[keep], z["f%d_labels_3d" % fi])
+        assert np.abs(r["boxes_3d"].cpu().numpy()[keep] - z["f%d_boxes_3d" % fi]).max() < 2e-3
+        assert np.abs(r["scores_3d"].cpu().numpy()[keep] - z["f%d_scores_3d" % fi]).max() < 1e-3
+
+
+def test_engine_bf16_deviation_is_bounded_and_reported(hip_lib):
+    """bf16 activations through 60 convs cannot meet 1e-3 on logits; this pins the measured deviation instead."""
+    eng, z, rc = _small_engine("bf16")
+    worst = 0.0
+    for fi in range(1):   # later frames depend on data-dependent proposal sets that bf16 may flip
+        data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
+        o = eng.forward_frame(data, metas)
+        for l in range(4):
+            want = z["f%d_fpn%d_sample" % (fi, l)]                       # (N, C/16, h/2, w/3) NCHW sample
+            g = o["fpn"][l].float().permute(0, 3, 1, 2)[:, ::16, ::2, ::3].cpu().numpy()
+            rel = np.abs(g - want).max() / max(1e-6, np.abs(want).max())
+            worst = max(worst, rel)
+            assert rel < 0.08, "fpn level %d relative deviation %.3f" % (l, rel)
+    print("bf16 backbone+FPN max relative deviation vs fp32 reference: %.4f" % worst)
