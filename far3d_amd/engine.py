@@ -113,7 +113,7 @@ class Far3DEngine:
         # ---- backbone (a2)
         bb = {}
         w, b, _, _ = self._conv_bn("img_backbone.stem.stem_1")
-        bb["stem1"] = self._pack(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), b)          # 1x1 over the im2col'd image
+        bb["stem1"] = self._pack(F.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)), b)   # 1x1 over the 32-ch im2col
         bb["stem2"] = self._pack(*self._conv_bn("img_backbone.stem.stem_2"))
         bb["stem3"] = self._pack(*self._conv_bn("img_backbone.stem.stem_3", stride=2))
         stages = []

@@ -195,8 +195,10 @@ def init_state_dict(spec, seed=0, pc_range=(-152.4, -152.4, -5.0, 152.4, 152.4, 
             v = torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
             if "learnable_fc" in k:
                 v = v * 4.0                                   # metres-scale key-point offsets
-            if "multi_level_conv_obj" in k or "multi_level_conv_cls" in k:
-                v = v * 4.0                                   # spread 2D scores so peak picking is non-trivial
+            if k.startswith("img_neck."):
+                v = v * 0.5                                   # no ReLU/BN in the FPN: keep its outputs O(1)
+            if "multi_level_conv_" in k:
+                v = v * (0.1 if "conv_reg" in k else 0.5)     # 2D logits ~N(0,1.5): no sigmoid saturation, finite log-odds
         sd[k] = v
     return sd
 

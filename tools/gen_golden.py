@@ -101,7 +101,8 @@ def main():
                 assert a.shape == b.shape, (fi, name, a.shape, b.shape)
                 err = (a - b).abs().max().item() if a.numel() else 0.0
                 worst = max(worst, err)
-                assert err < 2e-4, "frame %d %s: oracle deviates from the reference by %.3e" % (fi, name, err)
+                scale = max(1.0, a.abs().max().item()) if a.numel() else 1.0   # box coordinates are metres / pixels
+                assert err < 2e-4 * scale, "frame %d %s: oracle deviates from the reference by %.3e" % (fi, name, err)
             assert torch.equal(r["result"]["labels_3d"], o["result"]["labels_3d"])
             assert torch.equal(r["roi"]["valid_indices"], o["roi"]["valid_indices"])
             M = r["roi"]["bbox2d_scores"].shape[0]
