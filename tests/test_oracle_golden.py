@@ -50,7 +50,8 @@ def test_oracle_reproduces_reference_golden_sequence():
                              ("bbox2d", torch.cat(o["roi"]["bbox_list"])), ("bbox2d_scores", o["roi"]["bbox2d_scores"])):
                 want = torch.from_numpy(z["f%d_%s" % (fi, key)])
                 assert got.shape == want.shape, (fi, key)
-                assert (got - want).abs().max().item() < 2e-4, (fi, key)   # logits tolerance: 1e-3 per north_star
+                scale = max(1.0, want.abs().max().item())   # box coordinates are metres / pixels -> relative tolerance
+                assert (got - want).abs().max().item() < 2e-4 * scale, (fi, key)   # north_star logit tolerance is 1e-3
             assert np.array_equal(o["result"]["labels_3d"].numpy(), z["f%d_labels_3d" % fi])
             assert np.array_equal(o["roi"]["valid_indices"].nonzero().numpy(), z["f%d_valid_idx" % fi])
             assert np.array_equal(o["roi"]["pred_depth"].argmax(1).numpy(), z["f%d_depth_argmax" % fi])
