@@ -1,0 +1,86 @@
+"""Camera-sharded multi-GPU execution of ONE sample: one process per GPU, each rank runs the
+per-camera stages (backbone, FPN+MLN, 2D head, proposals) for its cameras, ONE all-gather (RCCL over xGMI; `nccl`
+backend on ROCm) collects the token-major value maps and the adaptive-query records, and every rank runs the identical
+cross-camera decoder (deterministic kernels -> replicated streaming memory, no further exchange).
+
+The reference has no counterpart (it only replicates whole samples, tools/test.py:229-234); the decoder cannot be
+sharded by camera because its softmax spans cameras (models/utils/detr3d_transformer.py:540).
+
+Host logic here is device-agnostic so the shard / gather / un-pad arithmetic is covered by 2-process gloo tests on CPU;
+the compute itself has no CPU path.
+"""
+import torch
+import torch.distributed as dist
+
+
+def camera_shards(num_cams, world):
+    """Contiguous camera blocks, padded with -1 so every rank owns `per` slots (7 cameras -> 8 slots on 8 GPUs)."""
+    per = -(-num_cams // world)
+    return per, [[c if c < num_cams else -1 for c in range(r * per, (r + 1) * per)] for r in range(world)]
+
+
+def gather_camera_major(local, num_cams, group=None, async_op=False):
+    """All-gather equally-shaped per-rank blocks whose leading dim is `per` camera slots and drop the padding slots.
+
+    local: (per, ...) tensor (padding slots may hold anything).  Returns (work_or_None, fn) where fn() -> (num_cams, ...)
+    view of the gathered buffer; call work.wait() before fn() when async_op is set."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+    return work, (lambda: out[:num_cams])
+
+
+class ShardedFrame:
+    """Drives a Far3DEngine in camera-sharded mode.  Static-M proposal mode only (cfg['proposal_topk'] = K)."""
+
+    def __init__(self, engine, group=None):
+        if engine.cfg["proposal_topk"] is None:
+            raise ValueError("camera sharding needs the static proposal mode (proposal_topk=K): a data-dependent M "
+                             "would need a second, size-exchanging collective")
+        self.eng, self.group = engine, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.num_cams = engine.cfg["num_cams"]
+        self.per, shards = camera_shards(self.num_cams, self.world)
+        self.slots = shards[self.rank]
+        self.cams = [c for c in self.slots if c >= 0]
+
+    @torch.no_grad()
+    def forward_frame(self, data, img_metas):
+        eng = self.eng
+        cfg, dev = eng.cfg, eng.dev
+        K = cfg["proposal_topk"]
+        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
+        dd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "img"}
+        pending = {}
+
+        def start_gather(st):   # value maps are final right after the FPN: overlap their gather with the 2D head
+            tok = st["tokens"]
+            if len(self.cams) < self.per:
+                pad = torch.zeros((self.per - len(self.cams),) + tuple(tok.shape[1:]), dtype=tok.dtype, device=dev)
+                tok = torch.cat([tok, pad])
+            pending["tok"] = gather_camera_major(tok, self.num_cams, self.group, async_op=True)
+
+        if self.cams:
+            img = data["img"][0][self.cams].to(dev, torch.float32).contiguous()
+            eng.after_fpn = start_gather
+            try:
+                st = eng.camera_stage(img, dd, self.cams, pad_hw)
+            finally:
+                eng.after_fpn = None
+            rec = torch.cat([st["ref2d"], st["ctx"]], dim=1).view(len(self.cams), K, -1)
+            hw, starts = st["hw"], st["starts"]
+        else:           # idle rank (8 GPUs, 7 cameras): contributes padding only
+            from .synth import level_shapes, level_starts
+            hw = level_shapes(pad_hw, cfg["strides"])
+            starts, S = level_starts(hw)
+            start_gather(dict(tokens=torch.zeros((0, S, cfg["embed_dims"]), dtype=eng.prec["value"], device=dev)))
+            rec = torch.zeros((0, K, 3 + cfg["embed_dims"] + 1), dtype=torch.float32, device=dev)
+        if rec.shape[0] < self.per:
+            rec = torch.cat([rec, torch.zeros((self.per - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=dev)])
+        _, rec_fn = gather_camera_major(rec, self.num_cams, self.group)
+        work, tok_fn = pending["tok"]
+        work.wait()
+        tokens = tok_fn()
+        rec_all = rec_fn().reshape(self.num_cams * K, -1)
+        ref2d, ctx = rec_all[:, :3].contiguous(), rec_all[:, 3:].contiguous()
+        return eng.head_stage(tokens, ref2d, ctx, self.num_cams * K, dd, img_metas, hw, starts, pad_hw)

@@ -92,6 +92,8 @@ class Far3DEngine:
                 self.sd[ck] = v.detach().float()
         self.spec = weights.VOV_SPECS[self.cfg["backbone"]]
         self._bufs = {}
+        self.kernel_events = None   # set to {} to collect (start, stop) HIP event pairs around selected kernels
+        self.after_fpn = None       # hook(stage_dict) called right after the FPN (camera-sharded mode starts its gather)
         self.reset_memory()
         self.prev_scene = None
         self._prepare()
@@ -364,8 +366,15 @@ class Far3DEngine:
             Vc = ops.linear(ce, ly["wfc_full"])                         # (N,416) camera part + bias
             U = ops.linear(xq, ly["wfc"])                               # (A,416) query part
             offs = ops.linear(x, ly["lfc"])                             # (A,39)
+            ev = self.kernel_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
                                         num_groups=cfg["num_groups"])
+            if ev is not None:
+                e1.record()
+                ev.setdefault("aggregate_fwd", []).append((e0, e1))
             y = ops.linear(agg, ly["oproj"], res=x)
             x = ops.layernorm(y, *ly["norms"][1])
             # FFN: x + W2 relu(W1 x), hidden 1024 (SURVEY.md finding 4)
@@ -375,29 +384,31 @@ class Far3DEngine:
         return outs
 
     # ------------------------------------------------------------------------------------------ one frame
-    @torch.no_grad()
-    def forward_frame(self, data, img_metas):
+    def camera_stage(self, img, dd, cam_ids, pad_hw):
+        """Everything that is independent per camera: backbone, FPN (+MLN), 2D head, depth, proposal
+        selection and adaptive-query construction.  img (n,3,H,W) on device for the cameras `cam_ids` (global indices)."""
         cfg, dev = self.cfg, self.dev
-        img = data["img"]
-        if img.dim() == 5:
-            assert img.shape[0] == 1, "batch 1 per engine (one scene stream per GPU)"
-            img = img[0]
-        img = img.to(dev, torch.float32).contiguous()
-        N = img.shape[0]
-        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
-        dd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "img"}
-        lidar2img = dd["lidar2img"][0].float().contiguous()
-        # ---- camera-aware MLN codes (farhead.py:553-556)
-        intr = dd["intrinsics"][0].float() / 1e3
-        extr = dd["extrinsics"][0].float()[:, :3, :]
-        c14 = torch.cat([intr[:, 0, 0:1], intr[:, 1, 1:2], extr.flatten(1)], dim=-1).contiguous()
+        n = img.shape[0]
+        ids = torch.as_tensor(list(cam_ids), device=dev)
+        lidar2img = dd["lidar2img"][0].float()[ids].contiguous()
+        intr = dd["intrinsics"][0].float()[ids] / 1e3
+        extr = dd["extrinsics"][0].float()[ids][:, :3, :]
+        c14 = torch.cat([intr[:, 0, 0:1], intr[:, 1, 1:2], extr.flatten(1)], dim=-1).contiguous()   # farhead.py:553-556
         hh = self.sa["reduce"](c14, act="relu")
         mln_scale, mln_shift = self.sa["gamma"](hh), self.sa["beta"](hh)
-        # ---- a2-a4
+        ev = self.kernel_events
+        if ev is not None:
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
         feats = self.backbone(img)
+        if ev is not None:
+            b1.record()
+            ev.setdefault("backbone", []).append((b0, b1))
         raw, tokens, hw, starts = self.fpn(feats, mln_scale, mln_shift)
+        st = dict(tokens=tokens, hw=hw, starts=starts, raw=raw, lidar2img=lidar2img)
+        if self.after_fpn is not None:
+            self.after_fpn(st)                      # multi-GPU: start the all-gather of the value maps here
         cls, reg, depth_logit = self.roi_head(raw)
-        # ---- a5 + adaptive queries
         K = cfg["proposal_topk"]
         cap = K if K is not None else min(cfg["proposal_cap"], tokens.shape[1])
         wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
@@ -406,7 +417,13 @@ class Far3DEngine:
         ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, row_off, wgt, depth_logit,
                                                          cfg["depthnet"]["stride"], cfg["depthnet"], img2lidar, tokens,
                                                          cfg["pc_range"], score_thr=0.1)
-        M = N * K if K is not None else int(sel_cnt.sum().item())   # the reference's data-dependent M: one host sync
+        st.update(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit)
+        return st
+
+    def head_stage(self, tokens, ref2d, ctx, M, dd, img_metas, hw, starts, pad_hw):
+        """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12)."""
+        cfg, dev = self.cfg, self.dev
+        lidar2img = dd["lidar2img"][0].float().contiguous()
         ref2d, ctx = ref2d[:M], ctx[:M]
         # ---- scene change / memory (detectors/far3d.py:252-257)
         if img_metas[0]["scene_token"] != self.prev_scene:
@@ -458,9 +475,29 @@ class Far3DEngine:
         m["ts"] = m["ts"] - dd["timestamp"].unsqueeze(-1).unsqueeze(-1)
         m["pose"] = dd["ego_pose"].unsqueeze(1) @ m["pose"]
         outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
-                    fpn=raw, depth_logit=depth_logit, bbox2d=box2d[:M], bbox2d_scores=score2d[:M], sel_idx=sel_idx, sel_cnt=sel_cnt,
                     reference_points=ref)
         outs["result"] = self.decode(all_cls, all_box)
+        return outs
+
+    @torch.no_grad()
+    def forward_frame(self, data, img_metas):
+        """data: the reference's per-frame dict (img (1,N,3,H,W), lidar2img, intrinsics, extrinsics, ego_pose(_inv),
+        timestamp); tensors may live on the host (they are uploaded) or already on the device."""
+        cfg, dev = self.cfg, self.dev
+        img = data["img"]
+        if img.dim() == 5:
+            assert img.shape[0] == 1, "batch 1 per engine (one scene stream per GPU)"
+            img = img[0]
+        img = img.to(dev, torch.float32).contiguous()
+        N = img.shape[0]
+        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
+        dd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "img"}
+        st = self.camera_stage(img, dd, range(N), pad_hw)
+        K = cfg["proposal_topk"]
+        M = N * K if K is not None else int(st["sel_cnt"].sum().item())   # the reference's data-dependent M: one host sync
+        outs = self.head_stage(st["tokens"], st["ref2d"], st["ctx"], M, dd, img_metas, st["hw"], st["starts"], pad_hw)
+        outs.update(fpn=st["raw"], depth_logit=st["depth_logit"], bbox2d=st["box2d"][:M], bbox2d_scores=st["score2d"][:M],
+                    sel_idx=st["sel_idx"], sel_cnt=st["sel_cnt"])
         return outs
 
     # ------------------------------------------------------------------------------------------ a12: NMS-free decode
