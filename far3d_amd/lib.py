@@ -6,6 +6,11 @@ without a HIP device, this raises.  PyTorch is only used for device memory and s
 import ctypes
 import os
 
+# torch bundles its own HIP runtime (file libamdhip64.so, SONAME libamdhip64.so.7).  It MUST be mapped before our
+# library so that both share ONE runtime (and therefore streams / device pointers); loading ours first would pull in
+# /opt/rocm's copy and torch would then initialise a second runtime and report "no GPU".
+import torch  # noqa: F401  (import order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfar3d_hip.so")
 
