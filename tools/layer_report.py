@@ -1,0 +1,50 @@
+"""Per-layer conv efficiency from a rocprofv3 kernel trace of bench.py (last frame in the trace)."""
+import csv, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from far3d_amd import weights
+spec = weights.VOV_SPECS["V-99-eSE"]
+N, H, W = 7, 640, 960
+layers = []  # (name, npix, cout, K)
+h, w = H // 2, W // 2
+layers.append(("stem1", N*h*w, 64, 32)); layers.append(("stem2", N*h*w, 64, 64*9))
+h, w = h // 2, w // 2
+layers.append(("stem3", N*h*w, 128, 64*9))
+in_ch = 128
+for si in range(4):
+    sc, oc = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
+    if si > 0:
+        h, w = -(-h // 2), -(-w // 2)
+    for b in range(spec["block_per_stage"][si]):
+        c = in_ch
+        for i in range(5):
+            layers.append(("s%d.b%d.c%d" % (si+2, b, i), N*h*w, sc, c*9)); c = sc
+        layers.append(("s%d.b%d.cat" % (si+2, b), N*h*w, oc, in_ch + 5*sc)); in_ch = oc
+hw = [(80,120),(40,60),(20,30),(10,15)]
+for i, cin in zip((2,1,0), (1024,768,512)):
+    layers.append(("fpn.lat%d" % i, N*hw[i][0]*hw[i][1], 256, cin))
+for i in range(4):
+    layers.append(("fpn.out%d" % i, N*hw[i][0]*hw[i][1], 256, 256*9))
+for l in range(4):
+    p = N*hw[l][0]*hw[l][1]
+    layers += [("roi%d.cls0" % l, p, 256, 2304), ("roi%d.cls1" % l, p, 256, 2304), ("roi%d.reg0" % l, p, 256, 2304), ("roi%d.reg1" % l, p, 256, 2304),
+               ("roi%d.clsh" % l, p, 26, 256), ("roi%d.regh" % l, p, 5, 256)]
+p = N*80*120
+layers += [("depth.c0", p, 256, 2304), ("depth.c1", p, 256, 2304), ("depth.cls", p, 51, 256)]
+rows = list(csv.DictReader(open(sys.argv[1])))
+idx = max(i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"])
+ig = [r for r in rows[idx:] if "igemm_kernel" in r["Kernel_Name"]][:len(layers)]
+tot_t = tot_f = 0
+agg = {}
+for (name, npix, cout, K), r in zip(layers, ig):
+    t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    fl = 2.0 * npix * cout * K
+    var = r["Kernel_Name"].split("<")[1].split(">")[0].replace("unsigned short", "bf16")
+    blocks = int(r["Grid_Size_X"]) // 256 * int(r["Grid_Size_Y"])
+    key = name.split(".")[0]
+    a = agg.setdefault(key, [0.0, 0.0]); a[0] += t; a[1] += fl
+    tot_t += t; tot_f += fl
+    if len(sys.argv) > 2:
+        print("%-12s npix=%7d cout=%4d K=%5d %-14s blocks=%5d %8.1f us %7.1f TF/s" % (name, npix, cout, K, var, blocks, t*1e6, fl/t/1e12))
+for k, (t, f) in agg.items():
+    print("%-8s %8.3f ms %8.1f GFLOP %7.1f TF/s" % (k, t*1e3, f/1e9, f/t/1e12))
+print("total conv %.3f ms, %.1f GFLOP, %.1f TF/s" % (tot_t*1e3, tot_f/1e9, tot_f/tot_t/1e12))
