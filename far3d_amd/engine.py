@@ -79,8 +79,9 @@ class _Lin:
 
 
 class Far3DEngine:
-    def __init__(self, state_dict, cfg=None, device="cuda:0", precision="bf16"):
+    def __init__(self, state_dict, cfg=None, device="cuda:0", precision="bf16", parts=("backbone", "neck", "roi", "head")):
         _lib.require_device()
+        self.parts = tuple(parts)
         self.cfg = cfg or default_cfg()
         self.dev = torch.device(device)
         self.prec = PRECISIONS[precision]
@@ -112,6 +113,17 @@ class Far3DEngine:
     def _prepare(self):
         sd, cfg, dev = self.sd, self.cfg, self.dev
         f32 = lambda t: t.to(dev).float().contiguous()
+        if "backbone" in self.parts:
+            self._prepare_backbone()
+        if "neck" in self.parts:
+            self._prepare_neck_roi()
+        if "head" in self.parts:
+            self._prepare_head()
+        torch.cuda.synchronize(dev)
+
+    def _prepare_backbone(self):
+        sd, cfg, dev = self.sd, self.cfg, self.dev
+        f32 = lambda t: t.to(dev).float().contiguous()
         # ---- backbone (a2)
         bb = {}
         w, b, _, _ = self._conv_bn("img_backbone.stem.stem_1")
@@ -132,6 +144,10 @@ class Far3DEngine:
             stages.append(blocks)
         bb["stages"] = stages
         self.bb = bb
+
+    def _prepare_neck_roi(self):
+        sd, cfg, dev = self.sd, self.cfg, self.dev
+        f32 = lambda t: t.to(dev).float().contiguous()
         # ---- FPN (a3)
         nl = len(self.spec["stage_out_ch"]) - 1
         self.fpn_lat = [self._pack(sd["img_neck.lateral_convs.%d.conv.weight" % i], sd["img_neck.lateral_convs.%d.conv.bias" % i]) for i in range(nl)]
@@ -152,6 +168,10 @@ class Far3DEngine:
             convs=[self._pack(sd[r + "depthnet.depth_head.%d.0.weight" % i], sd[r + "depthnet.depth_head.%d.0.bias" % i], pad=1) for i in range(2)],
             gn=[(f32(sd[r + "depthnet.depth_head.%d.1.weight" % i]), f32(sd[r + "depthnet.depth_head.%d.1.bias" % i])) for i in range(2)],
             cls=self._pack(sd[r + "depthnet.depth_classifier.weight"], sd[r + "depthnet.depth_classifier.bias"]))
+
+    def _prepare_head(self):
+        sd, cfg, dev = self.sd, self.cfg, self.dev
+        f32 = lambda t: t.to(dev).float().contiguous()
         # ---- FarHead (a6, a10)
         h = "pts_bbox_head."
         dw = self.prec["dec_w"]
@@ -201,7 +221,6 @@ class Far3DEngine:
         qp = self._query_pos(self.ref_fixed)
         self.qpos_fixed = ops.row_affine_ln(qp, *self.rec_code["ego_pose_pe"], add=self.time0)
         self.tgt_fixed = ops.row_affine_ln(torch.zeros_like(qp), *self.rec_code["ego_pose_memory"])
-        torch.cuda.synchronize(dev)
 
     def _query_pos(self, ref):
         return self.qe[1](self.qe[0](pos2posemb3d(ref).contiguous(), act="relu"))

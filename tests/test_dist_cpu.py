@@ -1,0 +1,53 @@
+"""CPU, 2 processes, gloo: the camera-shard / all-gather / un-pad logic of far3d_amd.dist (no compute kernels run)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from far3d_amd import dist as fdist
+
+
+def test_camera_shards_layout():
+    assert fdist.camera_shards(7, 1) == (7, [[0, 1, 2, 3, 4, 5, 6]])
+    assert fdist.camera_shards(7, 2) == (4, [[0, 1, 2, 3], [4, 5, 6, -1]])
+    assert fdist.camera_shards(7, 4) == (2, [[0, 1], [2, 3], [4, 5], [6, -1]])
+    per, sh = fdist.camera_shards(7, 8)
+    assert per == 1 and sh[6] == [6] and sh[7] == [-1]
+    for w in (1, 2, 3, 4, 8):
+        per, sh = fdist.camera_shards(7, w)
+        flat = [c for s in sh for c in s]
+        assert [c for c in flat if c >= 0] == list(range(7)) and len(flat) == per * w and all(len(s) == per for s in sh)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    num_cams, S, C, K = 7, 5, 4, 3
+    per, shards = fdist.camera_shards(num_cams, world)
+    full_tok = torch.arange(num_cams * S * C, dtype=torch.float32).view(num_cams, S, C)
+    full_rec = torch.arange(num_cams * K * 6, dtype=torch.float32).view(num_cams, K, 6) * 0.5
+    mine = [c for c in shards[rank] if c >= 0]
+    tok = torch.cat([full_tok[mine], torch.full((per - len(mine), S, C), -7.0)])      # garbage in the padding slot
+    rec = torch.cat([full_rec[mine], torch.full((per - len(mine), K, 6), -7.0)])
+    work, tok_fn = fdist.gather_camera_major(tok, num_cams, async_op=True)
+    _, rec_fn = fdist.gather_camera_major(rec, num_cams)
+    work.wait()
+    ok = torch.equal(tok_fn(), full_tok) and torch.equal(rec_fn(), full_rec)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_camera_major_two_ranks_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
