@@ -17,6 +17,7 @@
 //   lane = group*8 + chunk, 4 channels per lane.  All 8 groups sample the same pixel (the reference
 //   replicates locations over groups, :555), so a bilinear sample is 4 fully-coalesced row loads.
 #include "common.hpp"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
 // Generic MSDA (mmcv contract).  value (bs,S,H,Dh) TV; shapes (L,2) i64 (h,w); lsi (L) i64;
@@ -120,18 +121,20 @@ struct AggParams {
   int q_per_xcd;
 };
 
-template <typename TV>
+template <typename TV, int ABL = 0>   // ABL: timing ablations (1: no gather, 2: no softmax, 3: neither) -- never shipped results
 __global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict__ feat,
                                                             const float* __restrict__ ref,
                                                             const float* __restrict__ offs,
                                                             const float* __restrict__ l2i,
                                                             const float* __restrict__ U,
                                                             const float* __restrict__ Vc,
+                                                            const int* __restrict__ perm,
                                                             float* __restrict__ out, AggParams prm) {
   // XCD-aware query mapping: workgroup b lands on XCD b%8 (observed dispatch order); give each XCD a
-  // contiguous query range so that camera-major adaptive queries share an L2.  Speed only.
-  const int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  // contiguous range of the (optionally camera-sorted) query order so that one XCD's L2 serves 1-2 cameras.  Speed only.
+  int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
   if (a >= prm.A) return;
+  if (perm) a = perm[a];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NP = prm.N * prm.P;
   const int NLP = NP * prm.L;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict
   }
 
   // ---- phase 2: softmax over cams x levels x points per group (detr3d_transformer.py:539-540)
-  {
+  if constexpr ((ABL & 2) == 0) {
     const int g = t & 7, r = t >> 3;
     float lg[AGG_MAX_NLP / 32];
     float mx = -INFINITY;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict
   const int g = lane >> 3;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const TV* fbase = feat + lane * 4;
-  for (int pair = wv; pair < NP; pair += 4) {
+  for (int pair = wv; pair < ((ABL & 1) ? 0 : NP); pair += 4) {
     const int mask = mask_s[pair];
     if (mask == 0) continue;  // wave-uniform
     const int n = pair / prm.P, p = pair - n * prm.P;
@@ -258,9 +261,185 @@ __global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict
   out[(long)a * 256 + t] = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v3 of the fused aggregation (the shipped kernel).  PMC counters on v1 showed the kernel VALU-bound (2.5k VALU
+// instructions per wave, L2 hit 60 %, HBM fetch == the 46 MB of value maps): every lane recomputed wave-uniform sample
+// geometry.  v3 computes each visible (camera, point, level) sample ONCE (one thread per camera-point in phase 1), stores a
+// 32-byte record {clamped top-left offset, dx, dy, weight row, 4 bilinear weights} in a compacted LDS list (deterministic
+// block scan), and the gather loop is reduced to: broadcast record read, 4 coalesced row loads, 16 FMAs -- NB samples in
+// flight per wave.  Softmax uses the hardware exp2 path and incremental (camera, logit) indices.
+// ------------------------------------------------------------------------------------------
+template <typename TV, int NB, int ABL = 0>
+__global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
+                                                           const float* __restrict__ offs, const float* __restrict__ l2i,
+                                                           const float* __restrict__ U, const float* __restrict__ Vc,
+                                                           const int* __restrict__ perm, float* __restrict__ out, AggParams prm) {
+  int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  if (a >= prm.A) return;
+  if (perm) a = perm[a];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NP = prm.N * prm.P, NLP = NP * prm.L, J = prm.L * prm.P;
+  float* w_s = reinterpret_cast<float*>(smem);                 // [NLP][8] softmax weights; reused as [4][256] reduction buffer
+  int4* rec_s = reinterpret_cast<int4*>(w_s + (NLP * 8 > 1024 ? NLP * 8 : 1024));   // [NLP][2] sample records
+  float* stat_s = reinterpret_cast<float*>(rec_s + 2 * NLP);   // [64]
+  int* scan_s = reinterpret_cast<int*>(stat_s + 64);           // [8]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+  // ---- phase 1: one thread per (camera, point): projection, per-level geometry (detr3d_transformer.py:524-525,547-552)
+  int mask = 0;
+  float u = 0.f, v = 0.f;
+  int n1 = 0, p1 = 0;
+  if (t < NP) {
+    n1 = t / prm.P; p1 = t - n1 * prm.P;
+    float k[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      k[d] = (ref[a * 3 + d] * prm.pc_span[d] + prm.pc_lo[d]) + offs[(long)a * prm.P * 3 + p1 * 3 + d];
+    const float* m = l2i + n1 * 16;
+    const float x = m[0] * k[0] + m[1] * k[1] + m[2] * k[2] + m[3];
+    const float y = m[4] * k[0] + m[5] * k[1] + m[6] * k[2] + m[7];
+    const float z = m[8] * k[0] + m[9] * k[1] + m[10] * k[2] + m[11];
+    const float zc = fmaxf(z, 1e-5f);
+    u = (x / zc) / prm.pad_w; v = (y / zc) / prm.pad_h;
+#pragma unroll
+    for (int l = 0; l < AGG_MAX_L; ++l) {
+      if (l < prm.L) {
+        const float h_im = v * prm.H[l] - 0.5f, w_im = u * prm.W[l] - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < prm.H[l] && w_im < prm.W[l]) mask |= 1 << l;
+      }
+    }
+  }
+  // deterministic compaction: exclusive scan of the per-thread visible-level counts
+  {
+    const int c = __popc(mask);
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int nb = __shfl_up(inc, o);
+      if (lane >= o) inc += nb;
+    }
+    if (lane == 63) scan_s[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += scan_s[k];
+    int pos = base + inc - c;
+    if (t == 255) scan_s[4] = base + inc;
+#pragma unroll
+    for (int l = 0; l < AGG_MAX_L; ++l) {
+      if ((mask >> l) & 1) {
+        const int Hl = prm.H[l], Wl = prm.W[l];
+        const float h_im = v * Hl - 0.5f, w_im = u * Wl - 0.5f;
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= Hl - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= Wl - 1;
+        const int y0 = t_ok ? h_low : 0, y1 = b_ok ? h_low + 1 : Hl - 1;
+        const int x0 = l_ok ? w_low : 0, x1 = r_ok ? w_low + 1 : Wl - 1;
+        int4 r0;
+        r0.x = ((n1 * prm.S + prm.start[l]) + y0 * Wl + x0) * 256;   // element offset of the (clamped) top-left pixel
+        r0.y = (x1 - x0) * 256;                                      // 0 when the right column is clamped away
+        r0.z = (y1 - y0) * Wl * 256;
+        r0.w = ((n1 * prm.L + l) * prm.P + p1) * 8;                  // row of this sample in w_s
+        float4 wq;
+        wq.x = (t_ok && l_ok) ? hh * hw : 0.f;
+        wq.y = (t_ok && r_ok) ? hh * lw : 0.f;
+        wq.z = (b_ok && l_ok) ? lh * hw : 0.f;
+        wq.w = (b_ok && r_ok) ? lh * lw : 0.f;
+        rec_s[2 * pos] = r0;
+        rec_s[2 * pos + 1] = make_int4(__float_as_int(wq.x), __float_as_int(wq.y), __float_as_int(wq.z), __float_as_int(wq.w));
+        ++pos;
+      }
+    }
+  }
+
+  // ---- phase 2: softmax over cams x levels x points per group (detr3d_transformer.py:539-540)
+  if constexpr ((ABL & 2) == 0) {
+    const int gg = t & 7, r = t >> 3;
+    float lg[AGG_MAX_NLP / 32];
+    float mx = -INFINITY;
+    int n = 0, j = r;   // idx = r + 32*i  ->  (camera n, logit j) tracked incrementally (J > 32)
+    while (j >= J) { j -= J; ++n; }
+    const float* Ua = U + (long)a * J * 8 + gg;
+    const float* Vg = Vc + gg;
+#pragma unroll
+    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
+      lg[i] = -INFINITY;
+      if (r + 32 * i < NLP) lg[i] = Ua[j * 8] + Vg[(n * J + j) * 8];
+      mx = fmaxf(mx, lg[i]);
+      j += 32;
+      while (j >= J) { j -= J; ++n; }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lane < 8) stat_s[wv * 8 + lane] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(stat_s[gg], stat_s[8 + gg]), fmaxf(stat_s[16 + gg], stat_s[24 + gg]));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
+      lg[i] = (r + 32 * i < NLP) ? __expf(lg[i] - mx) : 0.f;
+      sum += lg[i];
+    }
+    sum += __shfl_xor(sum, 8);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (lane < 8) stat_s[32 + wv * 8 + lane] = sum;
+    __syncthreads();
+    sum = (stat_s[32 + gg] + stat_s[40 + gg]) + (stat_s[48 + gg] + stat_s[56 + gg]);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
+      const int idx = r + 32 * i;
+      if (idx < NLP) w_s[idx * 8 + gg] = lg[i] * inv;
+    }
+  }
+  __syncthreads();
+  const int nsamp = (ABL & 1) ? 0 : scan_s[4];
+
+  // ---- phase 3: gather.  lane = group*8 + chunk (4 channels); a sample = 4 coalesced token-row loads.
+  const int g = lane >> 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const TV* fbase = feat + lane * 4;
+  for (int b0 = wv; b0 < nsamp; b0 += 4 * NB) {
+    float4 v1[NB], v2[NB], v3[NB], v4[NB];
+    float cw[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int si = b0 + 4 * i;
+      const bool ok = si < nsamp;
+      const int4 r0 = rec_s[2 * (ok ? si : 0)];
+      const int4 r1 = rec_s[2 * (ok ? si : 0) + 1];
+      const TV* p00 = fbase + r0.x;
+      v1[i] = load4(p00);
+      v2[i] = load4(p00 + r0.y);
+      v3[i] = load4(p00 + r0.z);
+      v4[i] = load4(p00 + r0.z + r0.y);
+      const float aw = ok ? w_s[r0.w + g] : 0.f;
+      cw[i][0] = aw * __int_as_float(r1.x); cw[i][1] = aw * __int_as_float(r1.y);
+      cw[i][2] = aw * __int_as_float(r1.z); cw[i][3] = aw * __int_as_float(r1.w);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      acc.x += (cw[i][0] * v1[i].x + cw[i][1] * v2[i].x) + (cw[i][2] * v3[i].x + cw[i][3] * v4[i].x);
+      acc.y += (cw[i][0] * v1[i].y + cw[i][1] * v2[i].y) + (cw[i][2] * v3[i].y + cw[i][3] * v4[i].y);
+      acc.z += (cw[i][0] * v1[i].z + cw[i][1] * v2[i].z) + (cw[i][2] * v3[i].z + cw[i][3] * v4[i].z);
+      acc.w += (cw[i][0] * v1[i].w + cw[i][1] * v2[i].w) + (cw[i][2] * v3[i].w + cw[i][3] * v4[i].w);
+    }
+  }
+
+  // ---- phase 4: cross-wave (= cross-camera/point) reduction through the (now dead) weight buffer; coalesced store
+  __syncthreads();
+  float* red_s = w_s;
+  *reinterpret_cast<float4*>(red_s + wv * 256 + lane * 4) = acc;
+  __syncthreads();
+  out[(long)a * 256 + t] = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
+}
+
 extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref,
                                        const float* offsets, const float* lidar2img, const float* U,
-                                       const float* Vc, float* out, int A, int N, int S, int C, int G,
+                                       const float* Vc, const int32_t* perm, float* out, int A, int N, int S, int C, int G,
                                        int P, int L, const int32_t* level_hw, const int32_t* level_start,
                                        const float* pc_range, float pad_h, float pad_w, void* stream) {
   FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && Vc && out && level_hw && level_start && pc_range,
@@ -271,7 +450,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
                   "far3d_aggregate_forward: N*P=%d (<=256) or N*P*L=%d (<=%d) too large", N * P, N * P * L, AGG_MAX_NLP);
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
-  FAR3D_CHECK_ARG(A >= 0 && S > 0, "far3d_aggregate_forward: bad sizes A=%d S=%d", A, S);
+  FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -289,12 +468,43 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   const size_t lds = (size_t)(N * P * L * 8 + 1024 + 2 * N * P + 64) * 4 + (size_t)N * P * 4;
   dim3 grid(8 * prm.q_per_xcd), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const char* abl_env = getenv("FAR3D_AGG_ABLATE");   // profiling aid only
+  const int abl = abl_env ? atoi(abl_env) : 0;
+  const char* v1_env = getenv("FAR3D_AGG_V1");   // A/B aid: the simple v1 kernel
+  if (!(v1_env && atoi(v1_env))) {
+    const int nlp8 = N * P * L * 8 > 1024 ? N * P * L * 8 : 1024;
+    const size_t lds3 = (size_t)nlp8 * 4 + (size_t)N * P * L * 32 + 64 * 4 + 64;
+    if (feat_dtype == FAR3D_DT_F32)
+      hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, block, lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 1)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 2)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4, 2>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 3)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4, 3>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 5)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 6)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 4)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else   // NB = 2 measured best on MI355X (8 waves/SIMD, 8 row loads in flight per wave)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
+    return FAR3D_OK;
+  }
   if (feat_dtype == FAR3D_DT_F32)
     hipLaunchKernelGGL(aggregate_fwd_kernel<float>, grid, block, lds, st, (const float*)feat, ref, offsets,
-                       lidar2img, U, Vc, out, prm);
+                       lidar2img, U, Vc, perm, out, prm);
+  else if (abl == 1)
+    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 1>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+  else if (abl == 2)
+    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 2>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+  else if (abl == 3)
+    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 3>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
   else
     hipLaunchKernelGGL(aggregate_fwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)feat, ref, offsets,
-                       lidar2img, U, Vc, out, prm);
+                       lidar2img, U, Vc, perm, out, prm);
   FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
   return FAR3D_OK;
 }

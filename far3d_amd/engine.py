@@ -368,6 +368,8 @@ class Far3DEngine:
         memk = (mem + mempos).contiguous()
         l2i = lidar2img[:, :3, :].flatten(1).contiguous()             # (N,12)
         outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
+        # reference points are fixed across the 6 layers: one camera-sorted workgroup order per frame (scheduling only)
+        perm = ops.camera_sorted_order(ref, lidar2img, cfg["pc_range"], pad_hw)
         qk = self._buf(("qk",), (A + Km, 2 * E), at)
         vb = self._buf(("v",), (A + Km, E), at)
         for li, ly in enumerate(self.layers):
@@ -390,7 +392,7 @@ class Far3DEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
-                                        num_groups=cfg["num_groups"])
+                                        num_groups=cfg["num_groups"], perm=perm)
             if ev is not None:
                 e1.record()
                 ev.setdefault("aggregate_fwd", []).append((e0, e1))

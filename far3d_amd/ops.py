@@ -86,7 +86,7 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, a
 
 
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None):
+                      num_groups=8, out=None, perm=None):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
@@ -112,11 +112,16 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
                          (tuple(U.shape), tuple(Vc.shape), tuple(lidar2img.shape), A, N, L, P, G))
     if out is None:
         out = torch.empty((A, C), dtype=torch.float32, device=feat.device)
+    if perm is not None:
+        _chk(perm, "perm", torch.int32, 1)
+        if perm.numel() != A:
+            raise ValueError("aggregate_forward: perm must have A entries")
     hw_keep, hw_p = _host_i32([list(x) for x in level_hw])
     st_keep, st_p = _host_i32(list(level_start))
     pc_keep, pc_p = _host_f32(list(pc_range))
     _lib.check(lib.far3d_aggregate_forward(_ptr(feat), _dt(feat), _ptr(ref), _ptr(offsets), _ptr(lidar2img),
-                                           _ptr(U), _ptr(Vc), _ptr(out), A, N, S, C, G, P, L, hw_p, st_p, pc_p,
+                                           _ptr(U), _ptr(Vc), _ptr(perm) if perm is not None else None, _ptr(out),
+                                           A, N, S, C, G, P, L, hw_p, st_p, pc_p,
                                            float(pad_hw[0]), float(pad_hw[1]), _stream(feat)),
                "far3d_aggregate_forward")
     return out
@@ -395,3 +400,18 @@ def row_affine_ln(x, gamma, beta, add=None, do_ln=True, eps=1e-5, out=None):
                                        rows, C, x.stride(0), bc(gamma), bc(add) if add is not None else 0, out.stride(0),
                                        float(eps), 1 if do_ln else 0, _stream(x)), "far3d_row_affine_ln")
     return out
+
+
+
+def camera_sorted_order(ref, lidar2img, pc_range, pad_hw):
+    """Query order for aggregate_forward's `perm`: queries sorted by the camera whose image centre their reference point
+    projects closest to (stable).  Pure scheduling hint -- results do not depend on it."""
+    pc = torch.as_tensor(pc_range, dtype=torch.float32, device=ref.device)
+    pts = ref * (pc[3:6] - pc[0:3]) + pc[0:3]
+    p = torch.einsum("nij,aj->nai", lidar2img[:, :3, :3], pts) + lidar2img[:, :3, 3][:, None, :]       # (N,A,3)
+    z = p[..., 2]
+    u = p[..., 0] / z.clamp(min=1e-5) / pad_hw[1] - 0.5
+    v = p[..., 1] / z.clamp(min=1e-5) / pad_hw[0] - 0.5
+    cost = torch.where(z > 1e-5, u * u + v * v, torch.full_like(z, 1e9))
+    cam = cost.argmin(dim=0)
+    return torch.sort(cam, stable=True).indices.to(torch.int32).contiguous()

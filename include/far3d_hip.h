@@ -55,10 +55,12 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * U (A,L*P*G) f32 and Vc (N,L*P*G) f32 with logits[a,n,(l*P+p)*G+g] = U[a,.] + Vc[n,.]
  *   ( = weights_fc((x+pos)[a] + cam_embed[n]) split by linearity; bias lives in Vc );
  * level_hw (L,2) int32 HOST (h,w); level_start (L) int32 HOST; pc_range 6 floats HOST;
- * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) f32.  Requires C=256, G=8, L<=4,
+ * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) f32.  perm: optional (A) int32 DEVICE permutation giving
+ * the order in which queries are assigned to workgroups (camera-sorted order keeps one XCD's L2 on 1-2 cameras); it never
+ * changes results (row a of `out` is always query a).  Requires C=256, G=8, L<=4,
  * N*P<=256, N*P*L<=384. */
 int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
-                            const float* lidar2img, const float* U, const float* Vc, float* out, int A,
+                            const float* lidar2img, const float* U, const float* Vc, const int32_t* perm, float* out, int A,
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
                             void* stream);
