@@ -15,6 +15,7 @@
 // Global -> register -> LDS staging with the next tile's loads in flight during the MFMAs, two LDS buffers,
 // one barrier per K step.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
@@ -106,10 +107,74 @@ __device__ __forceinline__ void store4(void* base, int dt, long off, const float
   }
 }
 
-template <typename TIn, typename TC, int WM, int WN>
+// Shared epilogue: lane (l31, hi) of wave (wm, wn) holds, per 32x32 tile (i, j), 4 consecutive channels x 1 pixel per quad.
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&acc)[WM][WN], int p0, int m0, int wm, int wn,
+                                               int l31, int hi, int HoWo, long Npix) {
+  // ---- epilogue: bias -> activation -> residual -> store (+ optional modulated second output)
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const long p = (long)p0 + (wn * WN + j) * 32 + l31;
+    if (p >= Npix) continue;
+    const int n = (int)(p / HoWo), pix = (int)(p - (long)n * HoWo);
+    long roff = 0;
+    if (P.res) {
+      const int oy = pix / P.Wo, ox = pix - oy * P.Wo;
+      const int ry = (P.Hr == P.Ho) ? oy : min((int)floorf(oy * ((float)P.Hr / P.Ho)), P.Hr - 1);
+      const int rx = (P.Wr == P.Wo) ? ox : min((int)floorf(ox * ((float)P.Wr / P.Wo)), P.Wr - 1);
+      roff = (long)n * P.res_img_stride + ((long)ry * P.Wr + rx) * P.ldr;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (wm * WM + i) * 32 + 8 * q + 4 * hi;
+        if (m >= P.Cout) continue;
+        const int nv = min(4, P.Cout - m);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        if (P.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += P.bias[m + e];
+        }
+        if (P.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (P.act == ACT_SWISH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
+        }
+        if (P.res) {
+          if (P.res_dt == FAR3D_DT_F32) {
+            const float* rp = reinterpret_cast<const float*>(P.res) + roff + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += rp[e];
+          } else {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(P.res) + roff + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf16_to_f32(rp[e]);
+          }
+        }
+        store4(P.y, P.y_dt, (long)n * P.y_img_stride + (long)pix * P.ldy + m, v, nv, P.y_vec != 0);
+        if (P.y2) {
+          float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) u[e] = P.y2_scale[(long)n * P.Cout + m + e] * v[e] + P.y2_shift[(long)n * P.Cout + m + e];
+          store4(P.y2, P.y2_dt, (long)n * P.y2_img_stride + (long)pix * P.ldy2 + m, u, nv, P.y2_vec != 0);
+        }
+      }
+    }
+  }
+}
+
+// WGM x WGN: arrangement of the 4 waves over (channels, pixels); WM x WN: 32x32 MFMA tiles per wave.
+template <typename TIn, typename TC, int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
   constexpr int E = Cfg<TC>::E, ROWB = Cfg<TC>::ROWB, KSUB = Cfg<TC>::KSUB;
-  constexpr int BM = 64 * WM, BP = 64 * WN;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   constexpr int CPR = 32 / E;                 // 16-B chunks per tile row
   constexpr int A_CH = BM * CPR / 256;        // weight chunks per thread
   constexpr int B_CH = BP * CPR / 256;        // pixel chunks per thread
@@ -117,7 +182,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
   unsigned char* As = smem;                               // [2][BM][ROWB]
   unsigned char* Bs = smem + 2 * BM * ROWB;               // [2][BP][ROWB]
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
   const int p0 = blockIdx.x * BP, m0 = blockIdx.y * BM;
   const int HoWo = P.Ho * P.Wo;
   const long Npix = (long)P.N * HoWo;
@@ -203,71 +268,145 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
     buf ^= 1;
   }
 
-  // ---- epilogue: bias -> activation -> residual -> store (+ optional modulated second output)
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const long p = (long)p0 + (wn * WN + j) * 32 + l31;
-    if (p >= Npix) continue;
-    const int n = (int)(p / HoWo), pix = (int)(p - (long)n * HoWo);
-    long roff = 0;
-    if (P.res) {
-      const int oy = pix / P.Wo, ox = pix - oy * P.Wo;
-      const int ry = (P.Hr == P.Ho) ? oy : min((int)floorf(oy * ((float)P.Hr / P.Ho)), P.Hr - 1);
-      const int rx = (P.Wr == P.Wo) ? ox : min((int)floorf(ox * ((float)P.Wr / P.Wo)), P.Wr - 1);
-      roff = (long)n * P.res_img_stride + ((long)ry * P.Wr + rx) * P.ldr;
-    }
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = m0 + (wm * WM + i) * 32 + 8 * q + 4 * hi;
-        if (m >= P.Cout) continue;
-        const int nv = min(4, P.Cout - m);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-        if (P.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += P.bias[m + e];
-        }
-        if (P.act == ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (P.act == ACT_SWISH) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
-        }
-        if (P.res) {
-          if (P.res_dt == FAR3D_DT_F32) {
-            const float* rp = reinterpret_cast<const float*>(P.res) + roff + m;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += rp[e];
-          } else {
-            const bf16_t* rp = reinterpret_cast<const bf16_t*>(P.res) + roff + m;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf16_to_f32(rp[e]);
-          }
-        }
-        store4(P.y, P.y_dt, (long)n * P.y_img_stride + (long)pix * P.ldy + m, v, nv, P.y_vec != 0);
-        if (P.y2) {
-          float u[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) u[e] = P.y2_scale[(long)n * P.Cout + m + e] * v[e] + P.y2_shift[(long)n * P.Cout + m + e];
-          store4(P.y2, P.y2_dt, (long)n * P.y2_img_stride + (long)pix * P.ldy2 + m, u, nv, P.y2_vec != 0);
-        }
-      }
-    }
-  }
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
 }
 
-template <typename TIn, typename TC, int WM, int WN>
+template <typename TIn, typename TC, int WGM, int WGN, int WM, int WN>
 static int launch_igemm(const IgemmParams& P, hipStream_t st) {
-  constexpr int BM = 64 * WM, BP = 64 * WN;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
   dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
   const size_t lds = (size_t)2 * (BM + BP) * Cfg<TC>::ROWB;
-  hipLaunchKernelGGL((igemm_kernel<TIn, TC, WM, WN>), grid, dim3(256), lds, st, P);
+  hipLaunchKernelGGL((igemm_kernel<TIn, TC, WGM, WGN, WM, WN>), grid, dim3(256), lds, st, P);
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast path: same tiling / epilogue, but the operands stream global -> LDS directly (LDS-DMA, `global_load_lds`
+// 16 B per lane, no VGPR staging) through an NS-deep ring, issued NS-1 K-steps ahead with counted `s_waitcnt vmcnt` and ONE
+// raw `s_barrier` per step.  An LDS-DMA instruction writes 1 KiB = 16 rows x 64 B linearly, so the 64-byte (BK = 32 bf16)
+// rows are unpadded; bank conflicts of the 16-lane `ds_read_b128` groups are removed by an XOR swizzle applied on the
+// SOURCE side: the lane that fills physical 16-B chunk pc of row r fetches logical chunk pc ^ ((r>>2)&3), and fragment
+// reads use the same involution.  Out-of-image taps read a 64-B zero page instead of branching.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[32];
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WGM, int WGN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int A_I = BM / 64, B_I = BP / 64, GL = A_I + B_I;      // LDS-DMA instructions per wave per stage
+  constexpr int STAGE = (BM + BP) * 64;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  const int p0 = blockIdx.x * BP, m0 = blockIdx.y * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int Ktot = P.KH * P.KW * P.cin_pad;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // lane -> (row within the 16-row group, physical chunk) -> logical chunk it must fetch
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);          // group bases are multiples of 16 rows, so (row>>2)&3 == (rg>>2)&3
+  const bf16_t* asrc[A_I];
+#pragma unroll
+  for (int i = 0; i < A_I; ++i) {
+    const int row = (wv * A_I + i) * 16 + rg;
+    asrc[i] = reinterpret_cast<const bf16_t*>(P.w) + (long)(m0 + row) * Ktot + lc * 8;
+  }
+  const bf16_t* bbase[B_I];
+  int boy[B_I], box[B_I];
+#pragma unroll
+  for (int j = 0; j < B_I; ++j) {
+    const int row = (wv * B_I + j) * 16 + rg;
+    const long p = (long)p0 + row;
+    if (p < Npix) {
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      bbase[j] = reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + lc * 8;
+      boy[j] = (rem / P.Wo) * P.stride - P.pad; box[j] = (rem % P.Wo) * P.stride - P.pad;
+    } else {
+      bbase[j] = nullptr; boy[j] = 0; box[j] = 0;
+    }
+  }
+  int i_tap = 0, i_c0 = 0;   // (tap, first channel) of the next K-step to be issued
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    const int ky = i_tap / P.KW, kx = i_tap - ky * P.KW;
+    const int kb = i_tap * P.cin_pad + i_c0;
+    unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_I; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(asrc[i] + kb), (lds_void_t*)(sbase + (wv * A_I + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < B_I; ++j) {
+      const int iy = boy[j] + ky, ix = box[j] + kx;
+      const bool ok = bbase[j] != nullptr && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const bf16_t* src = ok ? bbase[j] + ((long)iy * P.W + ix) * P.ldx + i_c0 : zero;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sbase + BM * 64 + (wv * B_I + j) * 1024), 16, 0, 0);
+    }
+    i_c0 += 32;
+    if (i_c0 >= P.cin_pad) { i_c0 = 0; ++i_tap; }
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = P.nsteps;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nsteps) issue(s);
+  // fragment read addresses: row r = tile row, logical chunk (kk*2 + hi) -> physical chunk ^ ((r>>2)&3)
+  int aoff[WM], boff[WN], aswz[WM], bswz[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) { const int r = (wm * WM + i) * 32 + l31; aoff[i] = r * 64; aswz[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) { const int r = (wn * WN + j) * 32 + l31; boff[j] = BM * 64 + r * 64; bswz[j] = (r >> 2) & 3; }
+
+  int stage = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + NS - 1 <= nsteps) wait_vmcnt<GL * (NS - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (step + NS - 1 < nsteps) {
+      int st2 = stage + NS - 1; if (st2 >= NS) st2 -= NS;
+      issue(st2);
+    }
+    const unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4_t af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(sb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(sb + boff[j] + (((kk * 2 + hi) ^ bswz[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
+    }
+    if (++stage == NS) stage = 0;
+  }
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
+}
+
+template <int WGM, int WGN, int WM, int WN, int NS>
+static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
+  const size_t lds = (size_t)NS * (BM + BP) * 64;
+  hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS>), grid, dim3(256), lds, st, P);
   return 0;
 }
 
@@ -310,8 +449,8 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
   const long Npix = (long)N * Ho * Wo;
-  // tile: 0 = auto.  1 = 128(ch) x 128(px), 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64
-  if (tile == 0) {
+  // tile: 0 = auto.  (channels x pixels per workgroup) 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64, 5 = 64x256
+  if (tile == 0) {   // fallback heuristic; far3d_amd/data/tuning_mi355x.json holds measured per-shape winners
     const long big = ((Npix + 127) / 128) * ((Cout + 127) / 128);
     if (Cout <= 64) tile = (Npix >= 128 * 512) ? 2 : 3;
     else if (big >= 512) tile = 1;
@@ -320,11 +459,23 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   }
 #define LAUNCH(TIN, TCC)                                                        \
   switch (tile) {                                                               \
-    case 1: launch_igemm<TIN, TCC, 2, 2>(P, st); break;                         \
-    case 2: launch_igemm<TIN, TCC, 1, 2>(P, st); break;                         \
-    case 3: launch_igemm<TIN, TCC, 1, 1>(P, st); break;                         \
-    case 4: launch_igemm<TIN, TCC, 2, 1>(P, st); break;                         \
+    case 1: launch_igemm<TIN, TCC, 2, 2, 2, 2>(P, st); break;                   \
+    case 2: launch_igemm<TIN, TCC, 2, 2, 1, 2>(P, st); break;                   \
+    case 3: launch_igemm<TIN, TCC, 2, 2, 1, 1>(P, st); break;                   \
+    case 4: launch_igemm<TIN, TCC, 2, 2, 2, 1>(P, st); break;                   \
+    case 5: launch_igemm<TIN, TCC, 1, 4, 2, 2>(P, st); break;                   \
     default: far3d_set_error("far3d_conv2d_nhwc: unknown tile %d", tile); return FAR3D_ERR_ARG; \
+  }
+  static const int no_dma = getenv("FAR3D_IGEMM_NODMA") ? atoi(getenv("FAR3D_IGEMM_NODMA")) : 0;
+  if (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && !no_dma && (Cin % 32) == 0 && P.x_vec && (tile == 1 || tile == 3 || tile == 4 || tile == 2)) {
+    switch (tile) {
+      case 1: launch_igemm_dma<2, 2, 2, 2, 3>(P, st); break;
+      case 2: launch_igemm_dma<2, 2, 1, 2, 4>(P, st); break;
+      case 3: launch_igemm_dma<2, 2, 1, 1, 4>(P, st); break;
+      case 4: launch_igemm_dma<2, 2, 2, 1, 4>(P, st); break;
+    }
+    FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
+    return FAR3D_OK;
   }
   if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32) { LAUNCH(float, float) }
   else if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_BF16) { LAUNCH(float, bf16_t) }

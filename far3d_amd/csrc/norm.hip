@@ -91,30 +91,52 @@ extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C,
                                                         int ldx, long img_stride, int rows_per_block) {
-  // thread -> 4 consecutive channels; threads of a block cover (256*4/C) rows at a time
+  // thread -> 4 consecutive channels; the 256 threads cover rstep = 256*4/C rows per pass; 4 passes are kept in flight.
+  // Partial sums are combined across the row-threads in LDS, so a workgroup issues 2*C atomics in total.
+  __shared__ float red[2][1024];
   const int n = blockIdx.y;
-  const int cq = C / 4;                       // float4 groups per row
+  const int cq = C / 4;
   const int tcol = threadIdx.x % cq, trow = threadIdx.x / cq;
   const int rstep = 256 / cq;
-  if (trow >= rstep) return;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(HW, r0 + rows_per_block);
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
-  const T* base = x + (long)n * img_stride + tcol * 4;
-  for (int r = r0 + trow; r < r1; r += rstep) {
-    const float4 v = load4(base + (long)r * ldx);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  if (trow < rstep) {
+    const T* base = x + (long)n * img_stride + tcol * 4;
+    int r = r0 + trow;
+    for (; r + 3 * rstep < r1; r += 4 * rstep) {
+      const float4 a = load4(base + (long)r * ldx), b = load4(base + (long)(r + rstep) * ldx);
+      const float4 c = load4(base + (long)(r + 2 * rstep) * ldx), d = load4(base + (long)(r + 3 * rstep) * ldx);
+      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+      s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+      q.x += (a.x * a.x + b.x * b.x) + (c.x * c.x + d.x * d.x); q.y += (a.y * a.y + b.y * b.y) + (c.y * c.y + d.y * d.y);
+      q.z += (a.z * a.z + b.z * b.z) + (c.z * c.z + d.z * d.z); q.w += (a.w * a.w + b.w * b.w) + (c.w * c.w + d.w * d.w);
+    }
+    for (; r < r1; r += rstep) {
+      const float4 a = load4(base + (long)r * ldx);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      q.x += a.x * a.x; q.y += a.y * a.y; q.z += a.z * a.z; q.w += a.w * a.w;
+    }
   }
-  float* dst = sums + ((long)n * C + tcol * 4) * 2;
-  atomicAdd(dst + 0, s.x); atomicAdd(dst + 1, q.x);
-  atomicAdd(dst + 2, s.y); atomicAdd(dst + 3, q.y);
-  atomicAdd(dst + 4, s.z); atomicAdd(dst + 5, q.z);
-  atomicAdd(dst + 6, s.w); atomicAdd(dst + 7, q.w);
+  // cross-row reduction: red[.][trow*C + c] would need rstep*C <= 1024 floats: rstep*C = 1024 exactly.
+  if (trow < rstep) {
+    *reinterpret_cast<float4*>(&red[0][trow * C + tcol * 4]) = s;
+    *reinterpret_cast<float4*>(&red[1][trow * C + tcol * 4]) = q;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float ss = 0.f, qq = 0.f;
+    for (int k = 0; k < rstep; ++k) { ss += red[0][k * C + c]; qq += red[1][k * C + c]; }
+    atomicAdd(sums + ((long)n * C + c) * 2, ss);
+    atomicAdd(sums + ((long)n * C + c) * 2 + 1, qq);
+  }
 }
 
 static int launch_chan_sums(const void* x, int dt, float* sums, int N, int HW, int C, int ldx, long img_stride, hipStream_t st) {
-  const int rows_per_block = 256;
+  // ~64 workgroups per image: enough to fill the chip with 7 images, few enough that atomics are negligible
+  int rows_per_block = (HW + 63) / 64;
+  const int rstep = 256 / (C / 4);
+  rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
   dim3 grid((HW + rows_per_block - 1) / rows_per_block, N), block(256);
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, sums, HW, C, ldx, img_stride, rows_per_block);

@@ -131,6 +131,18 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
 # implicit-GEMM convolution / linear
 # --------------------------------------------------------------------------------------------------
 ACT = {None: 0, "none": 0, "relu": 1, "swish": 2}
+_TUNING = None
+
+
+def _tuned_tile(Cout, Cin, k, stride, npix):
+    """Workgroup tile measured fastest on MI355X for this conv shape (tools/tune_conv.py); 0 = kernel heuristic."""
+    global _TUNING
+    if _TUNING is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tuning_mi355x.json")
+        _TUNING = json.load(open(path)) if os.path.exists(path) else {}
+    return int(_TUNING.get("%d,%d,%d,%d,%d" % (Cout, Cin, k, stride, npix), 0))
 
 
 class PackedConv:
@@ -199,6 +211,8 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
         if y2_scale.numel() != N * pc.Cout or y2_shift.numel() != N * pc.Cout or tuple(y2.shape) != tuple(out.shape):
             raise ValueError("conv2d_nhwc: y2/scale/shift shapes inconsistent")
         y2p, y2dt, sp, hp = _ptr(y2), _dt(y2), _ptr(y2_scale), _ptr(y2_shift)
+    if tile == 0 and x.dtype == torch.bfloat16:
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W)
     _lib.check(lib.far3d_conv2d_nhwc(
         _ptr(x), _dt(x), _ptr(pc.w), _dt(pc.w), _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
         N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],

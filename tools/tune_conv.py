@@ -1,0 +1,75 @@
+"""Sweep the workgroup tile of far3d_conv2d_nhwc for every distinct conv shape of the VoV-99 640x960x7 frame (bf16) and
+write the winners to far3d_amd/tuning_mi355x.json (key "Cout,Cin,k,stride,Npix").  Device time via hipGraph replay."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from far3d_amd import ops, weights
+
+def shapes():
+    spec = weights.VOV_SPECS["V-99-eSE"]
+    N, H, W = 7, 640, 960
+    out = []   # (name, N, H, W, Cin, Cout, k, stride)
+    h, w = H // 2, W // 2
+    out.append(("stem1", N, h, w, 32, 64, 1, 1)); out.append(("stem2", N, h, w, 64, 64, 3, 1)); out.append(("stem3", N, h, w, 64, 128, 3, 2))
+    h, w = h // 2, w // 2
+    in_ch = 128
+    for si in range(4):
+        sc, oc = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
+        if si > 0:
+            h, w = -(-h // 2), -(-w // 2)
+        for b in range(2 if spec["block_per_stage"][si] > 1 else 1):
+            out.append(("s%d.b%d.c0" % (si + 2, b), N, h, w, in_ch, sc, 3, 1))
+            out.append(("s%d.b%d.c1" % (si + 2, b), N, h, w, sc, sc, 3, 1))
+            out.append(("s%d.b%d.cat" % (si + 2, b), N, h, w, in_ch + 5 * sc, oc, 1, 1))
+            in_ch = oc
+    hw = [(80, 120), (40, 60), (20, 30), (10, 15)]
+    for i, cin in zip((2, 1, 0), (1024, 768, 512)):
+        out.append(("fpn.lat%d" % i, N, hw[i][0], hw[i][1], cin, 256, 1, 1))
+    for l in range(4):
+        out.append(("c256.l%d" % l, N, hw[l][0], hw[l][1], 256, 256, 3, 1))
+        out.append(("head26.l%d" % l, N, hw[l][0], hw[l][1], 256, 26, 1, 1))
+        out.append(("head5.l%d" % l, N, hw[l][0], hw[l][1], 256, 5, 1, 1))
+    out.append(("fpn.out3", N, 20, 30, 256, 256, 3, 2)); out.append(("depth.cls", N, 80, 120, 256, 51, 1, 1))
+    return out
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (3 * iters)
+
+def main():
+    dev = "cuda:0"
+    table, seen = {}, set()
+    for name, N, H, W, Cin, Cout, k, stride in shapes():
+        key = "%d,%d,%d,%d,%d" % (Cout, Cin, k, stride, N * H * W)
+        if key in seen:
+            continue
+        seen.add(key)
+        x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
+        pc = ops.PackedConv(torch.randn(Cout, Cin, k, k) * 0.05, torch.randn(Cout), stride=stride, pad=k // 2, dtype=torch.bfloat16, device=dev)
+        Ho, Wo = pc.out_hw(H, W)
+        y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
+        fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
+        res = {}
+        for tile in (0, 1, 2, 3, 4, 5):
+            t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile))
+            res[tile] = t
+        best = min((t, tl) for tl, t in res.items() if tl != 0)
+        table[key] = best[1]
+        print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %6.1f" % (tl, res[tl] * 1e6) for tl in (1, 2, 3, 4, 5)) +
+              " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
+    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x.json"), "w"), indent=0, sort_keys=True)
+
+if __name__ == "__main__":
+    main()
