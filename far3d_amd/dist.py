@@ -50,7 +50,7 @@ class ShardedFrame:
         cfg, dev = eng.cfg, eng.dev
         K = cfg["proposal_topk"]
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
-        dd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "img"}
+        dd = eng._stage_inputs(data)      # every rank keeps the (small) calibration inputs; images are sliced per rank
         pending = {}
 
         def start_gather(st):   # value maps are final right after the FPN: overlap their gather with the 2D head
@@ -61,7 +61,7 @@ class ShardedFrame:
             pending["tok"] = gather_camera_major(tok, self.num_cams, self.group, async_op=True)
 
         if self.cams:
-            img = data["img"][0][self.cams].to(dev, torch.float32).contiguous()
+            img = dd["img"][self.cams].contiguous()
             eng.after_fpn = start_gather
             try:
                 st = eng.camera_stage(img, dd, self.cams, pad_hw)

@@ -93,6 +93,12 @@ class Far3DEngine:
                 self.sd[ck] = v.detach().float()
         self.spec = weights.VOV_SPECS[self.cfg["backbone"]]
         self._bufs = {}
+        self._cam_ids = {}
+        self._in = None             # static input buffers (graph replay reads them)
+        self._graph = None
+        self._graph_outs = None
+        self.use_graph = False      # set True to capture the steady-state frame into one hipGraph (static proposal mode only)
+        self.eye4 = None
         self.kernel_events = None   # set to {} to collect (start, stop) HIP event pairs around selected kernels
         self.after_fpn = None       # hook(stage_dict) called right after the FPN (camera-sharded mode starts its gather)
         self.reset_memory()
@@ -326,26 +332,33 @@ class Far3DEngine:
     def reset_memory(self):
         self.mem = None
 
-    def _pre_update_memory(self, data, prev_exists):   # farhead.py:453-477
+    def _mem_init(self):
+        """Persistent streaming-memory buffers (fixed shapes so that a captured hipGraph can read/write them in place).
+        The reference grows the queue to 1280 and truncates to memory_len at the next frame (farhead.py:467-471,501-505);
+        truncating right after the update is the same thing."""
         cfg, dev = self.cfg, self.dev
-        Lm, E, P_ = cfg["memory_len"], cfg["embed_dims"], cfg["num_propagated"]
+        Lm, E = cfg["memory_len"], cfg["embed_dims"]
+        self.mem = dict(emb=torch.zeros(1, Lm, E, device=dev), ref=torch.zeros(1, Lm, 3, device=dev),
+                        ts=torch.zeros(1, Lm, 1, device=dev, dtype=torch.float64), pose=torch.zeros(1, Lm, 4, 4, device=dev),
+                        velo=torch.zeros(1, Lm, 2, device=dev))
+
+    def _pre_update_memory(self, data, prev_exists, fresh):   # farhead.py:453-477
+        cfg, dev = self.cfg, self.dev
+        P_ = cfg["num_propagated"]
         x = prev_exists
-        if self.mem is None:
-            self.mem = dict(emb=torch.zeros(1, Lm, E, device=dev), ref=torch.zeros(1, Lm, 3, device=dev),
-                            ts=torch.zeros(1, Lm, 1, device=dev), pose=torch.zeros(1, Lm, 4, 4, device=dev),
-                            velo=torch.zeros(1, Lm, 2, device=dev))
+        s = self.mem
+        if fresh:
+            m = {k: v.clone() for k, v in s.items()}
         else:
-            m = self.mem
-            m["ts"] = m["ts"] + data["timestamp"].unsqueeze(-1).unsqueeze(-1)
-            m["pose"] = data["ego_pose_inv"].unsqueeze(1) @ m["pose"]
-            m["ref"] = self._transform_ref(m["ref"], data["ego_pose_inv"])
-            for k in ("ts", "ref", "emb", "pose", "velo"):
-                m[k] = m[k][:, :Lm] * x.view(-1, *([1] * (m[k].dim() - 1)))
+            m = dict(ts=s["ts"] + data["timestamp"].unsqueeze(-1).unsqueeze(-1),
+                     pose=data["ego_pose_inv"].unsqueeze(1) @ s["pose"],
+                     ref=self._transform_ref(s["ref"], data["ego_pose_inv"]), emb=s["emb"], velo=s["velo"])
+            m = {k: v * x.view(-1, *([1] * (v.dim() - 1))).to(v.dtype) for k, v in m.items()}
         if P_ > 0:
-            m = self.mem
             pseudo = self.pseudo_ref * self.pc_span + self.pc_lo
             m["ref"] = torch.cat([m["ref"][:, :P_] + (1 - x).view(1, 1, 1) * pseudo, m["ref"][:, P_:]], dim=1)
-            m["pose"] = torch.cat([m["pose"][:, :P_] + (1 - x).view(1, 1, 1, 1) * torch.eye(4, device=dev), m["pose"][:, P_:]], dim=1)
+            m["pose"] = torch.cat([m["pose"][:, :P_] + (1 - x).view(1, 1, 1, 1) * self.eye4, m["pose"][:, P_:]], dim=1)
+        return m
 
     @staticmethod
     def _transform_ref(ref, pose):
@@ -369,7 +382,7 @@ class Far3DEngine:
         l2i = lidar2img[:, :3, :].flatten(1).contiguous()             # (N,12)
         outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
         # reference points are fixed across the 6 layers: one camera-sorted workgroup order per frame (scheduling only)
-        perm = ops.camera_sorted_order(ref, lidar2img, cfg["pc_range"], pad_hw)
+        perm = ops.camera_sorted_order(ref, lidar2img, self.pc_range, pad_hw)
         qk = self._buf(("qk",), (A + Km, 2 * E), at)
         vb = self._buf(("v",), (A + Km, E), at)
         for li, ly in enumerate(self.layers):
@@ -393,6 +406,7 @@ class Far3DEngine:
                 e0.record()
             agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
                                         num_groups=cfg["num_groups"], perm=perm)
+            self.last_agg = (tokens, ref, offs, lidar2img, U, Vc, hw, starts, pad_hw, perm)   # for isolated kernel timing
             if ev is not None:
                 e1.record()
                 ev.setdefault("aggregate_fwd", []).append((e0, e1))
@@ -410,7 +424,10 @@ class Far3DEngine:
         selection and adaptive-query construction.  img (n,3,H,W) on device for the cameras `cam_ids` (global indices)."""
         cfg, dev = self.cfg, self.dev
         n = img.shape[0]
-        ids = torch.as_tensor(list(cam_ids), device=dev)
+        key = tuple(cam_ids)
+        if key not in self._cam_ids:
+            self._cam_ids[key] = torch.as_tensor(list(key), device=dev)
+        ids = self._cam_ids[key]
         lidar2img = dd["lidar2img"][0].float()[ids].contiguous()
         intr = dd["intrinsics"][0].float()[ids] / 1e3
         extr = dd["extrinsics"][0].float()[ids][:, :3, :]
@@ -434,7 +451,7 @@ class Far3DEngine:
         cap = K if K is not None else min(cfg["proposal_cap"], tokens.shape[1])
         wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
         row_off = (torch.cumsum(sel_cnt, 0) - sel_cnt).to(torch.int32)
-        img2lidar = torch.linalg.inv(lidar2img).contiguous()
+        img2lidar = dd["img2lidar"][ids].contiguous()   # inverse(lidar2img), computed when the inputs are staged
         ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, row_off, wgt, depth_logit,
                                                          cfg["depthnet"]["stride"], cfg["depthnet"], img2lidar, tokens,
                                                          cfg["pc_range"], score_thr=0.1)
@@ -447,15 +464,15 @@ class Far3DEngine:
         lidar2img = dd["lidar2img"][0].float().contiguous()
         ref2d, ctx = ref2d[:M], ctx[:M]
         # ---- scene change / memory (detectors/far3d.py:252-257)
-        if img_metas[0]["scene_token"] != self.prev_scene:
+        fresh = img_metas[0]["scene_token"] != self.prev_scene or self.mem is None
+        if fresh:
             self.prev_scene = img_metas[0]["scene_token"]
             prev = torch.zeros(1, device=dev)
-            self.reset_memory()
+            self._mem_init()
         else:
             prev = torch.ones(1, device=dev)
-        self._pre_update_memory(dd, prev)
+        m = self._pre_update_memory(dd, prev, fresh)
         # ---- a6: queries
-        m = self.mem
         P_ = cfg["num_propagated"]
         if M > 0:
             qpos_a = ops.row_affine_ln(self._query_pos(ref2d), *self.rec_code["ego_pose_pe"], add=self.time0)
@@ -486,33 +503,51 @@ class Far3DEngine:
         sc = all_cls[-1].sigmoid().topk(1, dim=-1).values[..., 0:1]
         _, idx = torch.topk(sc, cfg["topk_proposals"], dim=1)
         g = lambda t: torch.gather(t, 1, idx.view(1, -1, *([1] * (t.dim() - 2))).repeat(1, 1, *t.shape[2:]))
-        rec_pose = torch.eye(4, device=dev).view(1, 1, 4, 4).repeat(1, A, 1, 1)
-        m["emb"] = torch.cat([g(outs_dec[-1][None]), m["emb"]], dim=1)
-        m["ts"] = torch.cat([g(torch.zeros_like(sc, dtype=torch.float64)), m["ts"]], dim=1)
-        m["pose"] = torch.cat([g(rec_pose), m["pose"]], dim=1)
-        m["ref"] = torch.cat([g(all_box[-1][..., :3]), m["ref"]], dim=1)
-        m["velo"] = torch.cat([g(all_box[-1][..., -2:]), m["velo"]], dim=1)
-        m["ref"] = self._transform_ref(m["ref"], dd["ego_pose"])
-        m["ts"] = m["ts"] - dd["timestamp"].unsqueeze(-1).unsqueeze(-1)
-        m["pose"] = dd["ego_pose"].unsqueeze(1) @ m["pose"]
+        Lm = cfg["memory_len"]
+        rec_pose = self.eye4.view(1, 1, 4, 4).repeat(1, A, 1, 1)
+        n_emb = torch.cat([g(outs_dec[-1][None]), m["emb"]], dim=1)[:, :Lm]
+        n_ts = torch.cat([g(torch.zeros_like(sc, dtype=torch.float64)), m["ts"]], dim=1)[:, :Lm]
+        n_pose = torch.cat([g(rec_pose), m["pose"]], dim=1)[:, :Lm]
+        n_ref = torch.cat([g(all_box[-1][..., :3]), m["ref"]], dim=1)[:, :Lm]
+        n_velo = torch.cat([g(all_box[-1][..., -2:]), m["velo"]], dim=1)[:, :Lm]
+        s_ = self.mem   # in-place update of the persistent buffers (graph-replay safe)
+        s_["emb"].copy_(n_emb)
+        s_["velo"].copy_(n_velo)
+        s_["ref"].copy_(self._transform_ref(n_ref, dd["ego_pose"]))
+        s_["ts"].copy_(n_ts - dd["timestamp"].unsqueeze(-1).unsqueeze(-1))
+        s_["pose"].copy_(dd["ego_pose"].unsqueeze(1) @ n_pose)
         outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
                     reference_points=ref)
         outs["result"] = self.decode(all_cls, all_box)
         return outs
 
-    @torch.no_grad()
-    def forward_frame(self, data, img_metas):
-        """data: the reference's per-frame dict (img (1,N,3,H,W), lidar2img, intrinsics, extrinsics, ego_pose(_inv),
-        timestamp); tensors may live on the host (they are uploaded) or already on the device."""
-        cfg, dev = self.cfg, self.dev
+    def _stage_inputs(self, data):
+        """Copy the frame's inputs into static device buffers (so a captured graph can be replayed on them) and derive
+        img2lidar = inverse(lidar2img) (farhead.py:798) -- the only step torch.linalg does for us, outside the graph."""
+        dev = self.dev
         img = data["img"]
         if img.dim() == 5:
             assert img.shape[0] == 1, "batch 1 per engine (one scene stream per GPU)"
             img = img[0]
-        img = img.to(dev, torch.float32).contiguous()
+        keys = ("lidar2img", "intrinsics", "extrinsics", "ego_pose", "ego_pose_inv", "timestamp")
+        if self._in is None or tuple(self._in["img"].shape) != tuple(img.shape):
+            self._in = dict(img=torch.empty(tuple(img.shape), dtype=torch.float32, device=dev))
+            for k in keys:
+                self._in[k] = torch.empty(tuple(data[k].shape), dtype=torch.float64 if k == "timestamp" else torch.float32, device=dev)
+            self._in["img2lidar"] = torch.empty(tuple(data["lidar2img"].shape[1:]), dtype=torch.float32, device=dev)
+            self._graph = None
+        self._in["img"].copy_(img, non_blocking=True)
+        for k in keys:
+            self._in[k].copy_(data[k], non_blocking=True)
+        self._in["img2lidar"].copy_(torch.linalg.inv(self._in["lidar2img"][0]))
+        if self.eye4 is None:
+            self.eye4 = torch.eye(4, device=dev)
+        return self._in
+
+    def _frame_body(self, dd, img_metas, pad_hw):
+        cfg = self.cfg
+        img = dd["img"]
         N = img.shape[0]
-        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
-        dd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "img"}
         st = self.camera_stage(img, dd, range(N), pad_hw)
         K = cfg["proposal_topk"]
         M = N * K if K is not None else int(st["sel_cnt"].sum().item())   # the reference's data-dependent M: one host sync
@@ -520,6 +555,24 @@ class Far3DEngine:
         outs.update(fpn=st["raw"], depth_logit=st["depth_logit"], bbox2d=st["box2d"][:M], bbox2d_scores=st["score2d"][:M],
                     sel_idx=st["sel_idx"], sel_cnt=st["sel_cnt"])
         return outs
+
+    @torch.no_grad()
+    def forward_frame(self, data, img_metas):
+        """data: the reference's per-frame dict (img (1,N,3,H,W), lidar2img, intrinsics, extrinsics, ego_pose(_inv),
+        timestamp); tensors may live on the host (they are uploaded) or already on the device.  With `use_graph` the
+        steady-state frame (same scene, static proposal mode) is captured once into a hipGraph and replayed."""
+        dd = self._stage_inputs(data)
+        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
+        steady = img_metas[0]["scene_token"] == self.prev_scene and self.mem is not None
+        if self.use_graph and steady and self.cfg["proposal_topk"] is not None and self.kernel_events is None:
+            if self._graph is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._graph_outs = self._frame_body(dd, img_metas, pad_hw)
+                self._graph = g
+            self._graph.replay()
+            return self._graph_outs
+        return self._frame_body(dd, img_metas, pad_hw)
 
     # ------------------------------------------------------------------------------------------ a12: NMS-free decode
     def decode(self, all_cls, all_box):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245

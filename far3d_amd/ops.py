@@ -420,7 +420,7 @@ def row_affine_ln(x, gamma, beta, add=None, do_ln=True, eps=1e-5, out=None):
 def camera_sorted_order(ref, lidar2img, pc_range, pad_hw):
     """Query order for aggregate_forward's `perm`: queries sorted by the camera whose image centre their reference point
     projects closest to (stable).  Pure scheduling hint -- results do not depend on it."""
-    pc = torch.as_tensor(pc_range, dtype=torch.float32, device=ref.device)
+    pc = pc_range if isinstance(pc_range, torch.Tensor) else torch.as_tensor(pc_range, dtype=torch.float32, device=ref.device)
     pts = ref * (pc[3:6] - pc[0:3]) + pc[0:3]
     p = torch.einsum("nij,aj->nai", lidar2img[:, :3, :3], pts) + lidar2img[:, :3, 3][:, None, :]       # (N,A,3)
     z = p[..., 2]
