@@ -301,7 +301,8 @@ template <int WGM, int WGN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
-  constexpr int A_I = BM / 64, B_I = BP / 64, GL = A_I + B_I;      // LDS-DMA instructions per wave per stage
+  constexpr int GA = BM / 16, GB = BP / 16, GT = GA + GB;      // 16-row groups = LDS-DMA instructions per stage
+  constexpr int GLW = (GT + 3) / 4;                              // per wave (slots past GT re-fetch an earlier group: benign)
   constexpr int STAGE = (BM + BP) * 64;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -315,40 +316,48 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
   // lane -> (row within the 16-row group, physical chunk) -> logical chunk it must fetch
   const int rg = lane >> 2, pc = lane & 3;
   const int lc = pc ^ ((rg >> 2) & 3);          // group bases are multiples of 16 rows, so (row>>2)&3 == (rg>>2)&3
-  const bf16_t* asrc[A_I];
+  const bf16_t* sbase_[GLW];                     // A slot: weight row pointer; B slot: image base (nullptr = past the end)
+  int soy[GLW], sox[GLW], sdst[GLW];
+  bool sisA[GLW];
 #pragma unroll
-  for (int i = 0; i < A_I; ++i) {
-    const int row = (wv * A_I + i) * 16 + rg;
-    asrc[i] = reinterpret_cast<const bf16_t*>(P.w) + (long)(m0 + row) * Ktot + lc * 8;
-  }
-  const bf16_t* bbase[B_I];
-  int boy[B_I], box[B_I];
-#pragma unroll
-  for (int j = 0; j < B_I; ++j) {
-    const int row = (wv * B_I + j) * 16 + rg;
-    const long p = (long)p0 + row;
-    if (p < Npix) {
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
-      bbase[j] = reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + lc * 8;
-      boy[j] = (rem / P.Wo) * P.stride - P.pad; box[j] = (rem % P.Wo) * P.stride - P.pad;
+  for (int i = 0; i < GLW; ++i) {
+    int q = wv + 4 * i;
+    if (q >= GT) q -= GT;
+    sisA[i] = q < GA;
+    if (sisA[i]) {
+      const int row = q * 16 + rg;
+      sbase_[i] = reinterpret_cast<const bf16_t*>(P.w) + (long)(m0 + row) * Ktot + lc * 8;
+      soy[i] = 0; sox[i] = 0;
+      sdst[i] = q * 1024;
     } else {
-      bbase[j] = nullptr; boy[j] = 0; box[j] = 0;
+      const int row = (q - GA) * 16 + rg;
+      const long p = (long)p0 + row;
+      sdst[i] = BM * 64 + (q - GA) * 1024;
+      if (p < Npix) {
+        const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+        sbase_[i] = reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + lc * 8;
+        soy[i] = (rem / P.Wo) * P.stride - P.pad; sox[i] = (rem % P.Wo) * P.stride - P.pad;
+      } else {
+        sbase_[i] = nullptr; soy[i] = 0; sox[i] = 0;
+      }
     }
   }
   int i_tap = 0, i_c0 = 0;   // (tap, first channel) of the next K-step to be issued
   auto issue = [&](int stage) __attribute__((always_inline)) {
     const int ky = i_tap / P.KW, kx = i_tap - ky * P.KW;
     const int kb = i_tap * P.cin_pad + i_c0;
-    unsigned char* sbase = smem + stage * STAGE;
+    unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < A_I; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(asrc[i] + kb), (lds_void_t*)(sbase + (wv * A_I + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < B_I; ++j) {
-      const int iy = boy[j] + ky, ix = box[j] + kx;
-      const bool ok = bbase[j] != nullptr && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-      const bf16_t* src = ok ? bbase[j] + ((long)iy * P.W + ix) * P.ldx + i_c0 : zero;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sbase + BM * 64 + (wv * B_I + j) * 1024), 16, 0, 0);
+    for (int i = 0; i < GLW; ++i) {
+      const bf16_t* src;
+      if (sisA[i]) {
+        src = sbase_[i] + kb;
+      } else {
+        const int iy = soy[i] + ky, ix = sox[i] + kx;
+        const bool ok = sbase_[i] != nullptr && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        src = ok ? sbase_[i] + ((long)iy * P.W + ix) * P.ldx + i_c0 : zero;
+      }
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sb + sdst[i]), 16, 0, 0);
     }
     i_c0 += 32;
     if (i_c0 >= P.cin_pad) { i_c0 = 0; ++i_tap; }
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
 
   int stage = 0;
   for (int step = 0; step < nsteps; ++step) {
-    if (step + NS - 1 <= nsteps) wait_vmcnt<GL * (NS - 2)>(); else wait_vmcnt<0>();
+    if (step + NS - 1 <= nsteps) wait_vmcnt<GLW * (NS - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (step + NS - 1 < nsteps) {
@@ -405,7 +414,12 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
   dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
-  const size_t lds = (size_t)NS * (BM + BP) * 64;
+  constexpr size_t lds = (size_t)NS * (BM + BP) * 64;
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS>), grid, dim3(256), lds, st, P);
   return 0;
 }
@@ -467,16 +481,30 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     default: far3d_set_error("far3d_conv2d_nhwc: unknown tile %d", tile); return FAR3D_ERR_ARG; \
   }
   static const int no_dma = getenv("FAR3D_IGEMM_NODMA") ? atoi(getenv("FAR3D_IGEMM_NODMA")) : 0;
-  if (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && !no_dma && (Cin % 32) == 0 && P.x_vec && (tile == 1 || tile == 3 || tile == 4 || tile == 2)) {
+  if (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && !no_dma && (Cin % 32) == 0 && P.x_vec) {
+    // (channels x pixels, ring depth): 1 128x128/3  2 64x128/4  3 64x64/4  4 128x64/4  7 160x128/3  8 192x128/3  9 224x128/3
+    // 10 192x64/6  12 256x64/5  13 256x128/3  14 128x128/4   (5 falls back to the register-staged 64x256)
+    bool done = true;
     switch (tile) {
       case 1: launch_igemm_dma<2, 2, 2, 2, 3>(P, st); break;
       case 2: launch_igemm_dma<2, 2, 1, 2, 4>(P, st); break;
       case 3: launch_igemm_dma<2, 2, 1, 1, 4>(P, st); break;
       case 4: launch_igemm_dma<2, 2, 2, 1, 4>(P, st); break;
+      case 7: launch_igemm_dma<1, 4, 5, 1, 3>(P, st); break;
+      case 8: launch_igemm_dma<1, 4, 6, 1, 3>(P, st); break;
+      case 9: launch_igemm_dma<1, 4, 7, 1, 3>(P, st); break;
+      case 10: launch_igemm_dma<2, 2, 3, 1, 6>(P, st); break;
+      case 12: launch_igemm_dma<2, 2, 4, 1, 5>(P, st); break;
+      case 13: launch_igemm_dma<2, 2, 4, 2, 3>(P, st); break;
+      case 14: launch_igemm_dma<2, 2, 2, 2, 4>(P, st); break;
+      default: done = false;
     }
-    FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
-    return FAR3D_OK;
+    if (done) {
+      FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
+      return FAR3D_OK;
+    }
   }
+  if (tile > 5) { far3d_set_error("far3d_conv2d_nhwc: tile %d needs the bf16 LDS-DMA path (Cin %% 32 == 0, aligned)", tile); return FAR3D_ERR_ARG; }
   if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32) { LAUNCH(float, float) }
   else if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_BF16) { LAUNCH(float, bf16_t) }
   else { LAUNCH(bf16_t, bf16_t) }

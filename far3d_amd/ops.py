@@ -158,7 +158,7 @@ class PackedConv:
         Cout, Cin, KH, KW = weight.shape
         device = device if device is not None else weight.device
         cin_pad = (Cin + 31) // 32 * 32
-        rows = (Cout + 127) // 128 * 128
+        rows = (Cout + 255) // 256 * 256 + 256   # zero rows so that ANY channel tile (<= 256 rows) may over-read
         w = torch.zeros(rows, KH * KW, cin_pad, dtype=torch.float32, device=weight.device)
         w[:Cout, :, :Cin] = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin)
         self.w = w.reshape(rows, KH * KW * cin_pad).to(dtype).to(device).contiguous()

@@ -74,14 +74,16 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  *   (ref: models/dense_heads/farhead.py:228-282, models/utils/detr3d_transformer.py:503-512,525-540).
  * x: NHWC activations (x_dt), pixel stride ldx elements, image stride x_img_stride elements; the pointer is
  *    pre-offset to the first input channel (channel slices of a wider buffer are fine).
- * w: packed weights (w_dt) [ceil(Cout/128)*128][KH*KW][ceil(Cin/32)*32], zero padded; bias [same rows] f32 or NULL.
+ * w: packed weights (w_dt) [R][KH*KW][ceil(Cin/32)*32] with R >= Cout + 256 rows (zero rows past Cout: channel tiles of up to
+ *    256 rows over-read), zero padded in Cin; bias [R] f32 or NULL.
  * y: NHWC output (y_dt), pixel stride ldy, image stride y_img_stride.  v = act(conv + bias) + res.
  * act: 0 none, 1 ReLU, 2 Swish.  res (optional, res_dt): NHWC Hr x Wr map added with nearest-neighbour upsampling
  *    (FPN top-down path); Hr=Ho, Wr=Wo gives a plain residual.
  * y2 (optional, y2_dt): second output y2 = y2_scale[n][m] * v + y2_shift[n][m] (FarHead's camera-aware MLN,
  *    ref: models/utils/misc.py:182-190, models/dense_heads/farhead.py:553-563) so that the FPN output conv writes
  *    the modulated token-major value maps directly.
- * tile: 0 auto, 1 = 128ch x 128px, 2 = 64 x 128, 3 = 64 x 64, 4 = 128 x 64 per workgroup. */
+ * tile: 0 auto; workgroup tile (channels x pixels): 1 128x128, 2 64x128, 3 64x64, 4 128x64, 5 64x256; bf16 LDS-DMA only:
+ *    7 160x128, 8 192x128, 9 224x128, 10 192x64, 12 256x64, 13 256x128, 14 128x128 (4-deep ring). */
 int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y, int y_dt,
                       int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
                       long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,

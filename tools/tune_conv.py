@@ -62,12 +62,12 @@ def main():
         y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         res = {}
-        for tile in (0, 1, 2, 3, 4, 5):
+        for tile in (0, 1, 2, 3, 4, 7, 8, 9, 10, 12, 13, 14):
             t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile))
             res[tile] = t
         best = min((t, tl) for tl, t in res.items() if tl != 0)
         table[key] = best[1]
-        print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %6.1f" % (tl, res[tl] * 1e6) for tl in (1, 2, 3, 4, 5)) +
+        print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %5.0f" % (tl, res[tl] * 1e6) for tl in (1, 2, 3, 4, 7, 8, 9, 10, 12, 13, 14)) +
               " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
     json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x.json"), "w"), indent=0, sort_keys=True)
 
