@@ -109,14 +109,14 @@ __device__ __forceinline__ void store4(void* base, int dt, long off, const float
 
 // Shared epilogue: lane (l31, hi) of wave (wm, wn) holds, per 32x32 tile (i, j), 4 consecutive channels x 1 pixel per quad.
 template <int WM, int WN>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&acc)[WM][WN], int p0, int m0, int wm, int wn,
-                                               int l31, int hi, int HoWo, long Npix) {
+__device__ __forceinline__ void igemm_epilogue_px(const IgemmParams& P, f32x16_t (&acc)[WM][WN], const int (&pn)[WN],
+                                                  const int (&ppix)[WN], int m0, int wm, int hi) {
   // ---- epilogue: bias -> activation -> residual -> store (+ optional modulated second output)
+  // pn[j] / ppix[j]: image index and linear pixel index (oy*Wo+ox) of this lane's pixel in tile column j (pn < 0: none)
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
-    const long p = (long)p0 + (wn * WN + j) * 32 + l31;
-    if (p >= Npix) continue;
-    const int n = (int)(p / HoWo), pix = (int)(p - (long)n * HoWo);
+    if (pn[j] < 0) continue;
+    const int n = pn[j], pix = ppix[j];
     long roff = 0;
     if (P.res) {
       const int oy = pix / P.Wo, ox = pix - oy * P.Wo;
@@ -167,6 +167,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&
       }
     }
   }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&acc)[WM][WN], int p0, int m0, int wm, int wn,
+                                               int l31, int hi, int HoWo, long Npix) {
+  int pn[WN], ppix[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const long p = (long)p0 + (wn * WN + j) * 32 + l31;
+    pn[j] = -1; ppix[j] = 0;
+    if (p < Npix) { pn[j] = (int)(p / HoWo); ppix[j] = (int)(p - (long)pn[j] * HoWo); }
+  }
+  igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
 }
 
 // WGM x WGN: arrangement of the 4 waves over (channels, pixels); WM x WN: 32x32 MFMA tiles per wave.
@@ -424,6 +437,151 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 bf16 convolution with an LDS-resident input patch.
+// The implicit-GEMM kernels above re-fetch the (shifted) input rows for each of the 9 taps: at 128x128 tiles that is
+// 16 KB of L2->LDS traffic per 0.5 M MACs and the CU's load path, not the matrix pipe, sets the pace (measured: MFMA
+// issue ~22 %).  Here a workgroup owns a TH x 32 pixel rectangle of one image: for every 32-channel slice of Cin the
+// (TH+2) x 34 halo patch is DMA'd to LDS ONCE and the 9 taps are shifted LDS reads of it; only the weights stream per
+// tap through an NSW-deep ring.  Traffic per 9 K-steps: 9 x BM x 64 B weights + one patch, i.e. ~3x less than before at
+// BM = 128, TH = 8.  Same XOR source swizzle / counted vmcnt / one raw barrier per step as igemm_dma_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WGM, int WGN, int WM, int WN, int NSW>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int tiles_x, int tiles_y) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
+  constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + 3) / 4;
+  constexpr int GA = BM / 16, GWL = (GA + 3) / 4, WST = BM * 64;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* pbuf = smem;                       // [2][PATCH_B]
+  unsigned char* wring = smem + 2 * PATCH_B;        // [NSW][WST]
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int x0 = tx * 32, y0 = ty * TH, m0 = blockIdx.y * BM;
+  const int Ktot = 9 * P.cin_pad;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);
+
+  // patch DMA sources (per 16-pixel group owned by this wave); channel offset is added per chunk
+  const bf16_t* psrc[GPL];
+  int pdst[GPL];
+#pragma unroll
+  for (int i = 0; i < GPL; ++i) {
+    int q = wv + 4 * i;
+    if (q >= PG) q -= PG;
+    pdst[i] = q * 1024;
+    const int idx = q * 16 + rg;
+    const int py = idx / PW, px = idx - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = idx < PPIX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    psrc[i] = ok ? reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + ((long)iy * P.W + ix) * P.ldx + lc * 8 : nullptr;
+  }
+  const bf16_t* wsrc[GWL];
+  int wdst[GWL];
+#pragma unroll
+  for (int i = 0; i < GWL; ++i) {
+    int q = wv + 4 * i;
+    if (q >= GA) q -= GA;
+    wdst[i] = q * 1024;
+    wsrc[i] = reinterpret_cast<const bf16_t*>(P.w) + (long)(m0 + q * 16 + rg) * Ktot + lc * 8;
+  }
+  auto issue_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < GPL; ++i) {
+      const bf16_t* src = psrc[i] ? psrc[i] + chunk * 32 : zero;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(pbuf + buf * PATCH_B + pdst[i]), 16, 0, 0);
+    }
+  };
+  int w_chunk = 0, w_tap = 0, w_stage = 0;   // next weight tile to issue
+  auto issue_w = [&]() __attribute__((always_inline)) {
+    const int kb = w_tap * P.cin_pad + w_chunk * 32;
+#pragma unroll
+    for (int i = 0; i < GWL; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + kb), (lds_void_t*)(wring + w_stage * WST + wdst[i]), 16, 0, 0);
+    if (++w_tap == 9) { w_tap = 0; ++w_chunk; }
+    if (++w_stage == NSW) w_stage = 0;
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = P.cin_pad / 32, nsteps = nchunks * 9;
+  issue_patch(0, 0);
+#pragma unroll
+  for (int s = 0; s < NSW - 1; ++s)
+    if (s < nsteps) issue_w();
+  int aoff[WM], aswz[WM], bbase[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) { const int r = (wm * WM + i) * 32 + l31; aoff[i] = r * 64; aswz[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bbase[j] = (wn * WN + j) * PW + l31;   // patch index of this lane's pixel for tap (0,0)
+
+  int stage = 0, chunk = 0, tap = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + NSW - 1 <= nsteps) wait_vmcnt<GWL * (NSW - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tap == 0 && chunk + 1 < nchunks) issue_patch(chunk + 1, (chunk + 1) & 1);   // older than the weights issued below
+    if (step + NSW - 1 < nsteps) issue_w();
+    const unsigned char* wb = wring + stage * WST;
+    const unsigned char* pb = pbuf + (chunk & 1) * PATCH_B;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int toff = ky * PW + kx;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4_t af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(wb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int idx = bbase[j] + toff;
+        bf[j] = *reinterpret_cast<const u32x4_t*>(pb + idx * 64 + (((kk * 2 + hi) ^ ((idx >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
+    }
+    if (++stage == NSW) stage = 0;
+    if (++tap == 9) { tap = 0; ++chunk; }
+  }
+  int pn[WN], ppix[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int y = y0 + wn * WN + j, x = x0 + l31;
+    pn[j] = (y < P.H && x < P.W) ? n : -1;
+    ppix[j] = y * P.W + x;
+  }
+  igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSW>
+static int launch_conv3x3_patch(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
+  constexpr int PG = (34 * (TH + 2) + 15) / 16;
+  constexpr size_t lds = (size_t)2 * PG * 1024 + (size_t)NSW * BM * 64;
+  const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
+  dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW>), grid, dim3(256), lds, st, P, tiles_x, tiles_y);
+  return 0;
+}
+
 // See include/far3d_hip.h for the argument contract.
 extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y,
                                  int y_dt, int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho,
@@ -499,12 +657,29 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
       case 14: launch_igemm_dma<2, 2, 2, 2, 4>(P, st); break;
       default: done = false;
     }
+    // LDS-patch 3x3 kernel: (channels x rows-of-32-pixels, weight ring): 20 128x8/4  21 128x4/4  22 160x8/3  23 192x8/3
+    // 24 192x4/4  25 64x8/4  26 256x4/3  27 224x4/3  28 160x4/4
+    if (!done && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W) {
+      done = true;
+      switch (tile) {
+        case 20: launch_conv3x3_patch<2, 2, 2, 4, 4>(P, st); break;
+        case 21: launch_conv3x3_patch<2, 2, 2, 2, 4>(P, st); break;
+        case 22: launch_conv3x3_patch<1, 4, 5, 2, 3>(P, st); break;
+        case 23: launch_conv3x3_patch<1, 4, 6, 2, 3>(P, st); break;
+        case 24: launch_conv3x3_patch<1, 4, 6, 1, 4>(P, st); break;
+        case 25: launch_conv3x3_patch<2, 2, 1, 4, 4>(P, st); break;
+        case 26: launch_conv3x3_patch<2, 2, 4, 2, 3>(P, st); break;
+        case 27: launch_conv3x3_patch<1, 4, 7, 1, 3>(P, st); break;
+        case 28: launch_conv3x3_patch<1, 4, 5, 1, 4>(P, st); break;
+        default: done = false;
+      }
+    }
     if (done) {
       FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
       return FAR3D_OK;
     }
   }
-  if (tile > 5) { far3d_set_error("far3d_conv2d_nhwc: tile %d needs the bf16 LDS-DMA path (Cin %% 32 == 0, aligned)", tile); return FAR3D_ERR_ARG; }
+  if (tile > 5) { far3d_set_error("far3d_conv2d_nhwc: tile %d needs the bf16 LDS-DMA path (Cin %% 32 == 0, aligned; 20+: 3x3 s1 p1)", tile); return FAR3D_ERR_ARG; }
   if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32) { LAUNCH(float, float) }
   else if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_BF16) { LAUNCH(float, bf16_t) }
   else { LAUNCH(bf16_t, bf16_t) }

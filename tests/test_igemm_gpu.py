@@ -135,3 +135,20 @@ def test_conv_asymmetric_weights_catch_transposes(hip_lib):
         y = ops.conv2d_nhwc(x.to(DEV), pc, out_dtype=torch.float32).cpu()
         want = F.conv2d(_rt(x, dt).permute(0, 3, 1, 2), w).permute(0, 2, 3, 1)
         assert torch.allclose(y, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26, 27, 28])
+def test_conv3x3_lds_patch_kernel(hip_lib, tile):
+    """3x3/s1/p1 bf16 kernel with the LDS-resident halo patch: ragged sizes (W % 32 != 0, H % TH != 0, Cout % BM != 0)."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(tile)
+    for (N, Cin, Cout, H, W) in ((2, 64, 200, 13, 45), (1, 96, 160, 20, 30), (3, 32, 64, 9, 70)):
+        x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        want = _ref_conv(x, w, b, 1, 1, "relu", torch.bfloat16)
+        pc = ops.PackedConv(w, b, stride=1, pad=1, dtype=torch.bfloat16, device=DEV)
+        buf = torch.zeros(N, H, W, Cin + 32, dtype=torch.bfloat16, device=DEV)   # read a channel slice of a wider buffer
+        buf[..., 16:16 + Cin] = x.permute(0, 2, 3, 1).to(torch.bfloat16).to(DEV)
+        y = ops.conv2d_nhwc(buf[..., 16:16 + Cin], pc, act="relu", out_dtype=torch.float32, tile=tile)
+        _close(y.cpu().permute(0, 3, 1, 2), want, Cin * 9)
