@@ -310,13 +310,13 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WGM, int WGN, int WM, int WN, int NS>
+template <int WGM, int WGN, int WM, int WN, int NS, int KPS = 1>   // KPS: 32-channel K chunks per barrier step
 __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
-  constexpr int GA = BM / 16, GB = BP / 16, GT = GA + GB;      // 16-row groups = LDS-DMA instructions per stage
+  constexpr int GA = BM / 16, GB = BP / 16, GT = GA + GB;      // 16-row groups = LDS-DMA instructions per chunk
   constexpr int GLW = (GT + 3) / 4;                              // per wave (slots past GT re-fetch an earlier group: benign)
-  constexpr int STAGE = (BM + BP) * 64;
+  constexpr int CHUNK = (BM + BP) * 64, STAGE = CHUNK * KPS;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
@@ -355,25 +355,30 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
       }
     }
   }
-  int i_tap = 0, i_c0 = 0;   // (tap, first channel) of the next K-step to be issued
+  int i_tap = 0, i_c0 = 0;   // (tap, first channel) of the next K chunk to be issued
+  const int ntaps = P.KH * P.KW;
   auto issue = [&](int stage) __attribute__((always_inline)) {
-    const int ky = i_tap / P.KW, kx = i_tap - ky * P.KW;
-    const int kb = i_tap * P.cin_pad + i_c0;
-    unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < GLW; ++i) {
-      const bf16_t* src;
-      if (sisA[i]) {
-        src = sbase_[i] + kb;
-      } else {
-        const int iy = soy[i] + ky, ix = sox[i] + kx;
-        const bool ok = sbase_[i] != nullptr && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-        src = ok ? sbase_[i] + ((long)iy * P.W + ix) * P.ldx + i_c0 : zero;
+    for (int kc = 0; kc < KPS; ++kc) {
+      const bool live = i_tap < ntaps;     // chunks past the end of K (last, partial step) are fed from the zero page
+      const int ky = i_tap / P.KW, kx = i_tap - ky * P.KW;
+      const int kb = i_tap * P.cin_pad + i_c0;
+      unsigned char* sb = smem + stage * STAGE + kc * CHUNK;
+#pragma unroll
+      for (int i = 0; i < GLW; ++i) {
+        const bf16_t* src;
+        if (sisA[i]) {
+          src = live ? sbase_[i] + kb : zero;
+        } else {
+          const int iy = soy[i] + ky, ix = sox[i] + kx;
+          const bool ok = live && sbase_[i] != nullptr && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+          src = ok ? sbase_[i] + ((long)iy * P.W + ix) * P.ldx + i_c0 : zero;
+        }
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sb + sdst[i]), 16, 0, 0);
       }
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sb + sdst[i]), 16, 0, 0);
+      i_c0 += 32;
+      if (i_c0 >= P.cin_pad) { i_c0 = 0; ++i_tap; }
     }
-    i_c0 += 32;
-    if (i_c0 >= P.cin_pad) { i_c0 = 0; ++i_tap; }
   };
 
   f32x16_t acc[WM][WN];
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = P.nsteps;
+  const int nsteps = (P.nsteps + KPS - 1) / KPS;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nsteps) issue(s);
@@ -397,43 +402,46 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
 
   int stage = 0;
   for (int step = 0; step < nsteps; ++step) {
-    if (step + NS - 1 <= nsteps) wait_vmcnt<GLW * (NS - 2)>(); else wait_vmcnt<0>();
+    if (NS > 2 && step + NS - 1 <= nsteps) wait_vmcnt<GLW * KPS * (NS > 2 ? NS - 2 : 0)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (step + NS - 1 < nsteps) {
       int st2 = stage + NS - 1; if (st2 >= NS) st2 -= NS;
       issue(st2);
     }
-    const unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      u32x4_t af[WM], bf[WN];
+    for (int kc = 0; kc < KPS; ++kc) {
+      const unsigned char* sb = smem + stage * STAGE + kc * CHUNK;
 #pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(sb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4_t af[WM], bf[WN];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(sb + boff[j] + (((kk * 2 + hi) ^ bswz[j]) << 4));
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(sb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+        for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(sb + boff[j] + (((kk * 2 + hi) ^ bswz[j]) << 4));
 #pragma unroll
-        for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
+      }
     }
     if (++stage == NS) stage = 0;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
 }
 
-template <int WGM, int WGN, int WM, int WN, int NS>
+template <int WGM, int WGN, int WM, int WN, int NS, int KPS = 1>
 static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
   dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
-  constexpr size_t lds = (size_t)NS * (BM + BP) * 64;
+  constexpr size_t lds = (size_t)NS * KPS * (BM + BP) * 64;
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS>), grid, dim3(256), lds, st, P);
+  hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), grid, dim3(256), lds, st, P);
   return 0;
 }
 
@@ -447,15 +455,16 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
 // tap through an NSW-deep ring.  Traffic per 9 K-steps: 9 x BM x 64 B weights + one patch, i.e. ~3x less than before at
 // BM = 128, TH = 8.  Same XOR source swizzle / counted vmcnt / one raw barrier per step as igemm_dma_kernel.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WGM, int WGN, int WM, int WN, int NSW>
+template <int WGM, int WGN, int WM, int WN, int NSW, int TPS = 1>   // TPS: taps per barrier step (1 or 3 = one kernel row)
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int tiles_x, int tiles_y) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(TPS == 1 || TPS == 3, "a step is one tap or one kernel row");
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
   constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + 3) / 4;
   constexpr int GA = BM / 16, GWL = (GA + 3) / 4, WST = BM * 64;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* pbuf = smem;                       // [2][PATCH_B]
-  unsigned char* wring = smem + 2 * PATCH_B;        // [NSW][WST]
+  unsigned char* wring = smem + 2 * PATCH_B;        // [NSW][TPS][WST]
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
   int bid = blockIdx.x;
@@ -500,11 +509,15 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int t
   };
   int w_chunk = 0, w_tap = 0, w_stage = 0;   // next weight tile to issue
   auto issue_w = [&]() __attribute__((always_inline)) {
-    const int kb = w_tap * P.cin_pad + w_chunk * 32;
 #pragma unroll
-    for (int i = 0; i < GWL; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + kb), (lds_void_t*)(wring + w_stage * WST + wdst[i]), 16, 0, 0);
-    if (++w_tap == 9) { w_tap = 0; ++w_chunk; }
+    for (int tp = 0; tp < TPS; ++tp) {
+      const int kb = (w_tap + tp) * P.cin_pad + w_chunk * 32;
+#pragma unroll
+      for (int i = 0; i < GWL; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + kb), (lds_void_t*)(wring + (w_stage * TPS + tp) * WST + wdst[i]), 16, 0, 0);
+    }
+    w_tap += TPS;
+    if (w_tap == 9) { w_tap = 0; ++w_chunk; }
     if (++w_stage == NSW) w_stage = 0;
   };
 
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int t
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nchunks = P.cin_pad / 32, nsteps = nchunks * 9;
+  const int nchunks = P.cin_pad / 32, nsteps = nchunks * (9 / TPS);
   issue_patch(0, 0);
 #pragma unroll
   for (int s = 0; s < NSW - 1; ++s)
@@ -529,32 +542,37 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int t
 
   int stage = 0, chunk = 0, tap = 0;
   for (int step = 0; step < nsteps; ++step) {
-    if (step + NSW - 1 <= nsteps) wait_vmcnt<GWL * (NSW - 2)>(); else wait_vmcnt<0>();
+    if (step + NSW - 1 <= nsteps) wait_vmcnt<GWL * TPS * (NSW - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (tap == 0 && chunk + 1 < nchunks) issue_patch(chunk + 1, (chunk + 1) & 1);   // older than the weights issued below
     if (step + NSW - 1 < nsteps) issue_w();
-    const unsigned char* wb = wring + stage * WST;
     const unsigned char* pb = pbuf + (chunk & 1) * PATCH_B;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int toff = ky * PW + kx;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      u32x4_t af[WM], bf[WN];
+    for (int tp = 0; tp < TPS; ++tp) {
+      const unsigned char* wb = wring + (stage * TPS + tp) * WST;
+      const int tcur = tap + tp;
+      const int ky = tcur / 3, kx = tcur - ky * 3;
+      const int toff = ky * PW + kx;
 #pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(wb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4_t af[WM], bf[WN];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int idx = bbase[j] + toff;
-        bf[j] = *reinterpret_cast<const u32x4_t*>(pb + idx * 64 + (((kk * 2 + hi) ^ ((idx >> 2) & 3)) << 4));
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(wb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int idx = bbase[j] + toff;
+          bf[j] = *reinterpret_cast<const u32x4_t*>(pb + idx * 64 + (((kk * 2 + hi) ^ ((idx >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
       }
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
     }
     if (++stage == NSW) stage = 0;
-    if (++tap == 9) { tap = 0; ++chunk; }
+    tap += TPS;
+    if (tap == 9) { tap = 0; ++chunk; }
   }
   int pn[WN], ppix[WN];
 #pragma unroll
@@ -566,19 +584,19 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int t
   igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
 }
 
-template <int WGM, int WGN, int WM, int WN, int NSW>
+template <int WGM, int WGN, int WM, int WN, int NSW, int TPS = 1>
 static int launch_conv3x3_patch(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds = (size_t)2 * PG * 1024 + (size_t)NSW * BM * 64;
+  constexpr size_t lds = (size_t)2 * PG * 1024 + (size_t)NSW * TPS * BM * 64;
   const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
   dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW>), grid, dim3(256), lds, st, P, tiles_x, tiles_y);
+  hipLaunchKernelGGL((conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW, TPS>), grid, dim3(256), lds, st, P, tiles_x, tiles_y);
   return 0;
 }
 
@@ -655,6 +673,20 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
       case 12: launch_igemm_dma<2, 2, 4, 1, 5>(P, st); break;
       case 13: launch_igemm_dma<2, 2, 4, 2, 3>(P, st); break;
       case 14: launch_igemm_dma<2, 2, 2, 2, 4>(P, st); break;
+      // several 32-channel K chunks per barrier step
+      case 15: launch_igemm_dma<2, 2, 2, 2, 3, 2>(P, st); break;   // 128x128, 2 chunks/step
+      case 16: launch_igemm_dma<2, 2, 2, 1, 3, 3>(P, st); break;   // 128x64, 3 chunks/step
+      case 17: launch_igemm_dma<2, 2, 1, 2, 3, 3>(P, st); break;   // 64x128, 3 chunks/step
+      case 18: launch_igemm_dma<2, 2, 1, 1, 3, 3>(P, st); break;   // 64x64, 3 chunks/step
+      case 19: launch_igemm_dma<2, 2, 2, 1, 3, 2>(P, st); break;   // 128x64, 2 chunks/step
+      // 2-deep rings: less LDS -> more resident workgroups per CU
+      case 43: launch_igemm_dma<2, 2, 2, 2, 2>(P, st); break;      // 128x128
+      case 44: launch_igemm_dma<2, 2, 2, 4, 2>(P, st); break;      // 128x256
+      case 45: launch_igemm_dma<2, 2, 4, 2, 2>(P, st); break;      // 256x128
+      case 46: launch_igemm_dma<2, 2, 2, 1, 2>(P, st); break;      // 128x64
+      case 47: launch_igemm_dma<2, 2, 1, 2, 2>(P, st); break;      // 64x128
+      case 48: launch_igemm_dma<2, 2, 1, 1, 2>(P, st); break;      // 64x64
+      case 49: launch_igemm_dma<2, 2, 2, 2, 2, 2>(P, st); break;   // 128x128, 2 chunks/step
       default: done = false;
     }
     // LDS-patch 3x3 kernel: (channels x rows-of-32-pixels, weight ring): 20 128x8/4  21 128x4/4  22 160x8/3  23 192x8/3
@@ -671,6 +703,20 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 26: launch_conv3x3_patch<2, 2, 4, 2, 3>(P, st); break;
         case 27: launch_conv3x3_patch<1, 4, 7, 1, 3>(P, st); break;
         case 28: launch_conv3x3_patch<1, 4, 5, 1, 4>(P, st); break;
+        // one kernel row (3 taps) per barrier step
+        case 30: launch_conv3x3_patch<2, 2, 1, 4, 3, 3>(P, st); break;   // 64 x 8 rows
+        case 31: launch_conv3x3_patch<2, 2, 2, 2, 3, 3>(P, st); break;   // 128 x 4 rows
+        case 32: launch_conv3x3_patch<2, 2, 1, 2, 3, 3>(P, st); break;   // 64 x 4 rows
+        case 33: launch_conv3x3_patch<2, 2, 2, 4, 2, 3>(P, st); break;   // 128 x 8 rows, 2-deep
+        case 34: launch_conv3x3_patch<2, 2, 1, 4, 4, 3>(P, st); break;   // 64 x 8 rows, 4-deep
+        case 35: launch_conv3x3_patch<1, 4, 3, 2, 3, 3>(P, st); break;   // 96 x 8 rows
+        case 36: launch_conv3x3_patch<1, 4, 1, 1, 3, 3>(P, st); break;   // 32 x 4 rows
+        case 37: launch_conv3x3_patch<1, 4, 2, 1, 3, 3>(P, st); break;   // 64 x 4 rows (1x4 waves)
+        case 38: launch_conv3x3_patch<2, 2, 1, 1, 3, 3>(P, st); break;   // 64 x 2 rows
+        case 39: launch_conv3x3_patch<2, 2, 1, 2, 2, 3>(P, st); break;   // 64 x 4 rows, 2-deep
+        case 40: launch_conv3x3_patch<1, 4, 1, 2, 3, 3>(P, st); break;   // 32 x 8 rows
+        case 41: launch_conv3x3_patch<2, 2, 2, 1, 3, 3>(P, st); break;   // 128 x 2 rows
+        case 42: launch_conv3x3_patch<2, 2, 1, 4, 2, 3>(P, st); break;   // 64 x 8 rows, 2-deep
         default: done = false;
       }
     }

@@ -32,9 +32,11 @@ def _close(got, want, K):
 
 @pytest.mark.parametrize("xdt,wdt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 15, 16, 17, 18, 19])
 def test_conv3x3_relu(hip_lib, xdt, wdt, tile):
     from far3d_amd import ops
+    if tile > 5 and not (xdt == torch.bfloat16 and wdt == torch.bfloat16):
+        pytest.skip("LDS-DMA tiles are bf16-only")
     g = torch.Generator().manual_seed(1)
     N, Cin, Cout, H, W = 2, 64, 96, 17, 23
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -137,7 +139,7 @@ def test_conv_asymmetric_weights_catch_transposes(hip_lib):
         assert torch.allclose(y, want, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26, 27, 28])
+@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42])
 def test_conv3x3_lds_patch_kernel(hip_lib, tile):
     """3x3/s1/p1 bf16 kernel with the LDS-resident halo patch: ragged sizes (W % 32 != 0, H % TH != 0, Cout % BM != 0)."""
     from far3d_amd import ops
@@ -152,3 +154,18 @@ def test_conv3x3_lds_patch_kernel(hip_lib, tile):
         buf[..., 16:16 + Cin] = x.permute(0, 2, 3, 1).to(torch.bfloat16).to(DEV)
         y = ops.conv2d_nhwc(buf[..., 16:16 + Cin], pc, act="relu", out_dtype=torch.float32, tile=tile)
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin * 9)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 14, 15, 16, 17, 18, 19, 43, 44, 45, 46, 47, 48, 49])
+def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
+    """1x1 conv over K = 160 / 1056 / 2144 channels: K chunk counts (5, 33, 67) that do not divide the chunks-per-step."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(100 + tile)
+    for (Cin, Cout, H, W) in ((160, 96, 7, 19), (1056, 512, 5, 9), (2144, 130, 3, 11)):
+        x = torch.randn(2, Cin, H, W, generator=g).to(torch.bfloat16).float()
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        want = _ref_conv(x, w, b, 1, 0, "relu", torch.bfloat16)
+        pc = ops.PackedConv(w, b, dtype=torch.bfloat16, device=DEV)
+        y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", out_dtype=torch.float32, tile=tile)
+        _close(y.cpu().permute(0, 3, 1, 2), want, Cin)
