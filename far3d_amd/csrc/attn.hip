@@ -45,7 +45,7 @@ __device__ __forceinline__ int vt_pos(int key) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
-                                                       const T* __restrict__ V, float* __restrict__ O, int Aq,
+                                                       const T* __restrict__ V, void* __restrict__ O, int out_dt, int Aq,
                                                        int Nk, int ldq, int ldk, int ldv, int ldo, float scale) {
   constexpr int KROW = ACfg<T>::KROW, VROW = ACfg<T>::VROW, KSUB = ACfg<T>::KSUB, CH = ACfg<T>::CH;
   constexpr int E = 16 / sizeof(T);
@@ -150,13 +150,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mloc);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = expf(m_run - m_use);   // m_run = -inf -> 0
+    const float alpha = (sizeof(T) == 2) ? __expf(m_run - m_use) : expf(m_run - m_use);   // m_run = -inf -> 0
     float psum = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = expf(s[u][r] - m_use);
+        const float p = (sizeof(T) == 2) ? __expf(s[u][r] - m_use) : expf(s[u][r] - m_use);
         s[u][r] = p;
         psum += p;
       }
@@ -198,15 +198,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   if (q_ok) {
     const float inv = 1.f / l_tot;
-    float* dst = O + (long)q * ldo + head * ATT_D + 4 * hi;
+    const long off = (long)q * ldo + head * ATT_D + 4 * hi;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
-      *reinterpret_cast<float4*>(dst + 8 * qd) =
-          make_float4(o[4 * qd] * inv, o[4 * qd + 1] * inv, o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4 r = make_float4(o[4 * qd] * inv, o[4 * qd + 1] * inv, o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+      if (out_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off + 8 * qd) = r;
+      else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(O) + off + 8 * qd) = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+    }
   }
 }
 
-extern "C" int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, float* out, int Aq,
+extern "C" int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq,
                                        int Nk, int heads, int head_dim, int ldq, int ldk, int ldv, int ldo,
                                        float scale, void* stream) {
   FAR3D_CHECK_ARG(q && k && v && out, "far3d_attention_forward: null pointer argument");
@@ -215,16 +217,17 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
   FAR3D_CHECK_ARG(dtype == FAR3D_DT_F32 || dtype == FAR3D_DT_BF16, "far3d_attention_forward: unsupported dtype %d", dtype);
   const int es = dtype == FAR3D_DT_F32 ? 4 : 2;
   FAR3D_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
-                  (ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && ldo % 4 == 0,
+                  (ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && ldo % 4 == 0 &&
+                  (out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16),
                   "far3d_attention_forward: pointers / row strides must be 16-byte aligned");
   dim3 grid((Aq + 127) / 128, heads), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FAR3D_DT_F32)
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v, out,
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                        Aq, Nk, ldq, ldk, ldv, ldo, scale);
   else
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       out, Aq, Nk, ldq, ldk, ldv, ldo, scale);
+                       out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale);
   FAR3D_CHECK_LAUNCH("far3d_attention_forward");
   return FAR3D_OK;
 }

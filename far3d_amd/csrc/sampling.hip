@@ -119,6 +119,7 @@ struct AggParams {
   float pc_lo[3], pc_span[3];
   float pad_w, pad_h;
   int q_per_xcd;
+  int out_dt;
 };
 
 template <typename TV, int ABL = 0>   // ABL: timing ablations (1: no gather, 2: no softmax, 3: neither) -- never shipped results
@@ -274,7 +275,7 @@ template <typename TV, int NB, int ABL = 0>
 __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ Vc,
-                                                           const int* __restrict__ perm, float* __restrict__ out, AggParams prm) {
+                                                           const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
   int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
   if (a >= prm.A) return;
   if (perm) a = perm[a];
@@ -434,12 +435,14 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   float* red_s = w_s;
   *reinterpret_cast<float4*>(red_s + wv * 256 + lane * 4) = acc;
   __syncthreads();
-  out[(long)a * 256 + t] = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
+  const float res = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
+  if (prm.out_dt == FAR3D_DT_F32) reinterpret_cast<float*>(out)[(long)a * 256 + t] = res;
+  else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + t] = f32_to_bf16(res);
 }
 
 extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref,
                                        const float* offsets, const float* lidar2img, const float* U,
-                                       const float* Vc, const int32_t* perm, float* out, int A, int N, int S, int C, int G,
+                                       const float* Vc, const int32_t* perm, void* out, int out_dt, int A, int N, int S, int C, int G,
                                        int P, int L, const int32_t* level_hw, const int32_t* level_start,
                                        const float* pc_range, float pad_h, float pad_w, void* stream) {
   FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && Vc && out && level_hw && level_start && pc_range,
@@ -465,6 +468,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   for (int d = 0; d < 3; ++d) { prm.pc_lo[d] = pc_range[d]; prm.pc_span[d] = pc_range[3 + d] - pc_range[d]; }
   prm.pad_w = pad_w; prm.pad_h = pad_h;
   prm.q_per_xcd = cdiv(A, 8);
+  prm.out_dt = out_dt;
+  FAR3D_CHECK_ARG(out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16, "far3d_aggregate_forward: unsupported output dtype %d", out_dt);
   const size_t lds = (size_t)(N * P * L * 8 + 1024 + 2 * N * P + 64) * 4 + (size_t)N * P * 4;
   dim3 grid(8 * prm.q_per_xcd), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -495,16 +500,16 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   }
   if (feat_dtype == FAR3D_DT_F32)
     hipLaunchKernelGGL(aggregate_fwd_kernel<float>, grid, block, lds, st, (const float*)feat, ref, offsets,
-                       lidar2img, U, Vc, perm, out, prm);
+                       lidar2img, U, Vc, perm, (float*)out, prm);
   else if (abl == 1)
-    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 1>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 1>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, (float*)out, prm);
   else if (abl == 2)
-    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 2>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 2>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, (float*)out, prm);
   else if (abl == 3)
-    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 3>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 3>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, (float*)out, prm);
   else
     hipLaunchKernelGGL(aggregate_fwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)feat, ref, offsets,
-                       lidar2img, U, Vc, perm, out, prm);
+                       lidar2img, U, Vc, perm, (float*)out, prm);
   FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
   return FAR3D_OK;
 }

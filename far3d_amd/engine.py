@@ -376,46 +376,53 @@ class Far3DEngine:
         A, E = tgt.shape
         Km = mem.shape[0]
         at = self.prec["attn"]
+        fast = at == torch.bfloat16     # bf16 mode: GEMM operands are handed over as bf16 copies (LDS-DMA GEMM path)
         x = tgt
         xq = x + qpos
-        memk = (mem + mempos).contiguous()
+        memk = (mem + mempos)
+        if fast:
+            xb, xqb, memb, memkb = x.to(at), xq.to(at), mem.to(at).contiguous(), memk.to(at).contiguous()
+        else:
+            xb, xqb, memb, memkb = x, xq, mem, memk.contiguous()
         l2i = lidar2img[:, :3, :].flatten(1).contiguous()             # (N,12)
         outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
         # reference points are fixed across the 6 layers: one camera-sorted workgroup order per frame (scheduling only)
         perm = ops.camera_sorted_order(ref, lidar2img, self.pc_range, pad_hw)
         qk = self._buf(("qk",), (A + Km, 2 * E), at)
         vb = self._buf(("v",), (A + Km, E), at)
+        ln_kw = dict(add=qpos, add_dtype=at, bf16_copy=fast)
         for li, ly in enumerate(self.layers):
             # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
-            ops.linear(xq, ly["qk"], out=qk[:A])
-            ops.linear(memk, ly["k"], out=qk[A:, E:])
-            ops.linear(x, ly["v"], out=vb[:A])
-            ops.linear(mem, ly["v"], out=vb[A:])
-            att = ops.attention_forward(qk[:A, :E], qk[:, E:], vb, num_heads=cfg["num_heads"])
+            ops.linear(xqb, ly["qk"], out=qk[:A])
+            ops.linear(memkb, ly["k"], out=qk[A:, E:])
+            ops.linear(xb, ly["v"], out=vb[:A])
+            ops.linear(memb, ly["v"], out=vb[A:])
+            att = ops.attention_forward(qk[:A, :E], qk[:, E:], vb, num_heads=cfg["num_heads"], out_dtype=at)
             y = ops.linear(att, ly["out"], res=x)
-            x, xq = ops.layernorm(y, *ly["norms"][0], add=qpos)
+            r = ops.layernorm(y, *ly["norms"][0], **ln_kw)
+            x, xqb = r[0], r[1]
+            xb = r[2] if fast else x
             # cross-attention: fused perspective-aware aggregation (detr3d_transformer.py:522-569)
             ce = ops.linear(ops.linear(l2i, ly["ce0"], act="relu"), ly["ce2"], act="relu")
             ce = ops.layernorm(ce, *ly["ce_ln"])
             Vc = ops.linear(ce, ly["wfc_full"])                         # (N,416) camera part + bias
-            U = ops.linear(xq, ly["wfc"])                               # (A,416) query part
-            offs = ops.linear(x, ly["lfc"])                             # (A,39)
-            ev = self.kernel_events
-            if ev is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            U = ops.linear(xqb, ly["wfc"])                              # (A,416) query part
+            offs = ops.linear(xb, ly["lfc"])                            # (A,39)
             agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
-                                        num_groups=cfg["num_groups"], perm=perm)
+                                        num_groups=cfg["num_groups"], perm=perm, out_dtype=at)
             self.last_agg = (tokens, ref, offs, lidar2img, U, Vc, hw, starts, pad_hw, perm)   # for isolated kernel timing
-            if ev is not None:
-                e1.record()
-                ev.setdefault("aggregate_fwd", []).append((e0, e1))
             y = ops.linear(agg, ly["oproj"], res=x)
-            x = ops.layernorm(y, *ly["norms"][1])
+            if fast:
+                x, xb = ops.layernorm(y, *ly["norms"][1], bf16_copy=True)
+            else:
+                x = ops.layernorm(y, *ly["norms"][1])
+                xb = x
             # FFN: x + W2 relu(W1 x), hidden 1024 (SURVEY.md finding 4)
-            hdn = ops.linear(x, ly["ffn1"], act="relu")
+            hdn = ops.linear(xb, ly["ffn1"], act="relu", out_dtype=at)
             y = ops.linear(hdn, ly["ffn2"], res=x)
-            x, xq = ops.layernorm(y, *ly["norms"][2], add=qpos, out=outs[li])
+            r = ops.layernorm(y, *ly["norms"][2], out=outs[li], **ln_kw)
+            x, xqb = r[0], r[1]
+            xb = r[2] if fast else x
         return outs
 
     # ------------------------------------------------------------------------------------------ one frame

@@ -25,13 +25,13 @@ SIGNATURES = {
     "far3d_device_count": (c_int, []),
     "far3d_device_arch": (c_int, [c_int, c_char_p, c_int]),
     "far3d_msda_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p] + [c_int] * 7 + [_p]),
-    "far3d_aggregate_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p, _p] + [c_int] * 7 +
+    "far3d_aggregate_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p, _p, c_int] + [c_int] * 7 +
                                 [_p, _p, _p, c_float, c_float, _p]),
     "far3d_conv2d_nhwc": (c_int, [_p, c_int, _p, c_int, _p, _p, c_int] + [c_int] * 5 + [c_long] + [c_int] * 4 +
                           [c_long] + [c_int] * 5 + [_p, c_int, c_int, c_long, c_int, c_int] +
                           [_p, c_int, c_int, c_long, _p, _p, c_int, _p]),
-    "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p] + [c_int] * 8 + [c_float, _p]),
-    "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, _p]),
+    "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p, c_int] + [c_int] * 8 + [c_float, _p]),
+    "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, _p]),
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
                                c_int, c_long, _p]),
     "far3d_groupnorm_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p]),

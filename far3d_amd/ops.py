@@ -86,7 +86,7 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, a
 
 
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None, perm=None):
+                      num_groups=8, out=None, perm=None, out_dtype=torch.float32):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
@@ -111,7 +111,7 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         raise ValueError("aggregate_forward: inconsistent shapes U%s Vc%s l2i%s (A=%d N=%d L=%d P=%d G=%d)" %
                          (tuple(U.shape), tuple(Vc.shape), tuple(lidar2img.shape), A, N, L, P, G))
     if out is None:
-        out = torch.empty((A, C), dtype=torch.float32, device=feat.device)
+        out = torch.empty((A, C), dtype=out_dtype, device=feat.device)
     if perm is not None:
         _chk(perm, "perm", torch.int32, 1)
         if perm.numel() != A:
@@ -120,7 +120,7 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     st_keep, st_p = _host_i32(list(level_start))
     pc_keep, pc_p = _host_f32(list(pc_range))
     _lib.check(lib.far3d_aggregate_forward(_ptr(feat), _dt(feat), _ptr(ref), _ptr(offsets), _ptr(lidar2img),
-                                           _ptr(U), _ptr(Vc), _ptr(perm) if perm is not None else None, _ptr(out),
+                                           _ptr(U), _ptr(Vc), _ptr(perm) if perm is not None else None, _ptr(out), _dt(out),
                                            A, N, S, C, G, P, L, hw_p, st_p, pc_p,
                                            float(pad_hw[0]), float(pad_hw[1]), _stream(feat)),
                "far3d_aggregate_forward")
@@ -239,7 +239,7 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
 # --------------------------------------------------------------------------------------------------
 # attention / normalisation / pooling
 # --------------------------------------------------------------------------------------------------
-def attention_forward(q, k, v, num_heads=8, out=None):
+def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32):
     """softmax(q k^T / sqrt(d)) v per head.  q (Aq,E), k/v (Nk,E) f32|bf16 with unit inner stride; out (Aq,E) f32."""
     lib = _lib.require_device()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
@@ -251,28 +251,31 @@ def attention_forward(q, k, v, num_heads=8, out=None):
     Nk = k.shape[0]
     hd = E // num_heads
     if out is None:
-        out = torch.empty((Aq, E), dtype=torch.float32, device=q.device)
-    _lib.check(lib.far3d_attention_forward(_ptr(q), _ptr(k), _ptr(v), _dt(q), _ptr(out), Aq, Nk, num_heads, hd,
+        out = torch.empty((Aq, E), dtype=out_dtype, device=q.device)
+    _lib.check(lib.far3d_attention_forward(_ptr(q), _ptr(k), _ptr(v), _dt(q), _ptr(out), _dt(out), Aq, Nk, num_heads, hd,
                                            q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                            float(hd) ** -0.5, _stream(q)), "far3d_attention_forward")
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None):
-    """Returns LN(x) (and LN(x)+add when `add` is given)."""
+def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=torch.float32, bf16_copy=False):
+    """Returns LN(x); with `add`: (LN(x), LN(x)+add [add_dtype]); with bf16_copy also a bf16 copy of LN(x) (last)."""
     lib = _lib.require_device()
     if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
         raise ValueError("layernorm: x must be (rows,C) f32 with unit inner stride")
     rows, C = x.shape
     y = out if out is not None else torch.empty((rows, C), dtype=torch.float32, device=x.device)
-    y2 = torch.empty_like(y) if add is not None else None
+    y2 = torch.empty((rows, C), dtype=add_dtype, device=x.device) if add is not None else None
+    yb = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device) if bf16_copy else None
     _lib.check(lib.far3d_layernorm(_ptr(x), _ptr(gamma) if gamma is not None else None,
                                    _ptr(beta) if beta is not None else None, _ptr(y), rows, C, x.stride(0), y.stride(0),
                                    float(eps), 1 if act == "relu" else 0,
                                    _ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
                                    _ptr(y2) if y2 is not None else None, y2.stride(0) if y2 is not None else 0,
-                                   _stream(x)), "far3d_layernorm")
-    return (y, y2) if add is not None else y
+                                   _dt(y2) if y2 is not None else 0, _ptr(yb) if yb is not None else None,
+                                   yb.stride(0) if yb is not None else 0, _stream(x)), "far3d_layernorm")
+    res = (y,) + ((y2,) if add is not None else ()) + ((yb,) if bf16_copy else ())
+    return res if len(res) > 1 else y
 
 
 def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):

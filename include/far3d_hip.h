@@ -55,12 +55,12 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * U (A,L*P*G) f32 and Vc (N,L*P*G) f32 with logits[a,n,(l*P+p)*G+g] = U[a,.] + Vc[n,.]
  *   ( = weights_fc((x+pos)[a] + cam_embed[n]) split by linearity; bias lives in Vc );
  * level_hw (L,2) int32 HOST (h,w); level_start (L) int32 HOST; pc_range 6 floats HOST;
- * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) f32.  perm: optional (A) int32 DEVICE permutation giving
+ * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) of dtype out_dt (f32 | bf16).  perm: optional (A) int32 DEVICE permutation giving
  * the order in which queries are assigned to workgroups (camera-sorted order keeps one XCD's L2 on 1-2 cameras); it never
  * changes results (row a of `out` is always query a).  Requires C=256, G=8, L<=4,
  * N*P<=256, N*P*L<=384. */
 int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
-                            const float* lidar2img, const float* U, const float* Vc, const int32_t* perm, float* out, int A,
+                            const float* lidar2img, const float* U, const float* Vc, const int32_t* perm, void* out, int out_dt, int A,
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
                             void* stream);
@@ -96,16 +96,18 @@ int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const fl
  *   statement of the wrapper models/utils/petr_transformer.py:286-326).  The in/out projections are
  *   far3d_conv2d_nhwc calls.
  * q (Aq, heads*32), k/v (Nk, heads*32) of `dtype` (F32 -> exact fp32 MFMA, BF16 -> bf16 MFMA), row strides
- * ldq/ldk/ldv elements; out (Aq, heads*32) f32, row stride ldo.  head_dim must be 32.  No masks (inference). */
-int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, float* out, int Aq, int Nk,
+ * ldq/ldk/ldv elements; out (Aq, heads*32) of dtype out_dt (f32 | bf16), row stride ldo.  head_dim must be 32.  No masks (inference). */
+int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq, int Nk,
                             int heads, int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 
 /* y = act(LayerNorm_C(x) * gamma + beta); optional y2 = y + add (next GEMM's "query + query_pos").
  * Replaces nn.LayerNorm at ref models/utils/detr3d_transformer.py:304-307,398-400,506-512 and
  * models/dense_heads/farhead.py:230-239,274-277.  x,y,add,y2: f32 rows with strides ldx,ldy,lda,ldy2 (multiples of 4);
- * gamma/beta may be NULL (no affine).  act: 0 none, 1 ReLU.  C multiple of 4, <= 1024. */
+ * gamma/beta may be NULL (no affine).  act: 0 none, 1 ReLU.  C multiple of 4, <= 1024.  y2 has dtype y2_dt (f32 | bf16);
+ * yb (optional) receives a bf16 copy of y (row stride ldyb) -- the next GEMM's operands without a conversion pass. */
 int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int ldx,
-                    int ldy, float eps, int act, const float* add, int lda, float* y2, int ldy2, void* stream);
+                    int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2, int y2_dt, void* yb, int ldyb,
+                    void* stream);
 
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
