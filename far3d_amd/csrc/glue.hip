@@ -1,0 +1,280 @@
+// Small fused kernels for the FarHead query / streaming-memory bookkeeping.
+// Each replaces a chain of 10-40 tiny tensor ops of the reference (every one of which costs a launch + a kernel
+// boundary on the GPU); arithmetic follows the reference expression by expression.
+#include "common.hpp"
+
+#define TWO_PI_F 6.283185307179586f
+#define TWO_PI_D 6.283185307179586
+
+// ------------------------------------------------------------------------------------------ pos2posemb3d
+// ref models/utils/positional_encoding.py:13-25: out = cat(emb(y), emb(x), emb(z)), emb(p)[i] = i even ? sin(p*2pi/dim_t[i]) : cos(..)
+__global__ __launch_bounds__(128) void posemb3d_kernel(const float* __restrict__ pos, const float* __restrict__ dim_t,
+                                                       float* __restrict__ out, int R) {
+  const int r = blockIdx.x, i = threadIdx.x;   // 128 threads: one frequency slot for the three coordinates
+  if (r >= R) return;
+  const float dt = dim_t[i];
+  const int src[3] = {1, 0, 2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float p = (pos[r * 3 + src[k]] * TWO_PI_F) / dt;
+    out[(long)r * 384 + k * 128 + i] = (i & 1) ? cosf(p) : sinf(p);
+  }
+}
+
+extern "C" int far3d_posemb3d(const float* pos, const float* dim_t128, float* out, int R, void* stream) {
+  FAR3D_CHECK_ARG(pos && dim_t128 && out && R >= 0, "far3d_posemb3d: bad arguments");
+  if (R == 0) return FAR3D_OK;
+  hipLaunchKernelGGL(posemb3d_kernel, dim3(R), dim3(128), 0, (hipStream_t)stream, pos, dim_t128, out, R);
+  FAR3D_CHECK_LAUNCH("far3d_posemb3d");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ memory: pre-update + codes
+// One workgroup per memory slot.  ref models/dense_heads/farhead.py:453-477 (pre_update_memory), :287,:297-298,:303
+// (temporal_alignment inputs), models/utils/misc.py:7-11,193-202, positional_encoding.py:27-80.
+//   state (persistent): emb (L,E) ref (L,3) ts (L) f64 pose (L,16) velo (L,2)
+//   out: m_emb m_ref m_ts m_pose m_velo (the pre-updated memory), temp_ref (L,3) normalised,
+//        nerf (L,180) = nerf_encoding([velo, ts, pose[:3,:]]) in f32, tpos (L,256) = pos2posemb1d(ts) (f64 math -> f32)
+struct MemPrepParams {
+  const float *emb, *ref, *pose, *velo;
+  const double* ts;
+  const float *ego_inv, *pseudo_ref, *dim_t256;   // (16), (P,3) normalised, (256)
+  const double* timestamp;                         // (1)
+  float *m_emb, *m_ref, *m_pose, *m_velo, *temp_ref, *nerf, *tpos;
+  double* m_ts;
+  int L, E, P;
+  float x;                 // prev_exists (1 steady state, 0 first frame of a scene)
+  int fresh;               // state is all zeros (skip the ego warp exactly like the reference's first frame)
+  float pc_lo[3], pc_span[3];
+};
+
+__global__ __launch_bounds__(256) void mem_prepare_kernel(MemPrepParams p) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  __shared__ float sh[32];     // [0:16) pose', [16:19) ref', [19:21) velo'
+  __shared__ double sh_ts;
+  const float x = p.x;
+  if (t < 16) {
+    float v;
+    if (p.fresh) {
+      v = p.pose[s * 16 + t];
+    } else {
+      const int i = t >> 2, j = t & 3;
+      v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v += p.ego_inv[i * 4 + k] * p.pose[s * 16 + k * 4 + j];
+      v *= x;
+    }
+    if (s < p.P) v += (1.f - x) * ((t >> 2) == (t & 3) ? 1.f : 0.f);
+    sh[t] = v;
+    p.m_pose[s * 16 + t] = v;
+  } else if (t < 19) {
+    const int i = t - 16;
+    float v;
+    if (p.fresh) {
+      v = p.ref[s * 3 + i];
+    } else {
+      v = p.ego_inv[i * 4 + 0] * p.ref[s * 3 + 0] + p.ego_inv[i * 4 + 1] * p.ref[s * 3 + 1] + p.ego_inv[i * 4 + 2] * p.ref[s * 3 + 2] +
+          p.ego_inv[i * 4 + 3];
+      v *= x;
+    }
+    if (s < p.P) v += (1.f - x) * (p.pseudo_ref[s * 3 + i] * p.pc_span[i] + p.pc_lo[i]);
+    sh[t] = v;
+    p.m_ref[s * 3 + i] = v;
+    p.temp_ref[s * 3 + i] = (v - p.pc_lo[i]) / p.pc_span[i];
+  } else if (t < 21) {
+    const float v = p.fresh ? p.velo[s * 2 + (t - 19)] : p.velo[s * 2 + (t - 19)] * x;
+    sh[t] = v;
+    p.m_velo[s * 2 + (t - 19)] = v;
+  } else if (t == 21) {
+    const double v = p.fresh ? p.ts[s] : (p.ts[s] + p.timestamp[0]) * (double)x;
+    sh_ts = v;
+    p.m_ts[s] = v;
+  }
+  for (int c = t; c < p.E; c += 256) p.m_emb[(long)s * p.E + c] = p.fresh ? p.emb[(long)s * p.E + c] : p.emb[(long)s * p.E + c] * x;
+  __syncthreads();
+  // nerf code: cat over f in {1,2,4,..,32} of [sin(v*f) (15), cos(v*f) (15)], v = [velo(2), ts(1), pose rows 0..2 (12)] as f32
+  if (t < 180) {
+    const int f = t / 30, r = t - f * 30, d = r % 15;
+    const float v = d < 2 ? sh[19 + d] : (d == 2 ? (float)sh_ts : sh[d - 3]);
+    const float a = v * (float)(1 << f);
+    p.nerf[(long)s * 180 + t] = r < 15 ? sinf(a) : cosf(a);
+  }
+  // time code: pos2posemb1d on the f64 timestamp, cast to f32 afterwards (farhead.py:303)
+  {
+    const double q = (sh_ts * TWO_PI_D) / (double)p.dim_t256[t];
+    p.tpos[(long)s * 256 + t] = (float)((t & 1) ? cos(q) : sin(q));
+  }
+}
+
+extern "C" int far3d_memory_prepare(const float* emb, const float* ref, const double* ts, const float* pose, const float* velo,
+                                    const float* ego_pose_inv, const double* timestamp, const float* pseudo_ref,
+                                    const float* dim_t256, float prev_exists, int fresh, const float* pc_range, int L, int E,
+                                    int P, float* m_emb, float* m_ref, double* m_ts, float* m_pose, float* m_velo,
+                                    float* temp_ref, float* nerf, float* tpos, void* stream) {
+  FAR3D_CHECK_ARG(emb && ref && ts && pose && velo && ego_pose_inv && timestamp && dim_t256 && pc_range && m_emb && m_ref && m_ts &&
+                  m_pose && m_velo && temp_ref && nerf && tpos && (P == 0 || pseudo_ref), "far3d_memory_prepare: null argument");
+  FAR3D_CHECK_ARG(L > 0 && E > 0 && P >= 0 && P <= L, "far3d_memory_prepare: bad sizes");
+  MemPrepParams p;
+  p.emb = emb; p.ref = ref; p.ts = ts; p.pose = pose; p.velo = velo; p.ego_inv = ego_pose_inv; p.timestamp = timestamp;
+  p.pseudo_ref = pseudo_ref; p.dim_t256 = dim_t256; p.m_emb = m_emb; p.m_ref = m_ref; p.m_ts = m_ts; p.m_pose = m_pose;
+  p.m_velo = m_velo; p.temp_ref = temp_ref; p.nerf = nerf; p.tpos = tpos; p.L = L; p.E = E; p.P = P; p.x = prev_exists; p.fresh = fresh;
+  for (int k = 0; k < 3; ++k) { p.pc_lo[k] = pc_range[k]; p.pc_span[k] = pc_range[3 + k] - pc_range[k]; }
+  hipLaunchKernelGGL(mem_prepare_kernel, dim3(L), dim3(256), 0, (hipStream_t)stream, p);
+  FAR3D_CHECK_LAUNCH("far3d_memory_prepare");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ heads: box finalisation + scores
+// ref models/dense_heads/farhead.py:649-664: xyz = sigmoid(reg[:3] + inverse_sigmoid(ref)) * range + min (mmdet
+// inverse_sigmoid: clamp to [0,1], eps 1e-5); also score[a] = max_c sigmoid(cls_last[a,c]) (farhead.py:490).
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ reg, const float* __restrict__ ref,
+                                                            const float* __restrict__ cls_last, float* __restrict__ box,
+                                                            float* __restrict__ score, int layers, int A, int code, int ncls,
+                                                            float lo0, float lo1, float lo2, float sp0, float sp1, float sp2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < layers * A) {
+    const int a = i % A;
+    const float lo[3] = {lo0, lo1, lo2}, sp[3] = {sp0, sp1, sp2};
+    const float* r = reg + (long)i * code;
+    float* b = box + (long)i * code;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float x = fminf(fmaxf(ref[a * 3 + k], 0.f), 1.f);
+      const float inv = logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+      const float z = r[k] + inv;
+      b[k] = (1.f / (1.f + expf(-z))) * sp[k] + lo[k];
+    }
+    for (int k = 3; k < code; ++k) b[k] = r[k];
+  }
+  if (i < A && score) {
+    const float* c = cls_last + (long)i * ncls;
+    float m = c[0];
+    for (int k = 1; k < ncls; ++k) m = fmaxf(m, c[k]);
+    score[i] = 1.f / (1.f + expf(-m));
+  }
+}
+
+extern "C" int far3d_head_finalize(const float* reg, const float* ref, const float* cls_last, float* box, float* score,
+                                   int layers, int A, int code_size, int num_classes, const float* pc_range, void* stream) {
+  FAR3D_CHECK_ARG(reg && ref && box && pc_range && layers > 0 && A >= 0 && code_size >= 3, "far3d_head_finalize: bad arguments");
+  FAR3D_CHECK_ARG(!score || cls_last, "far3d_head_finalize: score needs cls_last");
+  if (A == 0) return FAR3D_OK;
+  const int n = layers * A;
+  hipLaunchKernelGGL(head_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, reg, ref, cls_last, box, score,
+                     layers, A, code_size, num_classes, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0],
+                     pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]);
+  FAR3D_CHECK_LAUNCH("far3d_head_finalize");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ memory: post-update
+// ref models/dense_heads/farhead.py:479-508: push the top-K queries in front of the queue, truncate to L, warp by ego_pose.
+struct MemPostParams {
+  const float *m_emb, *m_ref, *m_pose, *m_velo;
+  const double* m_ts;
+  const long* topk;          // (K) indices into the A queries
+  const float *dec_last, *box_last, *ego_pose;   // (A,E), (A,code), (16)
+  const double* timestamp;
+  float *emb, *ref, *pose, *velo;
+  double* ts;
+  int L, E, K, code;
+};
+
+__global__ __launch_bounds__(256) void mem_post_kernel(MemPostParams p) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  const bool isnew = s < p.K;
+  const int src = isnew ? (int)p.topk[s] : s - p.K;
+  __shared__ float sh[20];
+  if (t < 16) sh[t] = isnew ? (((t >> 2) == (t & 3)) ? 1.f : 0.f) : p.m_pose[src * 16 + t];
+  else if (t < 19) sh[t] = isnew ? p.box_last[(long)src * p.code + (t - 16)] : p.m_ref[src * 3 + (t - 16)];
+  for (int c = t; c < p.E; c += 256) p.emb[(long)s * p.E + c] = isnew ? p.dec_last[(long)src * p.E + c] : p.m_emb[(long)src * p.E + c];
+  if (t >= 32 && t < 34) p.velo[s * 2 + (t - 32)] = isnew ? p.box_last[(long)src * p.code + p.code - 2 + (t - 32)] : p.m_velo[src * 2 + (t - 32)];
+  if (t == 34) p.ts[s] = (isnew ? 0.0 : p.m_ts[src]) - p.timestamp[0];
+  __syncthreads();
+  if (t < 16) {
+    const int i = t >> 2, j = t & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += p.ego_pose[i * 4 + k] * sh[k * 4 + j];
+    p.pose[s * 16 + t] = v;
+  } else if (t < 19) {
+    const int i = t - 16;
+    p.ref[s * 3 + i] = p.ego_pose[i * 4 + 0] * sh[16] + p.ego_pose[i * 4 + 1] * sh[17] + p.ego_pose[i * 4 + 2] * sh[18] + p.ego_pose[i * 4 + 3];
+  }
+}
+
+extern "C" int far3d_memory_post_update(const float* m_emb, const float* m_ref, const double* m_ts, const float* m_pose,
+                                        const float* m_velo, const int64_t* topk_idx, const float* dec_last, const float* box_last,
+                                        const float* ego_pose, const double* timestamp, int L, int E, int K, int code_size,
+                                        float* emb, float* ref, double* ts, float* pose, float* velo, void* stream) {
+  FAR3D_CHECK_ARG(m_emb && m_ref && m_ts && m_pose && m_velo && topk_idx && dec_last && box_last && ego_pose && timestamp && emb && ref &&
+                  ts && pose && velo, "far3d_memory_post_update: null argument");
+  FAR3D_CHECK_ARG(L > 0 && K >= 0 && K <= L && code_size >= 5, "far3d_memory_post_update: bad sizes");
+  MemPostParams p;
+  p.m_emb = m_emb; p.m_ref = m_ref; p.m_ts = m_ts; p.m_pose = m_pose; p.m_velo = m_velo; p.topk = (const long*)topk_idx;
+  p.dec_last = dec_last; p.box_last = box_last; p.ego_pose = ego_pose; p.timestamp = timestamp; p.emb = emb; p.ref = ref; p.ts = ts;
+  p.pose = pose; p.velo = velo; p.L = L; p.E = E; p.K = K; p.code = code_size;
+  hipLaunchKernelGGL(mem_post_kernel, dim3(L), dim3(256), 0, (hipStream_t)stream, p);
+  FAR3D_CHECK_LAUNCH("far3d_memory_post_update");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ add + cast
+// out_sum = a + b (dtype sum_dt), out_a = a (dtype a_dt, optional): the decoder's "query + query_pos" operands in one pass.
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, void* __restrict__ osum,
+                                                       int sum_dt, void* __restrict__ oa, int a_dt, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    const float4 s = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    if (sum_dt == FAR3D_DT_F32) reinterpret_cast<float4*>(osum)[i] = s;
+    else reinterpret_cast<uint2*>(osum)[i] = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+    if (oa) {
+      if (a_dt == FAR3D_DT_F32) reinterpret_cast<float4*>(oa)[i] = x;
+      else reinterpret_cast<uint2*>(oa)[i] = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
+    }
+  }
+}
+
+extern "C" int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, void* out_a, int a_dt, long n, void* stream) {
+  FAR3D_CHECK_ARG(a && b && out_sum && n >= 0 && (n % 4) == 0, "far3d_add_cast: bad arguments (n must be a multiple of 4)");
+  if (n == 0) return FAR3D_OK;
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out_sum, sum_dt, out_a, a_dt, n4);
+  FAR3D_CHECK_LAUNCH("far3d_add_cast");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ aggregation scheduling keys
+// key[a] = (camera whose image centre the reference point projects closest to, 8x8 image cell) -- see ops.camera_sorted_order
+__global__ __launch_bounds__(256) void agg_order_keys_kernel(const float* __restrict__ ref, const float* __restrict__ l2i,
+                                                             int* __restrict__ keys, int A, int N, float lo0, float lo1, float lo2,
+                                                             float sp0, float sp1, float sp2, float pad_h, float pad_w) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  const float X = ref[a * 3] * sp0 + lo0, Y = ref[a * 3 + 1] * sp1 + lo1, Z = ref[a * 3 + 2] * sp2 + lo2;
+  float best = 3.0e9f, bu = 0.f, bv = 0.f;
+  int cam = 0;
+  for (int n = 0; n < N; ++n) {
+    const float* m = l2i + n * 16;
+    const float x = m[0] * X + m[1] * Y + m[2] * Z + m[3], y = m[4] * X + m[5] * Y + m[6] * Z + m[7], z = m[8] * X + m[9] * Y + m[10] * Z + m[11];
+    const float zc = fmaxf(z, 1e-5f);
+    const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
+    const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
+    if (cost < best) { best = cost; cam = n; bu = u; bv = v; }
+  }
+  const int ub = (int)(fminf(fmaxf(bu + 0.5f, 0.f), 0.999f) * 8.f), vb = (int)(fminf(fmaxf(bv + 0.5f, 0.f), 0.999f) * 8.f);
+  keys[a] = (cam * 8 + vb) * 8 + ub;
+}
+
+extern "C" int far3d_agg_order_keys(const float* ref, const float* lidar2img, int32_t* keys, int A, int N, const float* pc_range,
+                                    float pad_h, float pad_w, void* stream) {
+  FAR3D_CHECK_ARG(ref && lidar2img && keys && pc_range && A >= 0 && N > 0, "far3d_agg_order_keys: bad arguments");
+  if (A == 0) return FAR3D_OK;
+  hipLaunchKernelGGL(agg_order_keys_kernel, dim3((A + 255) / 256), dim3(256), 0, (hipStream_t)stream, ref, lidar2img, keys, A, N,
+                     pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2],
+                     pad_h, pad_w);
+  FAR3D_CHECK_LAUNCH("far3d_agg_order_keys");
+  return FAR3D_OK;
+}

@@ -217,6 +217,8 @@ class Far3DEngine:
             self.layers.append(ly)
         # ---- frame-invariant pieces of temporal_alignment (farhead.py:284-303): the current frame's ego motion is the
         # identity, so its MLN(180) codes are constants, and the 644 learned queries never change.
+        mk_dim_t = lambda n: (10000 ** (2 * torch.div(torch.arange(n, dtype=torch.float32, device=dev), 2, rounding_mode="floor") / n)).contiguous()
+        self.dim_t128, self.dim_t256 = mk_dim_t(128), mk_dim_t(256)
         eye = torch.eye(4, device=dev)[:3, :].flatten()
         rec = nerf_encoding(torch.cat([torch.zeros(3, device=dev), eye])[None])              # (1,180)
         self.rec_code = {}
@@ -229,7 +231,7 @@ class Far3DEngine:
         self.tgt_fixed = ops.row_affine_ln(torch.zeros_like(qp), *self.rec_code["ego_pose_memory"])
 
     def _query_pos(self, ref):
-        return self.qe[1](self.qe[0](pos2posemb3d(ref).contiguous(), act="relu"))
+        return self.qe[1](self.qe[0](ops.posemb3d(ref.contiguous(), self.dim_t128), act="relu"))
 
     def _buf(self, key, shape, dtype):
         b = self._bufs.get(key)
@@ -378,16 +380,14 @@ class Far3DEngine:
         at = self.prec["attn"]
         fast = at == torch.bfloat16     # bf16 mode: GEMM operands are handed over as bf16 copies (LDS-DMA GEMM path)
         x = tgt
-        xq = x + qpos
-        memk = (mem + mempos)
-        if fast:
-            xb, xqb, memb, memkb = x.to(at), xq.to(at), mem.to(at).contiguous(), memk.to(at).contiguous()
-        else:
-            xb, xqb, memb, memkb = x, xq, mem, memk.contiguous()
+        xqb, xb = ops.add_cast(x, qpos, at, at if fast else None)
+        memkb, memb = ops.add_cast(mem, mempos, at, at if fast else None)
+        if not fast:
+            xb, memb = x, mem
         l2i = lidar2img[:, :3, :].flatten(1).contiguous()             # (N,12)
         outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
         # reference points are fixed across the 6 layers: one camera-sorted workgroup order per frame (scheduling only)
-        perm = ops.camera_sorted_order(ref, lidar2img, self.pc_range, pad_hw)
+        perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw)
         qk = self._buf(("qk",), (A + Km, 2 * E), at)
         vb = self._buf(("v",), (A + Km, E), at)
         ln_kw = dict(add=qpos, add_dtype=at, bf16_copy=fast)
@@ -474,21 +474,17 @@ class Far3DEngine:
         fresh = img_metas[0]["scene_token"] != self.prev_scene or self.mem is None
         if fresh:
             self.prev_scene = img_metas[0]["scene_token"]
-            prev = torch.zeros(1, device=dev)
             self._mem_init()
-        else:
-            prev = torch.ones(1, device=dev)
-        m = self._pre_update_memory(dd, prev, fresh)
-        # ---- a6: queries
+        # ---- a6: memory pre-update + temporal codes (one kernel), then the adaptive / propagated queries
         P_ = cfg["num_propagated"]
+        m, temp_ref, mem_code, tpos = ops.memory_prepare(self.mem, dd["ego_pose_inv"], dd["timestamp"], self.pseudo_ref, self.dim_t256,
+                                                         0.0 if fresh else 1.0, fresh, cfg["pc_range"], P_)
         if M > 0:
             qpos_a = ops.row_affine_ln(self._query_pos(ref2d), *self.rec_code["ego_pose_pe"], add=self.time0)
             tgt_a = ops.row_affine_ln(self.ce[1](self.ce[0](ctx, act="relu")), *self.rec_code["ego_pose_memory"])
-        temp_ref = ((m["ref"][0] - self.pc_lo) / self.pc_span).contiguous()
-        mem_code = nerf_encoding(torch.cat([m["velo"][0], m["ts"][0], m["pose"][0][:, :3, :].flatten(1)], dim=-1).float()).contiguous()
-        t_emb = ops.layernorm(self.te(pos2posemb(m["ts"][0, :, 0], 256).float().contiguous()), *self.te_ln)
+        t_emb = ops.layernorm(self.te(tpos), *self.te_ln)
         temp_pos = self._mln_rows(self._query_pos(temp_ref), mem_code, "ego_pose_pe", add=t_emb)
-        temp_mem = self._mln_rows(m["emb"][0].contiguous(), mem_code, "ego_pose_memory")
+        temp_mem = self._mln_rows(m["emb"][0], mem_code, "ego_pose_memory")
         parts_t, parts_q, parts_r = [self.tgt_fixed], [self.qpos_fixed], [self.ref_fixed]
         if M > 0:
             parts_t.append(tgt_a); parts_q.append(qpos_a); parts_r.append(ref2d)
@@ -503,26 +499,13 @@ class Far3DEngine:
         c1 = ops.layernorm(self.cls_b[0](flat), *self.cls_ln[0], act="relu")
         c2 = ops.layernorm(self.cls_b[1](c1), *self.cls_ln[1], act="relu")
         all_cls = self.cls_b[2](c2).view(cfg["num_layers"], 1, A, cfg["num_classes"])
-        rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](flat, act="relu"), act="relu")).view(cfg["num_layers"], 1, A, cfg["code_size"])
-        xyz = (rr[..., 0:3] + inverse_sigmoid(ref)[None, None]).sigmoid() * self.pc_span + self.pc_lo
-        all_box = torch.cat([xyz, rr[..., 3:]], dim=-1)
-        # ---- a11: memory post-update (farhead.py:479-508)
-        sc = all_cls[-1].sigmoid().topk(1, dim=-1).values[..., 0:1]
-        _, idx = torch.topk(sc, cfg["topk_proposals"], dim=1)
-        g = lambda t: torch.gather(t, 1, idx.view(1, -1, *([1] * (t.dim() - 2))).repeat(1, 1, *t.shape[2:]))
-        Lm = cfg["memory_len"]
-        rec_pose = self.eye4.view(1, 1, 4, 4).repeat(1, A, 1, 1)
-        n_emb = torch.cat([g(outs_dec[-1][None]), m["emb"]], dim=1)[:, :Lm]
-        n_ts = torch.cat([g(torch.zeros_like(sc, dtype=torch.float64)), m["ts"]], dim=1)[:, :Lm]
-        n_pose = torch.cat([g(rec_pose), m["pose"]], dim=1)[:, :Lm]
-        n_ref = torch.cat([g(all_box[-1][..., :3]), m["ref"]], dim=1)[:, :Lm]
-        n_velo = torch.cat([g(all_box[-1][..., -2:]), m["velo"]], dim=1)[:, :Lm]
-        s_ = self.mem   # in-place update of the persistent buffers (graph-replay safe)
-        s_["emb"].copy_(n_emb)
-        s_["velo"].copy_(n_velo)
-        s_["ref"].copy_(self._transform_ref(n_ref, dd["ego_pose"]))
-        s_["ts"].copy_(n_ts - dd["timestamp"].unsqueeze(-1).unsqueeze(-1))
-        s_["pose"].copy_(dd["ego_pose"].unsqueeze(1) @ n_pose)
+        rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](flat, act="relu"), act="relu"))
+        nl = cfg["num_layers"]
+        box_flat, sc = ops.head_finalize(rr, ref, all_cls[-1][0], cfg["pc_range"], nl, cfg["num_classes"])
+        all_box = box_flat.view(nl, 1, A, cfg["code_size"])
+        # ---- a11: memory post-update (farhead.py:479-508): top-k by max-class score, push, truncate, ego warp -- in place
+        idx = torch.topk(sc, cfg["topk_proposals"], dim=0).indices
+        ops.memory_post_update(m, idx, outs_dec[-1], all_box[-1][0], dd["ego_pose"], dd["timestamp"], self.mem)
         outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
                     reference_points=ref)
         outs["result"] = self.decode(all_cls, all_box)

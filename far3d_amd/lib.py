@@ -41,6 +41,12 @@ SIGNATURES = {
     "far3d_proposal_gather": (c_int, [_p, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, _p, _p, c_int, c_int, c_int, c_int,
                                       c_float, c_float, c_int, _p, _p, c_int, c_int, _p, c_float, _p, _p, _p, _p, _p]),
     "far3d_row_affine_ln": (c_int, [_p, _p, _p, _p, _p] + [c_int] * 6 + [c_float, c_int, _p]),
+    "far3d_posemb3d": (c_int, [_p, _p, _p, c_int, _p]),
+    "far3d_memory_prepare": (c_int, [_p] * 9 + [c_float, c_int, _p, c_int, c_int, c_int] + [_p] * 9),
+    "far3d_head_finalize": (c_int, [_p] * 5 + [c_int] * 4 + [_p, _p]),
+    "far3d_memory_post_update": (c_int, [_p] * 10 + [c_int] * 4 + [_p] * 6),
+    "far3d_add_cast": (c_int, [_p, _p, _p, c_int, _p, c_int, c_long, _p]),
+    "far3d_agg_order_keys": (c_int, [_p, _p, _p, c_int, c_int, _p, c_float, c_float, _p]),
 }
 
 _lib = None

@@ -135,14 +135,23 @@ _TUNING = None
 
 
 def _tuned_tile(Cout, Cin, k, stride, npix):
-    """Workgroup tile measured fastest on MI355X for this conv shape (tools/tune_conv.py); 0 = kernel heuristic."""
+    """Workgroup tile measured fastest on MI355X for this conv shape (tools/tune_conv.py); 0 = kernel heuristic.
+    Shapes that were not swept (e.g. fewer cameras per rank in camera-sharded mode) borrow the entry of the same layer
+    geometry with the closest pixel count."""
     global _TUNING
     if _TUNING is None:
         import json
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tuning_mi355x.json")
-        _TUNING = json.load(open(path)) if os.path.exists(path) else {}
-    return int(_TUNING.get("%d,%d,%d,%d,%d" % (Cout, Cin, k, stride, npix), 0))
+        raw = json.load(open(path)) if os.path.exists(path) else {}
+        _TUNING = {}
+        for key, tile in raw.items():
+            co, ci, kk, st, npx = (int(v) for v in key.split(","))
+            _TUNING.setdefault((co, ci, kk, st), []).append((npx, int(tile)))
+    cands = _TUNING.get((Cout, Cin, k, stride))
+    if not cands:
+        return 0
+    return min(cands, key=lambda c: abs(c[0] - npix))[1]
 
 
 class PackedConv:
@@ -420,9 +429,10 @@ def row_affine_ln(x, gamma, beta, add=None, do_ln=True, eps=1e-5, out=None):
 
 
 
-def camera_sorted_order(ref, lidar2img, pc_range, pad_hw):
+def camera_sorted_order(ref, lidar2img, pc_range, pad_hw, spatial=True):
     """Query order for aggregate_forward's `perm`: queries sorted by the camera whose image centre their reference point
-    projects closest to (stable).  Pure scheduling hint -- results do not depend on it."""
+    projects closest to, then (spatial=True) by image tile (8 x 8 coarse cells, row-major) inside that camera, so that
+    consecutive workgroups of one XCD touch neighbouring pixels.  Pure scheduling hint -- results do not depend on it."""
     pc = pc_range if isinstance(pc_range, torch.Tensor) else torch.as_tensor(pc_range, dtype=torch.float32, device=ref.device)
     pts = ref * (pc[3:6] - pc[0:3]) + pc[0:3]
     p = torch.einsum("nij,aj->nai", lidar2img[:, :3, :3], pts) + lidar2img[:, :3, 3][:, None, :]       # (N,A,3)
@@ -431,4 +441,85 @@ def camera_sorted_order(ref, lidar2img, pc_range, pad_hw):
     v = p[..., 1] / z.clamp(min=1e-5) / pad_hw[0] - 0.5
     cost = torch.where(z > 1e-5, u * u + v * v, torch.full_like(z, 1e9))
     cam = cost.argmin(dim=0)
-    return torch.sort(cam, stable=True).indices.to(torch.int32).contiguous()
+    key = cam
+    if spatial:
+        uu = torch.gather(u, 0, cam[None])[0]
+        vv = torch.gather(v, 0, cam[None])[0]
+        ub = ((uu + 0.5).clamp(0, 0.999) * 8).long()
+        vb = ((vv + 0.5).clamp(0, 0.999) * 8).long()
+        key = (cam * 8 + vb) * 8 + ub
+    return torch.sort(key, stable=True).indices.to(torch.int32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# fused FarHead bookkeeping (glue.hip)
+# --------------------------------------------------------------------------------------------------
+def posemb3d(pos, dim_t128):
+    lib = _lib.require_device()
+    _chk(pos, "pos", torch.float32, 2)
+    out = torch.empty((pos.shape[0], 384), dtype=torch.float32, device=pos.device)
+    _lib.check(lib.far3d_posemb3d(_ptr(pos), _ptr(dim_t128), _ptr(out), pos.shape[0], _stream(pos)), "far3d_posemb3d")
+    return out
+
+
+def memory_prepare(state, ego_pose_inv, timestamp, pseudo_ref, dim_t256, prev_exists, fresh, pc_range, num_propagated):
+    """state: dict emb (1,L,E) ref (1,L,3) ts (1,L,1) f64 pose (1,L,4,4) velo (1,L,2).  Returns (m dict, temp_ref, nerf, tpos)."""
+    lib = _lib.require_device()
+    L, E = state["emb"].shape[1], state["emb"].shape[2]
+    dev = state["emb"].device
+    m = {k: torch.empty_like(v) for k, v in state.items()}
+    temp_ref = torch.empty((L, 3), dtype=torch.float32, device=dev)
+    nerf = torch.empty((L, 180), dtype=torch.float32, device=dev)
+    tpos = torch.empty((L, 256), dtype=torch.float32, device=dev)
+    pk, pp = _host_f32(list(pc_range))
+    _lib.check(lib.far3d_memory_prepare(_ptr(state["emb"]), _ptr(state["ref"]), _ptr(state["ts"]), _ptr(state["pose"]), _ptr(state["velo"]),
+                                        _ptr(ego_pose_inv), _ptr(timestamp), _ptr(pseudo_ref) if pseudo_ref is not None else None,
+                                        _ptr(dim_t256), float(prev_exists), 1 if fresh else 0, pp, L, E, int(num_propagated),
+                                        _ptr(m["emb"]), _ptr(m["ref"]), _ptr(m["ts"]), _ptr(m["pose"]), _ptr(m["velo"]),
+                                        _ptr(temp_ref), _ptr(nerf), _ptr(tpos), _stream(temp_ref)), "far3d_memory_prepare")
+    return m, temp_ref, nerf, tpos
+
+
+def head_finalize(reg, ref, cls_last, pc_range, layers, num_classes):
+    """reg (layers*A, code) -> box (layers*A, code) with metres in [:3]; score (A,) = max-class sigmoid of the last layer."""
+    lib = _lib.require_device()
+    A, code = ref.shape[0], reg.shape[1]
+    box = torch.empty_like(reg)
+    score = torch.empty((A,), dtype=torch.float32, device=reg.device)
+    pk, pp = _host_f32(list(pc_range))
+    _lib.check(lib.far3d_head_finalize(_ptr(reg), _ptr(ref), _ptr(cls_last), _ptr(box), _ptr(score), layers, A, code, num_classes, pp,
+                                       _stream(reg)), "far3d_head_finalize")
+    return box, score
+
+
+def memory_post_update(m, topk_idx, dec_last, box_last, ego_pose, timestamp, state):
+    lib = _lib.require_device()
+    L, E = state["emb"].shape[1], state["emb"].shape[2]
+    _chk(topk_idx, "topk_idx", torch.int64, 1)
+    _lib.check(lib.far3d_memory_post_update(_ptr(m["emb"]), _ptr(m["ref"]), _ptr(m["ts"]), _ptr(m["pose"]), _ptr(m["velo"]), _ptr(topk_idx),
+                                            _ptr(dec_last), _ptr(box_last), _ptr(ego_pose), _ptr(timestamp), L, E, topk_idx.numel(),
+                                            box_last.shape[1], _ptr(state["emb"]), _ptr(state["ref"]), _ptr(state["ts"]),
+                                            _ptr(state["pose"]), _ptr(state["velo"]), _stream(dec_last)), "far3d_memory_post_update")
+
+
+def add_cast(a, b, sum_dtype, a_dtype=None):
+    """Returns (a+b as sum_dtype, a as a_dtype or None) in one pass; a,b f32 contiguous, same shape (b may be broadcast-free)."""
+    lib = _lib.require_device()
+    _chk(a, "a", torch.float32)
+    _chk(b, "b", torch.float32)
+    osum = torch.empty(a.shape, dtype=sum_dtype, device=a.device)
+    oa = torch.empty(a.shape, dtype=a_dtype, device=a.device) if a_dtype is not None else None
+    _lib.check(lib.far3d_add_cast(_ptr(a), _ptr(b), _ptr(osum), _dt(osum), _ptr(oa) if oa is not None else None,
+                                  _dt(oa) if oa is not None else 0, a.numel(), _stream(a)), "far3d_add_cast")
+    return osum, oa
+
+
+def aggregation_order(ref, lidar2img, pc_range, pad_hw):
+    """Same result as camera_sorted_order(spatial=True) with one key kernel + one sort."""
+    lib = _lib.require_device()
+    A = ref.shape[0]
+    keys = torch.empty((A,), dtype=torch.int32, device=ref.device)
+    pk, pp = _host_f32(list(pc_range))
+    _lib.check(lib.far3d_agg_order_keys(_ptr(ref), _ptr(lidar2img), _ptr(keys), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
+                                        _stream(ref)), "far3d_agg_order_keys")
+    return torch.sort(keys, stable=True).indices.to(torch.int32)

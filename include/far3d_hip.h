@@ -162,6 +162,40 @@ int far3d_proposal_gather(const float* const* reg, int nreg, int N, int L, const
 int far3d_row_affine_ln(const float* x, const float* gamma, const float* beta, const float* add, float* y, int rows, int C,
                         int ldx, int ldg, int lda, int ldy, float eps, int do_ln, void* stream);
 
+/* --- fused FarHead bookkeeping kernels (far3d_amd/csrc/glue.hip); each replaces a chain of tiny tensor ops ------------- */
+
+/* pos2posemb3d, ref models/utils/positional_encoding.py:13-25.  pos (R,3) f32, dim_t128 (128) f32 = 1e4^(2*floor(i/2)/128),
+ * out (R,384) f32 = cat(emb(y), emb(x), emb(z)). */
+int far3d_posemb3d(const float* pos, const float* dim_t128, float* out, int R, void* stream);
+
+/* Streaming-memory pre-update + temporal codes, ref models/dense_heads/farhead.py:453-477,287,297-303.
+ * state: emb (L,E) ref (L,3) ts (L) f64 pose (L,4,4) velo (L,2); ego_pose_inv (4,4); timestamp (1) f64 DEVICE;
+ * pseudo_ref (P,3) normalised; prev_exists 0/1; fresh != 0: the state is the all-zero first-frame memory (no ego warp).
+ * out: the pre-updated memory m_*, temp_ref (L,3) normalised, nerf (L,180) f32, tpos (L,256) f32 (pos2posemb1d in f64). */
+int far3d_memory_prepare(const float* emb, const float* ref, const double* ts, const float* pose, const float* velo,
+                         const float* ego_pose_inv, const double* timestamp, const float* pseudo_ref, const float* dim_t256,
+                         float prev_exists, int fresh, const float* pc_range, int L, int E, int P, float* m_emb, float* m_ref,
+                         double* m_ts, float* m_pose, float* m_velo, float* temp_ref, float* nerf, float* tpos, void* stream);
+
+/* Box-code finalisation of the shared reg branch + memory scores, ref models/dense_heads/farhead.py:649-664,490.
+ * reg (layers*A, code) f32, ref (A,3), cls_last (A,ncls) logits of the last layer (may be NULL with score NULL). */
+int far3d_head_finalize(const float* reg, const float* ref, const float* cls_last, float* box, float* score, int layers, int A,
+                        int code_size, int num_classes, const float* pc_range, void* stream);
+
+/* Streaming-memory post-update, ref models/dense_heads/farhead.py:479-508: the K top-scoring queries (topk_idx, int64
+ * DEVICE) are pushed in front, the queue is truncated to L and warped by ego_pose; writes the persistent state in place. */
+int far3d_memory_post_update(const float* m_emb, const float* m_ref, const double* m_ts, const float* m_pose, const float* m_velo,
+                             const int64_t* topk_idx, const float* dec_last, const float* box_last, const float* ego_pose,
+                             const double* timestamp, int L, int E, int K, int code_size, float* emb, float* ref, double* ts,
+                             float* pose, float* velo, void* stream);
+
+/* out_sum = a + b (sum_dt), out_a = a (a_dt, optional); n elements, multiple of 4 (decoder "query + query_pos" operands). */
+int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, void* out_a, int a_dt, long n, void* stream);
+
+/* Scheduling keys for far3d_aggregate_forward's `perm`: (nearest camera, 8x8 image cell) per reference point. */
+int far3d_agg_order_keys(const float* ref, const float* lidar2img, int32_t* keys, int A, int N, const float* pc_range, float pad_h,
+                         float pad_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
