@@ -47,14 +47,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                        const T* __restrict__ V, void* __restrict__ O, int out_dt, int Aq,
                                                        int Nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+  // Workgroup = 64 queries of one head.  Waves 0,1 walk the first half of the keys for queries [0,32) / [32,64), waves 2,3 the
+  // second half for the same queries (flash-decoding style split); the two partial (max, sum, O) states are merged through
+  // LDS at the end.  Twice as many workgroups (fills the 256 CUs) and half as many serial key tiles per wave.
   constexpr int KROW = ACfg<T>::KROW, VROW = ACfg<T>::VROW, KSUB = ACfg<T>::KSUB, CH = ACfg<T>::CH;
   constexpr int E = 16 / sizeof(T);
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_KT * KROW];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[(sizeof(T) == 2 ? ATT_D : ATT_KT) * VROW];
+  constexpr int KBYTES = ATT_KT * KROW, VBYTES = (sizeof(T) == 2 ? ATT_D : ATT_KT) * VROW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KBYTES + 2 * VBYTES];
+  unsigned char* KsAll = smem;
+  unsigned char* VsAll = smem + 2 * KBYTES;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int half = wv >> 1;
   const int head = blockIdx.y;
-  const int q = blockIdx.x * 128 + wv * 32 + l31;
+  const int q = blockIdx.x * 64 + (wv & 1) * 32 + l31;
   const bool q_ok = q < Aq;
+  const int ntiles = (Nk + ATT_KT - 1) / ATT_KT;
+  const int htiles = (ntiles + 1) / 2;          // tiles per half; half 1 may have one fewer (or none)
+  unsigned char* Ks = KsAll + half * KBYTES;
+  unsigned char* Vs = VsAll + half * VBYTES;
 
   // Q fragments (B operand: column = query), held in registers for the whole key loop
   u32x4_t qf[KSUB];
@@ -73,17 +83,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
     }
   }
 
-  // cooperative K/V tile staging: chunk id -> (key, 16-B piece of the 32-dim head slice)
+  // cooperative staging of TWO K/V tiles per iteration (one per half): chunk id -> (half, key, 16-B piece)
   constexpr int CPK = ATT_D * sizeof(T) / 16;  // 16-B chunks per key row: 4 (bf16) / 8 (f32)
-  u32x4_t kreg[CH], vreg[CH];
-  auto gload = [&](int tile) __attribute__((always_inline)) {
+  constexpr int CH2 = 2 * CH;
+  u32x4_t kreg[CH2], vreg[CH2];
+  auto gload = [&](int it) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int id = t + c * 256, key = id / CPK, ck = id % CPK;
-      const int gk = tile * ATT_KT + key;
+    for (int c = 0; c < CH2; ++c) {
+      const int id = t + c * 256, h = id / (ATT_KT * CPK), rem = id % (ATT_KT * CPK), key = rem / CPK, ck = rem % CPK;
+      const int tl = it + h * htiles;
+      const int gk = tl * ATT_KT + key;
       kreg[c] = u32x4_t{0u, 0u, 0u, 0u};
       vreg[c] = u32x4_t{0u, 0u, 0u, 0u};
-      if (gk < Nk) {
+      if (tl < ntiles && gk < Nk) {
         kreg[c] = *reinterpret_cast<const u32x4_t*>(K + (long)gk * ldk + head * ATT_D + ck * E);
         vreg[c] = *reinterpret_cast<const u32x4_t*>(V + (long)gk * ldv + head * ATT_D + ck * E);
       }
@@ -91,19 +103,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
   };
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int id = t + c * 256, key = id / CPK, ck = id % CPK;
-      *reinterpret_cast<u32x4_t*>(Ks + key * KROW + ck * 16) = kreg[c];
+    for (int c = 0; c < CH2; ++c) {
+      const int id = t + c * 256, h = id / (ATT_KT * CPK), rem = id % (ATT_KT * CPK), key = rem / CPK, ck = rem % CPK;
+      *reinterpret_cast<u32x4_t*>(KsAll + h * KBYTES + key * KROW + ck * 16) = kreg[c];
+      unsigned char* vs = VsAll + h * VBYTES;
       if constexpr (sizeof(T) == 2) {
         const int pos = vt_pos(key);
         const uint32_t w[4] = {vreg[c].x, vreg[c].y, vreg[c].z, vreg[c].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const uint16_t val = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-          *reinterpret_cast<uint16_t*>(Vs + (ck * 8 + e) * VROW + pos * 2) = val;
+          *reinterpret_cast<uint16_t*>(vs + (ck * 8 + e) * VROW + pos * 2) = val;
         }
       } else {
-        *reinterpret_cast<u32x4_t*>(Vs + key * VROW + ck * 16) = vreg[c];
+        *reinterpret_cast<u32x4_t*>(vs + key * VROW + ck * 16) = vreg[c];
       }
     }
   };
@@ -113,95 +126,114 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (Nk + ATT_KT - 1) / ATT_KT;
   gload(0);
   lstore();
   __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const bool more = tile + 1 < ntiles;
-    if (more) gload(tile + 1);
-
-    // ---- S^T = K Q^T for the two 32-key sub-tiles
-    f32x16_t s[2];
+  for (int it = 0; it < htiles; ++it) {
+    const bool more = it + 1 < htiles;
+    if (more) gload(it + 1);
+    const int tile = it + half * htiles;
+    if (tile < ntiles) {   // wave-uniform
+      // ---- S^T = K Q^T for the two 32-key sub-tiles
+      f32x16_t s[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < KSUB; ++kk) {
-        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Ks + (u * 32 + l31) * KROW + kk * 32 + hi * 16);
-        mma_att<T>(s[u], a, qf[kk]);
-      }
-    }
-    // ---- online softmax (per-lane query)
-    const int kbase = tile * ATT_KT + 4 * hi;
-    float mloc = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[u][r];
-        if constexpr (sizeof(T) == 2) v *= scale;
-        const int key = kbase + u * 32 + (r & 3) + 8 * (r >> 2);
-        v = key < Nk ? v : -INFINITY;
-        s[u][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (sizeof(T) == 2) ? __expf(m_run - m_use) : expf(m_run - m_use);   // m_run = -inf -> 0
-    float psum = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = (sizeof(T) == 2) ? __expf(s[u][r] - m_use) : expf(s[u][r] - m_use);
-        s[u][r] = p;
-        psum += p;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-
-    // ---- O^T += V^T P^T
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          u32x4_t b;
-          b.x = pack_bf16x2(s[u][8 * g + 0], s[u][8 * g + 1]);
-          b.y = pack_bf16x2(s[u][8 * g + 2], s[u][8 * g + 3]);
-          b.z = pack_bf16x2(s[u][8 * g + 4], s[u][8 * g + 5]);
-          b.w = pack_bf16x2(s[u][8 * g + 6], s[u][8 * g + 7]);
-          const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Vs + l31 * VROW + ((u * 32 + 16 * g) + hi * 8) * 2);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), o, 0, 0, 0);
+        for (int kk = 0; kk < KSUB; ++kk) {
+          const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Ks + (u * 32 + l31) * KROW + kk * 32 + hi * 16);
+          mma_att<T>(s[u], a, qf[kk]);
         }
-    } else {
+      }
+      // ---- online softmax (per-lane query)
+      const int kbase = tile * ATT_KT + 4 * hi;
+      float mloc = -INFINITY;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const float a = *reinterpret_cast<const float*>(Vs + key * VROW + l31 * 4);
-          o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[u][r], o, 0, 0, 0);
+          float v = s[u][r];
+          if constexpr (sizeof(T) == 2) v *= scale;
+          const int key = kbase + u * 32 + (r & 3) + 8 * (r >> 2);
+          v = key < Nk ? v : -INFINITY;
+          s[u][r] = v;
+          mloc = fmaxf(mloc, v);
         }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float m_new = fmaxf(m_run, mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = (sizeof(T) == 2) ? __expf(m_run - m_use) : expf(m_run - m_use);   // m_run = -inf -> 0
+      float psum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = (sizeof(T) == 2) ? __expf(s[u][r] - m_use) : expf(s[u][r] - m_use);
+          s[u][r] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+
+      // ---- O^T += V^T P^T
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            u32x4_t b;
+            b.x = pack_bf16x2(s[u][8 * g + 0], s[u][8 * g + 1]);
+            b.y = pack_bf16x2(s[u][8 * g + 2], s[u][8 * g + 3]);
+            b.z = pack_bf16x2(s[u][8 * g + 4], s[u][8 * g + 5]);
+            b.w = pack_bf16x2(s[u][8 * g + 6], s[u][8 * g + 7]);
+            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Vs + l31 * VROW + ((u * 32 + 16 * g) + hi * 8) * 2);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), o, 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float a = *reinterpret_cast<const float*>(Vs + key * VROW + l31 * 4);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[u][r], o, 0, 0, 0);
+          }
+      }
     }
     __syncthreads();
     if (more) lstore();
     __syncthreads();
   }
 
-  // ---- normalise and store: lane (q,hi) holds d = (r&3) + 8*(r>>2) + 4*hi
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  if (q_ok) {
-    const float inv = 1.f / l_tot;
+  // ---- merge the two key halves: waves 2,3 publish (m, l, O) per lane, waves 0,1 combine and store
+  float l_tot = l_run + __shfl_xor(l_run, 32);   // both lane halves of a query share m_run
+  float* mb = reinterpret_cast<float*>(smem);    // [2 waves][18][64 lanes]
+  if (half == 1) {
+    float* dst = mb + (wv & 1) * 18 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r * 64] = o[r];
+    dst[16 * 64] = m_run;
+    dst[17 * 64] = l_tot;
+  }
+  __syncthreads();
+  if (half == 0 && q_ok) {
+    const float* src = mb + (wv & 1) * 18 * 64 + lane;
+    const float m2 = src[16 * 64], l2 = src[17 * 64];
+    const float m = fmaxf(m_run, m2);
+    const float mu = (m == -INFINITY) ? 0.f : m;
+    const float a1 = expf(m_run - mu), a2 = expf(m2 - mu);   // a half that saw no key has m = -inf -> weight 0
+    const float inv = 1.f / (l_tot * a1 + l2 * a2);
     const long off = (long)q * ldo + head * ATT_D + 4 * hi;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      const float4 r = make_float4(o[4 * qd] * inv, o[4 * qd + 1] * inv, o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+      float4 r;
+      r.x = (o[4 * qd] * a1 + src[(4 * qd) * 64] * a2) * inv;
+      r.y = (o[4 * qd + 1] * a1 + src[(4 * qd + 1) * 64] * a2) * inv;
+      r.z = (o[4 * qd + 2] * a1 + src[(4 * qd + 2) * 64] * a2) * inv;
+      r.w = (o[4 * qd + 3] * a1 + src[(4 * qd + 3) * 64] * a2) * inv;
       if (out_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off + 8 * qd) = r;
       else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(O) + off + 8 * qd) = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
     }
@@ -220,7 +252,7 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
                   (ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && ldo % 4 == 0 &&
                   (out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16),
                   "far3d_attention_forward: pointers / row strides must be 16-byte aligned");
-  dim3 grid((Aq + 127) / 128, heads), block(256);
+  dim3 grid((Aq + 63) / 64, heads), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FAR3D_DT_F32)
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
