@@ -38,15 +38,14 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
 // round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct LoadCvt;
 template <> struct LoadCvt<float> {

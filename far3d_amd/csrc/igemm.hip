@@ -113,31 +113,37 @@ __device__ __forceinline__ void igemm_epilogue_px(const IgemmParams& P, f32x16_t
                                                   const int (&ppix)[WN], int m0, int wm, int hi) {
   // ---- epilogue: bias -> activation -> residual -> store (+ optional modulated second output)
   // pn[j] / ppix[j]: image index and linear pixel index (oy*Wo+ox) of this lane's pixel in tile column j (pn < 0: none)
+  long yoff[WN], roff[WN], y2off[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
-    if (pn[j] < 0) continue;
-    const int n = pn[j], pix = ppix[j];
-    long roff = 0;
-    if (P.res) {
+    const int n = pn[j] < 0 ? 0 : pn[j], pix = ppix[j];
+    yoff[j] = (long)n * P.y_img_stride + (long)pix * P.ldy;
+    y2off[j] = (long)n * P.y2_img_stride + (long)pix * P.ldy2;
+    roff[j] = 0;
+    if (P.res && pn[j] >= 0) {
       const int oy = pix / P.Wo, ox = pix - oy * P.Wo;
       const int ry = (P.Hr == P.Ho) ? oy : min((int)floorf(oy * ((float)P.Hr / P.Ho)), P.Hr - 1);
       const int rx = (P.Wr == P.Wo) ? ox : min((int)floorf(ox * ((float)P.Wr / P.Wo)), P.Wr - 1);
-      roff = (long)n * P.res_img_stride + ((long)ry * P.Wr + rx) * P.ldr;
+      roff[j] = (long)n * P.res_img_stride + ((long)ry * P.Wr + rx) * P.ldr;
     }
+  }
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+  for (int i = 0; i < WM; ++i) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int m = m0 + (wm * WM + i) * 32 + 8 * q + 4 * hi;
-        if (m >= P.Cout) continue;
-        const int nv = min(4, P.Cout - m);
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + (wm * WM + i) * 32 + 8 * q + 4 * hi;
+      if (m >= P.Cout) continue;
+      const int nv = min(4, P.Cout - m);
+      // bias rows are padded (include/far3d_hip.h) and 16-byte aligned: one vector load, hoisted out of the pixel loop
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + m);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        if (pn[j] < 0) continue;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-        if (P.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += P.bias[m + e];
-        }
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         if (P.act == ACT_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -147,22 +153,23 @@ __device__ __forceinline__ void igemm_epilogue_px(const IgemmParams& P, f32x16_t
         }
         if (P.res) {
           if (P.res_dt == FAR3D_DT_F32) {
-            const float* rp = reinterpret_cast<const float*>(P.res) + roff + m;
+            const float* rp = reinterpret_cast<const float*>(P.res) + roff[j] + m;
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < nv) v[e] += rp[e];
           } else {
-            const bf16_t* rp = reinterpret_cast<const bf16_t*>(P.res) + roff + m;
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(P.res) + roff[j] + m;
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf16_to_f32(rp[e]);
           }
         }
-        store4(P.y, P.y_dt, (long)n * P.y_img_stride + (long)pix * P.ldy + m, v, nv, P.y_vec != 0);
+        store4(P.y, P.y_dt, yoff[j] + m, v, nv, P.y_vec != 0);
         if (P.y2) {
+          const long so = (long)pn[j] * P.Cout + m;
           float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (e < nv) u[e] = P.y2_scale[(long)n * P.Cout + m + e] * v[e] + P.y2_shift[(long)n * P.Cout + m + e];
-          store4(P.y2, P.y2_dt, (long)n * P.y2_img_stride + (long)pix * P.ldy2 + m, u, nv, P.y2_vec != 0);
+            if (e < nv) u[e] = P.y2_scale[so + e] * v[e] + P.y2_shift[so + e];
+          store4(P.y2, P.y2_dt, y2off[j] + m, u, nv, P.y2_vec != 0);
         }
       }
     }
@@ -600,6 +607,192 @@ static int launch_conv3x3_patch(const IgemmParams& P, hipStream_t st) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant of the LDS-patch 3x3 kernel (same data movement: double-buffered halo patch + 2-deep ring
+// of 3-tap weight slabs, one barrier per kernel row).  PMC on the kernel above showed the matrix pipe 30 % busy with
+// waves parked 42 % of the time: the compiler issued each tap's `ds_read_b128`s, then `s_waitcnt lgkmcnt(0)`, then the
+// MFMAs, six times per step, and spent ~9 VALU per MFMA recomputing swizzled LDS addresses.  Here
+//   * every fragment address is a per-lane VGPR computed once + a compile-time immediate (chunk parity, ring stage, tap
+//     are compile-time: the loop body is two chunks = six steps, fully unrolled),
+//   * fragments are double-buffered in registers: the reads of tap/k-half i+1 are issued before the MFMAs of i,
+//   * the next chunk's patch is issued AFTER the next step's weights so that `vmcnt(GPL)` keeps it in flight for two steps.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int KY, int POFF, int WOFF, int WST>
+__device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
+                                                     const int (&baddr)[2][WN + 2][3], f32x16_t (&acc)[WM][WN]) {
+  u32x4_t af[2][WM], bf[2][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + aaddr[0][i]);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bf[0][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + baddr[0][j + KY][0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int cur = it & 1, nxt = cur ^ 1;
+    if (it + 1 < 6) {
+      const int tp = (it + 1) >> 1, kk = (it + 1) & 1;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[nxt][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + tp * WST + aaddr[kk][i]);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + baddr[kk][j + KY][tp]);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next fragments' reads ahead of this iteration's MFMAs
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][i], bf[cur][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParams P, int tiles_x, int tiles_y) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
+  constexpr int NW = WGM * WGN;                      // waves per workgroup (4, 8 or 16)
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
+  constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + NW - 1) / NW;
+  constexpr int GA = BM / 16, WSLOTS = 3 * GA, GWL = (WSLOTS + NW - 1) / NW, WST = BM * 64;
+  constexpr int WBASE = 2 * PATCH_B;                // weight ring: [2 stages][3 taps][WST]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int x0 = tx * 32, y0 = ty * TH, m0 = blockIdx.y * BM;
+  const int Ktot = 9 * P.cin_pad;
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);
+
+  // LDS-DMA through buffer descriptors (`buffer_load_dwordx4 ... offen lds`): per-lane byte offset in a VGPR computed once,
+  // the K position in an SGPR, out-of-image halo pixels get an out-of-range offset and the hardware writes zeros.
+  // (MUBUF rather than `global_load_lds`: the compiler treats the latter as a FLAT access that may touch LDS and
+  // then degrades every `s_waitcnt lgkmcnt(n)` to lgkmcnt(0), which serialises the fragment pipeline below.)
+  constexpr unsigned OOB = 0x80000000u;
+  const long img_bytes = (long)P.H * P.W * P.ldx * 2;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride), 0, (int)(img_bytes < 0x7fffffffL ? img_bytes : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+  unsigned pvoff[GPL], wvoff[GWL];
+  int pdst[GPL], wdst[GWL];
+#pragma unroll
+  for (int i = 0; i < GPL; ++i) {       // every wave issues exactly GPL patch pieces (slots past PG re-fetch an earlier one)
+    int q = wv + NW * i;
+    if (q >= PG) q -= PG;
+    pdst[i] = q * 1024;
+    const int idx = q * 16 + rg;
+    const int py = idx / PW, px = idx - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = idx < PPIX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    pvoff[i] = ok ? (unsigned)((((long)iy * P.W + ix) * P.ldx + lc * 8) * 2) : OOB;
+  }
+  int wtap[GWL];                        // weight slot = (tap of the kernel row, 16-row group); slots past WSLOTS are skipped
+#pragma unroll
+  for (int i = 0; i < GWL; ++i) {
+    const int q = wv + NW * i;
+    wtap[i] = q < WSLOTS ? q / GA : -1;
+    const int g = q % GA;
+    wdst[i] = (q / GA) * WST + g * 1024;
+    wvoff[i] = (unsigned)(((g * 16 + rg) * Ktot + lc * 8) * 2);
+  }
+  auto issue_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < GPL; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + buf * PATCH_B + pdst[i]), 16, pvoff[i], chunk * 64, 0, 0);
+  };
+  auto issue_w = [&](int chunk, int ky, int stage) __attribute__((always_inline)) {   // one kernel row: taps 3*ky .. 3*ky+2
+#pragma unroll
+    for (int i = 0; i < GWL; ++i) {
+      if (wtap[i] < 0) continue;        // wave-uniform
+      const int kb = (ky * 3 + wtap[i]) * P.cin_pad + chunk * 32;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + WBASE + stage * 3 * WST + wdst[i]), 16, wvoff[i], kb * 2, 0, 0);
+    }
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addresses (bytes from smem): [k-half][...]; the k-half flips bit 5 of the swizzled chunk
+  int aaddr[2][WM], baddr[2][WN + 2][3];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    aaddr[0][i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+    aaddr[1][i] = aaddr[0][i] ^ 32;
+  }
+#pragma unroll
+  for (int r = 0; r < WN + 2; ++r)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int idx = (wn * WN + r) * PW + l31 + kx;
+      baddr[0][r][kx] = idx * 64 + ((hi ^ ((idx >> 2) & 3)) << 4);
+      baddr[1][r][kx] = baddr[0][r][kx] ^ 32;
+    }
+
+  const int nchunks = P.cin_pad / 32;
+  issue_patch(0, 0);
+  issue_w(0, 0, 0);
+  // step (chunk c, kernel row ky) reads weight stage (3c + ky) & 1 and patch buffer c & 1
+#define FAR3D_PIPE_STEP(PAR, KY, CH)                                                                                   \
+  {                                                                                                                    \
+    constexpr int STG = (PAR * 3 + KY) & 1;                                                                            \
+    const bool more_patch = (KY == 0) && ((CH) + 1 < nchunks);                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (KY == 1 && (CH) + 1 < nchunks) wait_vmcnt<GPL>(); else wait_vmcnt<0>();                                        \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    asm volatile("" ::: "memory");                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (KY < 2) issue_w((CH), KY + 1, STG ^ 1);                                                                        \
+    else if ((CH) + 1 < nchunks) issue_w((CH) + 1, 0, STG ^ 1);                                                        \
+    if (more_patch) issue_patch((CH) + 1, (PAR) ^ 1);                                                                  \
+    patch_step_pipelined<WM, WN, KY, (PAR) * PATCH_B, WBASE + STG * 3 * WST, WST>(smem, aaddr, baddr, acc);            \
+  }
+  for (int c = 0; c < nchunks; c += 2) {
+    FAR3D_PIPE_STEP(0, 0, c)
+    FAR3D_PIPE_STEP(0, 1, c)
+    FAR3D_PIPE_STEP(0, 2, c)
+    if (c + 1 < nchunks) {
+      FAR3D_PIPE_STEP(1, 0, c + 1)
+      FAR3D_PIPE_STEP(1, 1, c + 1)
+      FAR3D_PIPE_STEP(1, 2, c + 1)
+    }
+  }
+#undef FAR3D_PIPE_STEP
+  int pn[WN], ppix[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int y = y0 + wn * WN + j, x = x0 + l31;
+    pn[j] = (y < P.H && x < P.W) ? n : -1;
+    ppix[j] = y * P.W + x;
+  }
+  igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
+#endif
+}
+
+template <int WGM, int WGN, int WM, int WN>
+static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
+  constexpr int PG = (34 * (TH + 2) + 15) / 16;
+  constexpr size_t lds = (size_t)2 * PG * 1024 + (size_t)2 * 3 * BM * 64;
+  const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
+  dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
+  return 0;
+}
+
 // See include/far3d_hip.h for the argument contract.
 extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y,
                                  int y_dt, int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho,
@@ -717,6 +910,26 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 40: launch_conv3x3_patch<1, 4, 1, 2, 3, 3>(P, st); break;   // 32 x 8 rows
         case 41: launch_conv3x3_patch<2, 2, 2, 1, 3, 3>(P, st); break;   // 128 x 2 rows
         case 42: launch_conv3x3_patch<2, 2, 1, 4, 2, 3>(P, st); break;   // 64 x 8 rows, 2-deep
+        // software-pipelined kernel (register double-buffered fragments, immediate-offset LDS addressing)
+        case 50: launch_conv3x3_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 4 rows
+        case 51: launch_conv3x3_pipe<1, 4, 2, 1>(P, st); break;   // 64 x 4 rows (1x4 waves)
+        case 52: launch_conv3x3_pipe<1, 4, 1, 1>(P, st); break;   // 32 x 4 rows
+        case 53: launch_conv3x3_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 4 rows
+        case 54: launch_conv3x3_pipe<1, 4, 1, 2>(P, st); break;   // 32 x 8 rows
+        case 55: launch_conv3x3_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 2 rows
+        case 56: launch_conv3x3_pipe<2, 2, 2, 4>(P, st); break;   // 128 x 8 rows
+        case 57: launch_conv3x3_pipe<2, 2, 1, 4>(P, st); break;   // 64 x 8 rows
+        case 58: launch_conv3x3_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 2 rows
+        case 59: launch_conv3x3_pipe<1, 4, 3, 1>(P, st); break;   // 96 x 4 rows
+        // 8 / 16 waves per workgroup sharing one patch + weight slab
+        case 60: launch_conv3x3_pipe<2, 4, 1, 2>(P, st); break;   // 64 x 8 rows, 8 waves
+        case 61: launch_conv3x3_pipe<2, 4, 1, 1>(P, st); break;   // 64 x 4 rows, 8 waves
+        case 62: launch_conv3x3_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 4 rows, 8 waves
+        case 63: launch_conv3x3_pipe<2, 8, 1, 1>(P, st); break;   // 64 x 8 rows, 16 waves
+        case 64: launch_conv3x3_pipe<1, 8, 2, 1>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
+        case 65: launch_conv3x3_pipe<1, 8, 1, 1>(P, st); break;   // 32 x 8 rows, 8 waves
+        case 66: launch_conv3x3_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 4 rows, 16 waves
+        case 67: launch_conv3x3_pipe<4, 2, 1, 1>(P, st); break;   // 128 x 2 rows, 8 waves
         default: done = false;
       }
     }

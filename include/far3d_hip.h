@@ -75,7 +75,7 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  * x: NHWC activations (x_dt), pixel stride ldx elements, image stride x_img_stride elements; the pointer is
  *    pre-offset to the first input channel (channel slices of a wider buffer are fine).
  * w: packed weights (w_dt) [R][KH*KW][ceil(Cin/32)*32] with R >= Cout + 256 rows (zero rows past Cout: channel tiles of up to
- *    256 rows over-read), zero padded in Cin; bias [R] f32 or NULL.
+ *    256 rows over-read), zero padded in Cin; bias [R] f32 (16-byte aligned) or NULL.
  * y: NHWC output (y_dt), pixel stride ldy, image stride y_img_stride.  v = act(conv + bias) + res.
  * act: 0 none, 1 ReLU, 2 Swish.  res (optional, res_dt): NHWC Hr x Wr map added with nearest-neighbour upsampling
  *    (FPN top-down path); Hr=Ho, Wr=Wo gives a plain residual.

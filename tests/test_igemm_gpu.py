@@ -139,7 +139,8 @@ def test_conv_asymmetric_weights_catch_transposes(hip_lib):
         assert torch.allclose(y, want, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42])
+@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42,
+                                  50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67])
 def test_conv3x3_lds_patch_kernel(hip_lib, tile):
     """3x3/s1/p1 bf16 kernel with the LDS-resident halo patch: ragged sizes (W % 32 != 0, H % TH != 0, Cout % BM != 0)."""
     from far3d_amd import ops
