@@ -793,6 +793,175 @@ static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 convolution (= GEMM  y[pix][ch] = sum_k x[pix][k] w[ch][k]) with the same pipeline as conv3x3_pipe_kernel:
+// buffer-descriptor LDS-DMA (one VGPR offset per piece, K position in an SGPR, pixels past the end read as zeros),
+// 64 channels of K per barrier step (two 32-channel sub-tiles in the proven 64-byte-row XOR-swizzled layout), 2-deep ring,
+// fragments double-buffered in registers with counted lgkmcnt, 4 / 8 / 16 waves per workgroup.
+// Workgroups are numbered so that one XCD (round-robin dispatch: id % 8) owns a pixel tile for ALL of its channel tiles
+// back to back: the activation tile is fetched from HBM once and re-read from that XCD's L2.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int SOFF, int BM, int SUBB, int NIT>
+__device__ __forceinline__ void gemm_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
+                                                    const int (&baddr)[2][WN], f32x16_t (&acc)[WM][WN]) {
+  // iteration it = (sub-tile it>>1, k-half it&1); sub-tile s lives at SOFF + s * SUBB, activations after the BM weight rows
+  u32x4_t af[2][WM], bf[2][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + aaddr[0][i]);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bf[0][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + baddr[0][j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int cur = it & 1, nxt = cur ^ 1;
+    if (it + 1 < NIT) {
+      const int sb = ((it + 1) >> 1) * SUBB, kk = (it + 1) & 1;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[nxt][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + sb + aaddr[kk][i]);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + sb + baddr[kk][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][i], bf[cur][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int GA = BM / 16, GB = BP / 16;                     // 1 KB DMA pieces per 32-channel sub-tile
+  constexpr int AW = (GA + NW - 1) / NW, BW = (GB + NW - 1) / NW;
+  constexpr bool A_EXACT = GA % NW == 0, B_EXACT = GB % NW == 0;
+  constexpr int SUB = (BM + BP) * 64, STAGE = 2 * SUB;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  // XCD-aware numbering: id % 8 = XCD; inside an XCD channel tiles are consecutive for a fixed pixel tile
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= npt) return;
+  const int p0 = pt * BP, m0 = ct * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int Ktot = P.cin_pad;
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);
+  constexpr unsigned OOB = 0x80000000u;
+  const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)(x_bytes < 0x7fffffffL ? x_bytes : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+  unsigned avoff[AW], bvoff[BW];
+#pragma unroll
+  for (int i = 0; i < AW; ++i) {
+    const int g = wv + NW * i;
+    avoff[i] = (unsigned)(((g * 16 + rg) * Ktot + lc * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < BW; ++i) {
+    const int g = wv + NW * i;
+    const long p = (long)p0 + g * 16 + rg;
+    if (p < Npix) {
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      bvoff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + lc * 8) * 2);
+    } else {
+      bvoff[i] = OOB;
+    }
+  }
+  // one step = NSUBS 32-channel sub-tiles starting at sub-tile index 2*step
+  auto issue = [&](int step, int stage_off, int nsubs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      if (sidx >= nsubs) break;
+      const int kb = (2 * step + sidx) * 64;                 // bytes along K
+#pragma unroll
+      for (int i = 0; i < AW; ++i) {
+        const int g = wv + NW * i;
+        if (A_EXACT || g < GA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + stage_off + sidx * SUB + g * 1024), 16, avoff[i], kb, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BW; ++i) {
+        const int g = wv + NW * i;
+        if (B_EXACT || g < GB)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + stage_off + sidx * SUB + BM * 64 + g * 1024), 16, bvoff[i], kb, 0, 0);
+      }
+    }
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aaddr[2][WM], baddr[2][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    aaddr[0][i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+    aaddr[1][i] = aaddr[0][i] ^ 32;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int r = (wn * WN + j) * 32 + l31;
+    baddr[0][j] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+    baddr[1][j] = baddr[0][j] ^ 32;
+  }
+  const int nsub = P.cin_pad / 32, nfull = nsub >> 1, tail = nsub & 1;   // full (64-channel) steps + an optional 32-channel one
+  if (nfull > 0) issue(0, 0, 2); else issue(0, 0, 1);
+#define FAR3D_GEMM_SYNC()                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    wait_vmcnt<0>();                                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define FAR3D_GEMM_STEP(STG, S)                                                                              \
+  {                                                                                                          \
+    FAR3D_GEMM_SYNC()                                                                                        \
+    if ((S) + 1 < nfull) issue((S) + 1, ((STG) ^ 1) * STAGE, 2);                                             \
+    else if (tail) issue((S) + 1, ((STG) ^ 1) * STAGE, 1);                                                   \
+    gemm_step_pipelined<WM, WN, (STG) * STAGE, BM, SUB, 4>(smem, aaddr, baddr, acc);                         \
+  }
+  for (int s2 = 0; s2 < nfull; s2 += 2) {
+    FAR3D_GEMM_STEP(0, s2)
+    if (s2 + 1 < nfull) FAR3D_GEMM_STEP(1, s2 + 1)
+  }
+  if (tail) {
+    FAR3D_GEMM_SYNC()
+    if (nfull & 1) gemm_step_pipelined<WM, WN, STAGE, BM, SUB, 2>(smem, aaddr, baddr, acc);
+    else           gemm_step_pipelined<WM, WN, 0, BM, SUB, 2>(smem, aaddr, baddr, acc);
+  }
+#undef FAR3D_GEMM_STEP
+#undef FAR3D_GEMM_SYNC
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
+#endif
+}
+
+template <int WGM, int WGN, int WM, int WN>
+static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
+  constexpr size_t lds = (size_t)2 * 2 * (BM + BP) * 64;
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
+  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
+  return 0;
+}
+
 // See include/far3d_hip.h for the argument contract.
 extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y,
                                  int y_dt, int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho,
@@ -881,6 +1050,25 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
       case 48: launch_igemm_dma<2, 2, 1, 1, 2>(P, st); break;      // 64x64
       case 49: launch_igemm_dma<2, 2, 2, 2, 2, 2>(P, st); break;   // 128x128, 2 chunks/step
       default: done = false;
+    }
+    if (!done && KH == 1 && KW == 1 && stride == 1 && pad == 0) {   // pipelined GEMM kernel (channels x pixels, waves)
+      done = true;
+      switch (tile) {
+        case 70: launch_gemm1x1_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 128, 4 waves
+        case 71: launch_gemm1x1_pipe<2, 4, 2, 1>(P, st); break;   // 128 x 128, 8 waves
+        case 72: launch_gemm1x1_pipe<2, 4, 2, 2>(P, st); break;   // 128 x 256, 8 waves
+        case 73: launch_gemm1x1_pipe<4, 2, 2, 2>(P, st); break;   // 256 x 128, 8 waves
+        case 74: launch_gemm1x1_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 128, 4 waves
+        case 75: launch_gemm1x1_pipe<2, 4, 1, 1>(P, st); break;   // 64 x 128, 8 waves
+        case 76: launch_gemm1x1_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 64, 4 waves
+        case 77: launch_gemm1x1_pipe<4, 4, 2, 1>(P, st); break;   // 256 x 128, 16 waves
+        case 78: launch_gemm1x1_pipe<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
+        case 79: launch_gemm1x1_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves (1x2 tiles per wave)
+        case 80: launch_gemm1x1_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
+        case 81: launch_gemm1x1_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
+        case 82: launch_gemm1x1_pipe<4, 4, 2, 2>(P, st); break;   // 256 x 256, 16 waves
+        default: done = false;
+      }
     }
     // LDS-patch 3x3 kernel: (channels x rows-of-32-pixels, weight ring): 20 128x8/4  21 128x4/4  22 160x8/3  23 192x8/3
     // 24 192x4/4  25 64x8/4  26 256x4/3  27 224x4/3  28 160x4/4

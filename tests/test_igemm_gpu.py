@@ -157,12 +157,13 @@ def test_conv3x3_lds_patch_kernel(hip_lib, tile):
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin * 9)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 14, 15, 16, 17, 18, 19, 43, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 14, 15, 16, 17, 18, 19, 43, 44, 45, 46, 47, 48, 49,
+                                  70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82])
 def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
     """1x1 conv over K = 160 / 1056 / 2144 channels: K chunk counts (5, 33, 67) that do not divide the chunks-per-step."""
     from far3d_amd import ops
     g = torch.Generator().manual_seed(100 + tile)
-    for (Cin, Cout, H, W) in ((160, 96, 7, 19), (1056, 512, 5, 9), (2144, 130, 3, 11)):
+    for (Cin, Cout, H, W) in ((160, 96, 7, 19), (1056, 512, 5, 9), (2144, 130, 3, 11), (32, 40, 23, 31), (64, 300, 4, 5)):
         x = torch.randn(2, Cin, H, W, generator=g).to(torch.bfloat16).float()
         w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05
         b = torch.randn(Cout, generator=g)
