@@ -42,6 +42,7 @@ struct IgemmParams {
   int act, y_dt, y2_dt, ldy2;
   int res_dt, ldr, Hr, Wr;
   int x_vec, y_vec, y2_vec, res_vec;
+  int y_rows16;         // plain bf16 output whose pixel rows take 16-byte stores (LDS-transposed coalesced epilogue)
 };
 
 template <typename TC> struct Cfg;
@@ -187,6 +188,53 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&
     if (p < Npix) { pn[j] = (int)(p / HoWo); ppix[j] = (int)(p - (long)pn[j] * HoWo); }
   }
   igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
+}
+
+// Coalesced epilogue for plain bf16 outputs: the workgroup's BM x BPX tile is transposed through LDS (rows of BM channels,
+// +16 B of padding: conflict-free 8-byte writes from the MFMA layout, 16-byte row reads) and leaves as 16-byte stores
+// that cover whole pixel rows (the MFMA layout alone gives 8-byte pieces 2*ldy bytes apart).  pix_off(pl) -> element
+// offset of local pixel pl in y, or -1.  smem must hold BPX * (2*BM + 16) bytes and is free once every wave has passed
+// the first barrier.
+template <int NW, int WM, int WN, int BM, int BPX, typename PixFn>
+__device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned char* smem, f32x16_t (&acc)[WM][WN], int m0,
+                                                int wm, int wn, int l31, int hi, PixFn pix_off) {
+  constexpr int RS = BM * 2 + 16, CPP = BM / 8, NT = 64 * NW;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cl = (wm * WM + i) * 32 + 8 * q + 4 * hi;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + m0 + cl);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int pl = (wn * WN + j) * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (P.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (P.act == ACT_SWISH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
+        }
+        *reinterpret_cast<uint2*>(smem + pl * RS + cl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+  }
+  __syncthreads();
+  bf16_t* y = reinterpret_cast<bf16_t*>(P.y);
+#pragma unroll 2
+  for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
+    const int pl = idx / CPP, c = idx - pl * CPP;
+    if (m0 + c * 8 >= P.Cout) continue;
+    const long off = pix_off(pl);
+    if (off < 0) continue;
+    *reinterpret_cast<u32x4_t*>(y + off + m0 + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+  }
 }
 
 // WGM x WGN: arrangement of the 4 waves over (channels, pixels); WM x WN: 32x32 MFMA tiles per wave.
@@ -766,6 +814,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     }
   }
 #undef FAR3D_PIPE_STEP
+  if (P.y_rows16) {
+    epilogue_rows16<NW, WM, WN, BM, TH * 32>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
+      const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
+      return (y < P.H && x < P.W) ? (long)n * P.y_img_stride + ((long)y * P.W + x) * P.ldy : -1L;
+    });
+    return;
+  }
   int pn[WN], ppix[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -781,7 +836,8 @@ template <int WGM, int WGN, int WM, int WN>
 static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds = (size_t)2 * PG * 1024 + (size_t)2 * 3 * BM * 64;
+  constexpr size_t lds_ring = (size_t)2 * PG * 1024 + (size_t)2 * 3 * BM * 64, lds_out = (size_t)TH * 32 * (BM * 2 + 16);
+  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
   dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
   static bool attr_set = false;
@@ -942,6 +998,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   }
 #undef FAR3D_GEMM_STEP
 #undef FAR3D_GEMM_SYNC
+  if (P.y_rows16) {
+    epilogue_rows16<NW, WM, WN, BM, BP>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
+      const long p = (long)p0 + pl;
+      if (p >= Npix) return -1L;
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      return (long)n * P.y_img_stride + (long)rem * P.ldy;
+    });
+    return;
+  }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
 #endif
 }
@@ -951,7 +1016,8 @@ static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
   const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
-  constexpr size_t lds = (size_t)2 * 2 * (BM + BP) * 64;
+  constexpr size_t lds_ring = (size_t)2 * 2 * (BM + BP) * 64, lds_out = (size_t)BP * (BM * 2 + 16);
+  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -999,6 +1065,8 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.x_vec = aligned(x, 16) && (ldx % ve == 0) && (x_img_stride % ve == 0) && (long)ve * xe % 16 == 0;
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
+  static const int no_rows16 = getenv("FAR3D_IGEMM_NO_ROWS16") ? atoi(getenv("FAR3D_IGEMM_NO_ROWS16")) : 0;
+  P.y_rows16 = !no_rows16 && y_dt == FAR3D_DT_BF16 && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   const long Npix = (long)N * Ho * Wo;
   // tile: 0 = auto.  (channels x pixels per workgroup) 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64, 5 = 64x256

@@ -171,3 +171,25 @@ def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
         pc = ops.PackedConv(w, b, dtype=torch.bfloat16, device=DEV)
         y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", out_dtype=torch.float32, tile=tile)
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin)
+
+
+@pytest.mark.parametrize("tile", [50, 52, 53, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67, 70, 71, 72, 73, 74, 75, 77, 78, 79, 80, 81, 82])
+def test_pipelined_kernels_bf16_output_coalesced_rows(hip_lib, tile):
+    """bf16 outputs of the pipelined kernels leave through the LDS-transposed 16-byte row stores: ragged tiles
+    (Cout % BM != 0, W % 32 != 0, pixel count % BP != 0), output written into a channel slice of a wider buffer whose
+    neighbours must stay untouched."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(500 + tile)
+    k = 3 if tile < 70 else 1
+    for (N, Cin, Cout, H, W) in ((2, 64, 200, 13, 45), (3, 96, 40, 9, 37)):
+        x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
+        w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        want = _ref_conv(x, w, b, 1, k // 2, "relu", torch.bfloat16)
+        pc = ops.PackedConv(w, b, stride=1, pad=k // 2, dtype=torch.bfloat16, device=DEV)
+        buf = torch.full((N, H, W, Cout + 24), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, out=buf[..., 8:8 + Cout], act="relu", tile=tile)
+        got = buf[..., 8:8 + Cout].float().cpu().permute(0, 3, 1, 2)
+        tol = 2e-6 * (Cin * k * k) ** 0.5 * max(1.0, want.abs().max().item()) + 1e-5 + want.abs().max().item() * 2 ** -8   # + bf16 rounding of y
+        assert (got - want).abs().max().item() < tol
+        assert (buf[..., :8] == 7.0).all() and (buf[..., 8 + Cout:] == 7.0).all()

@@ -30,6 +30,11 @@ def shapes():
         out.append(("head26.l%d" % l, N, hw[l][0], hw[l][1], 256, 26, 1, 1))
         out.append(("head5.l%d" % l, N, hw[l][0], hw[l][1], 256, 5, 1, 1))
     out.append(("fpn.out3", N, 20, 30, 256, 256, 3, 2)); out.append(("depth.cls", N, 80, 120, 256, 51, 1, 1))
+    # decoder linears (A = 1544 queries, 768 memory rows, 644 adaptive proposals)
+    for nm, M, ci, co in (("dec.qk", 1544, 256, 512), ("dec.v", 1544, 256, 256), ("dec.memk", 768, 256, 256), ("dec.wfc", 1544, 256, 416),
+                          ("dec.lfc", 1544, 256, 39), ("dec.ffn1", 1544, 256, 1024), ("dec.ffn2", 1544, 1024, 256), ("dec.m644", 644, 256, 256),
+                          ("dec.m300", 300, 256, 256), ("dec.ce", 7, 256, 256)):
+        out.append((nm, 1, 1, M, ci, co, 1, 1))
     return out
 
 def timeit(fn, iters=10):
@@ -55,6 +60,8 @@ def main():
     for name, N, H, W, Cin, Cout, k, stride in shapes():
         if only and int(only) != k:
             continue
+        if os.environ.get("ONLY_NAME") and not name.startswith(os.environ["ONLY_NAME"]):
+            continue
         key = "%d,%d,%d,%d,%d" % (Cout, Cin, k, stride, N * H * W)
         if key in seen:
             continue
@@ -65,7 +72,7 @@ def main():
         y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         res = {}
-        tiles = ((0, 1, 2, 3, 4, 18, 43, 45, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82) if (k == 1 and stride == 1) else ()) + ((39, 50, 51, 52, 53, 54, 55, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67) if (k == 3 and stride == 1) else ())
+        tiles = ((0, 1, 2, 3, 4, 18, 43, 45, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81) if (k == 1 and stride == 1) else ()) + ((39, 50, 51, 52, 53, 54, 55, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67) if (k == 3 and stride == 1) else ())
         for tile in tiles:
             t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile))
             res[tile] = t
