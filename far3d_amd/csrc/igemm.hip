@@ -42,6 +42,7 @@ struct IgemmParams {
   int act, y_dt, y2_dt, ldy2;
   int res_dt, ldr, Hr, Wr;
   int x_vec, y_vec, y2_vec, res_vec;
+  float* chan_sum;      // optional [N][Cout][2] f32: [n][m][0] += sum over pixels of the stored y (rows16 epilogue only)
   int y_rows16;         // plain bf16 output whose pixel rows take 16-byte stores (LDS-transposed coalesced epilogue)
 };
 
@@ -195,9 +196,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&
 // that cover whole pixel rows (the MFMA layout alone gives 8-byte pieces 2*ldy bytes apart).  pix_off(pl) -> element
 // offset of local pixel pl in y, or -1.  smem must hold BPX * (2*BM + 16) bytes and is free once every wave has passed
 // the first barrier.
-template <int NW, int WM, int WN, int BM, int BPX, typename PixFn>
+template <int NW, int WM, int WN, int BM, int BPX, typename PixFn, typename ImgFn>
 __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned char* smem, f32x16_t (&acc)[WM][WN], int m0,
-                                                int wm, int wn, int l31, int hi, PixFn pix_off) {
+                                                int wm, int wn, int l31, int hi, PixFn pix_off, ImgFn img_of) {
   constexpr int RS = BM * 2 + 16, CPP = BM / 8, NT = 64 * NW;
   __syncthreads();
 #pragma unroll
@@ -234,6 +235,34 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
     const long off = pix_off(pl);
     if (off < 0) continue;
     *reinterpret_cast<u32x4_t*>(y + off + m0 + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+  }
+  if (P.chan_sum) {
+    // per-image channel sums of the tile (eSE average pool, models/backbones/vovnet.py:95-101) from the staged bf16 values:
+    // thread = (channel pair, pixel phase); img_of(pl) -> image of local pixel pl or -1; one atomic per channel per image
+    constexpr int CP = BM / 2, G = NT / CP > 0 ? NT / CP : 1;
+    const int cp = threadIdx.x % CP, ph = threadIdx.x / CP;
+    if (ph < G && m0 + 2 * cp < P.Cout) {
+      int cur = -1;
+      float s0 = 0.f, s1 = 0.f;
+      for (int pl = ph; pl < BPX; pl += G) {
+        const int n = img_of(pl);
+        if (n != cur) {
+          if (cur >= 0) {
+            atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0);
+            atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1);
+          }
+          cur = n; s0 = 0.f; s1 = 0.f;
+        }
+        if (n >= 0) {
+          const unsigned u = *reinterpret_cast<const unsigned*>(smem + pl * RS + cp * 4);
+          s0 += __uint_as_float(u << 16); s1 += __uint_as_float(u & 0xffff0000u);
+        }
+      }
+      if (cur >= 0) {
+        atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0);
+        atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1);
+      }
+    }
   }
 }
 
@@ -666,9 +695,9 @@ static int launch_conv3x3_patch(const IgemmParams& P, hipStream_t st) {
 //   * fragments are double-buffered in registers: the reads of tap/k-half i+1 are issued before the MFMAs of i,
 //   * the next chunk's patch is issued AFTER the next step's weights so that `vmcnt(GPL)` keeps it in flight for two steps.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int KY, int POFF, int WOFF, int WST>
+template <int WM, int WN, int KY, int POFF, int WOFF, int WST, typename Dma>
 __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
-                                                     const int (&baddr)[2][WN + 2][3], f32x16_t (&acc)[WM][WN]) {
+                                                     const int (&baddr)[2][WN + 2][3], f32x16_t (&acc)[WM][WN], Dma dma) {
   u32x4_t af[2][WM], bf[2][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + aaddr[0][i]);
@@ -691,17 +720,20 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
 #pragma unroll
       for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][i], bf[cur][j]);
     __builtin_amdgcn_sched_barrier(0);
+    dma(it);        // this iteration's share of the next step's LDS-DMA pieces: their issue cost hides under the MFMAs above
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int WGM, int WGN, int WM, int WN>
+template <int WGM, int WGN, int WM, int WN, int NSW = 2>   // NSW: weight ring depth (kernel rows prefetched NSW-1 steps ahead)
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParams P, int tiles_x, int tiles_y) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int NW = WGM * WGN;                      // waves per workgroup (4, 8 or 16)
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
   constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + NW - 1) / NW;
   constexpr int GA = BM / 16, WSLOTS = 3 * GA, GWL = (WSLOTS + NW - 1) / NW, WST = BM * 64;
-  constexpr int WBASE = 2 * PATCH_B;                // weight ring: [2 stages][3 taps][WST]
+  static_assert(NSW == 2 || NSW == 3, "weight ring of 2 or 3 kernel rows");
+  constexpr int WBASE = 2 * PATCH_B;                // weight ring: [NSW stages][3 taps][WST]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
@@ -746,18 +778,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     wdst[i] = (q / GA) * WST + g * 1024;
     wvoff[i] = (unsigned)(((g * 16 + rg) * Ktot + lc * 8) * 2);
   }
+  auto patch_piece = [&](int i, int chunk, int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + buf * PATCH_B + pdst[i]), 16, pvoff[i], chunk * 64, 0, 0);
+  };
+  auto w_piece = [&](int i, int chunk, int ky, int stage) __attribute__((always_inline)) {   // kernel row ky: taps 3*ky .. 3*ky+2
+    if (wtap[i] < 0) return;            // wave-uniform
+    const int kb = (ky * 3 + wtap[i]) * P.cin_pad + chunk * 32;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + WBASE + stage * 3 * WST + wdst[i]), 16, wvoff[i], kb * 2, 0, 0);
+  };
   auto issue_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < GPL; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + buf * PATCH_B + pdst[i]), 16, pvoff[i], chunk * 64, 0, 0);
+    for (int i = 0; i < GPL; ++i) patch_piece(i, chunk, buf);
   };
-  auto issue_w = [&](int chunk, int ky, int stage) __attribute__((always_inline)) {   // one kernel row: taps 3*ky .. 3*ky+2
+  auto issue_w = [&](int chunk, int ky, int stage) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < GWL; ++i) {
-      if (wtap[i] < 0) continue;        // wave-uniform
-      const int kb = (ky * 3 + wtap[i]) * P.cin_pad + chunk * 32;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + WBASE + stage * 3 * WST + wdst[i]), 16, wvoff[i], kb * 2, 0, 0);
-    }
+    for (int i = 0; i < GWL; ++i) w_piece(i, chunk, ky, stage);
   };
 
   f32x16_t acc[WM][WN];
@@ -786,22 +821,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     }
 
   const int nchunks = P.cin_pad / 32;
-  issue_patch(0, 0);
-  issue_w(0, 0, 0);
-  // step (chunk c, kernel row ky) reads weight stage (3c + ky) & 1 and patch buffer c & 1
+  // `s_waitcnt vmcnt` counts this wave's own pieces, oldest first: nwv weight pieces per step (GWL or GWL-1), GPL patch pieces
+  const int nwv = (WSLOTS - wv + NW - 1) / NW;
+  const bool wfull = nwv == GWL;
+#define FAR3D_WAITC(NWS, PA)                                                                                          \
+  {                                                                                                                    \
+    if (wfull) { if (PA) wait_vmcnt<(NWS) * GWL + GPL>(); else wait_vmcnt<(NWS) * GWL>(); }                            \
+    else       { if (PA) wait_vmcnt<(NWS) * (GWL - 1) + GPL>(); else wait_vmcnt<(NWS) * (GWL - 1)>(); }                \
+  }
+  if (NSW == 2) {
+    issue_patch(0, 0);
+    issue_w(0, 0, 0);
+  } else {
+    issue_w(0, 0, 0);
+    issue_patch(0, 0);
+    issue_w(0, 1, 1);
+  }
+  // step s = 3c + ky reads weight stage s % NSW and patch buffer c & 1; after its barrier it issues the weights of step
+  // s + NSW - 1 and (ky == 0) the next chunk's patch.  Pieces issued after W(s), which may stay in flight at the top of
+  // step s:  NSW 2: the patch when ky == 1;  NSW 3: W(s+1), plus the patch when ky != 0.
 #define FAR3D_PIPE_STEP(PAR, KY, CH)                                                                                   \
   {                                                                                                                    \
-    constexpr int STG = (PAR * 3 + KY) & 1;                                                                            \
-    const bool more_patch = (KY == 0) && ((CH) + 1 < nchunks);                                                         \
+    constexpr int STG = NSW == 2 ? ((PAR * 3 + KY) & 1) : KY;                                                          \
+    const bool more = (CH) + 1 < nchunks;                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (KY == 1 && (CH) + 1 < nchunks) wait_vmcnt<GPL>(); else wait_vmcnt<0>();                                        \
+    if (NSW == 2) {                                                                                                    \
+      if (KY == 1 && more) wait_vmcnt<GPL>(); else wait_vmcnt<0>();                                                    \
+    } else {                                                                                                           \
+      const bool have_next = KY < 2 || more, patch_after = KY != 0 && more;                                            \
+      if (have_next) FAR3D_WAITC(1, patch_after) else wait_vmcnt<0>();                                                 \
+    }                                                                                                                  \
     __builtin_amdgcn_s_barrier();                                                                                      \
     asm volatile("" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (KY < 2) issue_w((CH), KY + 1, STG ^ 1);                                                                        \
-    else if ((CH) + 1 < nchunks) issue_w((CH) + 1, 0, STG ^ 1);                                                        \
-    if (more_patch) issue_patch((CH) + 1, (PAR) ^ 1);                                                                  \
-    patch_step_pipelined<WM, WN, KY, (PAR) * PATCH_B, WBASE + STG * 3 * WST, WST>(smem, aaddr, baddr, acc);            \
+    /* next pieces: weights of step s + NSW - 1 (chunk wc, row wk, stage ws) first, then (ky == 0) the next patch */   \
+    const int wc = (NSW == 2 ? (KY < 2) : (KY == 0)) ? (CH) : (CH) + 1;                                                \
+    constexpr int wk = (KY + NSW - 1) % 3, ws = NSW == 2 ? (STG ^ 1) : wk;                                             \
+    const bool do_w = wc < nchunks, do_p = KY == 0 && more;                                                            \
+    constexpr int PIECES = GWL + GPL, PPI = (PIECES + 5) / 6;                                                          \
+    patch_step_pipelined<WM, WN, KY, (PAR) * PATCH_B, WBASE + STG * 3 * WST, WST>(smem, aaddr, baddr, acc,             \
+      [&](int it) __attribute__((always_inline)) {                                                                     \
+        _Pragma("unroll")                                                                                              \
+        for (int k = it * PPI; k < (it + 1) * PPI && k < PIECES; ++k) {                                                \
+          if (k < GWL) { if (do_w) w_piece(k, wc, wk, ws); }                                                           \
+          else if (do_p) patch_piece(k - GWL, (CH) + 1, (PAR) ^ 1);                                                    \
+        }                                                                                                              \
+      });                                                                                                              \
   }
   for (int c = 0; c < nchunks; c += 2) {
     FAR3D_PIPE_STEP(0, 0, c)
@@ -813,12 +878,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
       FAR3D_PIPE_STEP(1, 2, c + 1)
     }
   }
+#undef FAR3D_WAITC
 #undef FAR3D_PIPE_STEP
   if (P.y_rows16) {
     epilogue_rows16<NW, WM, WN, BM, TH * 32>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
       return (y < P.H && x < P.W) ? (long)n * P.y_img_stride + ((long)y * P.W + x) * P.ldy : -1L;
-    });
+    }, [&](int pl) -> int { return (y0 + (pl >> 5) < P.H && x0 + (pl & 31) < P.W) ? n : -1; });
     return;
   }
   int pn[WN], ppix[WN];
@@ -832,23 +898,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
 #endif
 }
 
-template <int WGM, int WGN, int WM, int WN>
+template <int WGM, int WGN, int WM, int WN, int NSW = 2>
 static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds_ring = (size_t)2 * PG * 1024 + (size_t)2 * 3 * BM * 64, lds_out = (size_t)TH * 32 * (BM * 2 + 16);
+  constexpr size_t lds_ring = (size_t)2 * PG * 1024 + (size_t)NSW * 3 * BM * 64, lds_out = (size_t)TH * 32 * (BM * 2 + 16);
   constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
   dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
+  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
   return 0;
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // 1x1 / stride 1 convolution (= GEMM  y[pix][ch] = sum_k x[pix][k] w[ch][k]) with the same pipeline as conv3x3_pipe_kernel:
@@ -1004,7 +1069,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
       if (p >= Npix) return -1L;
       const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
-    });
+    }, [&](int pl) -> int { const long p = (long)p0 + pl; return p < Npix ? (int)(p / HoWo) : -1; });
     return;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
@@ -1034,7 +1099,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
                                  int Wo, int Cout, int ldy, long y_img_stride, int KH, int KW, int stride,
                                  int pad, int act, const void* res, int res_dt, int ldr, long res_img_stride,
                                  int Hr, int Wr, void* y2, int y2_dt, int ldy2, long y2_img_stride,
-                                 const float* y2_scale, const float* y2_shift, int tile, void* stream) {
+                                 const float* y2_scale, const float* y2_shift, float* chan_sum, int tile, void* stream) {
   FAR3D_CHECK_ARG(x && w && y, "far3d_conv2d_nhwc: null x/w/y");
   FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0,
                   "far3d_conv2d_nhwc: bad sizes N=%d H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d", N, H, W, Cin, Ho, Wo, Cout);
@@ -1066,6 +1131,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
   static const int no_rows16 = getenv("FAR3D_IGEMM_NO_ROWS16") ? atoi(getenv("FAR3D_IGEMM_NO_ROWS16")) : 0;
+  P.chan_sum = chan_sum;
   P.y_rows16 = !no_rows16 && y_dt == FAR3D_DT_BF16 && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   const long Npix = (long)N * Ho * Wo;
@@ -1076,6 +1142,10 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     else if (big >= 512) tile = 1;
     else if (((Npix + 63) / 64) * ((Cout + 127) / 128) >= 512) tile = 4;
     else tile = 3;
+  }
+  if (chan_sum && !(P.y_rows16 && tile >= 50 && x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && (Cin % 32) == 0 && P.x_vec)) {
+    far3d_set_error("far3d_conv2d_nhwc: chan_sum needs a pipelined tile (>= 50) with a plain, 16-byte-row bf16 output");
+    return FAR3D_ERR_ARG;
   }
 #define LAUNCH(TIN, TCC)                                                        \
   switch (tile) {                                                               \
@@ -1186,6 +1256,15 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 65: launch_conv3x3_pipe<1, 8, 1, 1>(P, st); break;   // 32 x 8 rows, 8 waves
         case 66: launch_conv3x3_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 4 rows, 16 waves
         case 67: launch_conv3x3_pipe<4, 2, 1, 1>(P, st); break;   // 128 x 2 rows, 8 waves
+        // 3-deep weight ring (kernel rows prefetched two steps ahead)
+        case 90: launch_conv3x3_pipe<2, 4, 1, 2, 3>(P, st); break;   // 64 x 8 rows, 8 waves
+        case 91: launch_conv3x3_pipe<2, 4, 1, 1, 3>(P, st); break;   // 64 x 4 rows, 8 waves
+        case 92: launch_conv3x3_pipe<1, 8, 1, 1, 3>(P, st); break;   // 32 x 8 rows, 8 waves
+        case 93: launch_conv3x3_pipe<1, 4, 1, 1, 3>(P, st); break;   // 32 x 4 rows, 4 waves
+        case 94: launch_conv3x3_pipe<2, 2, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 4 waves
+        case 95: launch_conv3x3_pipe<2, 8, 1, 1, 3>(P, st); break;   // 64 x 8 rows, 16 waves
+        case 96: launch_conv3x3_pipe<1, 8, 2, 1, 3>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
+        case 97: launch_conv3x3_pipe<2, 2, 1, 1, 3>(P, st); break;   // 64 x 2 rows, 4 waves
         default: done = false;
       }
     }

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
 
 extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                               float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
-                              long i_img_stride, int ldy, long y_img_stride, void* stream) {
+                              long i_img_stride, int ldy, long y_img_stride, int sums_ready, void* stream) {
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
   FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
                   "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4 and <= 1024)", C);
@@ -199,9 +199,11 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   // scratch: [N][C][2] sums followed by [N][C] gates
   float* sums = scratch;
   float* gate = scratch + (long)N * C * 2;
-  hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
-  if (e != hipSuccess) { far3d_set_error("far3d_ese_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
-  launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
+  if (!sums_ready) {
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
+    if (e != hipSuccess) { far3d_set_error("far3d_ese_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
+    launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
+  }
   hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;

@@ -192,7 +192,14 @@ def _nhwc_view(t, name):
     return t.stride(2), t.stride(0)
 
 
-def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0):
+def conv_tile(x, pc):
+    """The tile conv2d_nhwc(tile=0) will use for this input (0 = kernel heuristic)."""
+    N, H, W, Cin = x.shape
+    return _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W) if x.dtype == torch.bfloat16 else 0
+
+
+def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0,
+                chan_sum=None):
     """x: (N,H,W,Cin) NHWC view (f32|bf16).  pc: PackedConv.  out: optional (N,Ho,Wo,Cout) NHWC view to write
     into (e.g. a channel slice of an OSA concat buffer).  Returns out."""
     lib = _lib.require_device()
@@ -225,7 +232,8 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
     _lib.check(lib.far3d_conv2d_nhwc(
         _ptr(x), _dt(x), _ptr(pc.w), _dt(pc.w), _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
         N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],
-        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, tile, _stream(x)), "far3d_conv2d_nhwc")
+        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, _ptr(chan_sum) if chan_sum is not None else None, tile,
+        _stream(x)), "far3d_conv2d_nhwc")
     return out
 
 
@@ -287,8 +295,9 @@ def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=
     return res if len(res) > 1 else y
 
 
-def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
-    """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride)."""
+def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, sums_ready=False):
+    """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride).
+    sums_ready: scratch[:N*C*2] already holds the per-image channel sums (conv2d_nhwc(chan_sum=scratch))."""
     lib = _lib.require_device()
     N, H, W, C = x.shape
     ldx, xs = _nhwc_view(x, "x")
@@ -302,7 +311,7 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
     if scratch is None:
         scratch = torch.empty(N * C * 3, dtype=torch.float32, device=x.device)
     _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
-                                  ldx, xs, ldi, isd, ldy, ys, _stream(x)), "far3d_ese_nhwc")
+                                  ldx, xs, ldi, isd, ldy, ys, 1 if sums_ready else 0, _stream(x)), "far3d_ese_nhwc")
     return out
 
 

@@ -82,13 +82,16 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  * y2 (optional, y2_dt): second output y2 = y2_scale[n][m] * v + y2_shift[n][m] (FarHead's camera-aware MLN,
  *    ref: models/utils/misc.py:182-190, models/dense_heads/farhead.py:553-563) so that the FPN output conv writes
  *    the modulated token-major value maps directly.
+ * chan_sum (optional): [N][Cout][2] f32, element [n][m][0] += sum over pixels of the stored y (caller zeroes it): the eSE
+ *    average pool rides on the concat conv (then far3d_ese_nhwc(sums_ready=1)).  Needs a pipelined tile (>= 50), bf16 y,
+ *    no res / y2, 16-byte aligned rows (ldy, Cout multiples of 8).
  * tile: 0 auto; workgroup tile (channels x pixels): 1 128x128, 2 64x128, 3 64x64, 4 128x64, 5 64x256; bf16 LDS-DMA only:
  *    7 160x128, 8 192x128, 9 224x128, 10 192x64, 12 256x64, 13 256x128, 14 128x128 (4-deep ring). */
 int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y, int y_dt,
                       int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
                       long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,
                       int ldr, long res_img_stride, int Hr, int Wr, void* y2, int y2_dt, int ldy2,
-                      long y2_img_stride, const float* y2_scale, const float* y2_shift, int tile, void* stream);
+                      long y2_img_stride, const float* y2_scale, const float* y2_shift, float* chan_sum, int tile, void* stream);
 
 /* Multi-head self-attention core: out = softmax(q k^T * scale) v per head (flash-style, no score tensor in HBM).
  * Replaces the bmm/softmax/bmm inside torch.nn.MultiheadAttention as wrapped by mmcv's MultiheadAttention
@@ -112,10 +115,11 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
- * scratch: N*C*3 floats of device workspace. */
+ * scratch: N*C*3 floats of device workspace; sums_ready != 0: scratch[0 : N*C*2] already holds the channel sums
+ * (far3d_conv2d_nhwc's chan_sum), so the pooling pass is skipped. */
 int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
-                   int ldy, long y_img_stride, void* stream);
+                   int ldy, long y_img_stride, int sums_ready, void* stream);
 
 /* GroupNorm(groups, C) (+ReLU) on dense NHWC maps.  Replaces nn.GroupNorm(32, 256)+ReLU of the depth head,
  * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: N*C*2 + N*groups*2 floats. */

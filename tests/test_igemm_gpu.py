@@ -140,7 +140,7 @@ def test_conv_asymmetric_weights_catch_transposes(hip_lib):
 
 
 @pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42,
-                                  50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67])
+                                  50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 90, 91, 92, 93, 94, 95, 96, 97])
 def test_conv3x3_lds_patch_kernel(hip_lib, tile):
     """3x3/s1/p1 bf16 kernel with the LDS-resident halo patch: ragged sizes (W % 32 != 0, H % TH != 0, Cout % BM != 0)."""
     from far3d_amd import ops
@@ -173,15 +173,15 @@ def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin)
 
 
-@pytest.mark.parametrize("tile", [50, 52, 53, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67, 70, 71, 72, 73, 74, 75, 77, 78, 79, 80, 81, 82])
+@pytest.mark.parametrize("tile", [50, 52, 53, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67, 90, 92, 93, 95, 70, 71, 72, 73, 74, 75, 77, 78, 79, 80, 81, 82])
 def test_pipelined_kernels_bf16_output_coalesced_rows(hip_lib, tile):
     """bf16 outputs of the pipelined kernels leave through the LDS-transposed 16-byte row stores: ragged tiles
     (Cout % BM != 0, W % 32 != 0, pixel count % BP != 0), output written into a channel slice of a wider buffer whose
     neighbours must stay untouched."""
     from far3d_amd import ops
     g = torch.Generator().manual_seed(500 + tile)
-    k = 3 if tile < 70 else 1
-    for (N, Cin, Cout, H, W) in ((2, 64, 200, 13, 45), (3, 96, 40, 9, 37)):
+    k = 1 if 70 <= tile < 90 else 3
+    for (N, Cin, Cout, H, W) in ((2, 64, 200, 13, 45), (3, 96, 40, 9, 37), (1, 32, 64, 5, 33)):
         x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
         w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
         b = torch.randn(Cout, generator=g)
@@ -193,3 +193,25 @@ def test_pipelined_kernels_bf16_output_coalesced_rows(hip_lib, tile):
         tol = 2e-6 * (Cin * k * k) ** 0.5 * max(1.0, want.abs().max().item()) + 1e-5 + want.abs().max().item() * 2 ** -8   # + bf16 rounding of y
         assert (got - want).abs().max().item() < tol
         assert (buf[..., :8] == 7.0).all() and (buf[..., 8 + Cout:] == 7.0).all()
+
+
+@pytest.mark.parametrize("tile", [60, 65, 70, 75, 79, 80, 81])
+def test_pipelined_epilogue_channel_sums(hip_lib, tile):
+    """chan_sum: the pipelined kernels' row-store epilogue also accumulates per-image channel sums of the stored bf16
+    values (the eSE average pool); pixel tiles straddle images and the ragged edges must not contribute."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(900 + tile)
+    k = 3 if tile < 70 else 1
+    N, Cin, Cout, H, W = 3, 64, 168, 15, 37
+    x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    pc = ops.PackedConv(w, b, stride=1, pad=k // 2, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(N, Cout, 2, device=DEV)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=tile, chan_sum=sums)
+    want = y.float().sum(dim=(1, 2)).cpu()            # sums of the values actually stored
+    err = (sums[..., 0].cpu() - want).abs().max().item()
+    assert err < 1e-4 * max(1.0, want.abs().max().item()), err
+    assert sums[..., 1].abs().max().item() == 0.0
+    with pytest.raises(Exception):
+        ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=1, chan_sum=sums)
