@@ -199,11 +199,11 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   // scratch: [N][C][2] sums followed by [N][C] gates
   float* sums = scratch;
   float* gate = scratch + (long)N * C * 2;
-  if (!sums_ready) {
+  if (sums_ready == 0) {
     hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
     if (e != hipSuccess) { far3d_set_error("far3d_ese_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
-    launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
   }
+  if (sums_ready != 1) launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
   hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;

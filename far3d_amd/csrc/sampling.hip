@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict
 // block scan), and the gather loop is reduced to: broadcast record read, 4 coalesced row loads, 16 FMAs -- NB samples in
 // flight per wave.  Softmax uses the hardware exp2 path and incremental (camera, logit) indices.
 // ------------------------------------------------------------------------------------------
-template <typename TV, int NB, int ABL = 0>
+template <typename TV, int NB, int ABL = 0, int RP = 0>   // RP: bf16 row-pair gather (16-byte loads, both bilinear columns per instruction)
 __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ Vc,
@@ -399,6 +399,56 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   __syncthreads();
   const int nsamp = (ABL & 1) ? 0 : scan_s[4];
 
+  if constexpr (RP != 0 && sizeof(TV) == 2) {
+    // ---- phase 3 (bf16): lanes 0-31 take the left bilinear column, lanes 32-63 the right one; a lane owns 8 channels
+    // (16 bytes) of its pixel, so one instruction fetches the two adjacent 512-byte token rows of a sample's top (then
+    // bottom) tap pair.  Half the load instructions of the 8-byte layout, twice the samples in flight per VGPR; the two
+    // column partial sums are added once at the end (the weighted sum is linear).
+    typedef unsigned rp_u32x4 __attribute__((ext_vector_type(4)));
+    const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
+    float a8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] = 0.f;
+    const bf16_t* fb = reinterpret_cast<const bf16_t*>(feat) + l31 * 8;
+    for (int b0 = wv; b0 < nsamp; b0 += 4 * NB) {
+      rp_u32x4 vt[NB], vb[NB];
+      float wt[NB], wb[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int si = b0 + 4 * i;
+        const bool ok = si < nsamp;
+        const int4 r0 = rec_s[2 * (ok ? si : 0)];
+        const int4 r1 = rec_s[2 * (ok ? si : 0) + 1];
+        const bf16_t* p = fb + r0.x + (hi ? r0.y : 0);
+        vt[i] = *reinterpret_cast<const rp_u32x4*>(p);
+        vb[i] = *reinterpret_cast<const rp_u32x4*>(p + r0.z);
+        const float aw = ok ? w_s[r0.w + g] : 0.f;
+        wt[i] = aw * __int_as_float(hi ? r1.y : r1.x);
+        wb[i] = aw * __int_as_float(hi ? r1.w : r1.z);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a8[2 * k] += wt[i] * __uint_as_float(vt[i][k] << 16) + wb[i] * __uint_as_float(vb[i][k] << 16);
+          a8[2 * k + 1] += wt[i] * __uint_as_float(vt[i][k] & 0xffff0000u) + wb[i] * __uint_as_float(vb[i][k] & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] += __shfl_xor(a8[k], 32);
+    __syncthreads();
+    float* red_s = w_s;
+    if (hi == 0) {
+      *reinterpret_cast<float4*>(red_s + wv * 256 + l31 * 8) = make_float4(a8[0], a8[1], a8[2], a8[3]);
+      *reinterpret_cast<float4*>(red_s + wv * 256 + l31 * 8 + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
+    }
+    __syncthreads();
+    const float res = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
+    if (prm.out_dt == FAR3D_DT_F32) reinterpret_cast<float*>(out)[(long)a * 256 + t] = res;
+    else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + t] = f32_to_bf16(res);
+    return;
+  }
   // ---- phase 3: gather.  lane = group*8 + chunk (4 channels); a sample = 4 coalesced token-row loads.
   const int g = lane >> 3;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -493,8 +543,14 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else if (abl == 4)
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else   // NB = 2 measured best on MI355X (8 waves/SIMD, 8 row loads in flight per wave)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 7)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 8)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 8, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 9)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 6, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else   // row-pair gather, 2 samples (4 x 1 KB row-pair loads) in flight per wave: measured best (more in flight thrashes L2)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
     return FAR3D_OK;
   }

@@ -98,6 +98,13 @@ class Far3DEngine:
         self._graph = None
         self._graph_outs = None
         self.use_graph = False      # set True to capture the steady-state frame into one hipGraph (static proposal mode only)
+        # Optional forked HIP streams for independent small branches (FAR3D_MS=roi,dec,fork).  Off by default: inside a
+        # captured hipGraph the parallel branches measured SLOWER on ROCm 7.2 (8.14 -> 8.8-9.0 ms per frame), see DESIGN.md.
+        import os as _os
+        self.ms_parts = set(_os.environ.get("FAR3D_MS", "none").split(","))
+        self.multi_stream = True
+        self._side = None
+        self._side_dec = None
         self.eye4 = None
         self.kernel_events = None   # set to {} to collect (start, stop) HIP event pairs around selected kernels
         self.after_fpn = None       # hook(stage_dict) called right after the FPN (camera-sharded mode starts its gather)
@@ -233,6 +240,37 @@ class Far3DEngine:
     def _query_pos(self, ref):
         return self.qe[1](self.qe[0](ops.posemb3d(ref.contiguous(), self.dim_t128), act="relu"))
 
+    def _fork(self, fns):
+        """Run independent branches concurrently: fns[0] on the current stream, the rest on side streams that fork from it
+        and join back (inside a hipGraph capture this becomes parallel graph branches).  Returns the branches' results."""
+        if not self.multi_stream or len(fns) == 1 or "fork" not in self.ms_parts:
+            return [f() for f in fns]
+        cur = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(8)]
+        outs = [None] * len(fns)
+        used = []
+        for i, f in enumerate(fns[1:]):
+            st = self._side[i % len(self._side)]
+            if st not in used:
+                st.wait_stream(cur)
+                used.append(st)
+            with torch.cuda.stream(st):
+                outs[i + 1] = f()
+        outs[0] = fns[0]()
+        for st in used:
+            cur.wait_stream(st)
+
+        def keep(o):
+            if isinstance(o, torch.Tensor):
+                o.record_stream(cur)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    keep(v)
+        for o in outs[1:]:
+            keep(o)
+        return outs
+
     def _buf(self, key, shape, dtype):
         b = self._bufs.get(key)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
@@ -246,6 +284,11 @@ class Far3DEngine:
         act, spec = self.prec["act"], self.spec
         N = img.shape[0]
         Lb = spec["layer_per_block"]
+        # eSE workspaces (channel sums + gates, N*C*3 floats per block): one slab, zeroed once per frame
+        nblk = sum(len(b) for b in self.bb["stages"])
+        slab = self._buf(("ese_slab",), (nblk, N * max(spec["stage_out_ch"]) * 3), torch.float32)
+        slab.zero_()
+        ese_i = 0
         x = ops.stem_im2col(img, act)
         x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
@@ -283,7 +326,8 @@ class Far3DEngine:
                     nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, oc + Lb * sc), act)
                     out = nxt[..., :oc]
                 ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out,
-                             scratch=self._buf(("ese", si), (N * oc * 3,), torch.float32))
+                             scratch=slab[ese_i], sums_state="zeroed")
+                ese_i += 1
                 if not last:
                     cat, cur_in = nxt, oc
             stage_in = self._bufs[("stage", si)]
@@ -316,19 +360,29 @@ class Far3DEngine:
 
     # ------------------------------------------------------------------------------------------ a4: 2D head + depth
     def roi_head(self, raw):
-        cls, reg = [], []
-        for l, x in enumerate(raw):
-            lv = self.roi[l]
-            cf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["cls"][0], act="swish"), lv["cls"][1], act="swish")
-            rf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["reg"][0], act="swish"), lv["reg"][1], act="swish")
-            cls.append(ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32))
-            reg.append(ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32))
-        d = raw[0]
-        for i in range(2):
-            d = ops.conv2d_nhwc(d, self.depth["convs"][i])
-            d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True)
-        depth_logit = ops.conv2d_nhwc(d, self.depth["cls"], out_dtype=torch.float32)
-        return cls, reg, depth_logit
+        """YOLOX towers + depth head.  The four pyramid levels and the depth branch are independent: the small levels run
+        on side streams underneath the stride-8 level, which alone fills the GPU."""
+        def level(l):
+            def run():
+                x, lv = raw[l], self.roi[l]
+                cf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["cls"][0], act="swish"), lv["cls"][1], act="swish")
+                c = ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32)
+                rf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["reg"][0], act="swish"), lv["reg"][1], act="swish")
+                r = ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32)
+                return c, r
+            return run
+
+        def depth():
+            d = raw[0]
+            for i in range(2):
+                d = ops.conv2d_nhwc(d, self.depth["convs"][i])
+                d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True)
+            return ops.conv2d_nhwc(d, self.depth["cls"], out_dtype=torch.float32)
+
+        br = [level(0)] + [level(l) for l in range(1, len(raw))] + [depth]
+        res = self._fork(br) if "roi" in self.ms_parts else [f() for f in br]
+        cls, reg = [r[0] for r in res[:-1]], [r[1] for r in res[:-1]]
+        return cls, reg, res[-1]
 
     # ------------------------------------------------------------------------------------------ memory (a6/a11, tiny)
     def reset_memory(self):
@@ -388,26 +442,55 @@ class Far3DEngine:
         outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
         # reference points are fixed across the 6 layers: one camera-sorted workgroup order per frame (scheduling only)
         perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw)
-        qk = self._buf(("qk",), (A + Km, 2 * E), at)
-        vb = self._buf(("v",), (A + Km, E), at)
         ln_kw = dict(add=qpos, add_dtype=at, bf16_copy=fast)
+        L = len(self.layers)
+        qks = [self._buf(("qk", li), (A + Km, 2 * E), at) for li in range(L)]
+        vbs = [self._buf(("v", li), (A + Km, E), at) for li in range(L)]
+
+        # Work that does not depend on the evolving queries -- the memory rows' K/V projections and the camera-embedding
+        # chain (lidar2img -> cam_embed -> camera part of the attention logits) of every layer -- is issued up front on a
+        # side stream, layer 0 first; each layer waits on its own event, so all of it hides under the main chain.
+        Vcs = [None] * L
+        side_ev = [None] * L
+
+        def side_layer(li):
+            ly = self.layers[li]
+            ops.linear(memkb, ly["k"], out=qks[li][A:, E:])
+            ops.linear(memb, ly["v"], out=vbs[li][A:])
+            ce = ops.linear(ops.linear(l2i, ly["ce0"], act="relu"), ly["ce2"], act="relu")
+            ce = ops.layernorm(ce, *ly["ce_ln"])
+            Vcs[li] = ops.linear(ce, ly["wfc_full"])                    # (N,416) camera part + bias
+
+        cur = torch.cuda.current_stream(self.dev)
+        ms_dec = self.multi_stream and "dec" in self.ms_parts
+        if ms_dec:
+            if self._side_dec is None:
+                self._side_dec = torch.cuda.Stream(device=self.dev)
+            sst = self._side_dec
+            sst.wait_stream(cur)
+            with torch.cuda.stream(sst):
+                for li in range(L):
+                    side_layer(li)
+                    side_ev[li] = torch.cuda.Event()
+                    side_ev[li].record(sst)
+                    Vcs[li].record_stream(cur)
         for li, ly in enumerate(self.layers):
+            qk, vb = qks[li], vbs[li]
+            if not ms_dec:
+                side_layer(li)
             # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
-            ops.linear(xqb, ly["qk"], out=qk[:A])
-            ops.linear(memkb, ly["k"], out=qk[A:, E:])
-            ops.linear(xb, ly["v"], out=vb[:A])
-            ops.linear(memb, ly["v"], out=vb[A:])
+            self._fork([lambda: ops.linear(xqb, ly["qk"], out=qk[:A]), lambda: ops.linear(xb, ly["v"], out=vb[:A])])
+            if side_ev[li] is not None:
+                cur.wait_event(side_ev[li])
             att = ops.attention_forward(qk[:A, :E], qk[:, E:], vb, num_heads=cfg["num_heads"], out_dtype=at)
             y = ops.linear(att, ly["out"], res=x)
             r = ops.layernorm(y, *ly["norms"][0], **ln_kw)
             x, xqb = r[0], r[1]
             xb = r[2] if fast else x
             # cross-attention: fused perspective-aware aggregation (detr3d_transformer.py:522-569)
-            ce = ops.linear(ops.linear(l2i, ly["ce0"], act="relu"), ly["ce2"], act="relu")
-            ce = ops.layernorm(ce, *ly["ce_ln"])
-            Vc = ops.linear(ce, ly["wfc_full"])                         # (N,416) camera part + bias
-            U = ops.linear(xqb, ly["wfc"])                              # (A,416) query part
-            offs = ops.linear(xb, ly["lfc"])                            # (A,39)
+            U, offs = self._fork([lambda: ops.linear(xqb, ly["wfc"]),   # (A,416) query part of the logits
+                                  lambda: ops.linear(xb, ly["lfc"])])   # (A,39) learnable 3D offsets
+            Vc = Vcs[li]
             agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
                                         num_groups=cfg["num_groups"], perm=perm, out_dtype=at)
             self.last_agg = (tokens, ref, offs, lidar2img, U, Vc, hw, starts, pad_hw, perm)   # for isolated kernel timing
@@ -423,6 +506,8 @@ class Far3DEngine:
             r = ops.layernorm(y, *ly["norms"][2], out=outs[li], **ln_kw)
             x, xqb = r[0], r[1]
             xb = r[2] if fast else x
+        if ms_dec:
+            cur.wait_stream(self._side_dec)
         return outs
 
     # ------------------------------------------------------------------------------------------ one frame

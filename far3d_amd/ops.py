@@ -295,9 +295,10 @@ def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=
     return res if len(res) > 1 else y
 
 
-def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, sums_ready=False):
+def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, sums_state=None):
     """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride).
-    sums_ready: scratch[:N*C*2] already holds the per-image channel sums (conv2d_nhwc(chan_sum=scratch))."""
+    sums_state: None -> the call zeroes scratch and pools; "zeroed" -> scratch[:N*C*2] is already zero (one memset for a
+    whole slab of workspaces); "ready" -> it already holds the per-image channel sums (conv2d_nhwc(chan_sum=scratch))."""
     lib = _lib.require_device()
     N, H, W, C = x.shape
     ldx, xs = _nhwc_view(x, "x")
@@ -311,7 +312,8 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, sums_ready=Fals
     if scratch is None:
         scratch = torch.empty(N * C * 3, dtype=torch.float32, device=x.device)
     _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
-                                  ldx, xs, ldi, isd, ldy, ys, 1 if sums_ready else 0, _stream(x)), "far3d_ese_nhwc")
+                                  ldx, xs, ldi, isd, ldy, ys, {None: 0, "ready": 1, "zeroed": 2}[sums_state], _stream(x)),
+               "far3d_ese_nhwc")
     return out
 
 

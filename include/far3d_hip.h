@@ -115,8 +115,9 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
- * scratch: N*C*3 floats of device workspace; sums_ready != 0: scratch[0 : N*C*2] already holds the channel sums
- * (far3d_conv2d_nhwc's chan_sum), so the pooling pass is skipped. */
+ * scratch: N*C*3 floats of device workspace.  sums_ready: 0 = the call zeroes scratch[0 : N*C*2] and pools into it;
+ * 2 = the caller already zeroed it (one memset for many blocks); 1 = it already holds the channel sums
+ * (far3d_conv2d_nhwc's chan_sum) and the pooling pass is skipped. */
 int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
                    int ldy, long y_img_stride, int sums_ready, void* stream);
