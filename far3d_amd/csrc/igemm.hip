@@ -25,6 +25,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define ACT_RELU 1
 #define ACT_SWISH 2
 
+#define FAR3D_SUM_REPLICAS FAR3D_ESE_REPLICAS   // = XCDs of an MI355X; see epilogue_rows16
 struct IgemmParams {
   const void* x;        // input activations (TIn), NHWC with pixel stride ldx, channel offset pre-applied
   const void* w;        // packed weights (TC) [Cout_pad][taps][cin_pad]
@@ -238,8 +239,14 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
   }
   if (P.chan_sum) {
     // per-image channel sums of the tile (eSE average pool, models/backbones/vovnet.py:95-101) from the staged bf16 values:
-    // thread = (channel pair, pixel phase); img_of(pl) -> image of local pixel pl or -1; one atomic per channel per image
+    // thread = (channel pair, pixel phase); img_of(pl) -> image of local pixel pl or -1.
+    // Accumulation target: replica [xcc][n][c][2] where xcc = the XCD this workgroup runs on (hardware XCC_ID register), so
+    // every writer of a replica shares ONE L2 and the adds can be L2-local (workgroup-scope: no sc1, not sent to the
+    // memory side like an agent-scope atomic, which is what made a single shared array slower than a separate pooling
+    // kernel).  The kernel-end writeback publishes the replicas; the eSE gate kernel adds the FAR3D_SUM_REPLICAS copies.
     constexpr int CP = BM / 2, G = NT / CP > 0 ? NT / CP : 1;
+    const int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & (FAR3D_SUM_REPLICAS - 1);   // HW_REG_XCC_ID[3:0]
+    float* rep = P.chan_sum + (long)xcc * P.N * P.Cout * 2;
     const int cp = threadIdx.x % CP, ph = threadIdx.x / CP;
     if (ph < G && m0 + 2 * cp < P.Cout) {
       int cur = -1;
@@ -248,8 +255,8 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
         const int n = img_of(pl);
         if (n != cur) {
           if (cur >= 0) {
-            atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0);
-            atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1);
+            __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           cur = n; s0 = 0.f; s1 = 0.f;
         }
@@ -259,8 +266,8 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
         }
       }
       if (cur >= 0) {
-        atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0);
-        atomicAdd(P.chan_sum + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1);
+        __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
@@ -1069,7 +1076,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
       if (p >= Npix) return -1L;
       const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
-    }, [&](int pl) -> int { const long p = (long)p0 + pl; return p < Npix ? (int)(p / HoWo) : -1; });
+    }, [&, n0 = (int)((long)p0 / HoWo)](int pl) -> int {
+      const long p = (long)p0 + pl;
+      if (p >= Npix) return -1;
+      const long nb = (long)(n0 + 1) * HoWo;          // first pixel of the next image
+      return p < nb ? n0 : n0 + 1 + (int)((p - nb) / HoWo);
+    });
     return;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);

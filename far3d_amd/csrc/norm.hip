@@ -152,12 +152,16 @@ static int launch_chan_sums(const void* x, int dt, float* sums, int N, int HW, i
 // gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ); one wave per output channel.
 __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ sums, const float* __restrict__ fcw,
                                                        const float* __restrict__ fcb, float* __restrict__ gate, int C,
-                                                       float inv_hw) {
+                                                       float inv_hw, int replicas, long rep_stride) {
   const int n = blockIdx.y, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   float acc = 0.f;
-  for (int k = lane; k < C; k += 64) acc += fcw[(long)c * C + k] * (sums[((long)n * C + k) * 2] * inv_hw);
+  for (int k = lane; k < C; k += 64) {
+    float sk = 0.f;
+    for (int r = 0; r < replicas; ++r) sk += sums[r * rep_stride + ((long)n * C + k) * 2];   // per-XCD partial sums
+    acc += fcw[(long)c * C + k] * (sk * inv_hw);
+  }
   acc = wave_sum(acc);
   if (lane == 0) {
     const float z = acc + fcb[c];
@@ -197,14 +201,17 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
   // scratch: [N][C][2] sums followed by [N][C] gates
+  // sums_ready == 1: FAR3D_ESE_REPLICAS per-XCD copies [r][N][C][2] written by far3d_conv2d_nhwc(chan_sum); else one copy
+  const int replicas = sums_ready == 1 ? FAR3D_ESE_REPLICAS : 1;
   float* sums = scratch;
-  float* gate = scratch + (long)N * C * 2;
+  float* gate = scratch + (long)replicas * N * C * 2;
   if (sums_ready == 0) {
     hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
     if (e != hipSuccess) { far3d_set_error("far3d_ese_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
   }
   if (sums_ready != 1) launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
-  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW);
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, replicas,
+                     (long)N * C * 2);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;

@@ -105,6 +105,7 @@ class Far3DEngine:
         self.multi_stream = True
         self._side = None
         self._side_dec = None
+        self.fuse_ese = _os.environ.get("FAR3D_FUSE_ESE", "0") == "1"   # measured slower (8.13 -> 8.53 ms): off
         self.eye4 = None
         self.kernel_events = None   # set to {} to collect (start, stop) HIP event pairs around selected kernels
         self.after_fpn = None       # hook(stage_dict) called right after the FPN (camera-sharded mode starts its gather)
@@ -286,7 +287,7 @@ class Far3DEngine:
         Lb = spec["layer_per_block"]
         # eSE workspaces (channel sums + gates, N*C*3 floats per block): one slab, zeroed once per frame
         nblk = sum(len(b) for b in self.bb["stages"])
-        slab = self._buf(("ese_slab",), (nblk, N * max(spec["stage_out_ch"]) * 3), torch.float32)
+        slab = self._buf(("ese_slab",), (nblk, N * max(spec["stage_out_ch"]) * (2 * ops.ESE_REPLICAS + 1)), torch.float32)
         slab.zero_()
         ese_i = 0
         x = ops.stem_im2col(img, act)
@@ -318,7 +319,10 @@ class Far3DEngine:
                     dst = cat[..., cur_in + i * sc: cur_in + (i + 1) * sc]
                     ops.conv2d_nhwc(src, pc, out=dst, act="relu")
                     src = dst
-                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc), act), act="relu")
+                # bf16 path: the concat conv's epilogue also accumulates the eSE average pool (per-XCD replicas in the slab)
+                fused = self.fuse_ese and act == torch.bfloat16 and ops.conv_tile(cat, blk["concat"]) >= 50
+                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc), act), act="relu",
+                                     chan_sum=slab[ese_i] if fused else None)
                 if last:
                     out = self._buf(("stage", si), (N, H, W, oc), act)
                     nxt = None
@@ -326,7 +330,7 @@ class Far3DEngine:
                     nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, oc + Lb * sc), act)
                     out = nxt[..., :oc]
                 ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out,
-                             scratch=slab[ese_i], sums_state="zeroed")
+                             scratch=slab[ese_i], sums_state="ready" if fused else "zeroed")
                 ese_i += 1
                 if not last:
                     cat, cur_in = nxt, oc

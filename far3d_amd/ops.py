@@ -192,6 +192,9 @@ def _nhwc_view(t, name):
     return t.stride(2), t.stride(0)
 
 
+ESE_REPLICAS = 8   # FAR3D_ESE_REPLICAS in include/far3d_hip.h
+
+
 def conv_tile(x, pc):
     """The tile conv2d_nhwc(tile=0) will use for this input (0 = kernel heuristic)."""
     N, H, W, Cin = x.shape

@@ -19,6 +19,8 @@ extern "C" {
 
 #define FAR3D_DT_F32 0
 #define FAR3D_DT_BF16 1
+/* per-XCD replicas of the channel-sum array written by far3d_conv2d_nhwc(chan_sum) and read by far3d_ese_nhwc */
+#define FAR3D_ESE_REPLICAS 8
 
 #define FAR3D_OK 0
 #define FAR3D_ERR_ARG (-1)
@@ -82,8 +84,9 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  * y2 (optional, y2_dt): second output y2 = y2_scale[n][m] * v + y2_shift[n][m] (FarHead's camera-aware MLN,
  *    ref: models/utils/misc.py:182-190, models/dense_heads/farhead.py:553-563) so that the FPN output conv writes
  *    the modulated token-major value maps directly.
- * chan_sum (optional): [N][Cout][2] f32, element [n][m][0] += sum over pixels of the stored y (caller zeroes it): the eSE
- *    average pool rides on the concat conv (then far3d_ese_nhwc(sums_ready=1)).  Needs a pipelined tile (>= 50), bf16 y,
+ * chan_sum (optional): [FAR3D_ESE_REPLICAS][N][Cout][2] f32 (caller zeroes it); element [r][n][m][0] += sum over the pixels
+ *    handled on XCD r of the stored y: the eSE average pool rides on the concat conv (then far3d_ese_nhwc(sums_ready=1),
+ *    which adds the replicas).  Needs a pipelined tile (>= 50), bf16 y,
  *    no res / y2, 16-byte aligned rows (ldy, Cout multiples of 8).
  * tile: 0 auto; workgroup tile (channels x pixels): 1 128x128, 2 64x128, 3 64x64, 4 128x64, 5 64x256; bf16 LDS-DMA only:
  *    7 160x128, 8 192x128, 9 224x128, 10 192x64, 12 256x64, 13 256x128, 14 128x128 (4-deep ring). */
@@ -115,9 +118,9 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
- * scratch: N*C*3 floats of device workspace.  sums_ready: 0 = the call zeroes scratch[0 : N*C*2] and pools into it;
- * 2 = the caller already zeroed it (one memset for many blocks); 1 = it already holds the channel sums
- * (far3d_conv2d_nhwc's chan_sum) and the pooling pass is skipped. */
+ * scratch: device workspace, N*C*3 floats (sums_ready 0/2) or N*C*(2*FAR3D_ESE_REPLICAS+1) floats (sums_ready 1).
+ * sums_ready: 0 = the call zeroes scratch[0 : N*C*2] and pools into it; 2 = the caller already zeroed it (one memset for
+ * many blocks); 1 = scratch holds the per-XCD channel-sum replicas of far3d_conv2d_nhwc(chan_sum), pooling is skipped. */
 int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
                    int ldy, long y_img_stride, int sums_ready, void* stream);

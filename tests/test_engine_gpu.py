@@ -49,9 +49,9 @@ def test_engine_fp32_matches_reference_golden_sequence(hip_lib):
             assert err < tol, "frame %d %s: max abs err %.3e (tol %.1e)" % (fi, key, err, tol)
         r = o["result"]
         keep = r["keep"].cpu().numpy()
-        assert np.array_equal(r["labels_3d"].cpu().numpy()[keep], z["f%d_labels_3d" % fi])
-        assert np.abs(r["boxes_3d"].cpu().numpy()[keep] - z["f%d_boxes_3d" % fi]).max() < 2e-2
-        assert np.abs(r["scores_3d"].cpu().numpy()[keep] - z["f%d_scores_3d" % fi]).max() < 1e-3
+        from tests.conftest import assert_detections_match
+        assert_detections_match(tuple(r[k].cpu().numpy()[keep] for k in ("labels_3d", "boxes_3d", "scores_3d")),
+                                tuple(z["f%d_%s" % (fi, k)] for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi)
 
 
 def test_engine_bf16_deviation_is_bounded_and_reported(hip_lib):

@@ -207,11 +207,12 @@ def test_pipelined_epilogue_channel_sums(hip_lib, tile):
     w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
     b = torch.randn(Cout, generator=g)
     pc = ops.PackedConv(w, b, stride=1, pad=k // 2, dtype=torch.bfloat16, device=DEV)
-    sums = torch.zeros(N, Cout, 2, device=DEV)
+    sums = torch.zeros(ops.ESE_REPLICAS, N, Cout, 2, device=DEV)       # one replica per XCD
     y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=tile, chan_sum=sums)
     want = y.float().sum(dim=(1, 2)).cpu()            # sums of the values actually stored
-    err = (sums[..., 0].cpu() - want).abs().max().item()
+    got = sums.sum(dim=0)
+    err = (got[..., 0].cpu() - want).abs().max().item()
     assert err < 1e-4 * max(1.0, want.abs().max().item()), err
-    assert sums[..., 1].abs().max().item() == 0.0
+    assert got[..., 1].abs().max().item() == 0.0
     with pytest.raises(Exception):
         ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=1, chan_sum=sums)

@@ -31,9 +31,9 @@ def test_far3d_detector_from_config_reproduces_reference_boxes(hip_lib):
     for fi in range(rc["frames"]):
         data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
         res = det(return_loss=False, rescale=True, img_metas=metas, **data)[0]["pts_bbox"]
-        assert np.array_equal(res["labels_3d"].cpu().numpy(), z["f%d_labels_3d" % fi])
-        assert np.abs(res["scores_3d"].cpu().numpy() - z["f%d_scores_3d" % fi]).max() < 1e-3
-        assert np.abs(res["boxes_3d"].cpu().numpy() - z["f%d_boxes_3d" % fi]).max() < 2e-2
+        from tests.conftest import assert_detections_match
+        assert_detections_match(tuple(res[k].cpu().numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")),
+                                tuple(z["f%d_%s" % (fi, k)] for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi)
         assert np.abs(det.last_outs["all_cls_scores"].cpu().numpy() - z["f%d_all_cls_scores" % fi]).max() < 1e-3
 
 
