@@ -74,6 +74,18 @@ def cpu_baseline(args, cfg_over):
                        % (t_cam, t_head, torch.__version__, cores, ncpu))
 
 
+def agg_traffic():
+    """HBM bytes per launch of the aggregation kernel from the committed PMC pass (profiles/r1/aggregate_pmc.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/evidence_run.sh with PMC=1); None if absent."""
+    import os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "aggregate_pmc.json")
+    try:
+        with open(p) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,11 +192,11 @@ def main():
                                    "propagated), 2312 self-attn keys, 6 decoder layers, streaming memory on" % A,
                        "parallelism": "single GPU" if world == 1 else "camera-sharded x%d + 1 all-gather" % world,
                        "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)"},
-            "roofline": {"kernel": "aggregate_fwd_kernel (fused perspective-aware aggregation, one launch per decoder layer)",
+            "roofline": {"kernel": "aggregate_v3_kernel (fused perspective-aware aggregation, one launch per decoder layer)",
                          "bound": "hbm", "achieved": by / agg_t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": by / agg_t / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": by,
+                         "frac": by / agg_t / HBM_PEAK, "traffic": agg_traffic(), "algorithmic_bytes_per_launch": by,
                          "avg_launch_us": agg_t * 1e6, "timing": "HIP events around a hipGraph of 24 launches x 3 replays, live frame operands"},
-            "roofline_backbone": {"kernel": "igemm_kernel (VoV-99 convolutions, all launches of the backbone)", "bound": "mfma",
+            "roofline_backbone": {"kernel": "conv3x3_pipe_kernel + gemm1x1_pipe_kernel (VoV-99 backbone: all launches incl. eSE / pooling)", "bound": "mfma",
                                   "achieved": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                                   "unit": "TFLOP/s", "frac": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / MFMA_BF16_PEAK,
                                   "backbone_ms": bb_t * 1e3, "cameras_on_this_rank": ncam_local},
