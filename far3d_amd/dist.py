@@ -26,8 +26,19 @@ def gather_camera_major(local, num_cams, group=None, async_op=False):
     view of the gathered buffer; call work.wait() before fn() when async_op is set."""
     world = dist.get_world_size(group)
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # test rig only (several ranks sharing one GPU, tests/test_dist_gpu.py): gloo has no device collectives, stage via host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
+        out.copy_(host)
+        return _Done(), (lambda: out[:num_cams])
     work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
     return work, (lambda: out[:num_cams])
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 class ShardedFrame:
@@ -79,7 +90,8 @@ class ShardedFrame:
             rec = torch.cat([rec, torch.zeros((self.per - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=dev)])
         _, rec_fn = gather_camera_major(rec, self.num_cams, self.group)
         work, tok_fn = pending["tok"]
-        work.wait()
+        if work is not None:
+            work.wait()
         tokens = tok_fn()
         rec_all = rec_fn().reshape(self.num_cams * K, -1)
         ref2d, ctx = rec_all[:, :3].contiguous(), rec_all[:, 3:].contiguous()
