@@ -278,3 +278,69 @@ extern "C" int far3d_agg_order_keys(const float* ref, const float* lidar2img, in
   FAR3D_CHECK_LAUNCH("far3d_agg_order_keys");
   return FAR3D_OK;
 }
+
+__device__ __forceinline__ float glue_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------- camera embedding -> camera part of the attention logits
+// For every decoder layer l and camera n (models/utils/detr3d_transformer.py:497-505, 531-538):
+//   e  = LayerNorm(ReLU(W2 ReLU(W0 lidar2img[n][:3,:].flatten() + b0) + b2))       cam_embed = Linear-ReLU-Linear-ReLU-LN
+//   Vc = W3 e + b3                                                                  weights_fc applied to the camera term
+// (weights_fc(feat + cam_embed) = weights_fc(feat) + Vc by linearity; the query term U is a separate GEMM.)
+// The chain depends on the frame's calibration only, so all L layers run in ONE launch: block = (camera, layer), thread =
+// output channel, weights stored transposed ([in][out]) so a thread's column reads are coalesced across the block.
+__global__ __launch_bounds__(256) void cam_embed_chain_kernel(const float* __restrict__ l2i, const float* __restrict__ w0t,
+                                                              const float* __restrict__ b0, const float* __restrict__ w2t,
+                                                              const float* __restrict__ b2, const float* __restrict__ ln_g,
+                                                              const float* __restrict__ ln_b, const float* __restrict__ w3t,
+                                                              const float* __restrict__ b3, float* __restrict__ out, int N, int J,
+                                                              int Hd, float eps) {
+  const int n = blockIdx.x, l = blockIdx.y, t = threadIdx.x;
+  __shared__ float h0[256], h1[256], red[8];
+  const float* x = l2i + n * 12;
+  if (t < Hd) {                                   // hidden width Hd <= 256 (the reference uses embed_dims / 2 = 128)
+    float a0 = b0[l * Hd + t];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a0 += w0t[(l * 12 + k) * Hd + t] * x[k];
+    h0[t] = fmaxf(a0, 0.f);
+  }
+  __syncthreads();
+  float a = b2[l * 256 + t];
+  const float* w2 = w2t + (long)l * Hd * 256 + t;
+#pragma unroll 8
+  for (int k = 0; k < Hd; ++k) a += w2[k * 256] * h0[k];
+  a = fmaxf(a, 0.f);
+  // LayerNorm over the 256 channels (two-pass: mean, then centred variance)
+  float s = glue_wave_sum(a);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.f / 256.f);
+  const float d = a - mean;
+  s = glue_wave_sum(d * d);
+  if ((t & 63) == 0) red[4 + (t >> 6)] = s;
+  __syncthreads();
+  const float var = (red[4] + red[5] + red[6] + red[7]) * (1.f / 256.f);
+  h1[t] = d * (1.f / sqrtf(var + eps)) * ln_g[l * 256 + t] + ln_b[l * 256 + t];
+  __syncthreads();
+  for (int j = t; j < J; j += 256) {
+    float o = b3[l * J + j];
+    const float* w3 = w3t + (long)l * 256 * J + j;
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) o += w3[(long)k * J] * h1[k];
+    out[((long)l * N + n) * J + j] = o;
+  }
+}
+
+extern "C" int far3d_cam_embed_chain(const float* l2i, const float* w0t, const float* b0, const float* w2t, const float* b2,
+                                     const float* ln_g, const float* ln_b, const float* w3t, const float* b3, float* out,
+                                     int N, int L, int J, int Hd, float eps, void* stream) {
+  FAR3D_CHECK_ARG(l2i && w0t && b0 && w2t && b2 && ln_g && ln_b && w3t && b3 && out, "far3d_cam_embed_chain: null pointer argument");
+  FAR3D_CHECK_ARG(N > 0 && L > 0 && J > 0 && Hd > 0 && Hd <= 256, "far3d_cam_embed_chain: bad sizes N=%d L=%d J=%d Hd=%d", N, L, J, Hd);
+  hipLaunchKernelGGL(cam_embed_chain_kernel, dim3(N, L), dim3(256), 0, (hipStream_t)stream, l2i, w0t, b0, w2t, b2, ln_g, ln_b, w3t, b3,
+                     out, N, J, Hd, eps);
+  FAR3D_CHECK_LAUNCH("far3d_cam_embed_chain");
+  return FAR3D_OK;
+}

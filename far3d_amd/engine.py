@@ -223,6 +223,12 @@ class Far3DEngine:
                 ffn2=pk(sd[lp + "ffns.0.layers.1.weight"], sd[lp + "ffns.0.layers.1.bias"]),
                 norms=[(f32(sd[lp + "norms.%d.weight" % j]), f32(sd[lp + "norms.%d.bias" % j])) for j in range(3)])
             self.layers.append(ly)
+        cl = []
+        for i in range(cfg["num_layers"]):
+            c = h + "transformer.decoder.layers.%d.attentions.1." % i
+            cl.append((sd[c + "cam_embed.0.weight"], sd[c + "cam_embed.0.bias"], sd[c + "cam_embed.2.weight"], sd[c + "cam_embed.2.bias"],
+                       sd[c + "cam_embed.4.weight"], sd[c + "cam_embed.4.bias"], sd[c + "weights_fc.weight"], sd[c + "weights_fc.bias"]))
+        self.cam_chain = ops.pack_cam_embed_chain(cl, dev)
         # ---- frame-invariant pieces of temporal_alignment (farhead.py:284-303): the current frame's ego motion is the
         # identity, so its MLN(180) codes are constants, and the 644 learned queries never change.
         mk_dim_t = lambda n: (10000 ** (2 * torch.div(torch.arange(n, dtype=torch.float32, device=dev), 2, rounding_mode="floor") / n)).contiguous()
@@ -456,14 +462,13 @@ class Far3DEngine:
         # side stream, layer 0 first; each layer waits on its own event, so all of it hides under the main chain.
         Vcs = [None] * L
         side_ev = [None] * L
+        vc_all = ops.cam_embed_chain(l2i, self.cam_chain)             # all layers' camera terms: one launch (fp32 weights)
 
         def side_layer(li):
             ly = self.layers[li]
             ops.linear(memkb, ly["k"], out=qks[li][A:, E:])
             ops.linear(memb, ly["v"], out=vbs[li][A:])
-            ce = ops.linear(ops.linear(l2i, ly["ce0"], act="relu"), ly["ce2"], act="relu")
-            ce = ops.layernorm(ce, *ly["ce_ln"])
-            Vcs[li] = ops.linear(ce, ly["wfc_full"])                    # (N,416) camera part + bias
+            Vcs[li] = vc_all[li]                                        # (N,416) camera part + bias
 
         cur = torch.cuda.current_stream(self.dev)
         ms_dec = self.multi_stream and "dec" in self.ms_parts

@@ -34,6 +34,7 @@ SIGNATURES = {
     "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, _p]),
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
                                c_int, c_long, c_int, _p]),
+    "far3d_cam_embed_chain": (c_int, [_p] * 10 + [c_int, c_int, c_int, c_int, c_float, _p]),
     "far3d_groupnorm_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p]),
     "far3d_maxpool3x3s2_nhwc": (c_int, [_p, c_int, _p] + [c_int] * 7 + [c_long, _p]),
     "far3d_stem_im2col": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p]),

@@ -537,3 +537,27 @@ def aggregation_order(ref, lidar2img, pc_range, pad_hw):
     _lib.check(lib.far3d_agg_order_keys(_ptr(ref), _ptr(lidar2img), _ptr(keys), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
                                         _stream(ref)), "far3d_agg_order_keys")
     return torch.sort(keys, stable=True).indices.to(torch.int32)
+
+
+def cam_embed_chain(l2i, packed, eps=1e-5):
+    """Camera term of the aggregation logits for all decoder layers in one launch.  l2i (N,12) f32; packed: dict of stacked,
+    transposed fp32 weights (see pack_cam_embed_chain).  Returns (L,N,J) f32."""
+    lib = _lib.require_device()
+    N = l2i.shape[0]
+    L, E, J = packed["w3t"].shape
+    Hd = packed["w0t"].shape[2]
+    if E != 256 or l2i.shape[1] != 12 or tuple(packed["w2t"].shape) != (L, Hd, 256) or Hd > 256:
+        raise ValueError("cam_embed_chain: expects 12 -> Hd (<=256) -> 256 -> J weights, got %s" % {k: tuple(v.shape) for k, v in packed.items()})
+    out = torch.empty((L, N, J), dtype=torch.float32, device=l2i.device)
+    _lib.check(lib.far3d_cam_embed_chain(_ptr(l2i.contiguous()), _ptr(packed["w0t"]), _ptr(packed["b0"]), _ptr(packed["w2t"]),
+                                         _ptr(packed["b2"]), _ptr(packed["ln_g"]), _ptr(packed["ln_b"]), _ptr(packed["w3t"]),
+                                         _ptr(packed["b3"]), _ptr(out), N, L, J, Hd, eps, _stream(l2i)), "far3d_cam_embed_chain")
+    return out
+
+
+def pack_cam_embed_chain(layers, device):
+    """layers: list of (W0 (Hd,12), b0, W2 (256,Hd), b2, ln_g, ln_b, W3 (J,256), b3) per decoder layer (state-dict tensors)."""
+    f = lambda ts: torch.stack([t.detach().float() for t in ts]).contiguous().to(device)
+    return dict(w0t=f([l[0].t() for l in layers]), b0=f([l[1] for l in layers]), w2t=f([l[2].t() for l in layers]),
+                b2=f([l[3] for l in layers]), ln_g=f([l[4] for l in layers]), ln_b=f([l[5] for l in layers]),
+                w3t=f([l[6].t() for l in layers]), b3=f([l[7] for l in layers]))

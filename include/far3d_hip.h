@@ -204,6 +204,14 @@ int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, vo
 int far3d_agg_order_keys(const float* ref, const float* lidar2img, int32_t* keys, int A, int N, const float* pc_range, float pad_h,
                          float pad_w, void* stream);
 
+/* Camera embedding chain of ALL decoder layers in one launch (ref models/utils/detr3d_transformer.py:497-505, 531-538):
+ * out[l][n][:] = W3[l] LN(ReLU(W2[l] ReLU(W0[l] l2i[n] + b0[l]) + b2[l])) + b3[l]   (cam_embed -> camera term of weights_fc).
+ * l2i [N][12] = lidar2img[:, :3, :] flattened; weights fp32, TRANSPOSED to [in][out]: w0t [L][12][Hd], w2t [L][Hd][256],
+ * w3t [L][256][J]; b0 [L][Hd], b2/ln_g/ln_b [L][256], b3 [L][J]; out [L][N][J].  Embedding width 256, hidden Hd <= 256. */
+int far3d_cam_embed_chain(const float* l2i, const float* w0t, const float* b0, const float* w2t, const float* b2,
+                          const float* ln_g, const float* ln_b, const float* w3t, const float* b3, float* out, int N, int L,
+                          int J, int Hd, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,22 @@ def test_maxpool_ceil_mode(hip_lib, hw):
     gb = ops.maxpool3x3s2_nhwc(x.to(torch.bfloat16).to(DEV)).float().cpu()
     wb = F.max_pool2d(x.to(torch.bfloat16).float().permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1)
     assert torch.equal(gb, wb)
+
+
+def test_cam_embed_chain_matches_torch(hip_lib):
+    """All decoder layers' camera term (cam_embed MLP + LayerNorm + weights_fc) in one launch vs torch fp32."""
+    import torch.nn.functional as F
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(7)
+    L, N, J = 3, 5, 416
+    layers = []
+    for _ in range(L):
+        layers.append((torch.randn(128, 12, generator=g) * 0.3, torch.randn(128, generator=g) * 0.1, torch.randn(256, 128, generator=g) * 0.08,
+                       torch.randn(256, generator=g) * 0.1, 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g),
+                       torch.randn(J, 256, generator=g) * 0.05, torch.randn(J, generator=g) * 0.1))
+    l2i = torch.randn(N, 12, generator=g)
+    got = ops.cam_embed_chain(l2i.to("cuda:0"), ops.pack_cam_embed_chain(layers, "cuda:0")).cpu()
+    for l, (w0, b0, w2, b2, lg, lb, w3, b3) in enumerate(layers):
+        e = F.layer_norm(F.relu(F.linear(F.relu(F.linear(l2i, w0, b0)), w2, b2)), (256,), lg, lb)
+        want = F.linear(e, w3, b3)
+        assert (got[l] - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
