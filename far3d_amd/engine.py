@@ -174,6 +174,11 @@ class Far3DEngine:
             lv = {}
             for t in ("cls", "reg"):
                 lv[t] = [self._pack(*self._conv_bn(r + "multi_level_%s_convs.%d.%d" % (t, l, i), conv=".conv", norm=".bn", eps=1e-3)) for i in range(2)]
+            # the two towers' first convs read the same map: one 256 -> 512 conv (cls channels first), half the launches and
+            # twice the workgroups on the small levels
+            wc, bc, _, _ = self._conv_bn(r + "multi_level_cls_convs.%d.0" % l, conv=".conv", norm=".bn", eps=1e-3)
+            wr, br, _, _ = self._conv_bn(r + "multi_level_reg_convs.%d.0" % l, conv=".conv", norm=".bn", eps=1e-3)
+            lv["tower0"] = self._pack(torch.cat([wc, wr]), torch.cat([bc, br]), 1, 1)
             lv["cls_head"] = self._pack(sd[r + "multi_level_conv_cls.%d.weight" % l], sd[r + "multi_level_conv_cls.%d.bias" % l])
             lv["reg_head"] = self._pack(torch.cat([sd[r + "multi_level_conv_reg.%d.weight" % l], sd[r + "multi_level_conv_obj.%d.weight" % l]]),
                                         torch.cat([sd[r + "multi_level_conv_reg.%d.bias" % l], sd[r + "multi_level_conv_obj.%d.bias" % l]]))
@@ -375,9 +380,11 @@ class Far3DEngine:
         def level(l):
             def run():
                 x, lv = raw[l], self.roi[l]
-                cf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["cls"][0], act="swish"), lv["cls"][1], act="swish")
+                t0 = ops.conv2d_nhwc(x, lv["tower0"], act="swish")                 # (N,h,w,512): cls | reg
+                half = t0.shape[-1] // 2
+                cf = ops.conv2d_nhwc(t0[..., :half], lv["cls"][1], act="swish")
                 c = ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32)
-                rf = ops.conv2d_nhwc(ops.conv2d_nhwc(x, lv["reg"][0], act="swish"), lv["reg"][1], act="swish")
+                rf = ops.conv2d_nhwc(t0[..., half:], lv["reg"][1], act="swish")
                 r = ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32)
                 return c, r
             return run

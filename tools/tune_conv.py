@@ -27,6 +27,7 @@ def shapes():
         out.append(("fpn.lat%d" % i, N, hw[i][0], hw[i][1], cin, 256, 1, 1))
     for l in range(4):
         out.append(("c256.l%d" % l, N, hw[l][0], hw[l][1], 256, 256, 3, 1))
+        out.append(("c512.l%d" % l, N, hw[l][0], hw[l][1], 256, 512, 3, 1))
         out.append(("head26.l%d" % l, N, hw[l][0], hw[l][1], 256, 26, 1, 1))
         out.append(("head5.l%d" % l, N, hw[l][0], hw[l][1], 256, 5, 1, 1))
     out.append(("fpn.out3", N, 20, 30, 256, 256, 3, 2)); out.append(("depth.cls", N, 80, 120, 256, 51, 1, 1))
