@@ -121,7 +121,8 @@ def main():
     for fi in range(4):   # a few distinct frames, resident in HBM before the timed region
         data, metas = synth.make_frame(7, (640, 960), seed=0, frame_index=fi, device=dev)
         frames.append((data, metas))
-    runner = fdist.ShardedFrame(eng) if world > 1 else eng
+    # N > 1: per-rank hipGraphs for the per-camera stages and the replicated head, collectives eager in between
+    runner = fdist.ShardedFrame(eng, use_graph=not args.eager) if world > 1 else eng
     eng.use_graph = world == 1 and not args.eager   # whole steady-state frame as ONE hipGraph (no host launch gaps)
 
     def sync():

@@ -26,7 +26,7 @@ def _build(precision="fp32"):
     return engine.Far3DEngine(sd, cfg, device="cuda:0", precision=precision), rc
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, use_graph, frames):
     import torch.distributed as dist
     from far3d_amd import build, synth
     from far3d_amd import dist as fdist
@@ -34,9 +34,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         eng, rc = _build()
-        runner = fdist.ShardedFrame(eng)
+        runner = fdist.ShardedFrame(eng, use_graph=use_graph)
         outs = []
-        for fi in range(2):
+        for fi in range(frames):
             data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
             o = runner.forward_frame(data, metas)
             outs.append((o["all_cls_scores"].cpu().numpy(), o["all_bbox_preds"].cpu().numpy()))
@@ -46,13 +46,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])       # 3 cameras: 2 ranks -> (2, 1+pad); 4 ranks -> 1 each + one idle rank (the 8-GPU / 7-camera case)
-def test_sharded_frame_ranks_match_single_rank(hip_lib, world):
+# 3 cameras: 2 ranks -> (2, 1+pad); 4 ranks -> 1 each + one idle rank (the 8-GPU / 7-camera case).  use_graph: frame 0 runs
+# eagerly, frame 1 captures the two per-rank hipGraphs, frames 2-3 replay them (streaming memory updated in place).
+@pytest.mark.parametrize("world,use_graph,frames", [(2, False, 2), (2, True, 4), (4, True, 3)])
+def test_sharded_frame_ranks_match_single_rank(hip_lib, world, use_graph, frames):
     import torch.multiprocessing as mp
     from far3d_amd import synth
     eng, rc = _build()
     want = []
-    for fi in range(2):
+    for fi in range(frames):
         data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
         o = eng.forward_frame(data, metas)
         want.append((o["all_cls_scores"].cpu().numpy(), o["all_bbox_preds"].cpu().numpy()))
@@ -61,20 +63,24 @@ def test_sharded_frame_ranks_match_single_rank(hip_lib, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_graph, frames)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
+    try:
+        res = dict(q.get(timeout=150) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
     assert sorted(res) == list(range(world))
     for r in range(world):
-        for fi in range(2):
+        for fi in range(frames):
             for g, w in zip(res[r][fi], want[fi]):
                 assert g.shape == w.shape
                 tol = 1e-3 * max(1.0, np.abs(w).max() / 10.0)
                 assert np.abs(g - w).max() < tol, "rank %d frame %d: %.3e" % (r, fi, np.abs(g - w).max())
     # the replicated head is deterministic: both ranks hold the same streaming state, bit for bit
-    for fi in range(2):
+    for fi in range(frames):
         for r in range(1, world):
             assert np.array_equal(res[0][fi][0], res[r][fi][0])
