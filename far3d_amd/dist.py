@@ -107,7 +107,8 @@ class ShardedFrame:
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         dd = eng._stage_inputs(data)      # every rank keeps the (small) calibration inputs; images are sliced per rank
         scene = img_metas[0]["scene_token"]
-        steady = self.use_graph and scene == self._scene and eng.mem is not None
+        # an idle rank (no cameras) stays eager: it only pads the gathers and runs the head, and is never the slowest rank
+        steady = self.use_graph and bool(self.cams) and scene == self._scene and eng.mem is not None
         self._scene = scene
         if not steady:
             self._g_cam = self._g_head = None          # new scene: the captured branch decisions no longer hold
