@@ -116,38 +116,41 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
   __shared__ int s_cnt[1024 / 64];
   __shared__ int s_tot;
   __shared__ unsigned s_key;
-  // --- mode 1: find the K-th largest value by bisection on the (monotone, w >= 0) float bit pattern
+  // --- mode 1: find the K-th largest value by bisection on the (monotone, w >= 0) float bit pattern.  The camera's S <= 16*nt
+  // weights are read ONCE into registers; a pass = register compares + one wave reduction + ONE barrier (partials are double
+  // buffered and every thread adds the 16 wave partials itself), 31 passes.
   unsigned kth = __float_as_uint(thr);   // mode 0: strict threshold
+  int n_gt = 0;
   if (mode == 1) {
+    constexpr int MAXV = 16;
+    unsigned v[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) { const int i = t + k * nt; v[k] = i < S ? __float_as_uint(w[i]) : 0u; }   // padding 0 never counts (mid >= 1)
+    __shared__ int s_part[2][1024 / 64];
+    auto count_ge = [&](unsigned key, int slot) __attribute__((always_inline)) {
+      int c = 0;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) c += (v[k] >= key) ? 1 : 0;
+      for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+      if ((t & 63) == 0) s_part[slot][t >> 6] = c;
+      __syncthreads();
+      int tot = 0;
+      for (int k = 0; k < nt / 64; ++k) tot += s_part[slot][k];
+      return tot;
+    };
     unsigned lo = 0u, hi = 0x7f800000u;   // invariant: count(w >= lo) >= K, count(w >= hi) < K
+    int pass = 0;
     while (hi - lo > 1u) {
       const unsigned mid = lo + ((hi - lo) >> 1);
-      int c = 0;
-      for (int i = t; i < S; i += nt) c += (__float_as_uint(w[i]) >= mid) ? 1 : 0;
-      for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-      if ((t & 63) == 0) s_cnt[t >> 6] = c;
-      __syncthreads();
-      if (t == 0) { int tot = 0; for (int k = 0; k < nt / 64; ++k) tot += s_cnt[k]; s_tot = tot; }
-      __syncthreads();
-      if (s_tot >= cap) lo = mid; else hi = mid;
-      __syncthreads();
+      if (count_ge(mid, pass & 1) >= cap) lo = mid; else hi = mid;
+      ++pass;
     }
     kth = lo;   // value of the K-th largest element
+    n_gt = kth == 0xffffffffu ? 0 : count_ge(kth + 1u, pass & 1);   // strictly greater
+    __syncthreads();
   }
   // --- ordered compaction, chunk by chunk (chunk = workgroup size)
   // mode 0 keeps w > thr.  mode 1 keeps w > kth first-come AND as many w == kth (in index order) as needed.
-  int n_gt = 0;
-  if (mode == 1) {
-    int c = 0;
-    for (int i = t; i < S; i += nt) c += (__float_as_uint(w[i]) > kth) ? 1 : 0;
-    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-    if ((t & 63) == 0) s_cnt[t >> 6] = c;
-    __syncthreads();
-    if (t == 0) { int tot = 0; for (int k = 0; k < nt / 64; ++k) tot += s_cnt[k]; s_tot = tot; }
-    __syncthreads();
-    n_gt = s_tot;
-    __syncthreads();
-  }
   int base = 0, eq_left = (mode == 1) ? cap - n_gt : 0;
   for (int c0 = 0; c0 < S; c0 += nt) {
     const int i = c0 + t;
@@ -266,6 +269,7 @@ extern "C" int far3d_proposal_select(const float* const* cls, const float* const
   PropLevels lv;
   const int S = fill_levels(lv, L, level_hw, strides, cls, reg, ncls, nreg);
   FAR3D_CHECK_ARG(mode == 0 || (mode == 1 && cap <= S), "far3d_proposal_select: bad mode / K > S");
+  FAR3D_CHECK_ARG(mode == 0 || S <= 16 * 1024, "far3d_proposal_select: top-K mode keeps a camera's S=%d weights in registers (S <= 16384)", S);
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)N * S;
   const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -1,0 +1,32 @@
+"""GPU: 2D proposal selection (C ABI far3d_proposal_select) -- the static top-K mode against a sort of the kernel's own
+peak-weight map (the threshold mode is pinned by the golden sequence in test_engine_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("K", [1, 7, 92])
+def test_proposal_select_topk_matches_stable_sort(hip_lib, K):
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(3 + K)
+    N, ncls = 3, 26
+    hw = [(16, 24), (8, 12), (4, 6), (2, 3)]
+    cls = [(torch.randn(N, h, w, ncls, generator=g) * 2 - 1).to(DEV) for h, w in hw]
+    reg = [torch.randn(N, h, w, 5, generator=g).to(DEV) for h, w in hw]
+    # ties: quantise the logits of one camera so that many peaks share a weight
+    cls = [c.clone() for c in cls]
+    for c in cls:
+        c[1] = torch.round(c[1] * 2) / 2
+    reg = [r.clone() for r in reg]
+    for r in reg:
+        r[1, ..., 4] = torch.round(r[1, ..., 4] * 2) / 2
+    wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, (8, 16, 32, 64), K, thr=0.1, topk=True)
+    w = wgt.cpu().numpy()
+    idx = sel_idx.cpu().numpy()
+    assert (sel_cnt.cpu().numpy() == K).all()
+    for n in range(N):
+        order = np.argsort(-w[n], kind="stable")[:K]          # largest first, ties -> lower index
+        assert np.array_equal(idx[n], np.sort(order)), "camera %d" % n
