@@ -16,30 +16,33 @@
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int N, int H,
                                                           int W, int Ho, int Wo) {
-  // one thread per (n, oy, ox, tap); writes 3 channels; the 5 pad channels are written by tap 8's thread
-  const long total = (long)N * Ho * Wo * 9;
+  // one thread per output pixel: 9 taps x 3 channels gathered from the NCHW image, written as ONE 32-channel row
+  // (27 values + 5 zero pad channels) with 16-byte stores
+  const long total = (long)N * Ho * Wo;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % 9);
-    long p = i / 9;
+    long p = i;
     const int ox = (int)(p % Wo); p /= Wo;
     const int oy = (int)(p % Ho);
     const int n = (int)(p / Ho);
-    const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
-    float v[3] = {0.f, 0.f, 0.f};
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+    float v[32];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = img[(((long)n * 3 + c) * H + iy) * W + ix];
+    for (int k = 27; k < 32; ++k) v[k] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[tap * 3 + c] = ok ? img[(((long)n * 3 + c) * H + iy) * W + ix] : 0.f;
     }
-    T* dst = out + (((long)n * Ho + oy) * Wo + ox) * 32 + tap * 3;
+    T* dst = out + i * 32;
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if constexpr (sizeof(T) == 4) dst[c] = v[c]; else dst[c] = f32_to_bf16(v[c]);
-    }
-    if (tap == 8) {
+      for (int k = 0; k < 8; ++k) reinterpret_cast<float4*>(dst)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
 #pragma unroll
-      for (int c = 3; c < 8; ++c) {
-        if constexpr (sizeof(T) == 4) dst[c] = 0.f; else dst[c] = 0;
-      }
+      for (int k = 0; k < 4; ++k)
+        reinterpret_cast<uint4*>(dst)[k] = make_uint4(pack_bf16x2(v[8 * k], v[8 * k + 1]), pack_bf16x2(v[8 * k + 2], v[8 * k + 3]),
+                                                       pack_bf16x2(v[8 * k + 4], v[8 * k + 5]), pack_bf16x2(v[8 * k + 6], v[8 * k + 7]));
     }
   }
 }
@@ -48,7 +51,7 @@ extern "C" int far3d_stem_im2col(const float* img, void* out, int out_dt, int N,
   FAR3D_CHECK_ARG(img && out && N > 0 && H > 0 && W > 0, "far3d_stem_im2col: bad arguments");
   FAR3D_CHECK_ARG(out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16, "far3d_stem_im2col: unsupported dtype");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * Ho * Wo * 9;
+  const long total = (long)N * Ho * Wo;
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipStream_t st = (hipStream_t)stream;

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void cam_embed_chain_kernel(const float* __res
   __syncthreads();
   float a = b2[l * 256 + t];
   const float* w2 = w2t + (long)l * Hd * 256 + t;
-#pragma unroll 8
+#pragma unroll 32                       // latency-bound column reads: keep many loads in flight
   for (int k = 0; k < Hd; ++k) a += w2[k * 256] * h0[k];
   a = fmaxf(a, 0.f);
   // LayerNorm over the 256 channels (two-pass: mean, then centred variance)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void cam_embed_chain_kernel(const float* __res
   for (int j = t; j < J; j += 256) {
     float o = b3[l * J + j];
     const float* w3 = w3t + (long)l * 256 * J + j;
-#pragma unroll 8
+#pragma unroll 32
     for (int k = 0; k < 256; ++k) o += w3[(long)k * J] * h1[k];
     out[((long)l * N + n) * J + j] = o;
   }

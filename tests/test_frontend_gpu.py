@@ -30,3 +30,21 @@ def test_proposal_select_topk_matches_stable_sort(hip_lib, K):
     for n in range(N):
         order = np.argsort(-w[n], kind="stable")[:K]          # largest first, ties -> lower index
         assert np.array_equal(idx[n], np.sort(order)), "camera %d" % n
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stem_im2col_matches_unfold(hip_lib, dt):
+    """Stem conv input: (n, oy, ox, tap*3 + c) = img[n, c, 2*oy-1+ky, 2*ox-1+kx], zero padded, 5 zero pad channels."""
+    import torch.nn.functional as F
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 22, 38
+    img = torch.randn(N, 3, H, W, generator=g)
+    got = ops.stem_im2col(img.to(DEV), dt).float().cpu()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    cols = F.unfold(img, 3, padding=1, stride=2).view(N, 3, 9, Ho, Wo)          # (N, c, tap, oy, ox)
+    want = torch.zeros(N, Ho, Wo, 32)
+    want[..., :27] = cols.permute(0, 3, 4, 2, 1).reshape(N, Ho, Wo, 27)
+    if dt == torch.bfloat16:
+        want = want.to(torch.bfloat16).float()
+    assert got.shape == want.shape and torch.equal(got, want)
