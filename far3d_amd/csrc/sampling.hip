@@ -113,6 +113,8 @@ extern "C" int far3d_msda_forward(const void* value, int value_dtype, const int6
 // ------------------------------------------------------------------------------------------
 #define AGG_MAX_L 4
 #define AGG_MAX_NLP 384  // 12 softmax items per thread
+#define AGG_DEDUP_RCAP 88   // de-duplicated gather for queries with at most this many visible samples (4*RCAP taps) ...
+#define AGG_DEDUP_LCAP 192  // ... and at most this many distinct token rows
 struct AggParams {
   int A, N, S, P, L;
   int H[AGG_MAX_L], W[AGG_MAX_L], start[AGG_MAX_L];
@@ -282,9 +284,10 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NP = prm.N * prm.P, NLP = NP * prm.L, J = prm.L * prm.P;
   float* w_s = reinterpret_cast<float*>(smem);                 // [NLP][8] softmax weights; reused as [4][256] reduction buffer
-  int4* rec_s = reinterpret_cast<int4*>(w_s + (NLP * 8 > 1024 ? NLP * 8 : 1024));   // [NLP][2] sample records
-  float* stat_s = reinterpret_cast<float*>(rec_s + 2 * NLP);   // [64]
-  int* scan_s = reinterpret_cast<int*>(stat_s + 64);           // [8]
+  float* stat_s = w_s + (NLP * 8 > 1024 ? NLP * 8 : 1024);     // [64]
+  int* scan_s = reinterpret_cast<int*>(stat_s + 64);           // [16]
+  int4* rec_s = reinterpret_cast<int4*>(scan_s + 16);          // [NLP][2] sample records (compacted: only [0, nsamp) are live;
+                                                               //  the de-duplicating gather keeps its tables behind record RCAP)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 
   // ---- phase 1: one thread per (camera, point): projection, per-level geometry (detr3d_transformer.py:524-525,547-552)
@@ -399,6 +402,134 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   __syncthreads();
   const int nsamp = (ABL & 1) ? 0 : scan_s[4];
 
+  if constexpr (RP == 2 && sizeof(TV) == 2) {
+    // ---- phase 2.5 + 3 (bf16, de-duplicated gather).  The 13 points of a query land on few distinct pixels of the coarse
+    // pyramid levels (measured on the benchmark case: 228 non-zero bilinear taps -> 85 distinct token rows per query), so
+    // the taps are merged per token row first: an LDS hash table (open addressing, atomicCAS) elects one leader tap per row,
+    // leaders get compact slots (deterministic block scan), every tap adds softmax weight x bilinear weight of its 8 groups
+    // into its leader's weight vector (LDS float atomics), and the gather reads each distinct row ONCE.  Identical math up
+    // to fp32 reassociation.  Queries with more than RCAP visible samples or LCAP distinct rows keep the row-pair gather.
+    if (nsamp <= AGG_DEDUP_RCAP) {          // workgroup-uniform
+      constexpr int TCAP = 4 * AGG_DEDUP_RCAP, LCAP = AGG_DEDUP_LCAP, HT = 512;
+      int* key_s = reinterpret_cast<int*>(rec_s + 2 * AGG_DEDUP_RCAP);   // [TCAP] token-row element offset of tap i (-1: zero weight)
+      int* lead_s = key_s + TCAP;                           // [TCAP] compact slot of the tap's leader
+      int* tab_s = lead_s + TCAP;                           // [HT]   hash table: leader tap per token row
+      int* loff_s = tab_s + HT;                             // [LCAP] element offset of compact slot c
+      float* wl_s = reinterpret_cast<float*>(loff_s + LCAP);   // [LCAP][8] merged weights of compact slot c
+      const int T = 4 * nsamp;
+      for (int i = t; i < T; i += 256) {
+        const int4 r0 = rec_s[2 * (i >> 2)];
+        const int4 r1 = rec_s[2 * (i >> 2) + 1];
+        const int q = i & 3;
+        const int bw = q == 0 ? r1.x : q == 1 ? r1.y : q == 2 ? r1.z : r1.w;
+        key_s[i] = (__int_as_float(bw) != 0.f) ? r0.x + ((q & 1) ? r0.y : 0) + ((q & 2) ? r0.z : 0) : -1;
+      }
+      for (int i = t; i < HT; i += 256) tab_s[i] = -1;
+      for (int i = t; i < LCAP * 8; i += 256) wl_s[i] = 0.f;
+      __syncthreads();
+      int ld[2] = {-1, -1}, flag[2] = {0, 0};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = t + 256 * h;
+        if (i < T) {
+          const int k = key_s[i];
+          if (k >= 0) {
+            unsigned hs = ((unsigned)(k >> 8) * 2654435761u) >> 23;      // token index -> 9 bits
+            for (;;) {
+              const int old = atomicCAS(&tab_s[hs], -1, i);
+              if (old == -1) { ld[h] = i; break; }
+              if (key_s[old] == k) { ld[h] = old; break; }
+              hs = (hs + 1) & (HT - 1);
+            }
+            flag[h] = ld[h] == i ? 1 : 0;
+          }
+        }
+      }
+      {
+        const int c = flag[0] + flag[1];
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int nb = __shfl_up(inc, o);
+          if (lane >= o) inc += nb;
+        }
+        if (lane == 63) scan_s[8 + wv] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wv; ++k) base += scan_s[8 + k];
+        int pos = base + inc - c;
+        if (t == 255) scan_s[12] = base + inc;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = t + 256 * h;
+          if (i < T && flag[h]) {
+            lead_s[i] = pos;
+            if (pos < LCAP) loff_s[pos] = key_s[i];
+            ++pos;
+          }
+        }
+      }
+      __syncthreads();
+      const int nlead = scan_s[12];
+      if (nlead <= LCAP) {                    // workgroup-uniform
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = t + 256 * h;
+          if (i < T && ld[h] >= 0 && !flag[h]) lead_s[i] = lead_s[ld[h]];   // leaders' entries already hold their slot
+        }
+        __syncthreads();
+        for (int idx = t; idx < T * 8; idx += 256) {
+          const int i = idx >> 3, gq = idx & 7;
+          if (key_s[i] < 0) continue;
+          const int4 r0 = rec_s[2 * (i >> 2)];
+          const int4 r1 = rec_s[2 * (i >> 2) + 1];
+          const int q = i & 3;
+          const int bw = q == 0 ? r1.x : q == 1 ? r1.y : q == 2 ? r1.z : r1.w;
+          atomicAdd(&wl_s[lead_s[i] * 8 + gq], w_s[r0.w + gq] * __int_as_float(bw));
+        }
+        __syncthreads();
+        // gather: one instruction = two distinct token rows (lanes 0-31 / 32-63), 16 bytes (8 channels) per lane
+        typedef unsigned dd_u32x4 __attribute__((ext_vector_type(4)));
+        const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
+        float a8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] = 0.f;
+        const bf16_t* fb = reinterpret_cast<const bf16_t*>(feat) + l31 * 8;
+        for (int c0 = wv * 2; c0 < nlead; c0 += 8 * NB) {
+          dd_u32x4 vv[NB];
+          float ww[NB];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            const int c = c0 + 8 * i + hi;
+            const bool ok = c < nlead;
+            vv[i] = *reinterpret_cast<const dd_u32x4*>(fb + loff_s[ok ? c : 0]);
+            ww[i] = ok ? wl_s[c * 8 + g] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              a8[2 * k] += ww[i] * __uint_as_float(vv[i][k] << 16);
+              a8[2 * k + 1] += ww[i] * __uint_as_float(vv[i][k] & 0xffff0000u);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += __shfl_xor(a8[k], 32);
+        __syncthreads();
+        float* red_s = w_s;
+        if (hi == 0) {
+          *reinterpret_cast<float4*>(red_s + wv * 256 + l31 * 8) = make_float4(a8[0], a8[1], a8[2], a8[3]);
+          *reinterpret_cast<float4*>(red_s + wv * 256 + l31 * 8 + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
+        }
+        __syncthreads();
+        const float res = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
+        if (prm.out_dt == FAR3D_DT_F32) reinterpret_cast<float*>(out)[(long)a * 256 + t] = res;
+        else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + t] = f32_to_bf16(res);
+        return;
+      }
+    }
+  }
   if constexpr (RP != 0 && sizeof(TV) == 2) {
     // ---- phase 3 (bf16): lanes 0-31 take the left bilinear column, lanes 32-63 the right one; a lane owns 8 channels
     // (16 bytes) of its pixel, so one instruction fetches the two adjacent 512-byte token rows of a sample's top (then
@@ -528,7 +659,14 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   const char* v1_env = getenv("FAR3D_AGG_V1");   // A/B aid: the simple v1 kernel
   if (!(v1_env && atoi(v1_env))) {
     const int nlp8 = N * P * L * 8 > 1024 ? N * P * L * 8 : 1024;
-    const size_t lds3 = (size_t)nlp8 * 4 + (size_t)N * P * L * 32 + 64 * 4 + 64;
+    const size_t lds3_base = (size_t)nlp8 * 4 + 64 * 4 + 64 + (size_t)N * P * L * 32;
+    // de-duplication tables live behind record RCAP: keys + slots (4*RCAP ints each), 512-entry hash table, LCAP offsets + weight vectors
+    const size_t dd_tail = (size_t)AGG_DEDUP_RCAP * 32 + (size_t)4 * AGG_DEDUP_RCAP * 8 + 512 * 4 + (size_t)AGG_DEDUP_LCAP * (4 + 32);
+    const size_t lds3_dedup = (size_t)nlp8 * 4 + 64 * 4 + 64 + ((size_t)N * P * L * 32 > dd_tail ? (size_t)N * P * L * 32 : dd_tail);
+    // opt-in (FAR3D_AGG_DEDUP=1): measured SLOWER than the plain row-pair gather (30.6 vs 22.2 us per launch) although it reads
+    // 2.7x fewer token rows -- the extra barrier phases, CAS probes and LDS float atomics cost more than the gather saves
+    static const int no_dedup = !(getenv("FAR3D_AGG_DEDUP") && atoi(getenv("FAR3D_AGG_DEDUP")));
+    const size_t lds3 = lds3_base;
     if (feat_dtype == FAR3D_DT_F32)
       hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, block, lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else if (abl == 1)
@@ -549,6 +687,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 8, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else if (abl == 9)
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 6, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (!no_dedup && abl == 0)   // de-duplicated gather (row-pair gather for the rare queries above AGG_DEDUP_RCAP samples)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 2>), grid, block, lds3_dedup, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else   // row-pair gather, 2 samples (4 x 1 KB row-pair loads) in flight per wave: measured best (more in flight thrashes L2)
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");

@@ -85,3 +85,23 @@ def test_aggregate_invisible_queries_are_zero(hip_lib):
     out = cases.hip_aggregate(c, DEV)
     assert out.abs().max().item() == 0.0
     assert cases.oracle_aggregate(c).abs().max().item() == 0.0
+
+
+def test_aggregate_dedup_variant_matches_oracle(hip_lib):
+    """The opt-in de-duplicating gather (FAR3D_AGG_DEDUP=1, read once per process -> run in a child): per-token-row merged
+    weights via an LDS hash table; must equal the oracle like the default gather, incl. the fall-back for crowded queries."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch\n"
+            "from tests import cases\n"
+            "e = [cases.run_aggregate_case(cases.small_aggregate_case(s), 'cuda:0', torch.bfloat16) for s in range(2)]\n"
+            "e.append(cases.run_aggregate_case(cases.config2_aggregate_case(seed=0), 'cuda:0', torch.bfloat16))\n"
+            "e.append(cases.run_aggregate_case(cases.aggregate_case(7, (640, 960), 64, seed=3, offset_std=12.0), 'cuda:0', torch.bfloat16))\n"
+            "print('ERR', max(e))\n")
+    env = dict(os.environ, FAR3D_AGG_DEDUP="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = float([l for l in r.stdout.splitlines() if l.startswith("ERR")][-1].split()[1])
+    assert err < 5e-5, err
