@@ -124,7 +124,8 @@ class ShardedFrame:
         # ---- steady state: graph(per-camera stages) -> eager gathers -> graph(replicated head)
         if self._g_cam is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: the RCCL watchdog thread of the process group keeps polling its events while we capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._st = self._camera_part(dd, pad_hw, overlap=False)
             self._g_cam = g
         self._g_cam.replay()
@@ -140,7 +141,7 @@ class ShardedFrame:
             self._head_in[2].copy_(rec_all[:, 3:])
         if self._g_head is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._head_out = eng.head_stage(self._head_in[0], self._head_in[1], self._head_in[2], self.num_cams * K, dd, img_metas,
                                                 hw, starts, pad_hw)
             self._g_head = g
