@@ -1,0 +1,48 @@
+"""CPU: the measured tile table (far3d_amd/data/tuning_mi355x.json) must only name tiles the dispatcher of
+far3d_conv2d_nhwc implements for that kind of layer -- a stale id would only surface as a runtime error on the GPU box."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dispatch_ids():
+    src = open(os.path.join(ROOT, "far3d_amd", "csrc", "igemm.hip")).read()
+    ids = {"igemm": set(), "dma": set(), "patch": set(), "pipe3": set(), "gemm": set()}
+    for m in re.finditer(r"case (\d+): (launch_[a-z0-9_]+)<", src):
+        tile, fn = int(m.group(1)), m.group(2)
+        key = {"launch_igemm": "igemm", "launch_igemm_dma": "dma", "launch_conv3x3_patch": "patch",
+               "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm"}[fn]
+        ids[key].add(tile)
+    return ids
+
+
+def test_tuning_table_names_only_implemented_tiles():
+    ids = _dispatch_ids()
+    assert ids["pipe3"] and ids["gemm"] and ids["dma"], ids
+    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x.json")))
+    assert table, "empty tuning table"
+    for key, tile in table.items():
+        cout, cin, k, stride, npix = (int(v) for v in key.split(","))
+        assert cout > 0 and cin > 0 and npix > 0 and k in (1, 3) and stride in (1, 2), key
+        generic = ids["igemm"] | ids["dma"]                      # any kernel size / stride (bf16, Cin % 32 == 0 for the DMA ring)
+        if k == 3 and stride == 1:
+            allowed = generic | ids["patch"] | ids["pipe3"]
+        elif k == 1 and stride == 1:
+            allowed = generic | ids["gemm"]
+        else:
+            allowed = generic
+        assert tile in allowed, "tile %d is not dispatchable for layer %s" % (tile, key)
+        if tile in ids["dma"] | ids["patch"] | ids["pipe3"] | ids["gemm"]:
+            assert cin % 32 == 0, "LDS-DMA tile %d needs Cin %% 32 == 0 (%s)" % (tile, key)
+
+
+def test_tuned_tile_lookup_borrows_nearest_pixel_count():
+    from far3d_amd import ops
+    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x.json")))
+    key = next(k for k in table if k.startswith("192,192,3,1,"))
+    npix = int(key.split(",")[-1])
+    assert ops._tuned_tile(192, 192, 3, 1, npix) == table[key]
+    assert ops._tuned_tile(192, 192, 3, 1, npix // 7) == table[key]          # one camera of seven: same layer geometry
+    assert ops._tuned_tile(191, 192, 3, 1, npix) == 0                         # unknown layer -> kernel heuristic
