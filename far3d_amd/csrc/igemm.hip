@@ -538,165 +538,13 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 bf16 convolution with an LDS-resident input patch.
-// The implicit-GEMM kernels above re-fetch the (shifted) input rows for each of the 9 taps: at 128x128 tiles that is
-// 16 KB of L2->LDS traffic per 0.5 M MACs and the CU's load path, not the matrix pipe, sets the pace (measured: MFMA
-// issue ~22 %).  Here a workgroup owns a TH x 32 pixel rectangle of one image: for every 32-channel slice of Cin the
-// (TH+2) x 34 halo patch is DMA'd to LDS ONCE and the 9 taps are shifted LDS reads of it; only the weights stream per
-// tap through an NSW-deep ring.  Traffic per 9 K-steps: 9 x BM x 64 B weights + one patch, i.e. ~3x less than before at
-// BM = 128, TH = 8.  Same XOR source swizzle / counted vmcnt / one raw barrier per step as igemm_dma_kernel.
-// ------------------------------------------------------------------------------------------------------------------
-template <int WGM, int WGN, int WM, int WN, int NSW, int TPS = 1>   // TPS: taps per barrier step (1 or 3 = one kernel row)
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(IgemmParams P, int tiles_x, int tiles_y) {
-  static_assert(WGM * WGN == 4, "4 waves per workgroup");
-  static_assert(TPS == 1 || TPS == 3, "a step is one tap or one kernel row");
-  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
-  constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + 3) / 4;
-  constexpr int GA = BM / 16, GWL = (GA + 3) / 4, WST = BM * 64;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  unsigned char* pbuf = smem;                       // [2][PATCH_B]
-  unsigned char* wring = smem + 2 * PATCH_B;        // [NSW][TPS][WST]
-  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
-  int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
-  const int ty = bid % tiles_y;
-  const int n = bid / tiles_y;
-  const int x0 = tx * 32, y0 = ty * TH, m0 = blockIdx.y * BM;
-  const int Ktot = 9 * P.cin_pad;
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-  const int rg = lane >> 2, pc = lane & 3;
-  const int lc = pc ^ ((rg >> 2) & 3);
-
-  // patch DMA sources (per 16-pixel group owned by this wave); channel offset is added per chunk
-  const bf16_t* psrc[GPL];
-  int pdst[GPL];
-#pragma unroll
-  for (int i = 0; i < GPL; ++i) {
-    int q = wv + 4 * i;
-    if (q >= PG) q -= PG;
-    pdst[i] = q * 1024;
-    const int idx = q * 16 + rg;
-    const int py = idx / PW, px = idx - py * PW;
-    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool ok = idx < PPIX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-    psrc[i] = ok ? reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + ((long)iy * P.W + ix) * P.ldx + lc * 8 : nullptr;
-  }
-  const bf16_t* wsrc[GWL];
-  int wdst[GWL];
-#pragma unroll
-  for (int i = 0; i < GWL; ++i) {
-    int q = wv + 4 * i;
-    if (q >= GA) q -= GA;
-    wdst[i] = q * 1024;
-    wsrc[i] = reinterpret_cast<const bf16_t*>(P.w) + (long)(m0 + q * 16 + rg) * Ktot + lc * 8;
-  }
-  auto issue_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < GPL; ++i) {
-      const bf16_t* src = psrc[i] ? psrc[i] + chunk * 32 : zero;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(pbuf + buf * PATCH_B + pdst[i]), 16, 0, 0);
-    }
-  };
-  int w_chunk = 0, w_tap = 0, w_stage = 0;   // next weight tile to issue
-  auto issue_w = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int tp = 0; tp < TPS; ++tp) {
-      const int kb = (w_tap + tp) * P.cin_pad + w_chunk * 32;
-#pragma unroll
-      for (int i = 0; i < GWL; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + kb), (lds_void_t*)(wring + (w_stage * TPS + tp) * WST + wdst[i]), 16, 0, 0);
-    }
-    w_tap += TPS;
-    if (w_tap == 9) { w_tap = 0; ++w_chunk; }
-    if (++w_stage == NSW) w_stage = 0;
-  };
-
-  f32x16_t acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nchunks = P.cin_pad / 32, nsteps = nchunks * (9 / TPS);
-  issue_patch(0, 0);
-#pragma unroll
-  for (int s = 0; s < NSW - 1; ++s)
-    if (s < nsteps) issue_w();
-  int aoff[WM], aswz[WM], bbase[WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i) { const int r = (wm * WM + i) * 32 + l31; aoff[i] = r * 64; aswz[i] = (r >> 2) & 3; }
-#pragma unroll
-  for (int j = 0; j < WN; ++j) bbase[j] = (wn * WN + j) * PW + l31;   // patch index of this lane's pixel for tap (0,0)
-
-  int stage = 0, chunk = 0, tap = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    if (step + NSW - 1 <= nsteps) wait_vmcnt<GWL * TPS * (NSW - 2)>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (tap == 0 && chunk + 1 < nchunks) issue_patch(chunk + 1, (chunk + 1) & 1);   // older than the weights issued below
-    if (step + NSW - 1 < nsteps) issue_w();
-    const unsigned char* pb = pbuf + (chunk & 1) * PATCH_B;
-#pragma unroll
-    for (int tp = 0; tp < TPS; ++tp) {
-      const unsigned char* wb = wring + (stage * TPS + tp) * WST;
-      const int tcur = tap + tp;
-      const int ky = tcur / 3, kx = tcur - ky * 3;
-      const int toff = ky * PW + kx;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        u32x4_t af[WM], bf[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(wb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int idx = bbase[j] + toff;
-          bf[j] = *reinterpret_cast<const u32x4_t*>(pb + idx * 64 + (((kk * 2 + hi) ^ ((idx >> 2) & 3)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
-      }
-    }
-    if (++stage == NSW) stage = 0;
-    tap += TPS;
-    if (tap == 9) { tap = 0; ++chunk; }
-  }
-  int pn[WN], ppix[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int y = y0 + wn * WN + j, x = x0 + l31;
-    pn[j] = (y < P.H && x < P.W) ? n : -1;
-    ppix[j] = y * P.W + x;
-  }
-  igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
-}
-
-template <int WGM, int WGN, int WM, int WN, int NSW, int TPS = 1>
-static int launch_conv3x3_patch(const IgemmParams& P, hipStream_t st) {
-  constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
-  constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds = (size_t)2 * PG * 1024 + (size_t)NSW * TPS * BM * 64;
-  const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
-  dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
-  static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv3x3_patch_kernel<WGM, WGN, WM, WN, NSW, TPS>), grid, dim3(256), lds, st, P, tiles_x, tiles_y);
-  return 0;
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------
-// Software-pipelined variant of the LDS-patch 3x3 kernel (same data movement: double-buffered halo patch + 2-deep ring
-// of 3-tap weight slabs, one barrier per kernel row).  PMC on the kernel above showed the matrix pipe 30 % busy with
-// waves parked 42 % of the time: the compiler issued each tap's `ds_read_b128`s, then `s_waitcnt lgkmcnt(0)`, then the
-// MFMAs, six times per step, and spent ~9 VALU per MFMA recomputing swizzled LDS addresses.  Here
+// 3x3 / stride 1 / pad 1 bf16 convolution with an LDS-resident input patch, software pipelined.
+// A workgroup owns a TH x 32 pixel rectangle of one image: for every 32-channel slice of Cin the (TH+2) x 34 halo patch is
+// DMA'd to LDS ONCE (double buffered) and the 9 taps are shifted LDS reads of it; only the weights stream, one kernel row
+// (3 taps) per barrier step, through a 2- or 3-deep ring.  The first version of this kernel (global_load_lds, addresses
+// recomputed per tap) ran the matrix pipe 30 % busy with waves parked 42 % of the time: the compiler issued each tap's
+// `ds_read_b128`s, then `s_waitcnt lgkmcnt(0)`, then the MFMAs, six times per step, and spent ~9 VALU per MFMA on swizzled
+// LDS addresses (profiles/r1).  Here
 //   * every fragment address is a per-lane VGPR computed once + a compile-time immediate (chunk parity, ring stage, tap
 //     are compile-time: the loop body is two chunks = six steps, fully unrolled),
 //   * fragments are double-buffered in registers: the reads of tap/k-half i+1 are issued before the MFMAs of i,
@@ -1170,35 +1018,20 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   }
   static const int no_dma = getenv("FAR3D_IGEMM_NODMA") ? atoi(getenv("FAR3D_IGEMM_NODMA")) : 0;
   if (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && !no_dma && (Cin % 32) == 0 && P.x_vec) {
-    // (channels x pixels, ring depth): 1 128x128/3  2 64x128/4  3 64x64/4  4 128x64/4  7 160x128/3  8 192x128/3  9 224x128/3
-    // 10 192x64/6  12 256x64/5  13 256x128/3  14 128x128/4   (5 falls back to the register-staged 64x256)
+    // global_load_lds ring kernel (any kernel size / stride): (channels x pixels, ring depth) 1 128x128/3  2 64x128/4  3 64x64/4
+    // 4 128x64/4; 5 falls back to the register-staged 64x256
     bool done = true;
     switch (tile) {
       case 1: launch_igemm_dma<2, 2, 2, 2, 3>(P, st); break;
       case 2: launch_igemm_dma<2, 2, 1, 2, 4>(P, st); break;
       case 3: launch_igemm_dma<2, 2, 1, 1, 4>(P, st); break;
       case 4: launch_igemm_dma<2, 2, 2, 1, 4>(P, st); break;
-      case 7: launch_igemm_dma<1, 4, 5, 1, 3>(P, st); break;
-      case 8: launch_igemm_dma<1, 4, 6, 1, 3>(P, st); break;
-      case 9: launch_igemm_dma<1, 4, 7, 1, 3>(P, st); break;
-      case 10: launch_igemm_dma<2, 2, 3, 1, 6>(P, st); break;
-      case 12: launch_igemm_dma<2, 2, 4, 1, 5>(P, st); break;
-      case 13: launch_igemm_dma<2, 2, 4, 2, 3>(P, st); break;
-      case 14: launch_igemm_dma<2, 2, 2, 2, 4>(P, st); break;
       // several 32-channel K chunks per barrier step
-      case 15: launch_igemm_dma<2, 2, 2, 2, 3, 2>(P, st); break;   // 128x128, 2 chunks/step
-      case 16: launch_igemm_dma<2, 2, 2, 1, 3, 3>(P, st); break;   // 128x64, 3 chunks/step
-      case 17: launch_igemm_dma<2, 2, 1, 2, 3, 3>(P, st); break;   // 64x128, 3 chunks/step
       case 18: launch_igemm_dma<2, 2, 1, 1, 3, 3>(P, st); break;   // 64x64, 3 chunks/step
-      case 19: launch_igemm_dma<2, 2, 2, 1, 3, 2>(P, st); break;   // 128x64, 2 chunks/step
       // 2-deep rings: less LDS -> more resident workgroups per CU
       case 43: launch_igemm_dma<2, 2, 2, 2, 2>(P, st); break;      // 128x128
-      case 44: launch_igemm_dma<2, 2, 2, 4, 2>(P, st); break;      // 128x256
-      case 45: launch_igemm_dma<2, 2, 4, 2, 2>(P, st); break;      // 256x128
       case 46: launch_igemm_dma<2, 2, 2, 1, 2>(P, st); break;      // 128x64
-      case 47: launch_igemm_dma<2, 2, 1, 2, 2>(P, st); break;      // 64x128
       case 48: launch_igemm_dma<2, 2, 1, 1, 2>(P, st); break;      // 64x64
-      case 49: launch_igemm_dma<2, 2, 2, 2, 2, 2>(P, st); break;   // 128x128, 2 chunks/step
       default: done = false;
     }
     if (!done && KH == 1 && KW == 1 && stride == 1 && pad == 0) {   // pipelined GEMM kernel (channels x pixels, waves)
@@ -1216,38 +1049,13 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 79: launch_gemm1x1_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves (1x2 tiles per wave)
         case 80: launch_gemm1x1_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
         case 81: launch_gemm1x1_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
-        case 82: launch_gemm1x1_pipe<4, 4, 2, 2>(P, st); break;   // 256 x 256, 16 waves
         default: done = false;
       }
     }
-    // LDS-patch 3x3 kernel: (channels x rows-of-32-pixels, weight ring): 20 128x8/4  21 128x4/4  22 160x8/3  23 192x8/3
-    // 24 192x4/4  25 64x8/4  26 256x4/3  27 224x4/3  28 160x4/4
+    // pipelined LDS-patch 3x3 kernel: (channels x rows-of-32-pixels, waves)
     if (!done && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W) {
       done = true;
       switch (tile) {
-        case 20: launch_conv3x3_patch<2, 2, 2, 4, 4>(P, st); break;
-        case 21: launch_conv3x3_patch<2, 2, 2, 2, 4>(P, st); break;
-        case 22: launch_conv3x3_patch<1, 4, 5, 2, 3>(P, st); break;
-        case 23: launch_conv3x3_patch<1, 4, 6, 2, 3>(P, st); break;
-        case 24: launch_conv3x3_patch<1, 4, 6, 1, 4>(P, st); break;
-        case 25: launch_conv3x3_patch<2, 2, 1, 4, 4>(P, st); break;
-        case 26: launch_conv3x3_patch<2, 2, 4, 2, 3>(P, st); break;
-        case 27: launch_conv3x3_patch<1, 4, 7, 1, 3>(P, st); break;
-        case 28: launch_conv3x3_patch<1, 4, 5, 1, 4>(P, st); break;
-        // one kernel row (3 taps) per barrier step
-        case 30: launch_conv3x3_patch<2, 2, 1, 4, 3, 3>(P, st); break;   // 64 x 8 rows
-        case 31: launch_conv3x3_patch<2, 2, 2, 2, 3, 3>(P, st); break;   // 128 x 4 rows
-        case 32: launch_conv3x3_patch<2, 2, 1, 2, 3, 3>(P, st); break;   // 64 x 4 rows
-        case 33: launch_conv3x3_patch<2, 2, 2, 4, 2, 3>(P, st); break;   // 128 x 8 rows, 2-deep
-        case 34: launch_conv3x3_patch<2, 2, 1, 4, 4, 3>(P, st); break;   // 64 x 8 rows, 4-deep
-        case 35: launch_conv3x3_patch<1, 4, 3, 2, 3, 3>(P, st); break;   // 96 x 8 rows
-        case 36: launch_conv3x3_patch<1, 4, 1, 1, 3, 3>(P, st); break;   // 32 x 4 rows
-        case 37: launch_conv3x3_patch<1, 4, 2, 1, 3, 3>(P, st); break;   // 64 x 4 rows (1x4 waves)
-        case 38: launch_conv3x3_patch<2, 2, 1, 1, 3, 3>(P, st); break;   // 64 x 2 rows
-        case 39: launch_conv3x3_patch<2, 2, 1, 2, 2, 3>(P, st); break;   // 64 x 4 rows, 2-deep
-        case 40: launch_conv3x3_patch<1, 4, 1, 2, 3, 3>(P, st); break;   // 32 x 8 rows
-        case 41: launch_conv3x3_patch<2, 2, 2, 1, 3, 3>(P, st); break;   // 128 x 2 rows
-        case 42: launch_conv3x3_patch<2, 2, 1, 4, 2, 3>(P, st); break;   // 64 x 8 rows, 2-deep
         // software-pipelined kernel (register double-buffered fragments, immediate-offset LDS addressing)
         case 50: launch_conv3x3_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 4 rows
         case 51: launch_conv3x3_pipe<1, 4, 2, 1>(P, st); break;   // 64 x 4 rows (1x4 waves)
@@ -1255,7 +1063,6 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 53: launch_conv3x3_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 4 rows
         case 54: launch_conv3x3_pipe<1, 4, 1, 2>(P, st); break;   // 32 x 8 rows
         case 55: launch_conv3x3_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 2 rows
-        case 56: launch_conv3x3_pipe<2, 2, 2, 4>(P, st); break;   // 128 x 8 rows
         case 57: launch_conv3x3_pipe<2, 2, 1, 4>(P, st); break;   // 64 x 8 rows
         case 58: launch_conv3x3_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 2 rows
         case 59: launch_conv3x3_pipe<1, 4, 3, 1>(P, st); break;   // 96 x 4 rows
