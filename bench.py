@@ -158,7 +158,8 @@ def main():
         fn()
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: with N > 1 the RCCL watchdog thread keeps polling its events while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(iters):
                 fn()
         g.replay()
@@ -170,12 +171,16 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / (reps * iters)
 
-    tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_ = eng.last_agg
-    agg_out = torch.empty(ref_.shape[0], 256, device=dev)
-    agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
-                                                        num_groups=cfg["num_groups"], perm=perm_, out=agg_out), 24)]
-    img_local = eng._in["img"] if world == 1 else eng._in["img"][runner.cams].contiguous()
-    bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
+    agg_ms, bb_ms, timing_error = [], [], None
+    try:        # the per-kernel figures must never cost the headline line (e.g. a capture problem on one rank of N)
+        tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_ = eng.last_agg
+        agg_out = torch.empty(ref_.shape[0], 256, device=dev)
+        agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
+                                                            num_groups=cfg["num_groups"], perm=perm_, out=agg_out), 24)]
+        img_local = eng._in["img"] if world == 1 else eng._in["img"][runner.cams].contiguous()
+        bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
+    except Exception as e:   # noqa: BLE001
+        timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
 
     if rank == 0:
         evb = 2 if args.precision == "bf16" else 4
@@ -202,6 +207,16 @@ def main():
                                   "unit": "TFLOP/s", "frac": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / MFMA_BF16_PEAK,
                                   "backbone_ms": bb_t * 1e3, "cameras_on_this_rank": ncam_local},
         }
+        if timing_error:
+            line["kernel_timing_error"] = timing_error
+
+        def finite(o):           # strict JSON: no NaN / Infinity (a missing kernel timing becomes null)
+            if isinstance(o, dict):
+                return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+                return None
+            return o
+        line = finite(line)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line))
