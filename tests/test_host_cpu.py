@@ -1,0 +1,48 @@
+"""CPU: small pieces of host logic the GPU path relies on (BN folding, weight packing layout, camera-embedding packing)."""
+import torch
+import torch.nn.functional as F
+
+from far3d_amd import weights
+
+
+def test_fold_bn_equals_conv_then_eval_batchnorm():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 9, 11, generator=g)
+    w = torch.randn(7, 5, 3, 3, generator=g)
+    bw, bb = torch.rand(7, generator=g) + 0.5, torch.randn(7, generator=g)
+    mean, var = torch.randn(7, generator=g), torch.rand(7, generator=g) + 0.1
+    for eps in (1e-5, 1e-3):       # VoVNet / YOLOX towers
+        want = F.batch_norm(F.conv2d(x, w, padding=1), mean, var, bw, bb, training=False, eps=eps)
+        fw, fb = weights.fold_bn(w, bw, bb, mean, var, eps)
+        got = F.conv2d(x, fw, fb, padding=1)
+        assert (got - want).abs().max().item() < 1e-4
+
+
+def test_packed_conv_layout_tap_major_zero_padded():
+    """PackedConv: rows = channels (zero rows up to the over-read margin), K = (tap, cin_pad) with cin padded to 32."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(10, 40, 3, 3, generator=g)
+    b = torch.randn(10, generator=g)
+    pc = ops.PackedConv(w, b, stride=1, pad=1, dtype=torch.float32, device="cpu")
+    cin_pad = 64
+    assert pc.w.shape[1] == 9 * cin_pad and pc.w.shape[0] >= 10 + 256 and pc.bias.shape[0] == pc.w.shape[0]
+    wk = pc.w.view(pc.w.shape[0], 9, cin_pad)
+    for tap in range(9):
+        assert torch.equal(wk[:10, tap, :40], w[:, :, tap // 3, tap % 3])
+    assert wk[:10, :, 40:].abs().max().item() == 0.0 and wk[10:].abs().max().item() == 0.0
+    assert torch.equal(pc.bias[:10], b) and pc.bias[10:].abs().max().item() == 0.0
+    assert pc.out_hw(17, 23) == (17, 23)
+    assert ops.PackedConv(w, None, stride=2, pad=1, dtype=torch.float32, device="cpu").out_hw(17, 23) == (9, 12)
+
+
+def test_cam_embed_chain_packing_is_transposed_and_stacked():
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(2)
+    layers = [(torch.randn(128, 12, generator=g), torch.randn(128, generator=g), torch.randn(256, 128, generator=g),
+               torch.randn(256, generator=g), torch.randn(256, generator=g), torch.randn(256, generator=g),
+               torch.randn(416, 256, generator=g), torch.randn(416, generator=g)) for _ in range(3)]
+    p = ops.pack_cam_embed_chain(layers, "cpu")
+    assert p["w0t"].shape == (3, 12, 128) and p["w2t"].shape == (3, 128, 256) and p["w3t"].shape == (3, 256, 416)
+    assert torch.equal(p["w2t"][1], layers[1][2].t()) and torch.equal(p["b3"][2], layers[2][7])
+    assert all(v.is_contiguous() and v.dtype == torch.float32 for v in p.values())
