@@ -685,6 +685,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else if (abl == 8)
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 8, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else if (abl == 10)
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 1, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else if (abl == 9)
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 6, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else if (!no_dedup && abl == 0)   // de-duplicated gather (row-pair gather for the rare queries above AGG_DEDUP_RCAP samples)
