@@ -550,7 +550,7 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
 //   * fragments are double-buffered in registers: the reads of tap/k-half i+1 are issued before the MFMAs of i,
 //   * the next chunk's patch is issued AFTER the next step's weights so that `vmcnt(GPL)` keeps it in flight for two steps.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int KY, int POFF, int WOFF, int WST, typename Dma>
+template <int WM, int WN, int KY, int POFF, int WOFF, int WST, int NTAPS = 3, typename Dma>   // NTAPS: 3 = one kernel row, 9 = all taps
 __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
                                                      const int (&baddr)[2][WN + 2][3], f32x16_t (&acc)[WM][WN], Dma dma) {
   u32x4_t af[2][WM], bf[2][WN];
@@ -560,14 +560,14 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
   for (int j = 0; j < WN; ++j) bf[0][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + baddr[0][j + KY][0]);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
+  for (int it = 0; it < 2 * NTAPS; ++it) {
     const int cur = it & 1, nxt = cur ^ 1;
-    if (it + 1 < 6) {
-      const int tp = (it + 1) >> 1, kk = (it + 1) & 1;
+    if (it + 1 < 2 * NTAPS) {
+      const int tp = (it + 1) >> 1, kk = (it + 1) & 1;     // tap tp of this step = kernel row KY + tp / 3, column tp % 3
 #pragma unroll
       for (int i = 0; i < WM; ++i) af[nxt][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + tp * WST + aaddr[kk][i]);
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + baddr[kk][j + KY][tp]);
+      for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + baddr[kk][j + KY + tp / 3][tp % 3]);
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the next fragments' reads ahead of this iteration's MFMAs
 #pragma unroll
@@ -580,15 +580,19 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
   }
 }
 
-template <int WGM, int WGN, int WM, int WN, int NSW = 2>   // NSW: weight ring depth (kernel rows prefetched NSW-1 steps ahead)
+// NSW: weight ring depth (steps prefetched ahead + 1).  RPS: kernel rows per barrier step -- 1 (3 taps) or 3 (the whole 32-channel
+// chunk, 9 taps: a third of the barriers, for the layers too small to fill the chip with more than one workgroup per CU).
+template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParams P, int tiles_x, int tiles_y) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int NW = WGM * WGN;                      // waves per workgroup (4, 8 or 16)
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
   constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + NW - 1) / NW;
-  constexpr int GA = BM / 16, WSLOTS = 3 * GA, GWL = (WSLOTS + NW - 1) / NW, WST = BM * 64;
-  static_assert(NSW == 2 || NSW == 3, "weight ring of 2 or 3 kernel rows");
-  constexpr int WBASE = 2 * PATCH_B;                // weight ring: [NSW stages][3 taps][WST]
+  constexpr int TPSN = 3 * RPS;                      // taps per barrier step
+  constexpr int GA = BM / 16, WSLOTS = TPSN * GA, GWL = (WSLOTS + NW - 1) / NW, WST = BM * 64;
+  static_assert(NSW == 2 || NSW == 3, "weight ring of 2 or 3 steps");
+  static_assert(RPS == 1 || (RPS == 3 && NSW == 2), "whole-chunk steps use the 2-deep ring");
+  constexpr int WBASE = 2 * PATCH_B;                // weight ring: [NSW stages][TPSN taps][WST]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   auto w_piece = [&](int i, int chunk, int ky, int stage) __attribute__((always_inline)) {   // kernel row ky: taps 3*ky .. 3*ky+2
     if (wtap[i] < 0) return;            // wave-uniform
     const int kb = (ky * 3 + wtap[i]) * P.cin_pad + chunk * 32;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + WBASE + stage * 3 * WST + wdst[i]), 16, wvoff[i], kb * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + WBASE + stage * TPSN * WST + wdst[i]), 16, wvoff[i], kb * 2, 0, 0);
   };
   auto issue_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -684,6 +688,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     if (wfull) { if (PA) wait_vmcnt<(NWS) * GWL + GPL>(); else wait_vmcnt<(NWS) * GWL>(); }                            \
     else       { if (PA) wait_vmcnt<(NWS) * (GWL - 1) + GPL>(); else wait_vmcnt<(NWS) * (GWL - 1)>(); }                \
   }
+  if constexpr (RPS == 3) {
+    // whole-chunk steps: step c reads patch buffer / weight stage c & 1 (all 9 taps); both were issued during step c - 1
+    // (weights first, then the patch), so the top of every step waits for everything (vmcnt 0)
+    issue_patch(0, 0);
+    issue_w(0, 0, 0);
+#define FAR3D_PIPE_CHUNK(PAR, CH)                                                                                      \
+  {                                                                                                                    \
+    const bool more = (CH) + 1 < nchunks;                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    wait_vmcnt<0>();                                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    asm volatile("" ::: "memory");                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    constexpr int PIECES = GWL + GPL, PPI = (PIECES + 17) / 18;                                                        \
+    patch_step_pipelined<WM, WN, 0, (PAR) * PATCH_B, WBASE + (PAR) * TPSN * WST, WST, 9>(smem, aaddr, baddr, acc,      \
+      [&](int it) __attribute__((always_inline)) {                                                                     \
+        _Pragma("unroll")                                                                                              \
+        for (int k = it * PPI; k < (it + 1) * PPI && k < PIECES; ++k) {                                                \
+          if (!more) continue;                                                                                         \
+          if (k < GWL) w_piece(k, (CH) + 1, 0, (PAR) ^ 1);                                                             \
+          else patch_piece(k - GWL, (CH) + 1, (PAR) ^ 1);                                                              \
+        }                                                                                                              \
+      });                                                                                                              \
+  }
+    for (int c = 0; c < nchunks; c += 2) {
+      FAR3D_PIPE_CHUNK(0, c)
+      if (c + 1 < nchunks) FAR3D_PIPE_CHUNK(1, c + 1)
+    }
+#undef FAR3D_PIPE_CHUNK
+  } else {
   if (NSW == 2) {
     issue_patch(0, 0);
     issue_w(0, 0, 0);
@@ -735,6 +769,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   }
 #undef FAR3D_WAITC
 #undef FAR3D_PIPE_STEP
+  }   // RPS == 1
   if (P.y_rows16) {
     epilogue_rows16<NW, WM, WN, BM, TH * 32>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
@@ -753,20 +788,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
 #endif
 }
 
-template <int WGM, int WGN, int WM, int WN, int NSW = 2>
+template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1>
 static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds_ring = (size_t)2 * PG * 1024 + (size_t)NSW * 3 * BM * 64, lds_out = (size_t)TH * 32 * (BM * 2 + 16);
+  constexpr size_t lds_ring = (size_t)2 * PG * 1024 + (size_t)NSW * 3 * RPS * BM * 64, lds_out = (size_t)TH * 32 * (BM * 2 + 16);
   constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
   dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
+  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
   return 0;
 }
 
@@ -1084,6 +1119,11 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 95: launch_conv3x3_pipe<2, 8, 1, 1, 3>(P, st); break;   // 64 x 8 rows, 16 waves
         case 96: launch_conv3x3_pipe<1, 8, 2, 1, 3>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
         case 97: launch_conv3x3_pipe<2, 2, 1, 1, 3>(P, st); break;   // 64 x 2 rows, 4 waves
+        // whole-chunk steps (9 taps per barrier) for the layers with a single workgroup per CU
+        case 100: launch_conv3x3_pipe<2, 4, 1, 2, 2, 3>(P, st); break;   // 64 x 8 rows, 8 waves
+        case 101: launch_conv3x3_pipe<1, 8, 1, 1, 2, 3>(P, st); break;   // 32 x 8 rows, 8 waves
+        case 102: launch_conv3x3_pipe<1, 4, 1, 1, 2, 3>(P, st); break;   // 32 x 4 rows, 4 waves
+        case 103: launch_conv3x3_pipe<2, 4, 1, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 8 waves
         default: done = false;
       }
     }

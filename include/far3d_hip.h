@@ -90,8 +90,8 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  *    no res / y2, 16-byte aligned rows (ldy, Cout multiples of 8).
  * tile: 0 auto (host callers pass the measured choice of far3d_amd/data/tuning_mi355x.json).  Any dtype: 1 128x128, 2 64x128,
  *    3 64x64, 4 128x64, 5 64x256 (channels x pixels).  bf16 with Cin % 32 == 0 only: 18, 43, 46, 48 (LDS-DMA ring variants, any
- *    kernel size / stride); 50-67, 90-97 pipelined 3x3/s1/p1 kernel (channels x rows of 32 pixels, 4/8/16 waves, 2- or 3-deep
- *    weight ring); 70-81 pipelined 1x1/s1 GEMM kernel.  An id the layer cannot use is an error, not a silent fallback. */
+ *    kernel size / stride); 50-67, 90-97, 100-103 pipelined 3x3/s1/p1 kernel (channels x rows of 32 pixels, 4/8/16 waves, 2- or 3-deep
+ *    weight ring, one kernel row or -- 100-103 -- all 9 taps per barrier step); 70-81 pipelined 1x1/s1 GEMM kernel.  An id the layer cannot use is an error, not a silent fallback. */
 int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y, int y_dt,
                       int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
                       long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,

@@ -73,7 +73,9 @@ def main():
         y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         res = {}
-        tiles = ((0, 1, 2, 3, 4, 18, 43, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81) if (k == 1 and stride == 1) else ()) + ((50, 52, 60, 61, 63, 64, 65, 90, 91, 92, 93, 94, 95, 96, 97) if (k == 3 and stride == 1) else ())
+        tiles = ((0, 1, 2, 3, 4, 18, 43, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81) if (k == 1 and stride == 1) else ()) + ((50, 52, 60, 61, 63, 64, 65, 90, 92, 93, 96, 100, 101, 102, 103) if (k == 3 and stride == 1) else ())
+        if k == 3 and stride == 1 and os.environ.get("EXTRA_TILES"):
+            tiles = tiles + tuple(int(v) for v in os.environ["EXTRA_TILES"].split(","))
         for tile in tiles:
             t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile))
             res[tile] = t
