@@ -1,18 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: samples/sec (one sample = one 7-camera frame, end to end) at VoV-99, 640x960 (BASELINE.json).
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 100 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one full frame through the HIP engine: 7 x (3,640,960) synthetic images resident in HBM -> VoV-99 -> FPN ->
 2D head/depth -> 644 adaptive + 644 learned + 256 propagated queries (A = 1544) -> 6-layer decoder (self-attention over
 2312 keys, fused perspective-aware aggregation, FFN) -> heads -> streaming-memory update -> top-300 box decode on device.
-N > 1: the cameras of the SAME sample are sharded across ranks (strong scaling), one RCCL all-gather of the value maps.
+N > 1 (default --mode sharded): the cameras of the SAME sample are sharded across ranks (strong scaling), one RCCL all-gather
+of the value maps; --mode replicas: one independent scene stream per GPU (BASELINE configs[4]; weak scaling, no collective).
 Prints ONE JSON line on rank 0.
+
+Timing protocol (reference tools/analysis_tools/benchmark.py:84-111): `value` is K frames issued back to
+back between two device syncs (the contract of this file); `protocol.sync_per_frame` repeats the reference's own protocol --
+synchronise before and after EVERY frame, wall clock per frame -- and reports mean and p50 next to it.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,8 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
-MFMA_BF16_PEAK = 2.5e15    # dense bf16 FLOP/s
+MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}    # dense FLOP/s (same guide)
 BACKBONE_FLOP_PER_CAM = 2 * 201.87e9   # VoV-99 @ 640x960
+AGG_KERNEL = "aggregate_v4_kernel"
+K_PROP = 92                # adaptive-query count fixed at 644 = 7 x 92 (static shapes)
 
 
 def agg_algorithmic_bytes(N, S, C, A, P, G, L, ev):
@@ -31,10 +39,11 @@ def agg_algorithmic_bytes(N, S, C, A, P, G, L, ev):
     return N * S * C * ev + A * P * N * 2 * 4 + N * A * G * L * P * 4 + A * C * 4
 
 
-def cpu_baseline(args, cfg_over):
-    """The oracle (CPU port of the reference path, proven equal to the reference's own files by tools/gen_golden.py) on
-    this box's host cores.  Bounded sample: the per-camera stages are timed on ONE camera (x7: they are independent and
-    identical), the 7-camera FarHead + decoder + decode is timed in full, once."""
+def cpu_baseline_and_parity(precision, eng_frames):
+    """The oracle (CPU port of the reference path, proven equal to the reference's own files by tools/gen_golden.py) on this
+    box's host cores: frame 0 of the benchmark sequence, ALL 7 cameras, timed once (the bounded sample), then frame 1 (streaming
+    memory in use).  Its logits are the checker for the engine's first two frames (frame 0 eager, frame 1 = the captured
+    hipGraph's first replay): the `parity` block of the bench line."""
     from far3d_amd import synth, weights
     from oracle import far3d_oracle
     ncpu = os.cpu_count() or 1
@@ -50,50 +59,67 @@ def cpu_baseline(args, cfg_over):
         best = min(best, (time.perf_counter() - t0, th))
     cores = best[1]
     torch.set_num_threads(cores)
-    spec = weights.detector_spec("V-99-eSE")
-    sd = weights.init_state_dict(spec, seed=0)
-    ocfg = far3d_oracle.default_cfg(proposal_topk=cfg_over["proposal_topk"])
-    orc = far3d_oracle.Far3DOracle(sd, ocfg)
-    data, metas = synth.make_frame(7, (640, 960), seed=0, frame_index=0)
+    sd = weights.init_state_dict(weights.detector_spec("V-99-eSE"), seed=0)
+    orc = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K_PROP))
+    times, par = [], []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        feats1 = orc.fpn(orc.backbone(data["img"][0, :1]))
-        roi1 = orc.roi_head(feats1)
-        t_cam = time.perf_counter() - t0
-        feats = [f.repeat(7, 1, 1, 1) for f in feats1]       # same cost for the head regardless of the values
-        roi = {k: ([x.repeat(7, 1, 1, 1) for x in v] if isinstance(v, list) else v.repeat(7, 1, 1, 1)) for k, v in roi1.items()}
-        t0 = time.perf_counter()
-        roi.update(orc.get_bboxes(roi))
-        outs = orc.head_forward(feats, roi, data, data["img"].new_zeros(1), (640, 960))
-        orc.decode(outs)
-        t_head = time.perf_counter() - t0
-    t = 7 * t_cam + t_head
-    return dict(value=1.0 / t, unit="samples/s", cores=cores, kind="port",
-                sample="1 frame: per-camera stages (VoV-99+FPN+2D head) timed on 1 of 7 cameras x7 (%.2f s each), "
-                       "7-camera FarHead+decoder+decode in full (%.2f s); torch %s fp32, %d threads (fastest of a probe; host has %d logical CPUs)"
-                       % (t_cam, t_head, torch.__version__, cores, ncpu))
+        for fi, got in enumerate(eng_frames):
+            data, metas = synth.make_frame(7, (640, 960), seed=0, frame_index=fi, ego_motion=True)
+            t0 = time.perf_counter()
+            o = orc.simple_test(data, metas)
+            times.append(time.perf_counter() - t0)
+            # adaptive queries are comparable row by row only where both picked the same 2D peak: map them through (camera, cell)
+            want_sel = [(int(n), int(i)) for n, i, _ in o["roi"]["valid_indices"].nonzero().numpy()]
+            pos = {k: j for j, k in enumerate(want_sel)}
+            nq = 644
+            rows_g, rows_w = list(range(nq)), list(range(nq))
+            common = 0
+            for j, k in enumerate(got["sel"]):
+                if k in pos:
+                    rows_g.append(nq + j); rows_w.append(nq + pos[k]); common += 1
+            A = got["logits"].shape[2]
+            M = len(want_sel)
+            rows_g += list(range(nq + len(got["sel"]), A)); rows_w += list(range(nq + M, A))
+            d = (got["logits"][:, 0, rows_g] - o["all_cls_scores"][:, 0, rows_w]).abs()
+            par.append(dict(frame=fi, logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(),
+                            last_layer_logit_max_abs=d[-1].max().item(), proposals_in_common=common, proposals=M,
+                            rows_compared=len(rows_g), engine_path=got["path"]))
+    baseline = dict(value=1.0 / times[0], unit="samples/s", cores=cores, kind="port",
+                    sample="1 frame of the benchmark workload, all 7 cameras, whole path (VoV-99+FPN+2D head+FarHead+decoder+decode) "
+                           "timed once: %.2f s (second, streaming frame: %.2f s); torch %s fp32, %d threads (fastest of a probe; host has "
+                           "%d logical CPUs)" % (times[0], times[1] if len(times) > 1 else float("nan"), torch.__version__, cores, ncpu))
+    parity = dict(precision=precision, tolerance_north_star=1e-3, checker="oracle (fp32 CPU port of the reference path), same seeded weights/inputs",
+                  logit_max_abs=max(p["logit_max_abs"] for p in par), logit_mean_abs=max(p["logit_mean_abs"] for p in par),
+                  meets_1e-3=bool(max(p["logit_max_abs"] for p in par) < 1e-3), frames=par)
+    return baseline, parity
 
 
 def agg_traffic():
-    """HBM bytes per launch of the aggregation kernel from the committed PMC pass (profiles/r1/aggregate_pmc.json:
-    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/evidence_run.sh with PMC=1); None if absent."""
-    import os
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "aggregate_pmc.json")
+    """HBM bytes per launch of the aggregation kernel from the committed in-frame PMC pass (profiles/r2/aggregate_pmc.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes over `bench.py --eager`, tools/evidence_run.sh with
+    PMC=1).  Counters cannot be read from inside this process; the file carries the kernel name and the commit it was taken
+    at, and a figure for another kernel is not reported."""
+    p = os.path.join(ROOT, "profiles", "r2", "aggregate_pmc.json")
     try:
         with open(p) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+            j = json.load(f)
+        if j.get("kernel") != AGG_KERNEL:
+            return None, None
+        return j["hbm_bytes_per_launch"], "profiles/r2/aggregate_pmc.json @ %s (in-frame, eager bench)" % j.get("commit", "?")
+    except Exception:   # noqa: BLE001
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16_fp32dec", "bf16_fp32val"])
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--agg-variant", type=int, default=0, help="far3d_aggregate_forward kernel variant (A/B timing)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -110,37 +136,50 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sharded = world > 1 and args.mode == "sharded"
 
-    K = 92   # adaptive-query count fixed at 644 = 7 x 92 (static shapes)
-    cfg = engine.default_cfg(proposal_topk=K)
+    cfg = engine.default_cfg(proposal_topk=K_PROP)
     spec = weights.detector_spec(cfg["backbone"])
     sd = weights.init_state_dict(spec, seed=0)
     eng = engine.Far3DEngine(sd, cfg, device=dev, precision=args.precision)
+    eng.agg_variant = args.agg_variant
     del sd
     frames = []
-    for fi in range(4):   # a few distinct frames, resident in HBM before the timed region
-        data, metas = synth.make_frame(7, (640, 960), seed=0, frame_index=fi, device=dev)
-        frames.append((data, metas))
-    # N > 1: per-rank hipGraphs for the per-camera stages and the replicated head, collectives eager in between
-    runner = fdist.ShardedFrame(eng, use_graph=not args.eager) if world > 1 else eng
-    eng.use_graph = world == 1 and not args.eager   # whole steady-state frame as ONE hipGraph (no host launch gaps)
+    for fi in range(4):   # a few distinct frames (ego motion on), resident in HBM before the timed region
+        frames.append(synth.make_frame(7, (640, 960), seed=0 if not (world > 1 and not sharded) else rank, frame_index=fi, device=dev,
+                                       ego_motion=True))
+    # N > 1 sharded: per-rank hipGraphs for the per-camera stages and the replicated head, collectives eager in between
+    runner = fdist.ShardedFrame(eng, use_graph=not args.eager) if sharded else eng
+    eng.use_graph = (not sharded) and not args.eager   # whole steady-state frame as ONE hipGraph (no host launch gaps)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    step_i = 0
+    # ---- the first two frames of the sequence are kept for the parity check (frame 0: eager; frame 1: first graph replay)
+    eng_frames = []
+    for fi in range(2):
+        o = runner.forward_frame(*frames[fi])
+        cnt = o["sel_cnt"].cpu().numpy() if "sel_cnt" in o else None
+        sel = [(n, int(i)) for n in range(7) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()] if cnt is not None else []
+        eng_frames.append(dict(logits=o["all_cls_scores"].float().cpu().clone(), sel=sel,
+                               path="eager (first frame of the scene)" if fi == 0 or args.eager else "hipGraph replay"))
+    step_i = 2
     for _ in range(args.warmup):
         runner.forward_frame(*frames[step_i % len(frames)])
         step_i += 1
     sync()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for k in range(args.steps):
         out = runner.forward_frame(*frames[step_i % len(frames)])
+        evs[k + 1].record()
         step_i += 1
     sync()
     dt = time.perf_counter() - t0
+    dev_ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -148,6 +187,17 @@ def main():
     A = out["all_cls_scores"].shape[2]
     N, S, C = out["feat_flatten"].shape
     assert torch.isfinite(out["all_cls_scores"]).all(), "non-finite logits"
+
+    # ---- the reference's own protocol: sync before and after every frame (tools/analysis_tools/benchmark.py:84-111)
+    per_frame = []
+    for _ in range(min(args.steps, 50)):
+        sync()
+        t1 = time.perf_counter()
+        runner.forward_frame(*frames[step_i % len(frames)])
+        sync()
+        per_frame.append((time.perf_counter() - t1) * 1e3)
+        step_i += 1
+    per_frame.sort()
 
     # Kernel durations for the rooflines: HIP events (on the launch stream) around hipGraph replays that contain ONLY
     # that kernel, fed with this run's live tensors (last decoder layer's operands / the staged images) -- a launch-gap-free
@@ -174,37 +224,53 @@ def main():
     agg_ms, bb_ms, timing_error = [], [], None
     try:        # the per-kernel figures must never cost the headline line (e.g. a capture problem on one rank of N)
         tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_ = eng.last_agg
-        agg_out = torch.empty(ref_.shape[0], 256, device=dev)
+        agg_out = torch.empty(ref_.shape[0], 256, device=dev, dtype=eng.prec["dec"])
         agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
-                                                            num_groups=cfg["num_groups"], perm=perm_, out=agg_out), 24)]
-        img_local = eng._in["img"] if world == 1 else eng._in["img"][runner.cams].contiguous()
+                                                            num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
+                                                            variant=args.agg_variant), 24)]
+        img_local = eng._in["img"] if not sharded else eng._in["img"][runner.cams[0]:runner.cams[-1] + 1] if runner.cams else eng._in["img"][:0]
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
 
     if rank == 0:
-        evb = 2 if args.precision == "bf16" else 4
+        evb = 2 if eng.prec["value"] == torch.bfloat16 else 4
         agg_t = (sum(agg_ms) / len(agg_ms)) * 1e-3 if agg_ms else float("nan")
         by = agg_algorithmic_bytes(N, S, C, A, cfg["num_pts"], cfg["num_groups"], cfg["num_levels"], evb)
         bb_t = (sum(bb_ms) / len(bb_ms)) * 1e-3 if bb_ms else float("nan")
-        ncam_local = len(runner.cams) if world > 1 else 7
+        ncam_local = len(runner.cams) if sharded else 7
+        mfma_peak = MFMA_PEAK["bf16" if eng.prec["act"] == torch.bfloat16 else "fp32"]
+        samples = args.steps * (world if (world > 1 and not sharded) else 1)
+        traffic, traffic_src = agg_traffic()
+        try:
+            commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+        except Exception:   # noqa: BLE001
+            commit = None
         line = {
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
-            "value": args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": (args.steps / dt) / 6.4 if world == 1 else None,   # 6.4 samples/s (hardware not stated)
-            "dtype": args.precision, "data": "synthetic",
+            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak",
+            "vs_baseline": (samples / dt) / 6.4 if world == 1 else None,   # 6.4 samples/s (hardware not stated)
+            "dtype": "bf16" if args.precision.startswith("bf16") else args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 7 cameras 3x640x960, VoV-99, A=%d queries (644 learned + 644 adaptive + 256 "
-                                   "propagated), 2312 self-attn keys, 6 decoder layers, streaming memory on" % A,
-                       "parallelism": "single GPU" if world == 1 else "camera-sharded x%d + 1 all-gather" % world,
-                       "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)"},
-            "roofline": {"kernel": "aggregate_v3_kernel (fused perspective-aware aggregation, one launch per decoder layer)",
+                                   "propagated), 2312 self-attn keys, 6 decoder layers, streaming memory on, ego motion on" % A,
+                       "parallelism": "single GPU" if world == 1 else ("camera-sharded x%d + 1 all-gather" % world if sharded else
+                                                                       "%d independent scene streams (replicas, no collective)" % world),
+                       "precision_assignment": {k: str(v).replace("torch.", "") for k, v in eng.prec.items()},
+                       "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)", "commit": commit},
+            "protocol": {"pipelined": {"frames": args.steps, "mean_ms": dt / args.steps * 1e3, "p50_ms_device_events": dev_ms[len(dev_ms) // 2],
+                                       "what": "frames issued back to back, one sync at each end (this file's contract -> `value`)"},
+                         "sync_per_frame": {"frames": len(per_frame), "mean_ms": sum(per_frame) / len(per_frame), "p50_ms": per_frame[len(per_frame) // 2],
+                                            "samples_per_s_mean": 1e3 * len(per_frame) / sum(per_frame),
+                                            "what": "reference protocol (tools/analysis_tools/benchmark.py:84-111): device sync before and after every frame"}},
+            "roofline": {"kernel": AGG_KERNEL + " (fused perspective-aware aggregation, one launch per decoder layer)" if args.agg_variant in (0, 4)
+                         else "aggregate_v3_kernel (A/B variant %d)" % args.agg_variant,
                          "bound": "hbm", "achieved": by / agg_t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": by / agg_t / HBM_PEAK, "traffic": agg_traffic(), "algorithmic_bytes_per_launch": by,
+                         "frac": by / agg_t / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by,
                          "avg_launch_us": agg_t * 1e6, "timing": "HIP events around a hipGraph of 24 launches x 3 replays, live frame operands"},
             "roofline_backbone": {"kernel": "conv3x3_pipe_kernel + gemm1x1_pipe_kernel (VoV-99 backbone: all launches incl. eSE / pooling)", "bound": "mfma",
-                                  "achieved": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
-                                  "unit": "TFLOP/s", "frac": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / MFMA_BF16_PEAK,
+                                  "achieved": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / 1e12, "peak": mfma_peak / 1e12,
+                                  "unit": "TFLOP/s", "frac": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / mfma_peak,
                                   "backbone_ms": bb_t * 1e3, "cameras_on_this_rank": ncam_local},
         }
         if timing_error:
@@ -213,13 +279,14 @@ def main():
         def finite(o):           # strict JSON: no NaN / Infinity (a missing kernel timing becomes null)
             if isinstance(o, dict):
                 return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, list):
+                return [finite(v) for v in o]
             if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
                 return None
             return o
-        line = finite(line)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, cfg)
-        print(json.dumps(line))
+            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(args.precision, eng_frames)
+        print(json.dumps(finite(line)))
     if world > 1:
         dist.destroy_process_group()
 

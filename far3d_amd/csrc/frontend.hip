@@ -188,7 +188,6 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
 struct GatherParams {
   PropLevels lv;
   const int* sel_idx; const int* sel_cnt;    // (N,cap), (N)
-  const int* row_off;                         // (N) exclusive prefix of sel_cnt (device) -> output row of camera n
   const float* wgt;                           // (N,S) peak weights
   const float* depth_logit;                   // (N, hd, wd, nd) f32
   const float* img2lidar;                     // (N,4,4)
@@ -205,7 +204,8 @@ __global__ __launch_bounds__(64) void prop_gather_kernel(GatherParams g) {
   const int n = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
   if (j >= g.sel_cnt[n]) return;
   const int s = g.sel_idx[(long)n * g.cap + j];
-  const int row = g.row_off[n] + j;
+  int row = j;                                 // output row = exclusive prefix of sel_cnt over the cameras before n, + j
+  for (int k = 0; k < n; ++k) row += g.sel_cnt[k];
   const PropLevels& lv = g.lv;
   int l = 0;
 #pragma unroll
@@ -239,7 +239,10 @@ __global__ __launch_bounds__(64) void prop_gather_kernel(GatherParams g) {
     g.ref2d[row * 3 + 0] = c3[0]; g.ref2d[row * 3 + 1] = c3[1]; g.ref2d[row * 3 + 2] = c3[2];
     g.box2d[row * 4 + 0] = bcx; g.box2d[row * 4 + 1] = bcy; g.box2d[row * 4 + 2] = brx - tlx; g.box2d[row * 4 + 3] = bry - tly;
     g.score[row] = sc;
-    g.ctx[(long)row * (g.C + 1) + g.C] = logf(sc / (1.f - sc)) - g.thr_logodds;
+    // static top-K mode can pad a camera with zero-weight (non-peak) cells: clamp so their log-odds stay finite (a peak
+    // that passed the reference's `> score_thr` test is never below 1e-6, so threshold mode is unchanged)
+    const float scc = fmaxf(sc, 1e-6f);
+    g.ctx[(long)row * (g.C + 1) + g.C] = logf(scc / (1.f - scc)) - g.thr_logodds;
   }
   for (int c = lane; c < g.C; c += 64) {
     float fv;
@@ -284,19 +287,19 @@ extern "C" int far3d_proposal_select(const float* const* cls, const float* const
 }
 
 extern "C" int far3d_proposal_gather(const float* const* reg, int nreg, int N, int L, const int32_t* level_hw,
-                                     const int32_t* strides, const int* sel_idx, const int* sel_cnt, const int* row_off,
+                                     const int32_t* strides, const int* sel_idx, const int* sel_cnt,
                                      int cap, const float* weights, const float* depth_logit, int hd, int wd, int nd,
                                      int depth_stride, float depth_min, float depth_max, int depth_bins,
                                      const float* img2lidar, const void* feat, int feat_dt, int C, const float* pc_range,
                                      float score_thr, float* ref2d, float* ctx, float* box2d, float* score, void* stream) {
-  FAR3D_CHECK_ARG(reg && level_hw && strides && sel_idx && sel_cnt && row_off && weights && depth_logit && img2lidar && feat &&
+  FAR3D_CHECK_ARG(reg && level_hw && strides && sel_idx && sel_cnt && weights && depth_logit && img2lidar && feat &&
                   pc_range && ref2d && ctx && box2d && score, "far3d_proposal_gather: null argument");
   FAR3D_CHECK_ARG(L >= 1 && L <= PROP_MAX_L && N > 0 && cap > 0, "far3d_proposal_gather: bad sizes");
   GatherParams g;
   memset(&g, 0, sizeof(g));
   const float* none[PROP_MAX_L] = {nullptr, nullptr, nullptr, nullptr};
   fill_levels(g.lv, L, level_hw, strides, none, reg, 1, nreg);
-  g.sel_idx = sel_idx; g.sel_cnt = sel_cnt; g.row_off = row_off; g.wgt = weights; g.depth_logit = depth_logit;
+  g.sel_idx = sel_idx; g.sel_cnt = sel_cnt; g.wgt = weights; g.depth_logit = depth_logit;
   g.img2lidar = img2lidar; g.feat = feat; g.feat_dt = feat_dt; g.ref2d = ref2d; g.ctx = ctx; g.box2d = box2d; g.score = score;
   g.cap = cap; g.C = C; g.hd = hd; g.wd = wd; g.nd = nd; g.ds = depth_stride;
   g.depth_min = depth_min;

@@ -221,61 +221,33 @@ extern "C" int far3d_memory_post_update(const float* m_emb, const float* m_ref, 
 
 // ------------------------------------------------------------------------------------------ add + cast
 // out_sum = a + b (dtype sum_dt), out_a = a (dtype a_dt, optional): the decoder's "query + query_pos" operands in one pass.
+// a, b dense (rows, C) f32; the outputs may be row-strided (e.g. the two halves of one [a+b | a] merged-GEMM operand).
 __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, void* __restrict__ osum,
-                                                       int sum_dt, void* __restrict__ oa, int a_dt, long n4) {
+                                                       int sum_dt, void* __restrict__ oa, int a_dt, long n4, int c4, long ldsum, long lda) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
     const float4 s = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-    if (sum_dt == FAR3D_DT_F32) reinterpret_cast<float4*>(osum)[i] = s;
-    else reinterpret_cast<uint2*>(osum)[i] = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
+    const long r = i / c4, c = (i - r * c4) * 4;
+    if (sum_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(osum) + r * ldsum + c) = s;
+    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(osum) + r * ldsum + c) = make_uint2(pack_bf16x2(s.x, s.y), pack_bf16x2(s.z, s.w));
     if (oa) {
-      if (a_dt == FAR3D_DT_F32) reinterpret_cast<float4*>(oa)[i] = x;
-      else reinterpret_cast<uint2*>(oa)[i] = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
+      if (a_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(oa) + r * lda + c) = x;
+      else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(oa) + r * lda + c) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
     }
   }
 }
 
-extern "C" int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, void* out_a, int a_dt, long n, void* stream) {
-  FAR3D_CHECK_ARG(a && b && out_sum && n >= 0 && (n % 4) == 0, "far3d_add_cast: bad arguments (n must be a multiple of 4)");
-  if (n == 0) return FAR3D_OK;
-  const long n4 = n / 4;
+extern "C" int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, void* out_a, int a_dt, int rows, int C,
+                              long ld_sum, long ld_a, void* stream) {
+  FAR3D_CHECK_ARG(a && b && out_sum && rows >= 0 && C > 0 && (C % 4) == 0 && ld_sum >= C && ld_sum % 4 == 0 && (!out_a || (ld_a >= C && ld_a % 4 == 0)),
+                  "far3d_add_cast: bad arguments (C and the row strides must be multiples of 4)");
+  if (rows == 0) return FAR3D_OK;
+  const long n4 = (long)rows * C / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(add_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out_sum, sum_dt, out_a, a_dt, n4);
+  hipLaunchKernelGGL(add_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out_sum, sum_dt, out_a, a_dt, n4,
+                     C / 4, ld_sum, ld_a);
   FAR3D_CHECK_LAUNCH("far3d_add_cast");
-  return FAR3D_OK;
-}
-
-// ------------------------------------------------------------------------------------------ aggregation scheduling keys
-// key[a] = (camera whose image centre the reference point projects closest to, 8x8 image cell) -- see ops.camera_sorted_order
-__global__ __launch_bounds__(256) void agg_order_keys_kernel(const float* __restrict__ ref, const float* __restrict__ l2i,
-                                                             int* __restrict__ keys, int A, int N, float lo0, float lo1, float lo2,
-                                                             float sp0, float sp1, float sp2, float pad_h, float pad_w) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A) return;
-  const float X = ref[a * 3] * sp0 + lo0, Y = ref[a * 3 + 1] * sp1 + lo1, Z = ref[a * 3 + 2] * sp2 + lo2;
-  float best = 3.0e9f, bu = 0.f, bv = 0.f;
-  int cam = 0;
-  for (int n = 0; n < N; ++n) {
-    const float* m = l2i + n * 16;
-    const float x = m[0] * X + m[1] * Y + m[2] * Z + m[3], y = m[4] * X + m[5] * Y + m[6] * Z + m[7], z = m[8] * X + m[9] * Y + m[10] * Z + m[11];
-    const float zc = fmaxf(z, 1e-5f);
-    const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
-    const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
-    if (cost < best) { best = cost; cam = n; bu = u; bv = v; }
-  }
-  const int ub = (int)(fminf(fmaxf(bu + 0.5f, 0.f), 0.999f) * 8.f), vb = (int)(fminf(fmaxf(bv + 0.5f, 0.f), 0.999f) * 8.f);
-  keys[a] = (cam * 8 + vb) * 8 + ub;
-}
-
-extern "C" int far3d_agg_order_keys(const float* ref, const float* lidar2img, int32_t* keys, int A, int N, const float* pc_range,
-                                    float pad_h, float pad_w, void* stream) {
-  FAR3D_CHECK_ARG(ref && lidar2img && keys && pc_range && A >= 0 && N > 0, "far3d_agg_order_keys: bad arguments");
-  if (A == 0) return FAR3D_OK;
-  hipLaunchKernelGGL(agg_order_keys_kernel, dim3((A + 255) / 256), dim3(256), 0, (hipStream_t)stream, ref, lidar2img, keys, A, N,
-                     pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2],
-                     pad_h, pad_w);
-  FAR3D_CHECK_LAUNCH("far3d_agg_order_keys");
   return FAR3D_OK;
 }
 
@@ -297,10 +269,10 @@ __global__ __launch_bounds__(256) void cam_embed_chain_kernel(const float* __res
                                                               const float* __restrict__ b2, const float* __restrict__ ln_g,
                                                               const float* __restrict__ ln_b, const float* __restrict__ w3t,
                                                               const float* __restrict__ b3, float* __restrict__ out, int N, int J,
-                                                              int Hd, float eps) {
+                                                              int Hd, float eps, int ldl) {
   const int n = blockIdx.x, l = blockIdx.y, t = threadIdx.x;
   __shared__ float h0[256], h1[256], red[8];
-  const float* x = l2i + n * 12;
+  const float* x = l2i + n * ldl;     // first 12 floats of the row: lidar2img[n][:3,:] (ldl = 16 reads the 4x4 in place)
   if (t < Hd) {                                   // hidden width Hd <= 256 (the reference uses embed_dims / 2 = 128)
     float a0 = b0[l * Hd + t];
 #pragma unroll
@@ -336,11 +308,11 @@ __global__ __launch_bounds__(256) void cam_embed_chain_kernel(const float* __res
 
 extern "C" int far3d_cam_embed_chain(const float* l2i, const float* w0t, const float* b0, const float* w2t, const float* b2,
                                      const float* ln_g, const float* ln_b, const float* w3t, const float* b3, float* out,
-                                     int N, int L, int J, int Hd, float eps, void* stream) {
+                                     int N, int L, int J, int Hd, float eps, int ld_l2i, void* stream) {
   FAR3D_CHECK_ARG(l2i && w0t && b0 && w2t && b2 && ln_g && ln_b && w3t && b3 && out, "far3d_cam_embed_chain: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && L > 0 && J > 0 && Hd > 0 && Hd <= 256, "far3d_cam_embed_chain: bad sizes N=%d L=%d J=%d Hd=%d", N, L, J, Hd);
+  FAR3D_CHECK_ARG(N > 0 && L > 0 && J > 0 && Hd > 0 && Hd <= 256 && ld_l2i >= 12, "far3d_cam_embed_chain: bad sizes N=%d L=%d J=%d Hd=%d", N, L, J, Hd);
   hipLaunchKernelGGL(cam_embed_chain_kernel, dim3(N, L), dim3(256), 0, (hipStream_t)stream, l2i, w0t, b0, w2t, b2, ln_g, ln_b, w3t, b3,
-                     out, N, J, Hd, eps);
+                     out, N, J, Hd, eps, ld_l2i);
   FAR3D_CHECK_LAUNCH("far3d_cam_embed_chain");
   return FAR3D_OK;
 }

@@ -1025,9 +1025,8 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.x_vec = aligned(x, 16) && (ldx % ve == 0) && (x_img_stride % ve == 0) && (long)ve * xe % 16 == 0;
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
-  static const int no_rows16 = getenv("FAR3D_IGEMM_NO_ROWS16") ? atoi(getenv("FAR3D_IGEMM_NO_ROWS16")) : 0;
   P.chan_sum = chan_sum;
-  P.y_rows16 = !no_rows16 && y_dt == FAR3D_DT_BF16 && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
+  P.y_rows16 = y_dt == FAR3D_DT_BF16 && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   const long Npix = (long)N * Ho * Wo;
   // tile: 0 = auto.  (channels x pixels per workgroup) 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64, 5 = 64x256
@@ -1051,8 +1050,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     case 5: launch_igemm<TIN, TCC, 1, 4, 2, 2>(P, st); break;                   \
     default: far3d_set_error("far3d_conv2d_nhwc: unknown tile %d", tile); return FAR3D_ERR_ARG; \
   }
-  static const int no_dma = getenv("FAR3D_IGEMM_NODMA") ? atoi(getenv("FAR3D_IGEMM_NODMA")) : 0;
-  if (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && !no_dma && (Cin % 32) == 0 && P.x_vec) {
+  if (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && (Cin % 32) == 0 && P.x_vec) {
     // global_load_lds ring kernel (any kernel size / stride): (channels x pixels, ring depth) 1 128x128/3  2 64x128/4  3 64x64/4
     // 4 128x64/4; 5 falls back to the register-staged 64x256
     bool done = true;

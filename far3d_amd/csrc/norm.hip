@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float* __restrict__ y, int rows,
                                                         int C, int ldx, int ldy, float eps, int act,
                                                         const float* __restrict__ add, int lda, void* __restrict__ y2,
-                                                        int ldy2, int y2_dt, bf16_t* __restrict__ yb, int ldyb) {
+                                                        int ldy2, int y2_dt, void* __restrict__ yb, int ldyb, int yb_dt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       *reinterpret_cast<float4*>(y + (long)row * ldy + c) = o;
-      if (yb) *reinterpret_cast<uint2*>(yb + (long)row * ldyb + c) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      if (yb) {
+        if (yb_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(yb) + (long)row * ldyb + c) = o;
+        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(yb) + (long)row * ldyb + c) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      }
       if (y2) {
         const float4 a = *reinterpret_cast<const float4*>(add + (long)row * lda + c);
         const float4 q2 = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
@@ -71,31 +74,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
                                int ldx, int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2,
-                               int y2_dt, void* yb, int ldyb, void* stream) {
+                               int y2_dt, void* yb, int ldyb, int yb_dt, void* stream) {
   FAR3D_CHECK_ARG(x && y, "far3d_layernorm: null x/y");
   FAR3D_CHECK_ARG(rows >= 0 && C > 0 && (C % 4) == 0 && C <= 1024, "far3d_layernorm: C=%d must be a multiple of 4, <= 1024", C);
-  FAR3D_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && (!y2 || (add && lda % 4 == 0 && ldy2 % 4 == 0)),
-                  "far3d_layernorm: row strides must be multiples of 4 floats; y2 needs add");
+  FAR3D_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && (!y2 || (add && lda % 4 == 0 && ldy2 % 4 == 0)) && (!yb || ldyb % 4 == 0),
+                  "far3d_layernorm: row strides must be multiples of 4 elements; y2 needs add");
   if (rows == 0) return FAR3D_OK;
   dim3 grid((rows + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (C <= 256)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, (bf16_t*)yb, ldyb);
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt);
   else
-    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, (bf16_t*)yb, ldyb);
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt);
   FAR3D_CHECK_LAUNCH("far3d_layernorm");
   return FAR3D_OK;
 }
 
-// ---------------------------------------------------------------- per-(image, channel-group) sums over H*W
-// Used by eSE (group size 1 -> channel means) and GroupNorm (sum and sum of squares per group).
-// x NHWC (T), C channels, `cpg` channels per group.  Partial sums accumulate with one atomicAdd per
-// (workgroup, channel) into sums[n][C][2] (zeroed by the caller on the same stream).
+// ---------------------------------------------------------------- per-(image, channel) sums over H*W
+// Used by eSE (channel means) and GroupNorm (sum and sum of squares).  x NHWC (T), C channels.
+// DETERMINISTIC: workgroup (blk, n) writes its partial sums to part[n][blk][C][2] with plain stores; the consumer
+// (ese_gate_kernel / gn_stats_kernel) adds the `nblk` partials in index order.  No atomics, no memset -- run-to-run and
+// hipGraph-vs-eager results are bit-identical.
 template <typename T>
-__global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C,
+__global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                         int ldx, long img_stride, int rows_per_block) {
   // thread -> 4 consecutive channels; the 256 threads cover rstep = 256*4/C rows per pass; 4 passes are kept in flight.
-  // Partial sums are combined across the row-threads in LDS, so a workgroup issues 2*C atomics in total.
   __shared__ float red[2][1024];
   const int n = blockIdx.y;
   const int cq = C / 4;
@@ -121,51 +124,71 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
       q.x += a.x * a.x; q.y += a.y * a.y; q.z += a.z * a.z; q.w += a.w * a.w;
     }
   }
-  // cross-row reduction: red[.][trow*C + c] would need rstep*C <= 1024 floats: rstep*C = 1024 exactly.
+  // cross-row reduction through LDS: rstep*C = 1024 floats exactly
   if (trow < rstep) {
     *reinterpret_cast<float4*>(&red[0][trow * C + tcol * 4]) = s;
     *reinterpret_cast<float4*>(&red[1][trow * C + tcol * 4]) = q;
   }
   __syncthreads();
+  float* dst = part + ((long)n * gridDim.x + blockIdx.x) * C * 2;
   for (int c = threadIdx.x; c < C; c += 256) {
     float ss = 0.f, qq = 0.f;
     for (int k = 0; k < rstep; ++k) { ss += red[0][k * C + c]; qq += red[1][k * C + c]; }
-    atomicAdd(sums + ((long)n * C + c) * 2, ss);
-    atomicAdd(sums + ((long)n * C + c) * 2 + 1, qq);
+    *reinterpret_cast<float2*>(dst + 2 * c) = make_float2(ss, qq);
   }
 }
 
-static int launch_chan_sums(const void* x, int dt, float* sums, int N, int HW, int C, int ldx, long img_stride, hipStream_t st) {
-  // ~64 workgroups per image: enough to fill the chip with 7 images, few enough that atomics are negligible
-  int rows_per_block = (HW + 63) / 64;
+// number of partial-sum workgroups per image: >= 64 Ki elements per workgroup, at most FAR3D_SUMS_MAX_PARTS
+static int chan_sums_parts(int HW, int C) {
+  long n = ((long)HW * C) >> 16;
+  if (n < 1) n = 1;
+  if (n > FAR3D_SUMS_MAX_PARTS) n = FAR3D_SUMS_MAX_PARTS;
   const int rstep = 256 / (C / 4);
+  int rows_per_block = (int)((HW + n - 1) / n);
   rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
-  dim3 grid((HW + rows_per_block - 1) / rows_per_block, N), block(256);
+  return (HW + rows_per_block - 1) / rows_per_block;
+}
+
+static int launch_chan_sums(const void* x, int dt, float* part, int N, int HW, int C, int ldx, long img_stride, hipStream_t st) {
+  const int nblk = chan_sums_parts(HW, C);
+  const int rstep = 256 / (C / 4);
+  int rows_per_block = (HW + nblk - 1) / nblk;
+  rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
+  dim3 grid(nblk, N), block(256);
   if (dt == FAR3D_DT_F32)
-    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, sums, HW, C, ldx, img_stride, rows_per_block);
+    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block);
   else
-    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, sums, HW, C, ldx, img_stride, rows_per_block);
-  return 0;
+    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, part, HW, C, ldx, img_stride, rows_per_block);
+  return nblk;
 }
 
 // ---------------------------------------------------------------- eSE
-// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ); one wave per output channel.
+// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image: it first
+// adds the `nparts` partial sums of every input channel in index order (LDS), then each wave does 4 rows of the mat-vec.
+// partial (p, n, k) lives at sums[p * part_stride + n * img_stride + 2 * k].
 __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ sums, const float* __restrict__ fcw,
                                                        const float* __restrict__ fcb, float* __restrict__ gate, int C,
-                                                       float inv_hw, int replicas, long rep_stride) {
-  const int n = blockIdx.y, lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
-  float acc = 0.f;
-  for (int k = lane; k < C; k += 64) {
+                                                       float inv_hw, int nparts, long part_stride, long img_stride) {
+  __shared__ float mean[1024];
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < C; k += 256) {
     float sk = 0.f;
-    for (int r = 0; r < replicas; ++r) sk += sums[r * rep_stride + ((long)n * C + k) * 2];   // per-XCD partial sums
-    acc += fcw[(long)c * C + k] * (sk * inv_hw);
+    const float* p = sums + (long)n * img_stride + 2 * k;
+    for (int r = 0; r < nparts; ++r) sk += p[r * part_stride];
+    mean[k] = sk * inv_hw;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    const float z = acc + fcb[c];
-    gate[(long)n * C + c] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = blockIdx.x * 16 + wv * 4 + j;
+    if (c >= C) break;   // wave-uniform
+    float acc = 0.f;
+    for (int k = lane; k < C; k += 64) acc += fcw[(long)c * C + k] * mean[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float z = acc + fcb[c];
+      gate[(long)n * C + c] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
+    }
   }
 }
 
@@ -192,26 +215,22 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
   }
 }
 
+// scratch (floats): [N][nparts][C][2] partial sums (nparts <= FAR3D_SUMS_MAX_PARTS), then [N][C] gates at offset
+// N*FAR3D_SUMS_MAX_PARTS*C*2.  Size: N*C*(2*FAR3D_SUMS_MAX_PARTS+1) floats; never needs zeroing.
 extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                               float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
-                              long i_img_stride, int ldy, long y_img_stride, int sums_ready, void* stream) {
+                              long i_img_stride, int ldy, long y_img_stride, void* stream) {
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
-                  "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4 and <= 1024)", C);
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 1024 % C == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
+                  "far3d_ese_nhwc: bad sizes (C=%d must divide 1024)", C);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
-  // scratch: [N][C][2] sums followed by [N][C] gates
-  // sums_ready == 1: FAR3D_ESE_REPLICAS per-XCD copies [r][N][C][2] written by far3d_conv2d_nhwc(chan_sum); else one copy
-  const int replicas = sums_ready == 1 ? FAR3D_ESE_REPLICAS : 1;
   float* sums = scratch;
-  float* gate = scratch + (long)replicas * N * C * 2;
-  if (sums_ready == 0) {
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
-    if (e != hipSuccess) { far3d_set_error("far3d_ese_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
-  }
-  if (sums_ready != 1) launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
-  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, replicas,
-                     (long)N * C * 2);
+  float* gate = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
+  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
+  const long part_stride = (long)C * 2, img_stride = (long)nparts * C * 2;
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, nparts,
+                     part_stride, img_stride);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -226,13 +245,16 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
 }
 
 // ---------------------------------------------------------------- GroupNorm + ReLU (NHWC)
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ sums, float* __restrict__ stat, int C,
-                                                       int groups, float inv_cnt, float eps, int total) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int C,
+                                                       int groups, float inv_cnt, float eps, int total, int nparts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
   if (i >= total) return;
   const int n = i / groups, g = i % groups, cpg = C / groups;
   float s = 0.f, q = 0.f;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += sums[((long)n * C + c) * 2]; q += sums[((long)n * C + c) * 2 + 1]; }
+  for (int r = 0; r < nparts; ++r) {          // fixed order: deterministic
+    const float* p = part + ((long)n * nparts + r) * C * 2;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += p[2 * c]; q += p[2 * c + 1]; }
+  }
   const float mean = s * inv_cnt;
   const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
   stat[2 * i] = mean;
@@ -266,17 +288,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch,
                                     int N, int HW, int C, int groups, float eps, int relu, void* stream) {
   FAR3D_CHECK_ARG(x && gamma && beta && y && scratch, "far3d_groupnorm_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && 1024 % C == 0 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_groupnorm_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
-  float* sums = scratch;                         // [N][C][2]
-  float* stat = scratch + (long)N * C * 2;       // [N][groups][2]
-  hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st);
-  if (e != hipSuccess) { far3d_set_error("far3d_groupnorm_nhwc: memset: %s", hipGetErrorString(e)); return FAR3D_ERR_LAUNCH; }
-  launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
+  float* sums = scratch;                                              // [N][nparts][C][2]
+  float* stat = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;     // [N][groups][2]
+  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
   const int tot = N * groups;
   hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, sums, stat, C, groups,
-                     1.f / ((float)HW * (C / groups)), eps, tot);
+                     1.f / ((float)HW * (C / groups)), eps, tot, nparts);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;

@@ -1,0 +1,326 @@
+// Post-processing and per-frame calibration kernels: the pieces of the frame that used to
+// run as chains of ATen / rocPRIM / rocSOLVER launches (topk, sort, exp/atan2/cat, linalg.inv, nan_to_num).  All are
+// latency-bound single-workgroup (or tiny) kernels: the point is ONE graph node each instead of 5-20.
+//
+//   far3d_topk            descending top-K of n <= 40960 floats in one workgroup (bisection on the ordered bit pattern with the
+//                         values held in registers, ordered compaction, bitonic sort of the K winners).
+//                         Replaces torch.topk in post_update_memory, ref models/dense_heads/farhead.py:488-491.
+//   far3d_decode_topk     NMSFreeCoder.decode_single + FarHead.get_bboxes: sigmoid, top-max_num over A*num_classes, label/query
+//                         split, denormalize_bbox (exp, atan2), post_center_range mask, z -= h/2.
+//                         ref core/bbox/coders/nms_free_coder.py:39-91, core/bbox/util.py:25-52, farhead.py:1224-1245.
+//   far3d_camera_prep     img2lidar = inverse(lidar2img) (ref farhead.py:798) and the 14-float MLN camera code
+//                         (ref farhead.py:553-556).
+//   far3d_agg_order       camera / image-cell sorted query order for far3d_aggregate_forward (scheduling only).
+//   far3d_nan_to_num      torch.nan_to_num on the stacked decoder outputs (ref farhead.py:646) (+ optional bf16 copy).
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------ block-wide top-K
+// order-preserving map float -> uint (larger float <-> larger uint; -0 < +0; NaNs sort above +inf, like torch.topk)
+__device__ __forceinline__ unsigned ord_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_val(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+#define TOPK_THREADS 1024
+#define TOPK_MAXV 40          // values per thread held in registers: n <= 40960
+#define TOPK_MAXK 1024
+
+// Selects the K largest of vals[0..n) (ties -> lower index first) and leaves them sorted descending in
+// sel[0..K) as (ord_key << 32) | (0xffffffff - index).  All TOPK_THREADS threads must call; sel is LDS [TOPK_MAXK].
+__device__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, unsigned long long* sel) {
+  const int t = threadIdx.x;
+  __shared__ int s_part[2][TOPK_THREADS / 64];
+  __shared__ int s_cnt[TOPK_THREADS / 64];
+  unsigned v[TOPK_MAXV];
+#pragma unroll
+  for (int k = 0; k < TOPK_MAXV; ++k) {
+    const int i = t + k * TOPK_THREADS;
+    v[k] = i < n ? ord_key(vals[i]) : 0u;      // padding slots are excluded by the index test below, not by their value
+  }
+  auto count_ge = [&](unsigned key, int slot) __attribute__((always_inline)) {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < TOPK_MAXV; ++k) c += (v[k] >= key && (t + k * TOPK_THREADS) < n) ? 1 : 0;
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((t & 63) == 0) s_part[slot][t >> 6] = c;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < TOPK_THREADS / 64; ++k) tot += s_part[slot][k];
+    return tot;
+  };
+  // invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
+  unsigned long long lo = 0ull, hi = 0x100000000ull;
+  int pass = 0;
+  while (hi - lo > 1ull) {
+    const unsigned long long mid = lo + ((hi - lo) >> 1);
+    if (count_ge((unsigned)mid, pass & 1) >= K) lo = mid; else hi = mid;
+    ++pass;
+  }
+  const unsigned kth = (unsigned)lo;
+  const int n_gt = kth == 0xffffffffu ? 0 : count_ge(kth + 1u, pass & 1);
+  __syncthreads();
+  // ordered compaction (index order), keeping all keys > kth and the first K - n_gt keys == kth
+  int base = 0, eq_left = K - n_gt;
+#pragma unroll
+  for (int k = 0; k < TOPK_MAXV; ++k) {
+    const int c0 = k * TOPK_THREADS;
+    if (c0 >= n) break;
+    const int i = c0 + t;
+    const bool in = i < n;
+    const bool gt = in && v[k] > kth, eq = in && v[k] == kth;
+    const unsigned long long eqm = __ballot(eq);
+    const int eq_before = __popcll(eqm & ((1ull << (t & 63)) - 1ull));
+    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(eqm);
+    __syncthreads();
+    int eq_wave_off = 0, eq_chunk = 0;
+#pragma unroll
+    for (int w = 0; w < TOPK_THREADS / 64; ++w) { if (w < (t >> 6)) eq_wave_off += s_cnt[w]; eq_chunk += s_cnt[w]; }
+    __syncthreads();
+    const bool keep = gt || (eq && (eq_wave_off + eq_before) < eq_left);
+    const unsigned long long km = __ballot(keep);
+    const int k_before = __popcll(km & ((1ull << (t & 63)) - 1ull));
+    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(km);
+    __syncthreads();
+    int wave_off = 0, chunk = 0;
+#pragma unroll
+    for (int w = 0; w < TOPK_THREADS / 64; ++w) { if (w < (t >> 6)) wave_off += s_cnt[w]; chunk += s_cnt[w]; }
+    const int pos = base + wave_off + k_before;
+    if (keep && pos < K) sel[pos] = ((unsigned long long)v[k] << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+    base += chunk;
+    eq_left -= min(eq_left, eq_chunk);
+    __syncthreads();
+  }
+  // bitonic sort, descending, of the next power of two >= K entries (padding 0 sorts last)
+  int Kp = 1;
+  while (Kp < K) Kp <<= 1;
+  for (int i = K + t; i < Kp; i += TOPK_THREADS) sel[i] = 0ull;
+  __syncthreads();
+  for (int sz = 2; sz <= Kp; sz <<= 1) {
+    for (int st = sz >> 1; st > 0; st >>= 1) {
+      for (int i = t; i < Kp; i += TOPK_THREADS) {
+        const int j = i ^ st;
+        if (j > i) {
+          const unsigned long long a = sel[i], b = sel[j];
+          const bool desc = (i & sz) == 0;
+          if (desc ? (a < b) : (a > b)) { sel[i] = b; sel[j] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ vals, int n, int K, long* __restrict__ idx_out,
+                                                            float* __restrict__ val_out) {
+  __shared__ unsigned long long sel[TOPK_MAXK];
+  block_topk_sorted(vals, n, K, sel);
+  for (int i = threadIdx.x; i < K; i += TOPK_THREADS) {
+    const unsigned long long e = sel[i];
+    idx_out[i] = (long)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    if (val_out) val_out[i] = ord_val((unsigned)(e >> 32));
+  }
+}
+
+extern "C" int far3d_topk(const float* vals, int n, int K, int64_t* idx_out, float* val_out, void* stream) {
+  FAR3D_CHECK_ARG(vals && idx_out, "far3d_topk: null pointer argument");
+  FAR3D_CHECK_ARG(n > 0 && n <= TOPK_THREADS * TOPK_MAXV && K > 0 && K <= n && K <= TOPK_MAXK,
+                  "far3d_topk: need 0 < K <= min(n, %d), n <= %d (got n=%d K=%d)", TOPK_MAXK, TOPK_THREADS * TOPK_MAXV, n, K);
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
+  FAR3D_CHECK_LAUNCH("far3d_topk");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ NMS-free decode
+struct DecodeParams {
+  const float* cls;      // (A, ncls) logits of the last decoder layer
+  const float* box;      // (A, code) normalised box codes of the last layer (cx,cy,cz,log w,log l,log h,sin,cos[,vx,vy])
+  float* boxes;          // (K, code-1): cx,cy,cz - h/2,w,l,h,rot[,vx,vy]
+  float* scores;         // (K)
+  long* labels;          // (K)
+  unsigned char* keep;   // (K) 1 = centre inside post_center_range
+  int A, ncls, code, K;
+  float lo[3], hi[3];
+};
+
+__global__ __launch_bounds__(TOPK_THREADS) void decode_topk_kernel(DecodeParams p) {
+  __shared__ unsigned long long sel[TOPK_MAXK];
+  // sigmoid is monotone: the top-K of sigmoid(logits) is the top-K of the logits
+  block_topk_sorted(p.cls, p.A * p.ncls, p.K, sel);
+  for (int i = threadIdx.x; i < p.K; i += TOPK_THREADS) {
+    const unsigned long long e = sel[i];
+    const int idx = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    const float logit = ord_val((unsigned)(e >> 32));
+    const int q = idx / p.ncls;
+    p.labels[i] = (long)(idx - q * p.ncls);
+    p.scores[i] = 1.f / (1.f + expf(-logit));
+    const float* b = p.box + (long)q * p.code;
+    float* o = p.boxes + (long)i * (p.code - 1);
+    const float cx = b[0], cy = b[1], cz = b[2];
+    const float w = expf(b[3]), l = expf(b[4]), h = expf(b[5]);
+    o[0] = cx; o[1] = cy; o[2] = cz - h * 0.5f;
+    o[3] = w; o[4] = l; o[5] = h;
+    o[6] = atan2f(b[6], b[7]);
+    for (int k = 8; k < p.code; ++k) o[k - 1] = b[k];
+    p.keep[i] = (cx >= p.lo[0] && cy >= p.lo[1] && cz >= p.lo[2] && cx <= p.hi[0] && cy <= p.hi[1] && cz <= p.hi[2]) ? 1 : 0;
+  }
+}
+
+extern "C" int far3d_decode_topk(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
+                                 const float* post_center_range, float* boxes, float* scores, int64_t* labels,
+                                 unsigned char* keep, void* stream) {
+  FAR3D_CHECK_ARG(cls_last && box_last && post_center_range && boxes && scores && labels && keep, "far3d_decode_topk: null pointer argument");
+  FAR3D_CHECK_ARG(A > 0 && num_classes > 0 && code_size >= 8 && K > 0 && K <= TOPK_MAXK && (long)A * num_classes <= TOPK_THREADS * TOPK_MAXV &&
+                  K <= A * num_classes, "far3d_decode_topk: bad sizes A=%d ncls=%d code=%d K=%d (A*ncls <= %d, K <= %d)", A, num_classes,
+                  code_size, K, TOPK_THREADS * TOPK_MAXV, TOPK_MAXK);
+  DecodeParams p;
+  p.cls = cls_last; p.box = box_last; p.boxes = boxes; p.scores = scores; p.labels = (long*)labels; p.keep = keep;
+  p.A = A; p.ncls = num_classes; p.code = code_size; p.K = K;
+  for (int k = 0; k < 3; ++k) { p.lo[k] = post_center_range[k]; p.hi[k] = post_center_range[3 + k]; }
+  hipLaunchKernelGGL(decode_topk_kernel, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, p);
+  FAR3D_CHECK_LAUNCH("far3d_decode_topk");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ per-frame camera calibration
+// one thread per camera: 4x4 inverse by Gauss-Jordan with partial pivoting in f64 (rounded once to f32)
+__global__ __launch_bounds__(64) void camera_prep_kernel(const float* __restrict__ l2i, const float* __restrict__ intr,
+                                                         const float* __restrict__ extr, float* __restrict__ i2l,
+                                                         float* __restrict__ c14, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* m = l2i + n * 16;
+  if (i2l) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { a[i][j] = (double)m[i * 4 + j]; a[i][4 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+      int piv = c;
+      double best = fabs(a[c][c]);
+      for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+      if (piv != c) for (int j = 0; j < 8; ++j) { const double tmp = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = tmp; }
+      const double inv = 1.0 / a[c][c];          // singular input -> inf/nan, like torch.linalg.inv's garbage-in behaviour
+      for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+      for (int r = 0; r < 4; ++r) {
+        if (r == c) continue;
+        const double f = a[r][c];
+        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+      }
+    }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) i2l[n * 16 + i * 4 + j] = (float)a[i][4 + j];
+  }
+  if (c14) {            // [fx/1e3, fy/1e3, extrinsics[:3,:4] flat]  (farhead.py:553-556)
+    c14[n * 14 + 0] = intr[n * 16 + 0] / 1e3f;
+    c14[n * 14 + 1] = intr[n * 16 + 5] / 1e3f;
+    for (int k = 0; k < 12; ++k) c14[n * 14 + 2 + k] = extr[n * 16 + k];
+  }
+}
+
+extern "C" int far3d_camera_prep(const float* lidar2img, const float* intrinsics, const float* extrinsics, float* img2lidar,
+                                 float* c14, int N, void* stream) {
+  FAR3D_CHECK_ARG(lidar2img && N > 0 && (!c14 || (intrinsics && extrinsics)), "far3d_camera_prep: bad arguments");
+  hipLaunchKernelGGL(camera_prep_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, lidar2img, intrinsics, extrinsics,
+                     img2lidar, c14, N);
+  FAR3D_CHECK_LAUNCH("far3d_camera_prep");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ aggregation query order
+// key[a] = (camera whose image centre the reference point projects closest to) * 64 + 8x8 image cell; perm = queries sorted by
+// key (counting sort in LDS; the order inside one key is arbitrary -- perm only decides which workgroup handles which query).
+#define AGGO_MAX_BINS 1024
+__global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict__ ref, const float* __restrict__ l2i,
+                                                         int* __restrict__ perm, int A, int N, float lo0, float lo1, float lo2,
+                                                         float sp0, float sp1, float sp2, float pad_h, float pad_w) {
+  __shared__ int hist[AGGO_MAX_BINS];
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, nb = N * 64;
+  for (int i = t; i < AGGO_MAX_BINS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  constexpr int MAXQ = 8;   // A <= 8192
+  int key[MAXQ], rank[MAXQ];
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int a = t + k * 1024;
+    key[k] = -1;
+    if (a < A) {
+      const float X = ref[a * 3] * sp0 + lo0, Y = ref[a * 3 + 1] * sp1 + lo1, Z = ref[a * 3 + 2] * sp2 + lo2;
+      float best = 3.0e9f, bu = 0.f, bv = 0.f;
+      int cam = 0;
+      for (int n = 0; n < N; ++n) {
+        const float* m = l2i + n * 16;
+        const float x = m[0] * X + m[1] * Y + m[2] * Z + m[3], y = m[4] * X + m[5] * Y + m[6] * Z + m[7],
+                    z = m[8] * X + m[9] * Y + m[10] * Z + m[11];
+        const float zc = fmaxf(z, 1e-5f);
+        const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
+        const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
+        if (cost < best) { best = cost; cam = n; bu = u; bv = v; }
+      }
+      const int ub = (int)(fminf(fmaxf(bu + 0.5f, 0.f), 0.999f) * 8.f), vb = (int)(fminf(fmaxf(bv + 0.5f, 0.f), 0.999f) * 8.f);
+      key[k] = (cam * 8 + vb) * 8 + ub;
+      rank[k] = atomicAdd(&hist[key[k]], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive prefix over the nb <= 1024 bins: thread t owns bin t
+  int c = t < nb ? hist[t] : 0, inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o);
+    if ((t & 63) >= o) inc += up;
+  }
+  if ((t & 63) == 63) wsum[t >> 6] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+  __syncthreads();
+  if (t < AGGO_MAX_BINS) hist[t] = base + inc - c;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k)
+    if (key[k] >= 0) perm[hist[key[k]] + rank[k]] = t + k * 1024;
+}
+
+extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range,
+                               float pad_h, float pad_w, void* stream) {
+  FAR3D_CHECK_ARG(ref && lidar2img && perm && pc_range && A >= 0 && N > 0, "far3d_agg_order: bad arguments");
+  FAR3D_CHECK_ARG(A <= 8192 && N * 64 <= AGGO_MAX_BINS, "far3d_agg_order: A=%d (<= 8192) or N=%d (<= 16) too large", A, N);
+  if (A == 0) return FAR3D_OK;
+  hipLaunchKernelGGL(agg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ref, lidar2img, perm, A, N, pc_range[0],
+                     pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], pad_h,
+                     pad_w);
+  FAR3D_CHECK_LAUNCH("far3d_agg_order");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ nan_to_num
+// torch.nan_to_num defaults: nan -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX; in place, optional bf16 copy for the next GEMM.
+__global__ __launch_bounds__(256) void nan_to_num_kernel(float* __restrict__ x, bf16_t* __restrict__ xb, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    float* e = reinterpret_cast<float*>(&v);
+    bool dirty = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float f = e[k];
+      if (f != f) { e[k] = 0.f; dirty = true; }
+      else if (f == INFINITY) { e[k] = 3.4028234663852886e38f; dirty = true; }
+      else if (f == -INFINITY) { e[k] = -3.4028234663852886e38f; dirty = true; }
+    }
+    if (dirty) reinterpret_cast<float4*>(x)[i] = v;
+    if (xb) reinterpret_cast<uint2*>(xb)[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  }
+}
+
+extern "C" int far3d_nan_to_num(float* x, void* bf16_copy, long n, void* stream) {
+  FAR3D_CHECK_ARG(x && n >= 0 && (n % 4) == 0, "far3d_nan_to_num: bad arguments (n must be a multiple of 4)");
+  if (n == 0) return FAR3D_OK;
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)bf16_copy, n4);
+  FAR3D_CHECK_LAUNCH("far3d_nan_to_num");
+  return FAR3D_OK;
+}

@@ -113,8 +113,6 @@ extern "C" int far3d_msda_forward(const void* value, int value_dtype, const int6
 // ------------------------------------------------------------------------------------------
 #define AGG_MAX_L 4
 #define AGG_MAX_NLP 384  // 12 softmax items per thread
-#define AGG_DEDUP_RCAP 88   // de-duplicated gather for queries with at most this many visible samples (4*RCAP taps) ...
-#define AGG_DEDUP_LCAP 192  // ... and at most this many distinct token rows
 struct AggParams {
   int A, N, S, P, L;
   int H[AGG_MAX_L], W[AGG_MAX_L], start[AGG_MAX_L];
@@ -122,148 +120,8 @@ struct AggParams {
   float pad_w, pad_h;
   int q_per_xcd;
   int out_dt;
+  int ldU, ldO;   // row strides (floats) of U and of the key-point offsets
 };
-
-template <typename TV, int ABL = 0>   // ABL: timing ablations (1: no gather, 2: no softmax, 3: neither) -- never shipped results
-__global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict__ feat,
-                                                            const float* __restrict__ ref,
-                                                            const float* __restrict__ offs,
-                                                            const float* __restrict__ l2i,
-                                                            const float* __restrict__ U,
-                                                            const float* __restrict__ Vc,
-                                                            const int* __restrict__ perm,
-                                                            float* __restrict__ out, AggParams prm) {
-  // XCD-aware query mapping: workgroup b lands on XCD b%8 (observed dispatch order); give each XCD a
-  // contiguous range of the (optionally camera-sorted) query order so that one XCD's L2 serves 1-2 cameras.  Speed only.
-  int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
-  if (a >= prm.A) return;
-  if (perm) a = perm[a];
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int NP = prm.N * prm.P;
-  const int NLP = NP * prm.L;
-  const int J = prm.L * prm.P;            // logits per camera per group
-  float* w_s = reinterpret_cast<float*>(smem);                 // [NLP][8]
-  float* red_s = w_s + NLP * 8;                                 // [4][256]
-  float* uv_s = red_s + 1024;                                   // [NP][2]
-  float* stat_s = uv_s + 2 * NP;                                // [2][4][8]
-  int* mask_s = reinterpret_cast<int*>(stat_s + 64);            // [NP]
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-
-  // ---- phase 1: projection (detr3d_transformer.py:524-525,547-552)
-  if (t < NP) {
-    const int n = t / prm.P, p = t - n * prm.P;
-    float k[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-      k[d] = (ref[a * 3 + d] * prm.pc_span[d] + prm.pc_lo[d]) + offs[(long)a * prm.P * 3 + p * 3 + d];
-    const float* m = l2i + n * 16;
-    const float x = m[0] * k[0] + m[1] * k[1] + m[2] * k[2] + m[3];
-    const float y = m[4] * k[0] + m[5] * k[1] + m[6] * k[2] + m[7];
-    const float z = m[8] * k[0] + m[9] * k[1] + m[10] * k[2] + m[11];
-    const float zc = fmaxf(z, 1e-5f);
-    const float u = (x / zc) / prm.pad_w, v = (y / zc) / prm.pad_h;
-    int mask = 0;
-#pragma unroll
-    for (int l = 0; l < AGG_MAX_L; ++l) {
-      if (l < prm.L) {
-        const float h_im = v * prm.H[l] - 0.5f, w_im = u * prm.W[l] - 0.5f;
-        if (h_im > -1.f && w_im > -1.f && h_im < prm.H[l] && w_im < prm.W[l]) mask |= 1 << l;
-      }
-    }
-    uv_s[2 * t] = u;
-    uv_s[2 * t + 1] = v;
-    mask_s[t] = mask;
-  }
-
-  // ---- phase 2: softmax over cams x levels x points per group (detr3d_transformer.py:539-540)
-  if constexpr ((ABL & 2) == 0) {
-    const int g = t & 7, r = t >> 3;
-    float lg[AGG_MAX_NLP / 32];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
-      const int idx = r + 32 * i;
-      lg[i] = -INFINITY;
-      if (idx < NLP) {
-        const int n = idx / J, j = idx - n * J;
-        lg[i] = U[(long)a * J * 8 + j * 8 + g] + Vc[n * J * 8 + j * 8 + g];
-      }
-      mx = fmaxf(mx, lg[i]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 8));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (lane < 8) stat_s[wv * 8 + lane] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(stat_s[g], stat_s[8 + g]), fmaxf(stat_s[16 + g], stat_s[24 + g]));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
-      lg[i] = (r + 32 * i < NLP) ? expf(lg[i] - mx) : 0.f;
-      sum += lg[i];
-    }
-    sum += __shfl_xor(sum, 8);
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    if (lane < 8) stat_s[32 + wv * 8 + lane] = sum;
-    __syncthreads();
-    sum = (stat_s[32 + g] + stat_s[40 + g]) + (stat_s[48 + g] + stat_s[56 + g]);
-#pragma unroll
-    for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
-      const int idx = r + 32 * i;
-      if (idx < NLP) w_s[idx * 8 + g] = lg[i] / sum;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: gather (mmcv ms_deform_attn bilinear semantics; zeros outside)
-  const int g = lane >> 3;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const TV* fbase = feat + lane * 4;
-  for (int pair = wv; pair < ((ABL & 1) ? 0 : NP); pair += 4) {
-    const int mask = mask_s[pair];
-    if (mask == 0) continue;  // wave-uniform
-    const int n = pair / prm.P, p = pair - n * prm.P;
-    const float u = uv_s[2 * pair], v = uv_s[2 * pair + 1];
-#pragma unroll
-    for (int l = 0; l < AGG_MAX_L; ++l) {
-      if (l >= prm.L || !((mask >> l) & 1)) continue;
-      const int Hl = prm.H[l], Wl = prm.W[l];
-      const float h_im = v * Hl - 0.5f, w_im = u * Wl - 0.5f;
-      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-      const float lh = h_im - h_low, lw = w_im - w_low;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= Hl - 1;
-      const bool l_ok = w_low >= 0, r_ok = w_low + 1 <= Wl - 1;
-      const int hl_c = t_ok ? h_low : 0, hh_c = b_ok ? h_low + 1 : Hl - 1;
-      const int wl_c = l_ok ? w_low : 0, wh_c = r_ok ? w_low + 1 : Wl - 1;
-      const TV* lvl = fbase + ((long)n * prm.S + prm.start[l]) * 256;
-      float4 v1 = load4(lvl + (long)(hl_c * Wl + wl_c) * 256);
-      float4 v2 = load4(lvl + (long)(hl_c * Wl + wh_c) * 256);
-      float4 v3 = load4(lvl + (long)(hh_c * Wl + wl_c) * 256);
-      float4 v4 = load4(lvl + (long)(hh_c * Wl + wh_c) * 256);
-      const float aw = w_s[((n * prm.L + l) * prm.P + p) * 8 + g];
-      const float w1 = (t_ok && l_ok) ? hh * hw : 0.f;
-      const float w2 = (t_ok && r_ok) ? hh * lw : 0.f;
-      const float w3 = (b_ok && l_ok) ? lh * hw : 0.f;
-      const float w4 = (b_ok && r_ok) ? lh * lw : 0.f;
-      if (!(t_ok && l_ok)) v1 = make_float4(0, 0, 0, 0);
-      if (!(t_ok && r_ok)) v2 = make_float4(0, 0, 0, 0);
-      if (!(b_ok && l_ok)) v3 = make_float4(0, 0, 0, 0);
-      if (!(b_ok && r_ok)) v4 = make_float4(0, 0, 0, 0);
-      acc.x += aw * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x);
-      acc.y += aw * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y);
-      acc.z += aw * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z);
-      acc.w += aw * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
-    }
-  }
-
-  // ---- phase 4: cross-wave (= cross-camera/point) reduction, coalesced store
-  *reinterpret_cast<float4*>(red_s + wv * 256 + lane * 4) = acc;
-  __syncthreads();
-  out[(long)a * 256 + t] = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
-}
-
 
 // ------------------------------------------------------------------------------------------
 // v3 of the fused aggregation (the shipped kernel).  PMC counters on v1 showed the kernel VALU-bound (2.5k VALU
@@ -273,7 +131,7 @@ __global__ __launch_bounds__(256) void aggregate_fwd_kernel(const TV* __restrict
 // block scan), and the gather loop is reduced to: broadcast record read, 4 coalesced row loads, 16 FMAs -- NB samples in
 // flight per wave.  Softmax uses the hardware exp2 path and incremental (camera, logit) indices.
 // ------------------------------------------------------------------------------------------
-template <typename TV, int NB, int ABL = 0, int RP = 0>   // RP: bf16 row-pair gather (16-byte loads, both bilinear columns per instruction)
+template <typename TV, int NB, int RP = 0>   // RP: bf16 row-pair gather (16-byte loads, both bilinear columns per instruction)
 __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ Vc,
@@ -286,8 +144,7 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   float* w_s = reinterpret_cast<float*>(smem);                 // [NLP][8] softmax weights; reused as [4][256] reduction buffer
   float* stat_s = w_s + (NLP * 8 > 1024 ? NLP * 8 : 1024);     // [64]
   int* scan_s = reinterpret_cast<int*>(stat_s + 64);           // [16]
-  int4* rec_s = reinterpret_cast<int4*>(scan_s + 16);          // [NLP][2] sample records (compacted: only [0, nsamp) are live;
-                                                               //  the de-duplicating gather keeps its tables behind record RCAP)
+  int4* rec_s = reinterpret_cast<int4*>(scan_s + 16);          // [NLP][2] sample records (compacted: only [0, nsamp) are live)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 
   // ---- phase 1: one thread per (camera, point): projection, per-level geometry (detr3d_transformer.py:524-525,547-552)
@@ -299,7 +156,7 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
     float k[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-      k[d] = (ref[a * 3 + d] * prm.pc_span[d] + prm.pc_lo[d]) + offs[(long)a * prm.P * 3 + p1 * 3 + d];
+      k[d] = (ref[a * 3 + d] * prm.pc_span[d] + prm.pc_lo[d]) + offs[(long)a * prm.ldO + p1 * 3 + d];
     const float* m = l2i + n1 * 16;
     const float x = m[0] * k[0] + m[1] * k[1] + m[2] * k[2] + m[3];
     const float y = m[4] * k[0] + m[5] * k[1] + m[6] * k[2] + m[7];
@@ -358,13 +215,13 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   }
 
   // ---- phase 2: softmax over cams x levels x points per group (detr3d_transformer.py:539-540)
-  if constexpr ((ABL & 2) == 0) {
+  {
     const int gg = t & 7, r = t >> 3;
     float lg[AGG_MAX_NLP / 32];
     float mx = -INFINITY;
     int n = 0, j = r;   // idx = r + 32*i  ->  (camera n, logit j) tracked incrementally (J > 32)
     while (j >= J) { j -= J; ++n; }
-    const float* Ua = U + (long)a * J * 8 + gg;
+    const float* Ua = U + (long)a * prm.ldU + gg;
     const float* Vg = Vc + gg;
 #pragma unroll
     for (int i = 0; i < AGG_MAX_NLP / 32; ++i) {
@@ -400,136 +257,8 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
     }
   }
   __syncthreads();
-  const int nsamp = (ABL & 1) ? 0 : scan_s[4];
+  const int nsamp = scan_s[4];
 
-  if constexpr (RP == 2 && sizeof(TV) == 2) {
-    // ---- phase 2.5 + 3 (bf16, de-duplicated gather).  The 13 points of a query land on few distinct pixels of the coarse
-    // pyramid levels (measured on the benchmark case: 228 non-zero bilinear taps -> 85 distinct token rows per query), so
-    // the taps are merged per token row first: an LDS hash table (open addressing, atomicCAS) elects one leader tap per row,
-    // leaders get compact slots (deterministic block scan), every tap adds softmax weight x bilinear weight of its 8 groups
-    // into its leader's weight vector (LDS float atomics), and the gather reads each distinct row ONCE.  Identical math up
-    // to fp32 reassociation.  Queries with more than RCAP visible samples or LCAP distinct rows keep the row-pair gather.
-    if (nsamp <= AGG_DEDUP_RCAP) {          // workgroup-uniform
-      constexpr int TCAP = 4 * AGG_DEDUP_RCAP, LCAP = AGG_DEDUP_LCAP, HT = 512;
-      int* key_s = reinterpret_cast<int*>(rec_s + 2 * AGG_DEDUP_RCAP);   // [TCAP] token-row element offset of tap i (-1: zero weight)
-      int* lead_s = key_s + TCAP;                           // [TCAP] compact slot of the tap's leader
-      int* tab_s = lead_s + TCAP;                           // [HT]   hash table: leader tap per token row
-      int* loff_s = tab_s + HT;                             // [LCAP] element offset of compact slot c
-      float* wl_s = reinterpret_cast<float*>(loff_s + LCAP);   // [LCAP][8] merged weights of compact slot c
-      const int T = 4 * nsamp;
-      for (int i = t; i < T; i += 256) {
-        const int4 r0 = rec_s[2 * (i >> 2)];
-        const int4 r1 = rec_s[2 * (i >> 2) + 1];
-        const int q = i & 3;
-        const int bw = q == 0 ? r1.x : q == 1 ? r1.y : q == 2 ? r1.z : r1.w;
-        key_s[i] = (__int_as_float(bw) != 0.f) ? r0.x + ((q & 1) ? r0.y : 0) + ((q & 2) ? r0.z : 0) : -1;
-      }
-      for (int i = t; i < HT; i += 256) tab_s[i] = -1;
-      for (int i = t; i < LCAP * 8; i += 256) wl_s[i] = 0.f;
-      __syncthreads();
-      int ld[2] = {-1, -1}, flag[2] = {0, 0};
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = t + 256 * h;
-        if (i < T) {
-          const int k = key_s[i];
-          if (k >= 0) {
-            unsigned hs = ((unsigned)(k >> 8) * 2654435761u) >> 23;      // token index -> 9 bits
-            for (;;) {
-              const int old = atomicCAS(&tab_s[hs], -1, i);
-              if (old == -1) { ld[h] = i; break; }
-              if (key_s[old] == k) { ld[h] = old; break; }
-              hs = (hs + 1) & (HT - 1);
-            }
-            flag[h] = ld[h] == i ? 1 : 0;
-          }
-        }
-      }
-      {
-        const int c = flag[0] + flag[1];
-        int inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int nb = __shfl_up(inc, o);
-          if (lane >= o) inc += nb;
-        }
-        if (lane == 63) scan_s[8 + wv] = inc;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < wv; ++k) base += scan_s[8 + k];
-        int pos = base + inc - c;
-        if (t == 255) scan_s[12] = base + inc;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int i = t + 256 * h;
-          if (i < T && flag[h]) {
-            lead_s[i] = pos;
-            if (pos < LCAP) loff_s[pos] = key_s[i];
-            ++pos;
-          }
-        }
-      }
-      __syncthreads();
-      const int nlead = scan_s[12];
-      if (nlead <= LCAP) {                    // workgroup-uniform
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int i = t + 256 * h;
-          if (i < T && ld[h] >= 0 && !flag[h]) lead_s[i] = lead_s[ld[h]];   // leaders' entries already hold their slot
-        }
-        __syncthreads();
-        for (int idx = t; idx < T * 8; idx += 256) {
-          const int i = idx >> 3, gq = idx & 7;
-          if (key_s[i] < 0) continue;
-          const int4 r0 = rec_s[2 * (i >> 2)];
-          const int4 r1 = rec_s[2 * (i >> 2) + 1];
-          const int q = i & 3;
-          const int bw = q == 0 ? r1.x : q == 1 ? r1.y : q == 2 ? r1.z : r1.w;
-          atomicAdd(&wl_s[lead_s[i] * 8 + gq], w_s[r0.w + gq] * __int_as_float(bw));
-        }
-        __syncthreads();
-        // gather: one instruction = two distinct token rows (lanes 0-31 / 32-63), 16 bytes (8 channels) per lane
-        typedef unsigned dd_u32x4 __attribute__((ext_vector_type(4)));
-        const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
-        float a8[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a8[k] = 0.f;
-        const bf16_t* fb = reinterpret_cast<const bf16_t*>(feat) + l31 * 8;
-        for (int c0 = wv * 2; c0 < nlead; c0 += 8 * NB) {
-          dd_u32x4 vv[NB];
-          float ww[NB];
-#pragma unroll
-          for (int i = 0; i < NB; ++i) {
-            const int c = c0 + 8 * i + hi;
-            const bool ok = c < nlead;
-            vv[i] = *reinterpret_cast<const dd_u32x4*>(fb + loff_s[ok ? c : 0]);
-            ww[i] = ok ? wl_s[c * 8 + g] : 0.f;
-          }
-#pragma unroll
-          for (int i = 0; i < NB; ++i) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              a8[2 * k] += ww[i] * __uint_as_float(vv[i][k] << 16);
-              a8[2 * k + 1] += ww[i] * __uint_as_float(vv[i][k] & 0xffff0000u);
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a8[k] += __shfl_xor(a8[k], 32);
-        __syncthreads();
-        float* red_s = w_s;
-        if (hi == 0) {
-          *reinterpret_cast<float4*>(red_s + wv * 256 + l31 * 8) = make_float4(a8[0], a8[1], a8[2], a8[3]);
-          *reinterpret_cast<float4*>(red_s + wv * 256 + l31 * 8 + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
-        }
-        __syncthreads();
-        const float res = (red_s[t] + red_s[256 + t]) + (red_s[512 + t] + red_s[768 + t]);
-        if (prm.out_dt == FAR3D_DT_F32) reinterpret_cast<float*>(out)[(long)a * 256 + t] = res;
-        else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + t] = f32_to_bf16(res);
-        return;
-      }
-    }
-  }
   if constexpr (RP != 0 && sizeof(TV) == 2) {
     // ---- phase 3 (bf16): lanes 0-31 take the left bilinear column, lanes 32-63 the right one; a lane owns 8 channels
     // (16 bytes) of its pixel, so one instruction fetches the two adjacent 512-byte token rows of a sample's top (then
@@ -621,20 +350,321 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + t] = f32_to_bf16(res);
 }
 
+// ------------------------------------------------------------------------------------------
+// v4 of the fused aggregation: ONE WAVE PER QUERY, no block-wide phases, taps merged per token row without atomics.
+//
+// Why: the v3 counters (profiles/r1) showed no HBM over-fetch at all -- the kernel sat on (i) ~11 us of block-wide fixed
+// phases (3 barriers per query for the scan / softmax statistics) and (ii) L2 -> CU gather volume: every visible sample moved
+// 4 x 512 B although the 13 key points of a query land on few distinct tokens (228 bilinear taps -> ~85 distinct rows).
+//
+// The merge uses the tent form of bilinear interpolation: the weight of the token at integer (tx,ty) for a sample at
+// (px,py) is max(0,1-|px-tx|) * max(0,1-|py-ty|) -- exactly the four mmcv corner weights, zero for every other token, and
+// tokens outside the map simply do not exist (= zero padding; the `h_im > -1 ...` test of ms_deform_attn is implied).  So for a
+// (camera, level) whose 13 points span at most 64 tokens (a pw x ph patch, pw*ph = 64), lane T owns token T of the patch and
+// accumulates W[T][g] = sum_p softmax_w[p][g] * tent(p, T) in registers: dense, branch-free, no sort, no atomics.  Tokens with
+// a non-zero weight are appended (ballot + mbcnt) to a per-wave LDS list of {row offset, 8 group weights}; a (camera, level)
+// whose points spread wider falls back to one list entry per (point, corner).  The gather then walks the list: one 16-byte
+// load per lane = two 512-byte bf16 token rows per instruction (one 1-KiB fp32 row), 8 (4) channels per lane, UNR loads in
+// flight.  Same arithmetic as the reference up to fp32 re-association.
+// ------------------------------------------------------------------------------------------
+#define AGG4_CAP 192     // list entries per flush
+#define AGG4_UNR 4
+#define AGG4_MAX_N 16
+
+template <typename TV>
+__device__ __forceinline__ void agg4_gather(const TV* __restrict__ feat, const int* off_s, const float* wt_s, int cnt, int lane,
+                                            float (&acc)[8]) {
+  if constexpr (sizeof(TV) == 2) {
+    typedef unsigned g4_u32x4 __attribute__((ext_vector_type(4)));
+    const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
+    const bf16_t* fb = reinterpret_cast<const bf16_t*>(feat) + l31 * 8;
+    for (int k0 = 0; k0 < cnt; k0 += 2 * AGG4_UNR) {
+      g4_u32x4 v[AGG4_UNR];
+      float w[AGG4_UNR];
+#pragma unroll
+      for (int i = 0; i < AGG4_UNR; ++i) {
+        const int e = k0 + 2 * i + hi;
+        const bool ok = e < cnt;
+        v[i] = *reinterpret_cast<const g4_u32x4*>(fb + off_s[ok ? e : 0]);
+        w[i] = ok ? wt_s[e * 8 + g] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < AGG4_UNR; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[2 * k] += w[i] * __uint_as_float(v[i][k] << 16);
+          acc[2 * k + 1] += w[i] * __uint_as_float(v[i][k] & 0xffff0000u);
+        }
+      }
+    }
+  } else {
+    const int g = lane >> 3;
+    const float* fb = reinterpret_cast<const float*>(feat) + lane * 4;
+    for (int k0 = 0; k0 < cnt; k0 += AGG4_UNR) {
+      float4 v[AGG4_UNR];
+      float w[AGG4_UNR];
+#pragma unroll
+      for (int i = 0; i < AGG4_UNR; ++i) {
+        const int e = k0 + i;
+        const bool ok = e < cnt;
+        v[i] = *reinterpret_cast<const float4*>(fb + off_s[ok ? e : 0]);
+        w[i] = ok ? wt_s[e * 8 + g] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < AGG4_UNR; ++i) {
+        acc[0] += w[i] * v[i].x; acc[1] += w[i] * v[i].y; acc[2] += w[i] * v[i].z; acc[3] += w[i] * v[i].w;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int agg4_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename TV>
+__global__ __launch_bounds__(64) void aggregate_v4_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
+                                                          const float* __restrict__ offs, const float* __restrict__ l2i,
+                                                          const float* __restrict__ U, const float* __restrict__ Vc,
+                                                          const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
+  // XCD-aware query mapping: workgroup b lands on XCD b%8; each XCD gets a contiguous run of the camera-sorted order
+  int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  if (a >= prm.A) return;
+  if (perm) a = perm[a];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int P = prm.P, L = prm.L, N = prm.N;
+  const int NP = N * P, J = L * P, NLP = NP * L;
+  float* w_s = reinterpret_cast<float*>(smem);                            // [NLP][8] softmax weights, index = ((n*L+l)*P+p)*8+g
+  float2* uv_s = reinterpret_cast<float2*>(w_s + NLP * 8);                // [NP] normalised image coordinates
+  float4* bb_s = reinterpret_cast<float4*>(uv_s + ((NP + 1) & ~1));       // [AGG4_MAX_N] (umin, umax, vmin, vmax) per camera
+  int* off_s = reinterpret_cast<int*>(bb_s + AGG4_MAX_N);                 // [CAP] element offset of the token row
+  float* wt_s = reinterpret_cast<float*>(off_s + AGG4_CAP);               // [CAP][8] merged weight of the row, per group
+
+  // ---- logits: issue the loads first (their latency hides under the projection).  float4 index i4 covers logits
+  // 4*i4 .. 4*i4+3 of the flattened (camera, level*P+point, group) array: groups (i4&1)*4 .. +3.
+  constexpr int NV = AGG_MAX_NLP * 2 / 64;     // 12 float4 per lane
+  const int n4 = NLP * 2, J2 = J * 2;
+  float4 lg[NV];
+  {
+    int cam = lane / J2, rem = lane - cam * J2;
+    const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
+    const float4* V4 = reinterpret_cast<const float4*>(Vc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int i4 = i * 64 + lane;
+      lg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (i4 < n4) {
+        const float4 u = U4[rem], v = V4[i4];
+        lg[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+      }
+      rem += 64;
+      while (rem >= J2) { rem -= J2; ++cam; }
+    }
+  }
+
+  // ---- projection of the P key points into the N cameras (detr3d_transformer.py:524-525,547-552)
+  {
+    const float r0 = ref[a * 3] * prm.pc_span[0] + prm.pc_lo[0], r1 = ref[a * 3 + 1] * prm.pc_span[1] + prm.pc_lo[1],
+                r2 = ref[a * 3 + 2] * prm.pc_span[2] + prm.pc_lo[2];
+    for (int idx = lane; idx < NP; idx += 64) {
+      const int n = idx / P, p = idx - n * P;
+      const float* o = offs + (long)a * prm.ldO + p * 3;
+      const float k0 = r0 + o[0], k1 = r1 + o[1], k2 = r2 + o[2];
+      const float* m = l2i + n * 16;
+      const float x = m[0] * k0 + m[1] * k1 + m[2] * k2 + m[3];
+      const float y = m[4] * k0 + m[5] * k1 + m[6] * k2 + m[7];
+      const float z = m[8] * k0 + m[9] * k1 + m[10] * k2 + m[11];
+      const float zc = fmaxf(z, 1e-5f);
+      uv_s[idx] = make_float2((x / zc) / prm.pad_w, (y / zc) / prm.pad_h);
+    }
+  }
+  __syncthreads();
+  if (lane < N) {
+    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    for (int p = 0; p < P; ++p) {
+      const float2 q = uv_s[lane * P + p];
+      umin = fminf(umin, q.x); umax = fmaxf(umax, q.x);
+      vmin = fminf(vmin, q.y); vmax = fmaxf(vmax, q.y);
+    }
+    bb_s[lane] = make_float4(umin, umax, vmin, vmax);
+  }
+
+  // ---- softmax over cameras x levels x points per group (detr3d_transformer.py:539-540), all in registers + shuffles
+  {
+    float4 mx = lg[0];
+#pragma unroll
+    for (int i = 1; i < NV; ++i) {
+      mx.x = fmaxf(mx.x, lg[i].x); mx.y = fmaxf(mx.y, lg[i].y); mx.z = fmaxf(mx.z, lg[i].z); mx.w = fmaxf(mx.w, lg[i].w);
+    }
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) {      // lanes with equal (lane & 1) hold the same 4 groups
+      mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o));
+      mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o));
+    }
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool ok = i * 64 + lane < n4;
+      lg[i].x = ok ? __expf(lg[i].x - mx.x) : 0.f; lg[i].y = ok ? __expf(lg[i].y - mx.y) : 0.f;
+      lg[i].z = ok ? __expf(lg[i].z - mx.z) : 0.f; lg[i].w = ok ? __expf(lg[i].w - mx.w) : 0.f;
+      sm.x += lg[i].x; sm.y += lg[i].y; sm.z += lg[i].z; sm.w += lg[i].w;
+    }
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) {
+      sm.x += __shfl_xor(sm.x, o); sm.y += __shfl_xor(sm.y, o); sm.z += __shfl_xor(sm.z, o); sm.w += __shfl_xor(sm.w, o);
+    }
+    const float4 inv = make_float4(1.f / sm.x, 1.f / sm.y, 1.f / sm.z, 1.f / sm.w);
+    float4* w4 = reinterpret_cast<float4*>(w_s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int i4 = i * 64 + lane;
+      if (i4 < n4) w4[i4] = make_float4(lg[i].x * inv.x, lg[i].y * inv.y, lg[i].z * inv.z, lg[i].w * inv.w);
+    }
+  }
+  __syncthreads();
+
+  // ---- build the merged row list and gather it
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int cnt = 0;
+  for (int n = 0; n < N; ++n) {
+    const float4 bb = bb_s[n];
+#pragma unroll
+    for (int l = 0; l < AGG_MAX_L; ++l) {
+      if (l >= L) continue;
+      const int Wl = prm.W[l], Hl = prm.H[l];
+      const float Wf = (float)Wl, Hf = (float)Hl;
+      // token range that the 2x2 corner blocks of the P points can touch, clipped to the map (floor is monotone)
+      const float fx0 = fmaxf(floorf(bb.x * Wf - 0.5f), 0.f), fx1 = fminf(floorf(bb.y * Wf - 0.5f) + 1.f, Wf - 1.f);
+      const float fy0 = fmaxf(floorf(bb.z * Hf - 0.5f), 0.f), fy1 = fminf(floorf(bb.w * Hf - 0.5f) + 1.f, Hf - 1.f);
+      const int vis = agg4_uni((fx1 >= fx0 && fy1 >= fy0) ? 1 : 0);   // false for NaN / empty
+      if (!vis) continue;
+      const int x0 = agg4_uni((int)fx0), y0 = agg4_uni((int)fy0);
+      const int spanx = agg4_uni((int)(fx1 - fx0)) + 1, spany = agg4_uni((int)(fy1 - fy0)) + 1;
+      const int rowbase = (n * prm.S + prm.start[l]);
+      const float* wrow = w_s + ((n * L + l) * P) * 8;
+      int lw = 0;
+      while ((1 << lw) < spanx) ++lw;
+      if (lw <= 6 && spany <= (64 >> lw)) {
+        // -- patch mode: lane T owns token (x0 + T % pw, y0 + T / pw)
+        const int tx = x0 + (lane & ((1 << lw) - 1)), ty = y0 + (lane >> lw);
+        const bool active = tx < x0 + spanx && ty < y0 + spany;
+        const float ftx = (float)tx, fty = (float)ty;
+        float wa[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wa[k] = 0.f;
+        float any = 0.f;
+        for (int p = 0; p < P; ++p) {
+          const float2 q = uv_s[n * P + p];
+          const float px = q.x * Wf - 0.5f, py = q.y * Hf - 0.5f;
+          const float wx = fmaxf(1.f - fabsf(px - ftx), 0.f), wy = fmaxf(1.f - fabsf(py - fty), 0.f);
+          const float w = wx * wy;          // NaN coordinates give NaN here, like the reference's arithmetic would
+          const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
+          any = fmaxf(any, w);
+          wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
+          wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
+        }
+        const bool hit = active && any > 0.f;
+        const unsigned long long m = __ballot(hit);
+        const int c = __popcll(m);
+        if (cnt + c > AGG4_CAP) {          // wave-uniform
+          __syncthreads();
+          agg4_gather<TV>(feat, off_s, wt_s, cnt, lane, acc);
+          __syncthreads();
+          cnt = 0;
+        }
+        if (hit) {
+          const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+          off_s[pos] = (rowbase + ty * Wl + tx) * 256;
+          *reinterpret_cast<float4*>(wt_s + pos * 8) = make_float4(wa[0], wa[1], wa[2], wa[3]);
+          *reinterpret_cast<float4*>(wt_s + pos * 8 + 4) = make_float4(wa[4], wa[5], wa[6], wa[7]);
+        }
+        cnt += c;
+      } else {
+        // -- wide spread: one entry per (point, corner), mmcv's bilinear arithmetic as is
+        for (int i0 = 0; i0 < P * 4; i0 += 64) {
+          const int idx = i0 + lane;
+          bool hit = false;
+          int off = 0;
+          float bw = 0.f;
+          int p = 0;
+          if (idx < P * 4) {
+            p = idx >> 2;
+            const int tap = idx & 3;
+            const float2 q = uv_s[n * P + p];
+            const float h_im = q.y * Hf - 0.5f, w_im = q.x * Wf - 0.5f;
+            if (h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf) {
+              const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+              const float lh = h_im - h_low, lw_ = w_im - w_low;
+              const int ty = h_low + (tap >> 1), tx = w_low + (tap & 1);
+              bw = ((tap >> 1) ? lh : 1.f - lh) * ((tap & 1) ? lw_ : 1.f - lw_);
+              hit = ty >= 0 && ty <= Hl - 1 && tx >= 0 && tx <= Wl - 1 && bw != 0.f;
+              off = (rowbase + ty * Wl + tx) * 256;
+            }
+          }
+          const unsigned long long m = __ballot(hit);
+          const int c = __popcll(m);
+          if (cnt + c > AGG4_CAP) {
+            __syncthreads();
+            agg4_gather<TV>(feat, off_s, wt_s, cnt, lane, acc);
+            __syncthreads();
+            cnt = 0;
+          }
+          if (hit) {
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
+            off_s[pos] = off;
+            *reinterpret_cast<float4*>(wt_s + pos * 8) = make_float4(bw * a0.x, bw * a0.y, bw * a0.z, bw * a0.w);
+            *reinterpret_cast<float4*>(wt_s + pos * 8 + 4) = make_float4(bw * a1.x, bw * a1.y, bw * a1.z, bw * a1.w);
+          }
+          cnt += c;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  agg4_gather<TV>(feat, off_s, wt_s, cnt, lane, acc);
+
+  // ---- store (the cross-camera sum already happened in the accumulators)
+  if constexpr (sizeof(TV) == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], 32);      // two token rows per load: add the halves
+    if (lane < 32) {
+      if (prm.out_dt == FAR3D_DT_F32) {
+        float* o = reinterpret_cast<float*>(out) + (long)a * 256 + lane * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      } else {
+        bf16_t* o = reinterpret_cast<bf16_t*>(out) + (long)a * 256 + lane * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                                  pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+      }
+    }
+  } else {
+    if (prm.out_dt == FAR3D_DT_F32)
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)a * 256 + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + lane * 4) =
+          make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+  }
+}
+
 extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref,
                                        const float* offsets, const float* lidar2img, const float* U,
                                        const float* Vc, const int32_t* perm, void* out, int out_dt, int A, int N, int S, int C, int G,
                                        int P, int L, const int32_t* level_hw, const int32_t* level_start,
-                                       const float* pc_range, float pad_h, float pad_w, void* stream) {
+                                       const float* pc_range, float pad_h, float pad_w, int ldU, int ldOffs, int variant,
+                                       void* stream) {
   FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && Vc && out && level_hw && level_start && pc_range,
                   "far3d_aggregate_forward: null pointer argument");
   FAR3D_CHECK_ARG(C == 256 && G == 8, "far3d_aggregate_forward: fused kernel is built for C=256,G=8 (got C=%d G=%d)", C, G);
   FAR3D_CHECK_ARG(L >= 1 && L <= AGG_MAX_L, "far3d_aggregate_forward: L=%d out of range [1,%d]", L, AGG_MAX_L);
-  FAR3D_CHECK_ARG(N >= 1 && P >= 1 && N * P <= 256 && N * P * L <= AGG_MAX_NLP,
-                  "far3d_aggregate_forward: N*P=%d (<=256) or N*P*L=%d (<=%d) too large", N * P, N * P * L, AGG_MAX_NLP);
+  FAR3D_CHECK_ARG(N >= 1 && N <= AGG4_MAX_N && P >= 1 && N * P <= 256 && N * P * L <= AGG_MAX_NLP,
+                  "far3d_aggregate_forward: N=%d (<=%d), N*P=%d (<=256) or N*P*L=%d (<=%d) too large", N, AGG4_MAX_N, N * P, N * P * L, AGG_MAX_NLP);
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 4, "far3d_aggregate_forward: unknown kernel variant %d (0 auto, 3, 4)", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -650,64 +680,28 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   prm.pad_w = pad_w; prm.pad_h = pad_h;
   prm.q_per_xcd = cdiv(A, 8);
   prm.out_dt = out_dt;
+  prm.ldU = ldU > 0 ? ldU : L * P * G;
+  prm.ldO = ldOffs > 0 ? ldOffs : P * 3;
+  FAR3D_CHECK_ARG(prm.ldU >= L * P * G && prm.ldU % 4 == 0 && ((uintptr_t)U % 16) == 0 && prm.ldO >= P * 3,
+                  "far3d_aggregate_forward: U rows must be 16-byte aligned (ldU=%d) and strides >= row length", prm.ldU);
   FAR3D_CHECK_ARG(out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16, "far3d_aggregate_forward: unsupported output dtype %d", out_dt);
-  const size_t lds = (size_t)(N * P * L * 8 + 1024 + 2 * N * P + 64) * 4 + (size_t)N * P * 4;
-  dim3 grid(8 * prm.q_per_xcd), block(256);
+  dim3 grid(8 * prm.q_per_xcd);
   hipStream_t st = (hipStream_t)stream;
-  const char* abl_env = getenv("FAR3D_AGG_ABLATE");   // profiling aid only
-  const int abl = abl_env ? atoi(abl_env) : 0;
-  const char* v1_env = getenv("FAR3D_AGG_V1");   // A/B aid: the simple v1 kernel
-  if (!(v1_env && atoi(v1_env))) {
+  if (variant == 3) {     // workgroup-per-query kernel with per-sample row-pair gather (round 1)
     const int nlp8 = N * P * L * 8 > 1024 ? N * P * L * 8 : 1024;
-    const size_t lds3_base = (size_t)nlp8 * 4 + 64 * 4 + 64 + (size_t)N * P * L * 32;
-    // de-duplication tables live behind record RCAP: keys + slots (4*RCAP ints each), 512-entry hash table, LCAP offsets + weight vectors
-    const size_t dd_tail = (size_t)AGG_DEDUP_RCAP * 32 + (size_t)4 * AGG_DEDUP_RCAP * 8 + 512 * 4 + (size_t)AGG_DEDUP_LCAP * (4 + 32);
-    const size_t lds3_dedup = (size_t)nlp8 * 4 + 64 * 4 + 64 + ((size_t)N * P * L * 32 > dd_tail ? (size_t)N * P * L * 32 : dd_tail);
-    // opt-in (FAR3D_AGG_DEDUP=1): measured SLOWER than the plain row-pair gather (30.6 vs 22.2 us per launch) although it reads
-    // 2.7x fewer token rows -- the extra barrier phases, CAS probes and LDS float atomics cost more than the gather saves
-    static const int no_dedup = !(getenv("FAR3D_AGG_DEDUP") && atoi(getenv("FAR3D_AGG_DEDUP")));
-    const size_t lds3 = lds3_base;
+    const size_t lds3 = (size_t)nlp8 * 4 + 64 * 4 + 64 + (size_t)N * P * L * 32;
     if (feat_dtype == FAR3D_DT_F32)
-      hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, block, lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 1)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 2)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4, 2>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 3)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4, 3>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 5)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 6)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 4)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 4>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 7)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 8)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 8, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 10)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 1, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (abl == 9)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 6, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else if (!no_dedup && abl == 0)   // de-duplicated gather (row-pair gather for the rare queries above AGG_DEDUP_RCAP samples)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 2>), grid, block, lds3_dedup, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    else   // row-pair gather, 2 samples (4 x 1 KB row-pair loads) in flight per wave: measured best (more in flight thrashes L2)
-      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 0, 1>), grid, block, lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
-    return FAR3D_OK;
+      hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, dim3(256), lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else
+      hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 1>), grid, dim3(256), lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+  } else {
+    const int NP = N * P;
+    const size_t lds4 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + AGG4_CAP * 4 + (size_t)AGG4_CAP * 32;
+    if (feat_dtype == FAR3D_DT_F32)
+      hipLaunchKernelGGL(aggregate_v4_kernel<float>, grid, dim3(64), lds4, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    else
+      hipLaunchKernelGGL(aggregate_v4_kernel<bf16_t>, grid, dim3(64), lds4, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
   }
-  if (feat_dtype == FAR3D_DT_F32)
-    hipLaunchKernelGGL(aggregate_fwd_kernel<float>, grid, block, lds, st, (const float*)feat, ref, offsets,
-                       lidar2img, U, Vc, perm, (float*)out, prm);
-  else if (abl == 1)
-    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 1>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, (float*)out, prm);
-  else if (abl == 2)
-    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 2>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, (float*)out, prm);
-  else if (abl == 3)
-    hipLaunchKernelGGL((aggregate_fwd_kernel<bf16_t, 3>), grid, block, lds, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, (float*)out, prm);
-  else
-    hipLaunchKernelGGL(aggregate_fwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)feat, ref, offsets,
-                       lidar2img, U, Vc, perm, (float*)out, prm);
   FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");
   return FAR3D_OK;
 }

@@ -19,13 +19,17 @@ def camera_shards(num_cams, world):
     return per, [[c if c < num_cams else -1 for c in range(r * per, (r + 1) * per)] for r in range(world)]
 
 
-def gather_camera_major(local, num_cams, group=None, async_op=False):
+def gather_camera_major(local, num_cams, group=None, async_op=False, out=None):
     """All-gather equally-shaped per-rank blocks whose leading dim is `per` camera slots and drop the padding slots.
 
-    local: (per, ...) tensor (padding slots may hold anything).  Returns (work_or_None, fn) where fn() -> (num_cams, ...)
+    local: (per, ...) tensor (padding slots may hold anything).  out: optional preallocated (world*per, ...) destination (a
+    persistent buffer that a captured head graph reads in place).  Returns (work_or_None, fn) where fn() -> (num_cams, ...)
     view of the gathered buffer; call work.wait() before fn() when async_op is set."""
     world = dist.get_world_size(group)
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    shape = (world * local.shape[0],) + tuple(local.shape[1:])
+    if out is None:
+        out = torch.empty(shape, dtype=local.dtype, device=local.device)
+    assert tuple(out.shape) == shape and out.dtype == local.dtype and out.is_contiguous()
     if local.is_cuda and dist.get_backend(group) == "gloo":
         # test rig only (several ranks sharing one GPU, tests/test_dist_gpu.py): gloo has no device collectives, stage via host
         host = torch.empty(out.shape, dtype=out.dtype)
@@ -45,8 +49,8 @@ class ShardedFrame:
     """Drives a Far3DEngine in camera-sharded mode.  Static-M proposal mode only (cfg['proposal_topk'] = K).
 
     use_graph: replay the steady-state frame as TWO hipGraphs per rank -- the per-camera stages and the replicated head --
-    with the collectives issued eagerly between them (no collective is ever captured); the value-map gather then starts
-    after the 2D head instead of overlapping it."""
+    with the collectives issued eagerly between them (no collective is ever captured).  The graphs survive scene changes:
+    the first frame of a scene runs eagerly and resets the engine's streaming memory in place."""
 
     def __init__(self, engine, group=None, use_graph=False):
         if engine.cfg["proposal_topk"] is None:
@@ -60,90 +64,84 @@ class ShardedFrame:
         self.cams = [c for c in self.slots if c >= 0]
         self.use_graph = use_graph
         self._g_cam = self._g_head = None
-        self._st = self._head_in = self._head_out = None
+        self._st = self._head_out = None
+        self._tok_all = self._rec_all = None
         self._scene = None
 
-    def _camera_part(self, dd, pad_hw, overlap):
-        """Per-camera stages for this rank's cameras -> (padded tokens (per,S,E), padded records (per,K,3+E+1), hw, starts).
-        overlap: start the value-map gather from the after-FPN hook (eager mode) and return its handle instead of tokens."""
+    def _gather_bufs(self, tok, rec):
+        """Persistent all-gather destinations (allocated once): the replicated head -- eager or captured -- reads the value
+        maps and the adaptive-query records straight out of them, so a frame moves them exactly once."""
+        if self._tok_all is None or self._tok_all.shape[1:] != tok.shape[1:] or self._tok_all.dtype != tok.dtype:
+            self._tok_all = torch.empty((self.world * self.per,) + tuple(tok.shape[1:]), dtype=tok.dtype, device=tok.device)
+            self._rec_all = torch.empty((self.world * self.per,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+            self._g_head = None
+        return self._tok_all, self._rec_all
+
+    def _pad(self, t):
+        if t.shape[0] < self.per:
+            t = torch.cat([t, torch.zeros((self.per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)])
+        return t
+
+    def _camera_part(self, dd, pad_hw):
+        """Per-camera stages for this rank's cameras -> (padded tokens (per,S,E), padded records (per,K,E+1+3), hw, starts).
+        A record row is [context (E+1) | normalised reference point (3)] (context first: 16-byte aligned GEMM operand)."""
         eng, cfg, dev = self.eng, self.eng.cfg, self.eng.dev
         K = cfg["proposal_topk"]
-        pending = {}
-
-        def pad_tok(tok):
-            if tok.shape[0] < self.per:
-                tok = torch.cat([tok, torch.zeros((self.per - tok.shape[0],) + tuple(tok.shape[1:]), dtype=tok.dtype, device=dev)])
-            return tok
-
-        def start_gather(st):   # value maps are final right after the FPN: overlap their gather with the 2D head
-            pending["tok"] = gather_camera_major(pad_tok(st["tokens"]), self.num_cams, self.group, async_op=True)
-
+        E = cfg["embed_dims"]
         if self.cams:
             img = dd["img"][self.cams[0]:self.cams[-1] + 1]      # contiguous camera block: a view (no index tensor, capture-safe)
-            eng.after_fpn = start_gather if overlap else None
-            try:
-                st = eng.camera_stage(img, dd, self.cams, pad_hw)
-            finally:
-                eng.after_fpn = None
+            st = eng.camera_stage(img, dd, self.cams, pad_hw)
             tok = st["tokens"]
-            rec = torch.cat([st["ref2d"], st["ctx"]], dim=1).view(len(self.cams), K, -1)
+            rec = torch.cat([st["ctx"], st["ref2d"]], dim=1).view(len(self.cams), K, E + 4)
             hw, starts = st["hw"], st["starts"]
         else:           # idle rank (8 GPUs, 7 cameras): contributes padding only
             from .synth import level_shapes, level_starts
             hw = level_shapes(pad_hw, cfg["strides"])
             starts, S = level_starts(hw)
-            tok = torch.zeros((0, S, cfg["embed_dims"]), dtype=eng.prec["value"], device=dev)
-            if overlap:
-                start_gather(dict(tokens=tok))
-            rec = torch.zeros((0, K, 3 + cfg["embed_dims"] + 1), dtype=torch.float32, device=dev)
-        if rec.shape[0] < self.per:
-            rec = torch.cat([rec, torch.zeros((self.per - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=dev)])
-        return (pending.get("tok") if overlap else pad_tok(tok)), rec, hw, starts
+            tok = torch.zeros((0, S, E), dtype=eng.prec["value"], device=dev)
+            rec = torch.zeros((0, K, E + 4), dtype=torch.float32, device=dev)
+        return self._pad(tok), self._pad(rec), hw, starts
+
+    def _head(self, dd, img_metas, hw, starts, pad_hw):
+        K, E = self.eng.cfg["proposal_topk"], self.eng.cfg["embed_dims"]
+        M = self.num_cams * K
+        rec = self._rec_all[:self.num_cams].view(M, E + 4)
+        return self.eng.head_stage(self._tok_all[:self.num_cams], rec[:, E + 1:], rec[:, :E + 1], M, dd, img_metas, hw, starts, pad_hw)
 
     @torch.no_grad()
     def forward_frame(self, data, img_metas):
         eng = self.eng
-        K = eng.cfg["proposal_topk"]
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         dd = eng._stage_inputs(data)      # every rank keeps the (small) calibration inputs; images are sliced per rank
         scene = img_metas[0]["scene_token"]
         # an idle rank (no cameras) stays eager: it only pads the gathers and runs the head, and is never the slowest rank
-        steady = self.use_graph and bool(self.cams) and scene == self._scene and eng.mem is not None
+        steady = self.use_graph and scene == self._scene and eng._mem_valid
         self._scene = scene
-        if not steady:
-            self._g_cam = self._g_head = None          # new scene: the captured branch decisions no longer hold
-            pend, rec, hw, starts = self._camera_part(dd, pad_hw, overlap=True)
-            _, rec_fn = gather_camera_major(rec, self.num_cams, self.group)
-            work, tok_fn = pend
-            if work is not None:
-                work.wait()
-            tokens = tok_fn()
-            rec_all = rec_fn().reshape(self.num_cams * K, -1)
-            ref2d, ctx = rec_all[:, :3].contiguous(), rec_all[:, 3:].contiguous()
-            return eng.head_stage(tokens, ref2d, ctx, self.num_cams * K, dd, img_metas, hw, starts, pad_hw)
-        # ---- steady state: graph(per-camera stages) -> eager gathers -> graph(replicated head)
-        if self._g_cam is None:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of the process group keeps polling its events while we capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._st = self._camera_part(dd, pad_hw, overlap=False)
-            self._g_cam = g
-        self._g_cam.replay()
-        tok, rec, hw, starts = self._st
-        _, tok_fn = gather_camera_major(tok, self.num_cams, self.group)
-        _, rec_fn = gather_camera_major(rec, self.num_cams, self.group)
-        rec_all = rec_fn().reshape(self.num_cams * K, -1)
-        if self._head_in is None:
-            self._head_in = (tok_fn().clone(), rec_all[:, :3].contiguous(), rec_all[:, 3:].contiguous())
+        # ---- per-camera stages: eager, or one hipGraph per rank in steady state
+        if steady and self.cams:
+            if self._g_cam is None:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: the RCCL watchdog thread of the process group keeps polling its events while we capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._st = self._camera_part(dd, pad_hw)
+                self._g_cam = g
+            self._g_cam.replay()
+            tok, rec, hw, starts = self._st
         else:
-            self._head_in[0].copy_(tok_fn())
-            self._head_in[1].copy_(rec_all[:, :3])
-            self._head_in[2].copy_(rec_all[:, 3:])
+            tok, rec, hw, starts = self._camera_part(dd, pad_hw)
+        # ---- the ONE exchange of the frame (SURVEY.md §8(e)): value maps + adaptive-query records, never captured
+        tok_all, rec_all = self._gather_bufs(tok, rec)
+        work, _ = gather_camera_major(tok, self.num_cams, self.group, async_op=True, out=tok_all)
+        gather_camera_major(rec, self.num_cams, self.group, out=rec_all)
+        if work is not None:
+            work.wait()
+        # ---- replicated head on the gathered buffers: eager on the first frame of a scene (memory reset), else a hipGraph
+        if not steady:
+            return self._head(dd, img_metas, hw, starts, pad_hw)
         if self._g_head is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._head_out = eng.head_stage(self._head_in[0], self._head_in[1], self._head_in[2], self.num_cams * K, dd, img_metas,
-                                                hw, starts, pad_hw)
+                self._head_out = self._head(dd, img_metas, hw, starts, pad_hw)
             self._g_head = g
         self._g_head.replay()
         return self._head_out

@@ -19,9 +19,14 @@ from . import ops, weights
 from .synth import level_shapes, level_starts
 
 PRECISIONS = {
-    # activations/weights of the convs, value maps, decoder GEMM weights, attention operands
-    "bf16": dict(act=torch.bfloat16, value=torch.bfloat16, dec_w=torch.bfloat16, attn=torch.bfloat16),
-    "fp32": dict(act=torch.float32, value=torch.float32, dec_w=torch.float32, attn=torch.float32),
+    # act: activations/weights of the backbone / FPN / 2D-head convs; value: the token-major value maps the decoder samples;
+    # dec: decoder + FarHead GEMM operands (weights, attention q/k/v, GEMM inputs); the query stream, softmaxes, LayerNorms,
+    # projections and every accumulation are fp32 in all modes.
+    "bf16": dict(act=torch.bfloat16, value=torch.bfloat16, dec=torch.bfloat16),
+    "fp32": dict(act=torch.float32, value=torch.float32, dec=torch.float32),          # parity mode (exact-fp32 MFMA)
+    # mixed assignments measured by tools/error_budget.py
+    "bf16_fp32dec": dict(act=torch.bfloat16, value=torch.bfloat16, dec=torch.float32),
+    "bf16_fp32val": dict(act=torch.bfloat16, value=torch.float32, dec=torch.float32),
 }
 
 
@@ -84,8 +89,8 @@ class Far3DEngine:
         self.parts = tuple(parts)
         self.cfg = cfg or default_cfg()
         self.dev = torch.device(device)
-        self.prec = PRECISIONS[precision]
-        self.precision = precision
+        self.prec = dict(PRECISIONS[precision]) if isinstance(precision, str) else dict(precision)
+        self.precision = precision if isinstance(precision, str) else "custom"
         self.sd = {}
         for k, v in state_dict.items():
             ck = weights.canonical_key(k)
@@ -93,23 +98,12 @@ class Far3DEngine:
                 self.sd[ck] = v.detach().float()
         self.spec = weights.VOV_SPECS[self.cfg["backbone"]]
         self._bufs = {}
-        self._cam_ids = {}
         self._in = None             # static input buffers (graph replay reads them)
         self._graph = None
         self._graph_outs = None
         self.use_graph = False      # set True to capture the steady-state frame into one hipGraph (static proposal mode only)
-        # Optional forked HIP streams for independent small branches (FAR3D_MS=roi,dec,fork).  Off by default: inside a
-        # captured hipGraph the parallel branches measured SLOWER on ROCm 7.2 (8.14 -> 8.8-9.0 ms per frame), see DESIGN.md.
-        import os as _os
-        self.ms_parts = set(_os.environ.get("FAR3D_MS", "none").split(","))
-        self.multi_stream = True
-        self._side = None
-        self._side_dec = None
-        self.fuse_ese = _os.environ.get("FAR3D_FUSE_ESE", "0") == "1"   # measured slower (8.13 -> 8.53 ms): off
-        self.eye4 = None
-        self.kernel_events = None   # set to {} to collect (start, stop) HIP event pairs around selected kernels
-        self.after_fpn = None       # hook(stage_dict) called right after the FPN (camera-sharded mode starts its gather)
-        self.reset_memory()
+        self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
+        self.mem = None
         self.prev_scene = None
         self._prepare()
 
@@ -125,18 +119,16 @@ class Far3DEngine:
         return ops.PackedConv(w, b, stride=stride, pad=pad, dtype=self.prec["act"], device=self.dev)
 
     def _prepare(self):
-        sd, cfg, dev = self.sd, self.cfg, self.dev
-        f32 = lambda t: t.to(dev).float().contiguous()
         if "backbone" in self.parts:
             self._prepare_backbone()
         if "neck" in self.parts:
             self._prepare_neck_roi()
         if "head" in self.parts:
             self._prepare_head()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(self.dev)
 
     def _prepare_backbone(self):
-        sd, cfg, dev = self.sd, self.cfg, self.dev
+        sd, dev = self.sd, self.dev
         f32 = lambda t: t.to(dev).float().contiguous()
         # ---- backbone (a2)
         bb = {}
@@ -193,41 +185,55 @@ class Far3DEngine:
         f32 = lambda t: t.to(dev).float().contiguous()
         # ---- FarHead (a6, a10)
         h = "pts_bbox_head."
-        dw = self.prec["dec_w"]
+        dw = self.prec["dec"]
+        E = cfg["embed_dims"]
+        pk = lambda w, b=None: ops.PackedConv(w, b, dtype=dw, device=dev)
         L = lambda name, **kw: _Lin(sd, h + name, dw, dev, **kw)
+        W = lambda name: sd[h + name + ".weight"]
+        B = lambda name: sd[h + name + ".bias"]
         self.pc_range = f32(sd[h + "pc_range"])
-        self.pc_lo, self.pc_span = self.pc_range[:3], self.pc_range[3:6] - self.pc_range[:3]
         self.sa = dict(reduce=L("spatial_alignment.reduce.0"), gamma=L("spatial_alignment.gamma"), beta=L("spatial_alignment.beta"))
         self.qe = (L("query_embedding.0"), L("query_embedding.2"))
         self.ce = (L("context_embed.0"), L("context_embed.2"))
         self.te = L("time_embedding.0")
         self.te_ln = (f32(sd[h + "time_embedding.1.weight"]), f32(sd[h + "time_embedding.1.bias"]))
-        self.mln = {n: dict(reduce=L(n + ".reduce.0"), gamma=L(n + ".gamma"), beta=L(n + ".beta")) for n in ("ego_pose_pe", "ego_pose_memory")}
+        # MLN(180) of temporal_alignment (farhead.py:292-300): the two modules read the same code, so their `reduce` layers
+        # run as ONE GEMM (Cout 2E) and each module's gamma|beta as one GEMM over its half of the hidden rows
+        names = ("ego_pose_pe", "ego_pose_memory")
+        self.mln_reduce = pk(torch.cat([W(n + ".reduce.0") for n in names]), torch.cat([B(n + ".reduce.0") for n in names]))
+        self.mln_gb = {n: pk(torch.cat([W(n + ".gamma"), W(n + ".beta")]), torch.cat([B(n + ".gamma"), B(n + ".beta")])) for n in names}
         self.cls_b = (L("cls_branches.0.0"), L("cls_branches.0.3"), L("cls_branches.0.6"))
         self.cls_ln = [(f32(sd[h + "cls_branches.0.%d.weight" % j]), f32(sd[h + "cls_branches.0.%d.bias" % j])) for j in (1, 4)]
         self.reg_b = (L("reg_branches.0.0"), L("reg_branches.0.2"), L("reg_branches.0.4"))
         self.ref_fixed = f32(sd[h + "reference_points.weight"])
         self.pseudo_ref = f32(sd[h + "pseudo_reference_points.weight"]) if cfg["num_propagated"] > 0 else None
-        # ---- decoder layers (a7, a8)
-        E = cfg["embed_dims"]
+        # ---- decoder layers (a7, a8).  Merged GEMMs over the [x+pos | x] operand (K = 2E, block weights):
+        #   qkv:  [q | k | v] = [x+pos | x] @ [[Wq;Wk] 0; 0 Wv]^T          (mmcv MHA: pos on q/k only, detr3d_transformer.py:378-396)
+        #   wl:   [weights_fc(x+pos) | learnable_fc(x)]                     (detr3d_transformer.py:525,538; weights_fc bias is in Vc)
+        #   memkv (all layers at once): the memory rows' k / v of every layer, written under the layers' q/k/v column blocks
+        z = lambda r, c: torch.zeros(r, c)
         self.layers = []
+        memkv_w, memkv_b = [], []
+        nJ = cfg["num_groups"] * cfg["num_levels"] * cfg["num_pts"]
+        nO = cfg["num_pts"] * 3
         for i in range(cfg["num_layers"]):
             lp = h + "transformer.decoder.layers.%d." % i
             a, c = lp + "attentions.0.attn.", lp + "attentions.1."
             ipw, ipb = sd[a + "in_proj_weight"], sd[a + "in_proj_bias"]
-            pk = lambda w, b: ops.PackedConv(w, b, dtype=dw, device=dev)
+            wq, wk, wv = ipw[:E], ipw[E:2 * E], ipw[2 * E:]
+            qkv_w = torch.cat([torch.cat([wq, z(E, E)], 1), torch.cat([wk, z(E, E)], 1), torch.cat([z(E, E), wv], 1)])
+            memkv_w.append(torch.cat([z(E, 2 * E), torch.cat([wk, z(E, E)], 1), torch.cat([z(E, E), wv], 1)]))
+            memkv_b.append(torch.cat([torch.zeros(E), ipb[E:]]))
+            wl_w = torch.cat([torch.cat([sd[c + "weights_fc.weight"], z(nJ, E)], 1), torch.cat([z(nO, E), sd[c + "learnable_fc.weight"]], 1)])
+            wl_b = torch.cat([torch.zeros(nJ), sd[c + "learnable_fc.bias"]])
             ly = dict(
-                qk=pk(ipw[:2 * E], ipb[:2 * E]), k=pk(ipw[E:2 * E], ipb[E:2 * E]), v=pk(ipw[2 * E:], ipb[2 * E:]),
-                out=pk(sd[a + "out_proj.weight"], sd[a + "out_proj.bias"]),
-                wfc=pk(sd[c + "weights_fc.weight"], None), wfc_full=pk(sd[c + "weights_fc.weight"], sd[c + "weights_fc.bias"]),
-                lfc=pk(sd[c + "learnable_fc.weight"], sd[c + "learnable_fc.bias"]),
+                qkv=pk(qkv_w, ipb), out=pk(sd[a + "out_proj.weight"], sd[a + "out_proj.bias"]), wl=pk(wl_w, wl_b),
                 oproj=pk(sd[c + "output_proj.weight"], sd[c + "output_proj.bias"]),
-                ce0=pk(sd[c + "cam_embed.0.weight"], sd[c + "cam_embed.0.bias"]), ce2=pk(sd[c + "cam_embed.2.weight"], sd[c + "cam_embed.2.bias"]),
-                ce_ln=(f32(sd[c + "cam_embed.4.weight"]), f32(sd[c + "cam_embed.4.bias"])),
                 ffn1=pk(sd[lp + "ffns.0.layers.0.0.weight"], sd[lp + "ffns.0.layers.0.0.bias"]),
                 ffn2=pk(sd[lp + "ffns.0.layers.1.weight"], sd[lp + "ffns.0.layers.1.bias"]),
                 norms=[(f32(sd[lp + "norms.%d.weight" % j]), f32(sd[lp + "norms.%d.bias" % j])) for j in range(3)])
             self.layers.append(ly)
+        self.memkv = pk(torch.cat(memkv_w), torch.cat(memkv_b))
         cl = []
         for i in range(cfg["num_layers"]):
             c = h + "transformer.decoder.layers.%d.attentions.1." % i
@@ -235,53 +241,27 @@ class Far3DEngine:
                        sd[c + "cam_embed.4.weight"], sd[c + "cam_embed.4.bias"], sd[c + "weights_fc.weight"], sd[c + "weights_fc.bias"]))
         self.cam_chain = ops.pack_cam_embed_chain(cl, dev)
         # ---- frame-invariant pieces of temporal_alignment (farhead.py:284-303): the current frame's ego motion is the
-        # identity, so its MLN(180) codes are constants, and the 644 learned queries never change.
+        # identity, so its MLN(180) codes are constants, and the learned queries never change.
         mk_dim_t = lambda n: (10000 ** (2 * torch.div(torch.arange(n, dtype=torch.float32, device=dev), 2, rounding_mode="floor") / n)).contiguous()
         self.dim_t128, self.dim_t256 = mk_dim_t(128), mk_dim_t(256)
         eye = torch.eye(4, device=dev)[:3, :].flatten()
         rec = nerf_encoding(torch.cat([torch.zeros(3, device=dev), eye])[None])              # (1,180)
-        self.rec_code = {}
-        for n in ("ego_pose_pe", "ego_pose_memory"):
-            hh = self.mln[n]["reduce"](rec, act="relu")
-            self.rec_code[n] = (self.mln[n]["gamma"](hh), self.mln[n]["beta"](hh))             # (1,256) each
+        hh = ops.linear(rec, self.mln_reduce, act="relu")                                    # (1,2E): [pe | memory] hidden
+        self.rec_gb = {n: ops.linear(hh[:, j * E:(j + 1) * E], self.mln_gb[n]) for j, n in enumerate(names)}   # (1,2E) gamma|beta
         self.time0 = ops.layernorm(self.te(pos2posemb(torch.zeros(1, device=dev), 256)), *self.te_ln)   # (1,256)
         qp = self._query_pos(self.ref_fixed)
-        self.qpos_fixed = ops.row_affine_ln(qp, *self.rec_code["ego_pose_pe"], add=self.time0)
-        self.tgt_fixed = ops.row_affine_ln(torch.zeros_like(qp), *self.rec_code["ego_pose_memory"])
+        g, b = self._gb(self.rec_gb["ego_pose_pe"])
+        self.qpos_fixed = ops.row_affine_ln(qp, g, b, add=self.time0)
+        g, b = self._gb(self.rec_gb["ego_pose_memory"])
+        self.tgt_fixed = ops.row_affine_ln(torch.zeros_like(qp), g, b)
+        self._mem_alloc()
+
+    def _gb(self, gb):
+        E = self.cfg["embed_dims"]
+        return gb[:, :E], gb[:, E:]
 
     def _query_pos(self, ref):
-        return self.qe[1](self.qe[0](ops.posemb3d(ref.contiguous(), self.dim_t128), act="relu"))
-
-    def _fork(self, fns):
-        """Run independent branches concurrently: fns[0] on the current stream, the rest on side streams that fork from it
-        and join back (inside a hipGraph capture this becomes parallel graph branches).  Returns the branches' results."""
-        if not self.multi_stream or len(fns) == 1 or "fork" not in self.ms_parts:
-            return [f() for f in fns]
-        cur = torch.cuda.current_stream(self.dev)
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(8)]
-        outs = [None] * len(fns)
-        used = []
-        for i, f in enumerate(fns[1:]):
-            st = self._side[i % len(self._side)]
-            if st not in used:
-                st.wait_stream(cur)
-                used.append(st)
-            with torch.cuda.stream(st):
-                outs[i + 1] = f()
-        outs[0] = fns[0]()
-        for st in used:
-            cur.wait_stream(st)
-
-        def keep(o):
-            if isinstance(o, torch.Tensor):
-                o.record_stream(cur)
-            elif isinstance(o, (list, tuple)):
-                for v in o:
-                    keep(v)
-        for o in outs[1:]:
-            keep(o)
-        return outs
+        return self.qe[1](self.qe[0](ops.posemb3d(ref, self.dim_t128), act="relu"))
 
     def _buf(self, key, shape, dtype):
         b = self._bufs.get(key)
@@ -296,11 +276,8 @@ class Far3DEngine:
         act, spec = self.prec["act"], self.spec
         N = img.shape[0]
         Lb = spec["layer_per_block"]
-        # eSE workspaces (channel sums + gates, N*C*3 floats per block): one slab, zeroed once per frame
-        nblk = sum(len(b) for b in self.bb["stages"])
-        slab = self._buf(("ese_slab",), (nblk, N * max(spec["stage_out_ch"]) * (2 * ops.ESE_REPLICAS + 1)), torch.float32)
-        slab.zero_()
-        ese_i = 0
+        # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
+        scratch = self._buf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
         x = ops.stem_im2col(img, act)
         x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
@@ -330,19 +307,14 @@ class Far3DEngine:
                     dst = cat[..., cur_in + i * sc: cur_in + (i + 1) * sc]
                     ops.conv2d_nhwc(src, pc, out=dst, act="relu")
                     src = dst
-                # bf16 path: the concat conv's epilogue also accumulates the eSE average pool (per-XCD replicas in the slab)
-                fused = self.fuse_ese and act == torch.bfloat16 and ops.conv_tile(cat, blk["concat"]) >= 50
-                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc), act), act="relu",
-                                     chan_sum=slab[ese_i] if fused else None)
+                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc), act), act="relu")
                 if last:
                     out = self._buf(("stage", si), (N, H, W, oc), act)
                     nxt = None
                 else:
                     nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, oc + Lb * sc), act)
                     out = nxt[..., :oc]
-                ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out,
-                             scratch=slab[ese_i], sums_state="ready" if fused else "zeroed")
-                ese_i += 1
+                ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out, scratch=scratch)
                 if not last:
                     cat, cur_in = nxt, oc
             stage_in = self._bufs[("stage", si)]
@@ -375,237 +347,195 @@ class Far3DEngine:
 
     # ------------------------------------------------------------------------------------------ a4: 2D head + depth
     def roi_head(self, raw):
-        """YOLOX towers + depth head.  The four pyramid levels and the depth branch are independent: the small levels run
-        on side streams underneath the stride-8 level, which alone fills the GPU."""
-        def level(l):
-            def run():
-                x, lv = raw[l], self.roi[l]
-                t0 = ops.conv2d_nhwc(x, lv["tower0"], act="swish")                 # (N,h,w,512): cls | reg
-                half = t0.shape[-1] // 2
-                cf = ops.conv2d_nhwc(t0[..., :half], lv["cls"][1], act="swish")
-                c = ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32)
-                rf = ops.conv2d_nhwc(t0[..., half:], lv["reg"][1], act="swish")
-                r = ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32)
-                return c, r
-            return run
+        """YOLOX towers + depth head on the raw FPN maps."""
+        cls, reg = [], []
+        for l, x in enumerate(raw):
+            lv = self.roi[l]
+            t0 = ops.conv2d_nhwc(x, lv["tower0"], act="swish")                 # (N,h,w,512): cls | reg
+            half = t0.shape[-1] // 2
+            cf = ops.conv2d_nhwc(t0[..., :half], lv["cls"][1], act="swish")
+            cls.append(ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32))
+            rf = ops.conv2d_nhwc(t0[..., half:], lv["reg"][1], act="swish")
+            reg.append(ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32))
+        d = raw[0]
+        gscr = self._buf(("gn_scratch",), (d.shape[0] * 256 * 2 * ops.SUMS_MAX_PARTS + d.shape[0] * 64,), torch.float32)
+        for i in range(2):
+            d = ops.conv2d_nhwc(d, self.depth["convs"][i])
+            d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True, scratch=gscr)
+        return cls, reg, ops.conv2d_nhwc(d, self.depth["cls"], out_dtype=torch.float32)
 
-        def depth():
-            d = raw[0]
-            for i in range(2):
-                d = ops.conv2d_nhwc(d, self.depth["convs"][i])
-                d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True)
-            return ops.conv2d_nhwc(d, self.depth["cls"], out_dtype=torch.float32)
-
-        br = [level(0)] + [level(l) for l in range(1, len(raw))] + [depth]
-        res = self._fork(br) if "roi" in self.ms_parts else [f() for f in br]
-        cls, reg = [r[0] for r in res[:-1]], [r[1] for r in res[:-1]]
-        return cls, reg, res[-1]
-
-    # ------------------------------------------------------------------------------------------ memory (a6/a11, tiny)
-    def reset_memory(self):
-        self.mem = None
-
-    def _mem_init(self):
-        """Persistent streaming-memory buffers (fixed shapes so that a captured hipGraph can read/write them in place).
-        The reference grows the queue to 1280 and truncates to memory_len at the next frame (farhead.py:467-471,501-505);
-        truncating right after the update is the same thing."""
+    # ------------------------------------------------------------------------------------------ memory (a6/a11)
+    def _mem_alloc(self):
+        """Persistent streaming-memory buffers, allocated ONCE: a captured hipGraph reads / writes them in place, so a scene
+        change must never replace them (reset_memory zeroes them in place).  The reference grows the queue to 1280 and
+        truncates to memory_len at the next frame (farhead.py:467-471,501-505); truncating right after the update is the same."""
         cfg, dev = self.cfg, self.dev
         Lm, E = cfg["memory_len"], cfg["embed_dims"]
         self.mem = dict(emb=torch.zeros(1, Lm, E, device=dev), ref=torch.zeros(1, Lm, 3, device=dev),
                         ts=torch.zeros(1, Lm, 1, device=dev, dtype=torch.float64), pose=torch.zeros(1, Lm, 4, 4, device=dev),
                         velo=torch.zeros(1, Lm, 2, device=dev))
+        self._mem_valid = False
 
-    def _pre_update_memory(self, data, prev_exists, fresh):   # farhead.py:453-477
-        cfg, dev = self.cfg, self.dev
-        P_ = cfg["num_propagated"]
-        x = prev_exists
-        s = self.mem
-        if fresh:
-            m = {k: v.clone() for k, v in s.items()}
-        else:
-            m = dict(ts=s["ts"] + data["timestamp"].unsqueeze(-1).unsqueeze(-1),
-                     pose=data["ego_pose_inv"].unsqueeze(1) @ s["pose"],
-                     ref=self._transform_ref(s["ref"], data["ego_pose_inv"]), emb=s["emb"], velo=s["velo"])
-            m = {k: v * x.view(-1, *([1] * (v.dim() - 1))).to(v.dtype) for k, v in m.items()}
-        if P_ > 0:
-            pseudo = self.pseudo_ref * self.pc_span + self.pc_lo
-            m["ref"] = torch.cat([m["ref"][:, :P_] + (1 - x).view(1, 1, 1) * pseudo, m["ref"][:, P_:]], dim=1)
-            m["pose"] = torch.cat([m["pose"][:, :P_] + (1 - x).view(1, 1, 1, 1) * self.eye4, m["pose"][:, P_:]], dim=1)
-        return m
-
-    @staticmethod
-    def _transform_ref(ref, pose):
-        r = torch.cat([ref, torch.ones_like(ref[..., :1])], dim=-1)
-        return (pose.unsqueeze(1) @ r.unsqueeze(-1)).squeeze(-1)[..., :3]
-
-    def _mln_rows(self, x, code, name, add=None):
-        m = self.mln[name]
-        hh = m["reduce"](code, act="relu")
-        return ops.row_affine_ln(x, m["gamma"](hh), m["beta"](hh), add=add)
+    def reset_memory(self):
+        """Forget the streaming memory (detectors/far3d.py:252-257): the next frame is treated as the first of a scene."""
+        self._mem_valid = False
+        self.prev_scene = None
 
     # ------------------------------------------------------------------------------------------ a7/a8: decoder
-    def decoder(self, tgt, qpos, tokens, ref, hw, starts, mem, mempos, lidar2img, pad_hw):
+    def decoder(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A):
+        """X2 (A+Km, 2E) `dec` dtype: rows [:A] = [tgt+pos | tgt] of the queries, rows [A:] = [mem+mempos | mem] of the memory
+        keys; x0 (A,E) f32 = tgt; qpos (A,E) f32.  Returns the stacked post-LN outputs (layers, A, E) f32."""
         cfg = self.cfg
-        A, E = tgt.shape
-        Km = mem.shape[0]
-        at = self.prec["attn"]
-        fast = at == torch.bfloat16     # bf16 mode: GEMM operands are handed over as bf16 copies (LDS-DMA GEMM path)
-        x = tgt
-        xqb, xb = ops.add_cast(x, qpos, at, at if fast else None)
-        memkb, memb = ops.add_cast(mem, mempos, at, at if fast else None)
-        if not fast:
-            xb, memb = x, mem
-        l2i = lidar2img[:, :3, :].flatten(1).contiguous()             # (N,12)
-        outs = torch.empty((cfg["num_layers"], A, E), dtype=torch.float32, device=self.dev)
-        # reference points are fixed across the 6 layers: one camera-sorted workgroup order per frame (scheduling only)
-        perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw)
-        ln_kw = dict(add=qpos, add_dtype=at, bf16_copy=fast)
-        L = len(self.layers)
-        qks = [self._buf(("qk", li), (A + Km, 2 * E), at) for li in range(L)]
-        vbs = [self._buf(("v", li), (A + Km, E), at) for li in range(L)]
-
-        # Work that does not depend on the evolving queries -- the memory rows' K/V projections and the camera-embedding
-        # chain (lidar2img -> cam_embed -> camera part of the attention logits) of every layer -- is issued up front on a
-        # side stream, layer 0 first; each layer waits on its own event, so all of it hides under the main chain.
-        Vcs = [None] * L
-        side_ev = [None] * L
-        vc_all = ops.cam_embed_chain(l2i, self.cam_chain)             # all layers' camera terms: one launch (fp32 weights)
-
-        def side_layer(li):
-            ly = self.layers[li]
-            ops.linear(memkb, ly["k"], out=qks[li][A:, E:])
-            ops.linear(memb, ly["v"], out=vbs[li][A:])
-            Vcs[li] = vc_all[li]                                        # (N,416) camera part + bias
-
-        cur = torch.cuda.current_stream(self.dev)
-        ms_dec = self.multi_stream and "dec" in self.ms_parts
-        if ms_dec:
-            if self._side_dec is None:
-                self._side_dec = torch.cuda.Stream(device=self.dev)
-            sst = self._side_dec
-            sst.wait_stream(cur)
-            with torch.cuda.stream(sst):
-                for li in range(L):
-                    side_layer(li)
-                    side_ev[li] = torch.cuda.Event()
-                    side_ev[li].record(sst)
-                    Vcs[li].record_stream(cur)
+        E = cfg["embed_dims"]
+        nL = len(self.layers)
+        Kt = X2.shape[0]                      # A + memory keys
+        at = self.prec["dec"]
+        fast = at == torch.bfloat16
+        nJ = cfg["num_groups"] * cfg["num_levels"] * cfg["num_pts"]
+        nO = cfg["num_pts"] * 3
+        outs = self._buf(("outs_dec",), (nL, A, E), torch.float32)
+        # reference points are fixed across the layers: one camera-sorted workgroup order per frame (scheduling only)
+        perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32))
+        QKV = self._buf(("qkv",), (Kt, nL * 3 * E), at)          # per layer a [q | k | v] column block
+        XW = self._buf(("xw",), (A, 2 * E), at)                   # [x+pos | x] operand of the cross-attention GEMM
+        UL = self._buf(("ul",), (A, -(-(nJ + nO) // 64) * 64), torch.float32)    # [U (nJ) | key-point offsets (nO)] per query
+        x1 = self._buf(("x1",), (A, E), torch.float32)
+        x2 = self._buf(("x2",), (A, E), torch.float32)
+        x2b = self._buf(("x2b",), (A, E), at) if fast else None
+        # query-independent work first: the memory rows' K/V of all layers (one GEMM) and the camera term of the
+        # aggregation logits of all layers (one launch)
+        if Kt > A:
+            ops.linear(X2[A:], self.memkv, out=QKV[A:], out_dtype=at)
+        vc_all = ops.cam_embed_chain(lidar2img, self.cam_chain)             # (layers, N, nJ), bias included
+        x = x0
         for li, ly in enumerate(self.layers):
-            qk, vb = qks[li], vbs[li]
-            if not ms_dec:
-                side_layer(li)
+            c0 = li * 3 * E
             # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
-            self._fork([lambda: ops.linear(xqb, ly["qk"], out=qk[:A]), lambda: ops.linear(xb, ly["v"], out=vb[:A])])
-            if side_ev[li] is not None:
-                cur.wait_event(side_ev[li])
-            att = ops.attention_forward(qk[:A, :E], qk[:, E:], vb, num_heads=cfg["num_heads"], out_dtype=at)
+            ops.linear(X2[:A], ly["qkv"], out=QKV[:A, c0:c0 + 3 * E], out_dtype=at)
+            att = ops.attention_forward(QKV[:A, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
+                                        num_heads=cfg["num_heads"], out_dtype=at)
             y = ops.linear(att, ly["out"], res=x)
-            r = ops.layernorm(y, *ly["norms"][0], **ln_kw)
-            x, xqb = r[0], r[1]
-            xb = r[2] if fast else x
+            ops.layernorm(y, *ly["norms"][0], out=x1, add=qpos, y2=XW[:, :E], yb=XW[:, E:])
             # cross-attention: fused perspective-aware aggregation (detr3d_transformer.py:522-569)
-            U, offs = self._fork([lambda: ops.linear(xqb, ly["wfc"]),   # (A,416) query part of the logits
-                                  lambda: ops.linear(xb, ly["lfc"])])   # (A,39) learnable 3D offsets
-            Vc = Vcs[li]
-            agg = ops.aggregate_forward(tokens, ref, offs, lidar2img, U, Vc, hw, starts, cfg["pc_range"], pad_hw,
-                                        num_groups=cfg["num_groups"], perm=perm, out_dtype=at)
-            self.last_agg = (tokens, ref, offs, lidar2img, U, Vc, hw, starts, pad_hw, perm)   # for isolated kernel timing
-            y = ops.linear(agg, ly["oproj"], res=x)
+            ops.linear(XW, ly["wl"], out=UL[:, :nJ + nO])
+            agg = ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
+                                        cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out_dtype=at,
+                                        variant=self.agg_variant)
+            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm)
+            y = ops.linear(agg, ly["oproj"], res=x1)
             if fast:
-                x, xb = ops.layernorm(y, *ly["norms"][1], bf16_copy=True)
+                ops.layernorm(y, *ly["norms"][1], out=x2, yb=x2b)
             else:
-                x = ops.layernorm(y, *ly["norms"][1])
-                xb = x
+                ops.layernorm(y, *ly["norms"][1], out=x2)
             # FFN: x + W2 relu(W1 x), hidden 1024 (SURVEY.md finding 4)
-            hdn = ops.linear(xb, ly["ffn1"], act="relu", out_dtype=at)
-            y = ops.linear(hdn, ly["ffn2"], res=x)
-            r = ops.layernorm(y, *ly["norms"][2], out=outs[li], **ln_kw)
-            x, xqb = r[0], r[1]
-            xb = r[2] if fast else x
-        if ms_dec:
-            cur.wait_stream(self._side_dec)
+            hdn = ops.linear(x2b if fast else x2, ly["ffn1"], act="relu", out_dtype=at)
+            y = ops.linear(hdn, ly["ffn2"], res=x2)
+            ops.layernorm(y, *ly["norms"][2], out=outs[li], add=qpos, y2=X2[:A, :E], yb=X2[:A, E:])
+            x = outs[li]
         return outs
 
     # ------------------------------------------------------------------------------------------ one frame
     def camera_stage(self, img, dd, cam_ids, pad_hw):
         """Everything that is independent per camera: backbone, FPN (+MLN), 2D head, depth, proposal
-        selection and adaptive-query construction.  img (n,3,H,W) on device for the cameras `cam_ids` (global indices)."""
-        cfg, dev = self.cfg, self.dev
+        selection and adaptive-query construction.  img (n,3,H,W) on device for the contiguous camera block `cam_ids`."""
+        cfg = self.cfg
         n = img.shape[0]
-        key = tuple(cam_ids)
-        if key not in self._cam_ids:
-            self._cam_ids[key] = torch.as_tensor(list(key), device=dev)
-        ids = self._cam_ids[key]
-        lidar2img = dd["lidar2img"][0].float()[ids].contiguous()
-        intr = dd["intrinsics"][0].float()[ids] / 1e3
-        extr = dd["extrinsics"][0].float()[ids][:, :3, :]
-        c14 = torch.cat([intr[:, 0, 0:1], intr[:, 1, 1:2], extr.flatten(1)], dim=-1).contiguous()   # farhead.py:553-556
+        cam_ids = list(cam_ids)
+        lo, hi = cam_ids[0], cam_ids[-1] + 1
+        assert cam_ids == list(range(lo, hi)) and hi - lo == n, "camera_stage works on a contiguous block of cameras"
+        E = cfg["embed_dims"]
+        lidar2img = dd["lidar2img"][0, lo:hi]
+        # img2lidar = inverse(lidar2img) (farhead.py:798) and the 14-float MLN code (farhead.py:553-556): one launch
+        img2lidar, c14 = ops.camera_prep(lidar2img, dd["intrinsics"][0, lo:hi], dd["extrinsics"][0, lo:hi])
         hh = self.sa["reduce"](c14, act="relu")
-        mln_scale, mln_shift = self.sa["gamma"](hh), self.sa["beta"](hh)
-        ev = self.kernel_events
-        if ev is not None:
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            b0.record()
+        mln_scale, mln_shift = self.sa["gamma"](hh), self.sa["beta"](hh)           # (n, E) each
         feats = self.backbone(img)
-        if ev is not None:
-            b1.record()
-            ev.setdefault("backbone", []).append((b0, b1))
         raw, tokens, hw, starts = self.fpn(feats, mln_scale, mln_shift)
         st = dict(tokens=tokens, hw=hw, starts=starts, raw=raw, lidar2img=lidar2img)
-        if self.after_fpn is not None:
-            self.after_fpn(st)                      # multi-GPU: start the all-gather of the value maps here
         cls, reg, depth_logit = self.roi_head(raw)
         K = cfg["proposal_topk"]
         cap = K if K is not None else min(cfg["proposal_cap"], tokens.shape[1])
-        wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
-        row_off = (torch.cumsum(sel_cnt, 0) - sel_cnt).to(torch.int32)
-        img2lidar = dd["img2lidar"][ids].contiguous()   # inverse(lidar2img), computed when the inputs are staged
-        ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, row_off, wgt, depth_logit,
+        while True:
+            wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
+            if K is not None or cap >= tokens.shape[1]:
+                break
+            # threshold (reference) mode keeps EVERY peak above score_thr (yolox_head.py:429-438): a camera that fills the
+            # capacity may have lost peaks, so grow and redo (this mode syncs on M anyway)
+            if int(sel_cnt.max().item()) < cap:
+                break
+            cap = min(2 * cap, tokens.shape[1])
+        M = n * cap
+        out = (self._buf(("ref2d",), (M, 3), torch.float32), self._buf(("ctx",), (M, E + 1), torch.float32),
+               self._buf(("box2d",), (M, 4), torch.float32), self._buf(("score2d",), (M,), torch.float32))
+        # the log-odds threshold is the reference's hard-coded 0.1 (farhead.py:577), not cfg score_thr
+        ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, wgt, depth_logit,
                                                          cfg["depthnet"]["stride"], cfg["depthnet"], img2lidar, tokens,
-                                                         cfg["pc_range"], score_thr=0.1)
+                                                         cfg["pc_range"], score_thr=0.1, out=out)
         st.update(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit)
         return st
 
     def head_stage(self, tokens, ref2d, ctx, M, dd, img_metas, hw, starts, pad_hw):
         """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12)."""
-        cfg, dev = self.cfg, self.dev
-        lidar2img = dd["lidar2img"][0].float().contiguous()
-        ref2d, ctx = ref2d[:M], ctx[:M]
-        # ---- scene change / memory (detectors/far3d.py:252-257)
-        fresh = img_metas[0]["scene_token"] != self.prev_scene or self.mem is None
+        cfg = self.cfg
+        E = cfg["embed_dims"]
+        lidar2img = dd["lidar2img"][0]
+        # ---- scene change / memory (detectors/far3d.py:252-257): the persistent buffers are zeroed IN PLACE
+        fresh = img_metas[0]["scene_token"] != self.prev_scene or not self._mem_valid
         if fresh:
             self.prev_scene = img_metas[0]["scene_token"]
-            self._mem_init()
-        # ---- a6: memory pre-update + temporal codes (one kernel), then the adaptive / propagated queries
-        P_ = cfg["num_propagated"]
-        m, temp_ref, mem_code, tpos = ops.memory_prepare(self.mem, dd["ego_pose_inv"], dd["timestamp"], self.pseudo_ref, self.dim_t256,
-                                                         0.0 if fresh else 1.0, fresh, cfg["pc_range"], P_)
+            for v in self.mem.values():
+                v.zero_()
+            self._mem_valid = True
+        P_, Lm, nq = cfg["num_propagated"], cfg["memory_len"], cfg["num_query"]
+        A, Kt = nq + M + P_, nq + M + Lm
+        at = self.prec["dec"]
+        fast = at == torch.bfloat16
+        # query-major state buffers: rows [0,nq) learned queries (constant), [nq,nq+M) adaptive queries, then the Lm memory
+        # slots, whose first P_ are the propagated queries and whose rest are the extra self-attention keys
+        # (farhead.py:305-311) -- so tgt = TQ[:A], memory = TQ[A:], with no concatenation copies
+        old = self._bufs.get(("tq",))
+        TQ = self._buf(("tq",), (Kt, E), torch.float32)
+        QP = self._buf(("qp",), (Kt, E), torch.float32)
+        RF = self._buf(("rf",), (Kt, 3), torch.float32)
+        if TQ is not old:      # (re)allocated (M changed in threshold mode): write the constant learned-query rows once
+            TQ[:nq].copy_(self.tgt_fixed); QP[:nq].copy_(self.qpos_fixed); RF[:nq].copy_(self.ref_fixed)
+        # ---- a6: memory pre-update + temporal codes (one kernel)
+        m, _, mem_code, tpos = ops.memory_prepare(self.mem, dd["ego_pose_inv"], dd["timestamp"], self.pseudo_ref, self.dim_t256,
+                                                  0.0 if fresh else 1.0, fresh, cfg["pc_range"], P_, temp_ref_out=RF[nq + M:])
         if M > 0:
-            qpos_a = ops.row_affine_ln(self._query_pos(ref2d), *self.rec_code["ego_pose_pe"], add=self.time0)
-            tgt_a = ops.row_affine_ln(self.ce[1](self.ce[0](ctx, act="relu")), *self.rec_code["ego_pose_memory"])
+            RF[nq:nq + M].copy_(ref2d[:M])
+        # position codes of the adaptive queries and the memory slots in one pass (rows [nq, Kt))
+        qp_raw = self._query_pos(RF[nq:])
+        hh = ops.linear(mem_code, self.mln_reduce, act="relu", out_dtype=at)                  # (Lm, 2E): [pe | memory] hidden
+        gb_pe = ops.linear(hh[:, :E], self.mln_gb["ego_pose_pe"])                            # (Lm, 2E) gamma | beta
+        gb_mem = ops.linear(hh[:, E:], self.mln_gb["ego_pose_memory"])
         t_emb = ops.layernorm(self.te(tpos), *self.te_ln)
-        temp_pos = self._mln_rows(self._query_pos(temp_ref), mem_code, "ego_pose_pe", add=t_emb)
-        temp_mem = self._mln_rows(m["emb"][0], mem_code, "ego_pose_memory")
-        parts_t, parts_q, parts_r = [self.tgt_fixed], [self.qpos_fixed], [self.ref_fixed]
         if M > 0:
-            parts_t.append(tgt_a); parts_q.append(qpos_a); parts_r.append(ref2d)
-        parts_t.append(temp_mem[:P_]); parts_q.append(temp_pos[:P_]); parts_r.append(temp_ref[:P_])
-        tgt, qpos, ref = torch.cat(parts_t).contiguous(), torch.cat(parts_q).contiguous(), torch.cat(parts_r).contiguous()
-        A = tgt.shape[0]
-        outs_dec = self.decoder(tgt, qpos, tokens, ref, hw, starts, temp_mem[P_:].contiguous(), temp_pos[P_:].contiguous(),
-                                lidar2img, pad_hw)
-        outs_dec = torch.nan_to_num(outs_dec)
-        # ---- a10: shared heads over all 6 layers at once
-        flat = outs_dec.view(-1, outs_dec.shape[-1])
-        c1 = ops.layernorm(self.cls_b[0](flat), *self.cls_ln[0], act="relu")
-        c2 = ops.layernorm(self.cls_b[1](c1), *self.cls_ln[1], act="relu")
-        all_cls = self.cls_b[2](c2).view(cfg["num_layers"], 1, A, cfg["num_classes"])
-        rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](flat, act="relu"), act="relu"))
+            g, b = self._gb(self.rec_gb["ego_pose_pe"])
+            ops.row_affine_ln(qp_raw[:M], g, b, add=self.time0, out=QP[nq:nq + M])
+            g, b = self._gb(self.rec_gb["ego_pose_memory"])
+            ops.row_affine_ln(self.ce[1](self.ce[0](ctx[:M], act="relu")), g, b, out=TQ[nq:nq + M])
+        g, b = self._gb(gb_pe)
+        ops.row_affine_ln(qp_raw[M:], g, b, add=t_emb, out=QP[nq + M:])
+        g, b = self._gb(gb_mem)
+        ops.row_affine_ln(m["emb"][0], g, b, out=TQ[nq + M:])
+        X2 = self._buf(("x2op",), (Kt, 2 * E), at)
+        ops.add_cast(TQ, QP, at, out_sum=X2[:, :E], out_a=X2[:, E:])
+        ref = RF[:A]
+        outs_dec = self.decoder(X2, TQ[:A], QP[:A], tokens, ref, hw, starts, lidar2img, pad_hw, A)
+        # ---- a10: shared heads over all layers at once (farhead.py:646-664)
+        flat = outs_dec.view(-1, E)
+        flatb = ops.nan_to_num_(flat, bf16_copy=fast)
+        hin = flatb if fast else flat
         nl = cfg["num_layers"]
+        r1 = ops.layernorm(self.cls_b[0](hin), *self.cls_ln[0], act="relu", bf16_copy=fast)
+        r2 = ops.layernorm(self.cls_b[1](r1[1] if fast else r1), *self.cls_ln[1], act="relu", bf16_copy=fast)
+        all_cls = self.cls_b[2](r2[1] if fast else r2).view(nl, 1, A, cfg["num_classes"])
+        rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](hin, act="relu", out_dtype=at), act="relu", out_dtype=at))
         box_flat, sc = ops.head_finalize(rr, ref, all_cls[-1][0], cfg["pc_range"], nl, cfg["num_classes"])
         all_box = box_flat.view(nl, 1, A, cfg["code_size"])
         # ---- a11: memory post-update (farhead.py:479-508): top-k by max-class score, push, truncate, ego warp -- in place
-        idx = torch.topk(sc, cfg["topk_proposals"], dim=0).indices
+        idx = ops.topk(sc, cfg["topk_proposals"])
         ops.memory_post_update(m, idx, outs_dec[-1], all_box[-1][0], dd["ego_pose"], dd["timestamp"], self.mem)
         outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
                     reference_points=ref)
@@ -613,8 +543,7 @@ class Far3DEngine:
         return outs
 
     def _stage_inputs(self, data):
-        """Copy the frame's inputs into static device buffers (so a captured graph can be replayed on them) and derive
-        img2lidar = inverse(lidar2img) (farhead.py:798) -- the only step torch.linalg does for us, outside the graph."""
+        """Copy the frame's inputs into static device buffers (so that a captured graph can be replayed on them)."""
         dev = self.dev
         img = data["img"]
         if img.dim() == 5:
@@ -625,14 +554,10 @@ class Far3DEngine:
             self._in = dict(img=torch.empty(tuple(img.shape), dtype=torch.float32, device=dev))
             for k in keys:
                 self._in[k] = torch.empty(tuple(data[k].shape), dtype=torch.float64 if k == "timestamp" else torch.float32, device=dev)
-            self._in["img2lidar"] = torch.empty(tuple(data["lidar2img"].shape[1:]), dtype=torch.float32, device=dev)
             self._graph = None
         self._in["img"].copy_(img, non_blocking=True)
         for k in keys:
             self._in[k].copy_(data[k], non_blocking=True)
-        self._in["img2lidar"].copy_(torch.linalg.inv(self._in["lidar2img"][0]))
-        if self.eye4 is None:
-            self.eye4 = torch.eye(4, device=dev)
         return self._in
 
     def _frame_body(self, dd, img_metas, pad_hw):
@@ -651,11 +576,13 @@ class Far3DEngine:
     def forward_frame(self, data, img_metas):
         """data: the reference's per-frame dict (img (1,N,3,H,W), lidar2img, intrinsics, extrinsics, ego_pose(_inv),
         timestamp); tensors may live on the host (they are uploaded) or already on the device.  With `use_graph` the
-        steady-state frame (same scene, static proposal mode) is captured once into a hipGraph and replayed."""
+        steady-state frame (same scene, static proposal mode) is captured once into a hipGraph and replayed; the first
+        frame of every scene runs eagerly (it resets the streaming memory in place, so the captured graph stays valid).
+        Outputs live in engine-owned buffers that the next frame overwrites: clone what must outlive it."""
         dd = self._stage_inputs(data)
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
-        steady = img_metas[0]["scene_token"] == self.prev_scene and self.mem is not None
-        if self.use_graph and steady and self.cfg["proposal_topk"] is not None and self.kernel_events is None:
+        steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
+        if self.use_graph and steady and self.cfg["proposal_topk"] is not None:
             if self._graph is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -668,12 +595,5 @@ class Far3DEngine:
     # ------------------------------------------------------------------------------------------ a12: NMS-free decode
     def decode(self, all_cls, all_box):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245
         cfg = self.cfg
-        cls = all_cls[-1][0].sigmoid()
-        box = all_box[-1][0]
-        scores, idx = cls.view(-1).topk(min(cfg["max_num"], cls.numel()))
-        labels = idx % cfg["num_classes"]
-        b = box[torch.div(idx, cfg["num_classes"], rounding_mode="floor")]
-        b = torch.cat([b[..., 0:3], b[..., 3:6].exp(), torch.atan2(b[..., 6:7], b[..., 7:8])], dim=-1)
-        mask = (b[..., :3] >= self.pc_range[:3]).all(1) & (b[..., :3] <= self.pc_range[3:]).all(1)
-        b = torch.cat([b[:, :2], b[:, 2:3] - b[:, 5:6] * 0.5, b[:, 3:]], dim=-1)
-        return dict(boxes_3d=b, scores_3d=scores, labels_3d=labels, keep=mask)
+        cls, box = all_cls[-1][0], all_box[-1][0]
+        return ops.decode_topk(cls, box, min(cfg["max_num"], cls.numel()), cfg.get("post_center_range", cfg["pc_range"]))

@@ -86,27 +86,31 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, a
 
 
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None, perm=None, out_dtype=torch.float32):
+                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
     offsets (A,P,3) f32 = learnable_fc(x); lidar2img (N,4,4) f32; U (A,L*P*G) f32 query part of the
     attention logits; Vc (N,L*P*G) f32 camera part (incl. bias); level_hw [(H,W)]*L; level_start [L];
     pc_range 6 floats; pad_hw (H,W) of the padded image.  Returns (A,256) f32 = sum over cameras of
-    MSDA(feat_n, project_n(ref+offsets), softmax_{n,l,p}(U+Vc)).
+    MSDA(feat_n, project_n(ref+offsets), softmax_{n,l,p}(U+Vc)).  U / offsets may be row-strided views (unit inner stride)
+    only through .contiguous() -- the kernel reads dense rows.  variant: see include/far3d_hip.h (0 = default).
     """
     lib = _lib.require_device()
     _chk(feat, "feat", ndim=3)
     _chk(ref, "ref", torch.float32, 2)
-    _chk(offsets, "offsets", torch.float32)
     _chk(lidar2img, "lidar2img", torch.float32, 3)
-    _chk(U, "U", torch.float32, 2)
     _chk(Vc, "Vc", torch.float32, 2)
     N, S, C = feat.shape
     A = ref.shape[0]
     L = len(level_hw)
     G = num_groups
-    P = offsets.numel() // max(A * 3, 1) if A > 0 else U.shape[1] // (L * G)
+    if offsets.dim() == 3:
+        offsets = offsets.reshape(A, -1)
+    for t, n in ((U, "U"), (offsets, "offsets")):     # row-strided views are fine (column blocks of a merged-GEMM output)
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and (A == 0 or t.stride(1) == 1)):
+            raise ValueError("aggregate_forward: %s must be a 2-D f32 device tensor with unit inner stride" % n)
+    P = offsets.shape[1] // 3
     if U.shape != (A, L * P * G) or Vc.shape != (N, L * P * G) or lidar2img.shape != (N, 4, 4):
         raise ValueError("aggregate_forward: inconsistent shapes U%s Vc%s l2i%s (A=%d N=%d L=%d P=%d G=%d)" %
                          (tuple(U.shape), tuple(Vc.shape), tuple(lidar2img.shape), A, N, L, P, G))
@@ -122,7 +126,8 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     _lib.check(lib.far3d_aggregate_forward(_ptr(feat), _dt(feat), _ptr(ref), _ptr(offsets), _ptr(lidar2img),
                                            _ptr(U), _ptr(Vc), _ptr(perm) if perm is not None else None, _ptr(out), _dt(out),
                                            A, N, S, C, G, P, L, hw_p, st_p, pc_p,
-                                           float(pad_hw[0]), float(pad_hw[1]), _stream(feat)),
+                                           float(pad_hw[0]), float(pad_hw[1]), U.stride(0) if A > 0 else 0,
+                                           offsets.stride(0) if A > 0 else 0, int(variant), _stream(feat)),
                "far3d_aggregate_forward")
     return out
 
@@ -192,7 +197,12 @@ def _nhwc_view(t, name):
     return t.stride(2), t.stride(0)
 
 
-ESE_REPLICAS = 8   # FAR3D_ESE_REPLICAS in include/far3d_hip.h
+ESE_REPLICAS = 8        # FAR3D_ESE_REPLICAS in include/far3d_hip.h
+SUMS_MAX_PARTS = 64     # FAR3D_SUMS_MAX_PARTS in include/far3d_hip.h
+
+
+def ese_scratch_floats(N, C):
+    return N * C * (2 * SUMS_MAX_PARTS + 1)
 
 
 def conv_tile(x, pc):
@@ -252,6 +262,9 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
     rv = None
     if res is not None:
         rv = res.as_strided((1, 1, M, pc.Cout), (M * res.stride(0), M * res.stride(0), res.stride(0), 1))
+    if tile == 0 and x.dtype == torch.bfloat16 and pc.w.dtype == torch.bfloat16 and x.shape[1] % 32 == 0 and \
+            _tuned_tile(pc.Cout, x.shape[1], 1, 1, M) == 0:
+        tile = 80     # untuned small GEMM: 64x64 pipelined tile (the winner on every decoder-sized shape of the table)
     conv2d_nhwc(xv, pc, out=ov, act=act, res=rv, tile=tile)
     return out
 
@@ -278,30 +291,39 @@ def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32):
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=torch.float32, bf16_copy=False):
-    """Returns LN(x); with `add`: (LN(x), LN(x)+add [add_dtype]); with bf16_copy also a bf16 copy of LN(x) (last)."""
+def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=torch.float32, bf16_copy=False, y2=None, yb=None):
+    """Returns LN(x); with `add`: (LN(x), LN(x)+add [add_dtype]); with bf16_copy also a bf16 copy of LN(x) (last).
+    y2 / yb: optional preallocated (rows,C) outputs (f32|bf16, unit inner stride, any row stride) for LN(x)+add and the
+    copy of LN(x) -- e.g. the two halves of one (rows,2C) [x+pos | x] merged-GEMM operand; they are returned in place of
+    freshly allocated ones."""
     lib = _lib.require_device()
     if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
         raise ValueError("layernorm: x must be (rows,C) f32 with unit inner stride")
     rows, C = x.shape
     y = out if out is not None else torch.empty((rows, C), dtype=torch.float32, device=x.device)
-    y2 = torch.empty((rows, C), dtype=add_dtype, device=x.device) if add is not None else None
-    yb = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device) if bf16_copy else None
+    if y2 is None and add is not None:
+        y2 = torch.empty((rows, C), dtype=add_dtype, device=x.device)
+    if yb is None and bf16_copy:
+        yb = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device)
+    if y2 is not None and add is None:
+        raise ValueError("layernorm: y2 needs add")
+    for t in (y, y2, yb):
+        if t is not None and (t.stride(1) != 1 or tuple(t.shape) != (rows, C)):
+            raise ValueError("layernorm: outputs must be (rows,C) with unit inner stride")
     _lib.check(lib.far3d_layernorm(_ptr(x), _ptr(gamma) if gamma is not None else None,
                                    _ptr(beta) if beta is not None else None, _ptr(y), rows, C, x.stride(0), y.stride(0),
                                    float(eps), 1 if act == "relu" else 0,
                                    _ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
                                    _ptr(y2) if y2 is not None else None, y2.stride(0) if y2 is not None else 0,
                                    _dt(y2) if y2 is not None else 0, _ptr(yb) if yb is not None else None,
-                                   yb.stride(0) if yb is not None else 0, _stream(x)), "far3d_layernorm")
-    res = (y,) + ((y2,) if add is not None else ()) + ((yb,) if bf16_copy else ())
+                                   yb.stride(0) if yb is not None else 0, _dt(yb) if yb is not None else 0, _stream(x)), "far3d_layernorm")
+    res = (y,) + ((y2,) if y2 is not None else ()) + ((yb,) if yb is not None else ())
     return res if len(res) > 1 else y
 
 
-def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, sums_state=None):
-    """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride).
-    sums_state: None -> the call zeroes scratch and pools; "zeroed" -> scratch[:N*C*2] is already zero (one memset for a
-    whole slab of workspaces); "ready" -> it already holds the per-image channel sums (conv2d_nhwc(chan_sum=scratch))."""
+def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
+    """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride).  scratch: optional
+    ese_scratch_floats(N, C) f32 workspace (never needs zeroing; the pooling is deterministic)."""
     lib = _lib.require_device()
     N, H, W, C = x.shape
     ldx, xs = _nhwc_view(x, "x")
@@ -313,10 +335,11 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, sums_state=None
         ldi, isd = _nhwc_view(identity, "identity")
         ip = _ptr(identity)
     if scratch is None:
-        scratch = torch.empty(N * C * 3, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
+    if scratch.numel() < ese_scratch_floats(N, C):
+        raise ValueError("ese_nhwc: scratch needs %d floats" % ese_scratch_floats(N, C))
     _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
-                                  ldx, xs, ldi, isd, ldy, ys, {None: 0, "ready": 1, "zeroed": 2}[sums_state], _stream(x)),
-               "far3d_ese_nhwc")
+                                  ldx, xs, ldi, isd, ldy, ys, _stream(x)), "far3d_ese_nhwc")
     return out
 
 
@@ -327,7 +350,7 @@ def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scr
     if out is None:
         out = torch.empty_like(x)
     if scratch is None:
-        scratch = torch.empty(N * C * 2 + N * groups * 2, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(N * C * 2 * SUMS_MAX_PARTS + N * groups * 2, dtype=torch.float32, device=x.device)
     _lib.check(lib.far3d_groupnorm_nhwc(_ptr(x), _dt(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), N, H * W, C,
                                         groups, float(eps), 1 if relu else 0, _stream(x)), "far3d_groupnorm_nhwc")
     return out
@@ -385,8 +408,8 @@ def proposal_select(cls_maps, reg_maps, strides, cap, thr=0.1, topk=False):
     dev = cls_maps[0].device
     sw = torch.empty((N, S), dtype=torch.float32, device=dev)
     wgt = torch.empty((N, S), dtype=torch.float32, device=dev)
-    sel_idx = torch.zeros((N, cap), dtype=torch.int32, device=dev)
-    sel_cnt = torch.zeros((N,), dtype=torch.int32, device=dev)
+    sel_idx = torch.empty((N, cap), dtype=torch.int32, device=dev)     # entries >= sel_cnt[n] are never read
+    sel_cnt = torch.empty((N,), dtype=torch.int32, device=dev)
     hk, hp = _host_i32([list(x) for x in hw])
     sk, sp = _host_i32(list(strides))
     ca, ra = _ptr_array(cls_maps), _ptr_array(reg_maps)
@@ -396,9 +419,10 @@ def proposal_select(cls_maps, reg_maps, strides, cap, thr=0.1, topk=False):
     return wgt, sel_idx, sel_cnt
 
 
-def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, row_off, weights, depth_logit, depth_stride, depth_cfg, img2lidar,
-                    feat, pc_range, score_thr=0.1):
-    """Returns ref2d (N*cap,3), ctx (N*cap,C+1), box2d (N*cap,4), score (N*cap); rows >= sum(sel_cnt) are untouched zeros."""
+def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, weights, depth_logit, depth_stride, depth_cfg, img2lidar,
+                    feat, pc_range, score_thr=0.1, out=None):
+    """Returns ref2d (N*cap,3), ctx (N*cap,C+1), box2d (N*cap,4), score (N*cap); rows >= sum(sel_cnt) are NOT written
+    (callers slice [:M]).  out: optional (ref2d, ctx, box2d, score) buffers to write into."""
     lib = _lib.require_device()
     L = len(reg_maps)
     N, cap = sel_idx.shape
@@ -409,16 +433,21 @@ def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, row_off, weights, depth
     C = feat.shape[2]
     dev = feat.device
     M = N * cap
-    ref2d = torch.zeros((M, 3), dtype=torch.float32, device=dev)
-    ctx = torch.zeros((M, C + 1), dtype=torch.float32, device=dev)
-    box2d = torch.zeros((M, 4), dtype=torch.float32, device=dev)
-    score = torch.zeros((M,), dtype=torch.float32, device=dev)
+    if out is not None:
+        ref2d, ctx, box2d, score = out
+    else:
+        ref2d = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        ctx = torch.empty((M, C + 1), dtype=torch.float32, device=dev)
+        box2d = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        score = torch.empty((M,), dtype=torch.float32, device=dev)
+    if ref2d.stride(0) != 3 or ctx.stride(0) != C + 1:
+        raise ValueError("proposal_gather: ref2d / ctx must be dense rows")
     hk, hp = _host_i32([list(x) for x in hw])
     sk, sp = _host_i32(list(strides))
     pk, pp = _host_f32(list(pc_range))
     ra = _ptr_array(reg_maps)
     _, hd, wd, nd = depth_logit.shape
-    _lib.check(lib.far3d_proposal_gather(ra, reg_maps[0].shape[3], N, L, hp, sp, _ptr(sel_idx), _ptr(sel_cnt), _ptr(row_off), cap,
+    _lib.check(lib.far3d_proposal_gather(ra, reg_maps[0].shape[3], N, L, hp, sp, _ptr(sel_idx), _ptr(sel_cnt), cap,
                                          _ptr(weights), _ptr(depth_logit), hd, wd, nd, int(depth_stride),
                                          float(depth_cfg["depth_min"]), float(depth_cfg["depth_max"]),
                                          int(depth_cfg["num_depth_bins"]), _ptr(img2lidar), _ptr(feat), _dt(feat), C, pp,
@@ -476,13 +505,16 @@ def posemb3d(pos, dim_t128):
     return out
 
 
-def memory_prepare(state, ego_pose_inv, timestamp, pseudo_ref, dim_t256, prev_exists, fresh, pc_range, num_propagated):
+def memory_prepare(state, ego_pose_inv, timestamp, pseudo_ref, dim_t256, prev_exists, fresh, pc_range, num_propagated,
+                   temp_ref_out=None):
     """state: dict emb (1,L,E) ref (1,L,3) ts (1,L,1) f64 pose (1,L,4,4) velo (1,L,2).  Returns (m dict, temp_ref, nerf, tpos)."""
     lib = _lib.require_device()
     L, E = state["emb"].shape[1], state["emb"].shape[2]
     dev = state["emb"].device
     m = {k: torch.empty_like(v) for k, v in state.items()}
-    temp_ref = torch.empty((L, 3), dtype=torch.float32, device=dev)
+    temp_ref = temp_ref_out if temp_ref_out is not None else torch.empty((L, 3), dtype=torch.float32, device=dev)
+    if tuple(temp_ref.shape) != (L, 3) or not temp_ref.is_contiguous():
+        raise ValueError("memory_prepare: temp_ref_out must be a contiguous (L,3) tensor")
     nerf = torch.empty((L, 180), dtype=torch.float32, device=dev)
     tpos = torch.empty((L, 256), dtype=torch.float32, device=dev)
     pk, pp = _host_f32(list(pc_range))
@@ -516,42 +548,106 @@ def memory_post_update(m, topk_idx, dec_last, box_last, ego_pose, timestamp, sta
                                             _ptr(state["pose"]), _ptr(state["velo"]), _stream(dec_last)), "far3d_memory_post_update")
 
 
-def add_cast(a, b, sum_dtype, a_dtype=None):
-    """Returns (a+b as sum_dtype, a as a_dtype or None) in one pass; a,b f32 contiguous, same shape (b may be broadcast-free)."""
+def add_cast(a, b, sum_dtype, a_dtype=None, out_sum=None, out_a=None):
+    """Returns (a+b as sum_dtype, a as a_dtype or None) in one pass; a,b (rows,C) f32 contiguous.  out_sum / out_a: optional
+    (rows,C) destinations with unit inner stride and any row stride (e.g. halves of one (rows,2C) operand buffer)."""
     lib = _lib.require_device()
-    _chk(a, "a", torch.float32)
-    _chk(b, "b", torch.float32)
-    osum = torch.empty(a.shape, dtype=sum_dtype, device=a.device)
-    oa = torch.empty(a.shape, dtype=a_dtype, device=a.device) if a_dtype is not None else None
+    _chk(a, "a", torch.float32, 2)
+    _chk(b, "b", torch.float32, 2)
+    rows, C = a.shape
+    osum = out_sum if out_sum is not None else torch.empty(a.shape, dtype=sum_dtype, device=a.device)
+    oa = out_a if out_a is not None else (torch.empty(a.shape, dtype=a_dtype, device=a.device) if a_dtype is not None else None)
+    for t in (osum, oa):
+        if t is not None and (tuple(t.shape) != (rows, C) or t.stride(1) != 1):
+            raise ValueError("add_cast: outputs must be (rows,C) with unit inner stride")
     _lib.check(lib.far3d_add_cast(_ptr(a), _ptr(b), _ptr(osum), _dt(osum), _ptr(oa) if oa is not None else None,
-                                  _dt(oa) if oa is not None else 0, a.numel(), _stream(a)), "far3d_add_cast")
+                                  _dt(oa) if oa is not None else 0, rows, C, osum.stride(0), oa.stride(0) if oa is not None else 0,
+                                  _stream(a)), "far3d_add_cast")
     return osum, oa
 
 
-def aggregation_order(ref, lidar2img, pc_range, pad_hw):
-    """Same result as camera_sorted_order(spatial=True) with one key kernel + one sort."""
+def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None):
+    """Query order for aggregate_forward's `perm` (camera, then 8x8 image cell), one single-workgroup launch.  Groups the
+    same way as camera_sorted_order(spatial=True); the order inside a cell is arbitrary (scheduling only)."""
     lib = _lib.require_device()
     A = ref.shape[0]
-    keys = torch.empty((A,), dtype=torch.int32, device=ref.device)
+    perm = out if out is not None else torch.empty((A,), dtype=torch.int32, device=ref.device)
     pk, pp = _host_f32(list(pc_range))
-    _lib.check(lib.far3d_agg_order_keys(_ptr(ref), _ptr(lidar2img), _ptr(keys), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
-                                        _stream(ref)), "far3d_agg_order_keys")
-    return torch.sort(keys, stable=True).indices.to(torch.int32)
+    _lib.check(lib.far3d_agg_order(_ptr(ref), _ptr(lidar2img), _ptr(perm), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
+                                   _stream(ref)), "far3d_agg_order")
+    return perm
+
+
+def topk(vals, K, with_values=False):
+    """Descending top-K indices (int64) of a 1-D f32 device tensor (n <= 40960, K <= 1024), ties -> lower index."""
+    lib = _lib.require_device()
+    _chk(vals, "vals", torch.float32, 1)
+    idx = torch.empty((K,), dtype=torch.int64, device=vals.device)
+    out = torch.empty((K,), dtype=torch.float32, device=vals.device) if with_values else None
+    _lib.check(lib.far3d_topk(_ptr(vals), vals.numel(), int(K), _ptr(idx), _ptr(out) if out is not None else None, _stream(vals)),
+               "far3d_topk")
+    return (idx, out) if with_values else idx
+
+
+def decode_topk(cls_last, box_last, K, post_center_range):
+    """NMS-free decode of the last layer: returns dict(boxes_3d (K,code-1), scores_3d (K), labels_3d (K) i64, keep (K) bool)."""
+    lib = _lib.require_device()
+    _chk(cls_last, "cls_last", torch.float32, 2)
+    _chk(box_last, "box_last", torch.float32, 2)
+    A, ncls = cls_last.shape
+    code = box_last.shape[1]
+    dev = cls_last.device
+    boxes = torch.empty((K, code - 1), dtype=torch.float32, device=dev)
+    scores = torch.empty((K,), dtype=torch.float32, device=dev)
+    labels = torch.empty((K,), dtype=torch.int64, device=dev)
+    keep = torch.empty((K,), dtype=torch.bool, device=dev)
+    rk, rp = _host_f32(list(post_center_range))
+    _lib.check(lib.far3d_decode_topk(_ptr(cls_last), _ptr(box_last), A, ncls, code, int(K), rp, _ptr(boxes), _ptr(scores), _ptr(labels),
+                                     _ptr(keep), _stream(cls_last)), "far3d_decode_topk")
+    return dict(boxes_3d=boxes, scores_3d=scores, labels_3d=labels, keep=keep)
+
+
+def camera_prep(lidar2img, intrinsics=None, extrinsics=None):
+    """lidar2img / intrinsics / extrinsics (N,4,4) f32 -> (img2lidar (N,4,4) = inverse(lidar2img), c14 (N,14) | None)."""
+    lib = _lib.require_device()
+    _chk(lidar2img, "lidar2img", torch.float32, 3)
+    N, dev = lidar2img.shape[0], lidar2img.device
+    i2l = torch.empty((N, 4, 4), dtype=torch.float32, device=dev)
+    c14 = None
+    if intrinsics is not None:
+        _chk(intrinsics, "intrinsics", torch.float32, 3)
+        _chk(extrinsics, "extrinsics", torch.float32, 3)
+        c14 = torch.empty((N, 14), dtype=torch.float32, device=dev)
+    _lib.check(lib.far3d_camera_prep(_ptr(lidar2img), _ptr(intrinsics) if c14 is not None else None,
+                                     _ptr(extrinsics) if c14 is not None else None, _ptr(i2l),
+                                     _ptr(c14) if c14 is not None else None, N, _stream(lidar2img)), "far3d_camera_prep")
+    return i2l, c14
+
+
+def nan_to_num_(x, bf16_copy=False):
+    """In-place torch.nan_to_num on a contiguous f32 tensor; optionally also returns a bf16 copy of the result."""
+    lib = _lib.require_device()
+    _chk(x, "x", torch.float32)
+    xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if bf16_copy else None
+    _lib.check(lib.far3d_nan_to_num(_ptr(x), _ptr(xb) if xb is not None else None, x.numel(), _stream(x)), "far3d_nan_to_num")
+    return xb
 
 
 def cam_embed_chain(l2i, packed, eps=1e-5):
-    """Camera term of the aggregation logits for all decoder layers in one launch.  l2i (N,12) f32; packed: dict of stacked,
-    transposed fp32 weights (see pack_cam_embed_chain).  Returns (L,N,J) f32."""
+    """Camera term of the aggregation logits for all decoder layers in one launch.  l2i: lidar2img (N,4,4) f32 (read in
+    place) or its (N,12) top-three-rows flattening; packed: dict of stacked, transposed fp32 weights (see
+    pack_cam_embed_chain).  Returns (L,N,J) f32."""
     lib = _lib.require_device()
     N = l2i.shape[0]
+    l2i = _chk(l2i.reshape(N, -1), "l2i", torch.float32, 2)
     L, E, J = packed["w3t"].shape
     Hd = packed["w0t"].shape[2]
-    if E != 256 or l2i.shape[1] != 12 or tuple(packed["w2t"].shape) != (L, Hd, 256) or Hd > 256:
+    if E != 256 or l2i.shape[1] not in (12, 16) or tuple(packed["w2t"].shape) != (L, Hd, 256) or Hd > 256:
         raise ValueError("cam_embed_chain: expects 12 -> Hd (<=256) -> 256 -> J weights, got %s" % {k: tuple(v.shape) for k, v in packed.items()})
     out = torch.empty((L, N, J), dtype=torch.float32, device=l2i.device)
-    _lib.check(lib.far3d_cam_embed_chain(_ptr(l2i.contiguous()), _ptr(packed["w0t"]), _ptr(packed["b0"]), _ptr(packed["w2t"]),
+    _lib.check(lib.far3d_cam_embed_chain(_ptr(l2i), _ptr(packed["w0t"]), _ptr(packed["b0"]), _ptr(packed["w2t"]),
                                          _ptr(packed["b2"]), _ptr(packed["ln_g"]), _ptr(packed["ln_b"]), _ptr(packed["w3t"]),
-                                         _ptr(packed["b3"]), _ptr(out), N, L, J, Hd, eps, _stream(l2i)), "far3d_cam_embed_chain")
+                                         _ptr(packed["b3"]), _ptr(out), N, L, J, Hd, eps, l2i.shape[1], _stream(l2i)), "far3d_cam_embed_chain")
     return out
 
 

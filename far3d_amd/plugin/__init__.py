@@ -137,7 +137,7 @@ class DeformableFeatureAggregationCuda(nn.Module):
 
     def _pack(self, dev):
         if self._packed is None or self._packed["dev"] != dev or self._packed["prec"] != self.precision:
-            dw = _engine.PRECISIONS[self.precision]["dec_w"]
+            dw = _engine.PRECISIONS[self.precision]["dec"]
             pk = lambda lin, bias=True: ops.PackedConv(lin.weight.data, lin.bias.data if bias else None, dtype=dw, device=dev)
             self._packed = dict(dev=dev, prec=self.precision, wfc=pk(self.weights_fc, False), wfc_full=pk(self.weights_fc),
                                 lfc=pk(self.learnable_fc), oproj=pk(self.output_proj), ce0=pk(self.cam_embed[0]), ce2=pk(self.cam_embed[2]),

@@ -21,6 +21,8 @@ extern "C" {
 #define FAR3D_DT_BF16 1
 /* per-XCD replicas of the channel-sum array written by far3d_conv2d_nhwc(chan_sum) and read by far3d_ese_nhwc */
 #define FAR3D_ESE_REPLICAS 8
+/* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */
+#define FAR3D_SUMS_MAX_PARTS 64
 
 #define FAR3D_OK 0
 #define FAR3D_ERR_ARG (-1)
@@ -57,15 +59,20 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * U (A,L*P*G) f32 and Vc (N,L*P*G) f32 with logits[a,n,(l*P+p)*G+g] = U[a,.] + Vc[n,.]
  *   ( = weights_fc((x+pos)[a] + cam_embed[n]) split by linearity; bias lives in Vc );
  * level_hw (L,2) int32 HOST (h,w); level_start (L) int32 HOST; pc_range 6 floats HOST;
+ * ldU / ldOffs: row strides in floats of U and offsets (0 = dense; U rows must stay 16-byte aligned) so both can be column
+ * blocks of one merged-GEMM output.
  * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) of dtype out_dt (f32 | bf16).  perm: optional (A) int32 DEVICE permutation giving
  * the order in which queries are assigned to workgroups (camera-sorted order keeps one XCD's L2 on 1-2 cameras); it never
- * changes results (row a of `out` is always query a).  Requires C=256, G=8, L<=4,
- * N*P<=256, N*P*L<=384. */
+ * changes results (row a of `out` is always query a).  Requires C=256, G=8, L<=4, N<=16,
+ * N*P<=256, N*P*L<=384.  variant: 0 = default kernel (4); 4 = one wave per query, bilinear taps merged per token row through
+ * the tent form of the interpolation weights (no atomics), LDS row list, 16-byte row gathers; 3 = round-1 kernel (workgroup
+ * per query, one gather per sample corner pair) kept for A/B measurements.  Both give the same result up to fp32
+ * re-association. */
 int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
                             const float* lidar2img, const float* U, const float* Vc, const int32_t* perm, void* out, int out_dt, int A,
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
-                            void* stream);
+                            int ldU, int ldOffs, int variant, void* stream);
 
 /* Implicit-GEMM convolution / linear layer on the matrix cores (bf16 MFMA, or exact-fp32 MFMA when w_dt = F32).
  * Replaces the torch/cuDNN convolutions and nn.Linear GEMMs of the path:
@@ -85,8 +92,8 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  *    ref: models/utils/misc.py:182-190, models/dense_heads/farhead.py:553-563) so that the FPN output conv writes
  *    the modulated token-major value maps directly.
  * chan_sum (optional): [FAR3D_ESE_REPLICAS][N][Cout][2] f32 (caller zeroes it); element [r][n][m][0] += sum over the pixels
- *    handled on XCD r of the stored y: the eSE average pool rides on the concat conv (then far3d_ese_nhwc(sums_ready=1),
- *    which adds the replicas).  Needs a pipelined tile (>= 50), bf16 y,
+ *    handled on XCD r of the stored y (an average pool riding on a conv epilogue; measured slower than the separate
+ *    pooling pass for eSE and not used by the engine).  Needs a pipelined tile (>= 50), bf16 y,
  *    no res / y2, 16-byte aligned rows (ldy, Cout multiples of 8).
  * tile: 0 auto (host callers pass the measured choice of far3d_amd/data/tuning_mi355x.json).  Any dtype: 1 128x128, 2 64x128,
  *    3 64x64, 4 128x64, 5 64x256 (channels x pixels).  bf16 with Cin % 32 == 0 only: 18, 43, 46, 48 (LDS-DMA ring variants, any
@@ -112,23 +119,25 @@ int far3d_attention_forward(const void* q, const void* k, const void* v, int dty
  * Replaces nn.LayerNorm at ref models/utils/detr3d_transformer.py:304-307,398-400,506-512 and
  * models/dense_heads/farhead.py:230-239,274-277.  x,y,add,y2: f32 rows with strides ldx,ldy,lda,ldy2 (multiples of 4);
  * gamma/beta may be NULL (no affine).  act: 0 none, 1 ReLU.  C multiple of 4, <= 1024.  y2 has dtype y2_dt (f32 | bf16);
- * yb (optional) receives a bf16 copy of y (row stride ldyb) -- the next GEMM's operands without a conversion pass. */
+ * yb (optional) receives a copy of y in dtype yb_dt (f32 | bf16; row stride ldyb) -- the next GEMM's operands without a
+ * conversion pass; y2 and yb may be the two halves of one [y+add | y] row (merged-GEMM input). */
 int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int ldx,
                     int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2, int y2_dt, void* yb, int ldyb,
-                    void* stream);
+                    int yb_dt, void* stream);
 
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
- * scratch: device workspace, N*C*3 floats (sums_ready 0/2) or N*C*(2*FAR3D_ESE_REPLICAS+1) floats (sums_ready 1).
- * sums_ready: 0 = the call zeroes scratch[0 : N*C*2] and pools into it; 2 = the caller already zeroed it (one memset for
- * many blocks); 1 = scratch holds the per-XCD channel-sum replicas of far3d_conv2d_nhwc(chan_sum), pooling is skipped. */
+ * scratch: device workspace, N*C*(2*FAR3D_SUMS_MAX_PARTS+1) floats, never needs zeroing: the average pool writes
+ * per-workgroup partial channel sums with plain stores and the gate kernel adds them in index order (deterministic: no
+ * atomics, bit-identical run to run and hipGraph vs eager).  C must divide 1024. */
 int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
-                   int ldy, long y_img_stride, int sums_ready, void* stream);
+                   int ldy, long y_img_stride, void* stream);
 
 /* GroupNorm(groups, C) (+ReLU) on dense NHWC maps.  Replaces nn.GroupNorm(32, 256)+ReLU of the depth head,
- * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: N*C*2 + N*groups*2 floats. */
+ * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: N*C*2*FAR3D_SUMS_MAX_PARTS + N*groups*2 floats (no zeroing
+ * needed; statistics are reduced deterministically from per-workgroup partial sums).  C must divide 1024. */
 int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch, int N,
                          int HW, int C, int groups, float eps, int relu, void* stream);
 
@@ -157,10 +166,11 @@ int far3d_proposal_select(const float* const* cls, const float* const* reg, int 
 /* Adaptive-query construction from the selected 2D peaks: 2D box decode (ref yolox_head.py:491-501 + xyxy->cxcywh :457),
  * depth bin argmax at round(centre/stride) (ref models/dense_heads/farhead.py:736-747), LID un-binning (:521-527),
  * un-projection with img2lidar = inverse(lidar2img) and pc_range normalisation (:792-811), context = value-map token ||
- * log-odds(score) - log-odds(thr) (:576-581,773-784).  row_off (N) int32 device = exclusive prefix of sel_cnt.
+ * log-odds(score) - log-odds(thr) (:576-581,773-784; the score is clamped to >= 1e-6 first so that zero-weight padding rows
+ * of the static top-K mode stay finite).  Camera n's rows start at sum(sel_cnt[:n]) (camera-major, like the reference).
  * Outputs: ref2d (M,3), ctx (M,C+1), box2d (M,4 cxcywh), score (M). */
 int far3d_proposal_gather(const float* const* reg, int nreg, int N, int L, const int32_t* level_hw, const int32_t* strides,
-                          const int* sel_idx, const int* sel_cnt, const int* row_off, int cap, const float* weights,
+                          const int* sel_idx, const int* sel_cnt, int cap, const float* weights,
                           const float* depth_logit, int hd, int wd, int nd, int depth_stride, float depth_min,
                           float depth_max, int depth_bins, const float* img2lidar, const void* feat, int feat_dt, int C,
                           const float* pc_range, float score_thr, float* ref2d, float* ctx, float* box2d, float* score,
@@ -199,20 +209,48 @@ int far3d_memory_post_update(const float* m_emb, const float* m_ref, const doubl
                              const double* timestamp, int L, int E, int K, int code_size, float* emb, float* ref, double* ts,
                              float* pose, float* velo, void* stream);
 
-/* out_sum = a + b (sum_dt), out_a = a (a_dt, optional); n elements, multiple of 4 (decoder "query + query_pos" operands). */
-int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, void* out_a, int a_dt, long n, void* stream);
+/* out_sum = a + b (sum_dt), out_a = a (a_dt, optional); a, b dense (rows, C) f32, outputs with row strides ld_sum / ld_a elements
+ * (multiples of 4): the decoder's [query + query_pos | query] merged-GEMM operand in one pass. */
+int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, void* out_a, int a_dt, int rows, int C, long ld_sum,
+                   long ld_a, void* stream);
 
-/* Scheduling keys for far3d_aggregate_forward's `perm`: (nearest camera, 8x8 image cell) per reference point. */
-int far3d_agg_order_keys(const float* ref, const float* lidar2img, int32_t* keys, int A, int N, const float* pc_range, float pad_h,
-                         float pad_w, void* stream);
+/* Query order for far3d_aggregate_forward's `perm`: queries sorted by (nearest camera, 8x8 image cell) of their reference
+ * point, one single-workgroup launch (keys + LDS counting sort).  A <= 8192, N <= 16.  Scheduling only. */
+int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range, float pad_h,
+                    float pad_w, void* stream);
+
+/* Descending top-K of n <= 40960 floats (ties -> lower index), one workgroup: idx_out (K) int64, val_out (K) f32 or NULL.
+ * Replaces torch.topk in post_update_memory, ref models/dense_heads/farhead.py:488-491 (K <= 1024). */
+int far3d_topk(const float* vals, int n, int K, int64_t* idx_out, float* val_out, void* stream);
+
+/* NMS-free box decode of the last decoder layer in ONE launch.  Replaces NMSFreeCoder.decode_single
+ * (ref core/bbox/coders/nms_free_coder.py:39-91), denormalize_bbox (ref core/bbox/util.py:25-52) and the z shift of
+ * FarHead.get_bboxes (ref models/dense_heads/farhead.py:1236-1238).  cls_last (A,num_classes) logits, box_last (A,code_size)
+ * = (cx,cy,cz,log w,log l,log h,sin,cos[,vx,vy]); post_center_range 6 floats HOST.  Outputs, sorted by descending score:
+ * boxes (K,code_size-1) = (cx,cy,cz-h/2,w,l,h,atan2(sin,cos)[,vx,vy]), scores (K) = sigmoid, labels (K) int64,
+ * keep (K) uint8 = centre (before the z shift) inside post_center_range (the reference drops the others).
+ * A*num_classes <= 40960, K <= 1024. */
+int far3d_decode_topk(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
+                      const float* post_center_range, float* boxes, float* scores, int64_t* labels, unsigned char* keep,
+                      void* stream);
+
+/* Per-frame camera calibration in one launch: img2lidar (N,4,4) = inverse(lidar2img) (ref models/dense_heads/farhead.py:798;
+ * Gauss-Jordan with partial pivoting in f64) and c14 (N,14) = [fx/1e3, fy/1e3, extrinsics[:3,:4]] (ref farhead.py:553-556).
+ * Either output may be NULL. */
+int far3d_camera_prep(const float* lidar2img, const float* intrinsics, const float* extrinsics, float* img2lidar, float* c14,
+                      int N, void* stream);
+
+/* torch.nan_to_num (nan -> 0, +-inf -> +-FLT_MAX) in place on n floats (multiple of 4), ref models/dense_heads/farhead.py:646;
+ * bf16_copy (optional) receives the sanitised values as bf16. */
+int far3d_nan_to_num(float* x, void* bf16_copy, long n, void* stream);
 
 /* Camera embedding chain of ALL decoder layers in one launch (ref models/utils/detr3d_transformer.py:497-505, 531-538):
  * out[l][n][:] = W3[l] LN(ReLU(W2[l] ReLU(W0[l] l2i[n] + b0[l]) + b2[l])) + b3[l]   (cam_embed -> camera term of weights_fc).
- * l2i [N][12] = lidar2img[:, :3, :] flattened; weights fp32, TRANSPOSED to [in][out]: w0t [L][12][Hd], w2t [L][Hd][256],
+ * l2i: row n holds lidar2img[n][:3,:] flattened in its first 12 floats, row stride ld_l2i (16 = the (N,4,4) tensor in place); weights fp32, TRANSPOSED to [in][out]: w0t [L][12][Hd], w2t [L][Hd][256],
  * w3t [L][256][J]; b0 [L][Hd], b2/ln_g/ln_b [L][256], b3 [L][J]; out [L][N][J].  Embedding width 256, hidden Hd <= 256. */
 int far3d_cam_embed_chain(const float* l2i, const float* w0t, const float* b0, const float* w2t, const float* b2,
                           const float* ln_g, const float* ln_b, const float* w3t, const float* b3, float* out, int N, int L,
-                          int J, int Hd, float eps, void* stream);
+                          int J, int Hd, float eps, int ld_l2i, void* stream);
 
 #ifdef __cplusplus
 }

@@ -251,6 +251,9 @@ class Far3DOracle:
             depths.append(torch.gather(dm, 0, flat.long().unsqueeze(1)))
         depths = torch.cat(depths, dim=0)                        # (M,1) bin indices (topk = 1 -> argmax bin)
         thr = torch.tensor([0.1])
+        # build-defined static top-K mode may pad a camera with zero-weight cells: keep their log-odds finite.  A peak that
+        # passed the reference's `> 0.1` test is never touched by this clamp, so threshold mode is the reference as is.
+        scores = scores.clamp(min=1e-6)
         log_odds = torch.log(scores / (1 - scores)) - torch.log(thr / (1 - thr))
         ctx = torch.cat([ctx, log_odds], dim=-1)                 # (M, C+1)
         d = self._bin_to_depth(depths)

@@ -100,3 +100,68 @@ def aggregation_ref(feat_flatten, ref, offsets, lidar2img, logits, level_hw, lev
     starts = torch.as_tensor(list(level_start), dtype=torch.long)
     out = msda_grid_sample(value, shapes, starts, p2d, w)                         # (N,A,C)
     return out.reshape(1, N, A, C).sum(1)[0]
+
+
+def aggregation_tent(feat_flatten, ref, offsets, lidar2img, logits, level_hw, level_start, pc_range, pad_hw, num_groups=8,
+                     max_patch=64):
+    """Scalar restatement of the *algorithm* of the v4 HIP kernel (far3d_amd/csrc/sampling.hip `aggregate_v4_kernel`), used
+    to prove on the CPU that its tent-weight / token-patch reformulation equals `aggregation_ref`:
+    bilinear weight of token (tx,ty) for a sample at (px,py) = max(0,1-|px-tx|)*max(0,1-|py-ty|); per (camera, level) the
+    P points are merged into per-token weights over the clipped bounding patch when it has <= max_patch tokens (power-of-two
+    width), else every (point, corner) is taken on its own.  Small cases only (python loops)."""
+    f = np.float32
+    feat = np.asarray(feat_flatten, dtype=np.float32)
+    N, S, C = feat.shape
+    A, P = offsets.shape[0], offsets.shape[1]
+    L, G = len(level_hw), num_groups
+    pc = np.asarray(pc_range, dtype=np.float32)
+    refm = np.asarray(ref, dtype=np.float32) * (pc[3:6] - pc[0:3]) + pc[0:3]
+    kp = refm[:, None, :] + np.asarray(offsets, dtype=np.float32)                       # (A,P,3)
+    l2i = np.asarray(lidar2img, dtype=np.float32)
+    lg = np.asarray(logits, dtype=np.float32).reshape(A, N * L * P, G)
+    w = np.exp(lg - lg.max(axis=1, keepdims=True))
+    w = (w / w.sum(axis=1, keepdims=True)).reshape(A, N, L, P, G)
+    out = np.zeros((A, C), dtype=np.float32)
+    stats = dict(patch=0, wide=0, rows=0)
+    for a in range(A):
+        for n in range(N):
+            m = l2i[n]
+            xyz = kp[a] @ m[:3, :3].T + m[:3, 3]
+            zc = np.maximum(xyz[:, 2], f(1e-5))
+            u = xyz[:, 0] / zc / f(pad_hw[1])
+            v = xyz[:, 1] / zc / f(pad_hw[0])
+            for l, (Hl, Wl) in enumerate(level_hw):
+                px, py = u * f(Wl) - f(0.5), v * f(Hl) - f(0.5)
+                fx0, fx1 = max(np.floor(px.min()), 0.0), min(np.floor(px.max()) + 1.0, Wl - 1.0)
+                fy0, fy1 = max(np.floor(py.min()), 0.0), min(np.floor(py.max()) + 1.0, Hl - 1.0)
+                if not (fx1 >= fx0 and fy1 >= fy0):
+                    continue
+                x0, y0, sx, sy = int(fx0), int(fy0), int(fx1 - fx0) + 1, int(fy1 - fy0) + 1
+                base = level_start[l]
+                pw = 1
+                while pw < sx:
+                    pw *= 2
+                acc = np.zeros((G, C // G), dtype=np.float32)
+                if pw <= max_patch and sy <= max_patch // pw:
+                    stats["patch"] += 1
+                    for ty in range(y0, y0 + sy):
+                        for tx in range(x0, x0 + sx):
+                            tw = np.maximum(1 - np.abs(px - tx), 0) * np.maximum(1 - np.abs(py - ty), 0)   # (P,)
+                            if tw.max() > 0:
+                                stats["rows"] += 1
+                                wg = (tw[:, None] * w[a, n, l]).sum(0)                                      # (G,)
+                                acc += wg[:, None] * feat[n, base + ty * Wl + tx].reshape(G, C // G)
+                else:
+                    stats["wide"] += 1
+                    for p in range(P):
+                        if not (py[p] > -1 and px[p] > -1 and py[p] < Hl and px[p] < Wl):
+                            continue
+                        hl, wl = int(np.floor(py[p])), int(np.floor(px[p]))
+                        lh, lw = py[p] - hl, px[p] - wl
+                        for (yy, xx, bw) in ((hl, wl, (1 - lh) * (1 - lw)), (hl, wl + 1, (1 - lh) * lw),
+                                             (hl + 1, wl, lh * (1 - lw)), (hl + 1, wl + 1, lh * lw)):
+                            if 0 <= yy <= Hl - 1 and 0 <= xx <= Wl - 1 and bw != 0:
+                                stats["rows"] += 1
+                                acc += (bw * w[a, n, l, p])[:, None] * feat[n, base + yy * Wl + xx].reshape(G, C // G)
+                out[a] += acc.reshape(C)
+    return torch.from_numpy(out), stats

@@ -42,17 +42,27 @@ def oracle_aggregate(case, value_dtype=torch.float32):
                                     num_groups=case["G"])
 
 
-def hip_aggregate(case, device, value_dtype=torch.float32):
+def near_aggregate_case(seed=0, A=96):
+    """Queries a few metres from the cameras with metre-scale offsets: the 13 points of a query spread over many tokens of
+    the fine levels (wide-spread path of the v4 kernel) and over several cameras, some behind the camera."""
+    c = aggregate_case(num_cams=7, pad_hw=(640, 960), A=A, seed=seed, offset_std=1.5)
+    g = torch.Generator().manual_seed(seed + 77)
+    c["ref"] = 0.5 + (torch.rand(A, 3, generator=g) - 0.5) * torch.tensor([0.08, 0.08, 0.4])   # +-12 m in x/y, +-2 m in z
+    return c
+
+
+def hip_aggregate(case, device, value_dtype=torch.float32, variant=0, perm=None):
     from far3d_amd import ops
     d = lambda t: t.to(device).contiguous()
     return ops.aggregate_forward(d(case["feat"].to(value_dtype)), d(case["ref"]), d(case["offsets"]),
                                  d(case["lidar2img"]), d(case["U"]), d(case["Vc"]), case["level_hw"],
-                                 case["level_start"], case["pc_range"], case["pad_hw"], num_groups=case["G"])
+                                 case["level_start"], case["pc_range"], case["pad_hw"], num_groups=case["G"], variant=variant,
+                                 perm=perm)
 
 
-def run_aggregate_case(case, device, value_dtype=torch.float32):
+def run_aggregate_case(case, device, value_dtype=torch.float32, variant=0):
     want = oracle_aggregate(case, value_dtype)
-    got = hip_aggregate(case, device, value_dtype).float().cpu()
+    got = hip_aggregate(case, device, value_dtype, variant).float().cpu()
     return (got - want).abs().max().item()
 
 

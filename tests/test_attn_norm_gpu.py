@@ -136,7 +136,11 @@ def test_cam_embed_chain_matches_torch(hip_lib):
                        torch.randn(256, generator=g) * 0.1, 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g),
                        torch.randn(J, 256, generator=g) * 0.05, torch.randn(J, generator=g) * 0.1))
     l2i = torch.randn(N, 12, generator=g)
-    got = ops.cam_embed_chain(l2i.to("cuda:0"), ops.pack_cam_embed_chain(layers, "cuda:0")).cpu()
+    packed = ops.pack_cam_embed_chain(layers, "cuda:0")
+    got = ops.cam_embed_chain(l2i.to("cuda:0"), packed).cpu()
+    # the engine hands over lidar2img (N,4,4) itself: rows are read in place with stride 16
+    l44 = torch.cat([l2i, torch.randn(N, 4, generator=g)], dim=1).view(N, 4, 4)
+    assert torch.equal(ops.cam_embed_chain(l44.to("cuda:0"), packed).cpu(), got)
     for l, (w0, b0, w2, b2, lg, lb, w3, b3) in enumerate(layers):
         e = F.layer_norm(F.relu(F.linear(F.relu(F.linear(l2i, w0, b0)), w2, b2)), (256,), lg, lb)
         want = F.linear(e, w3, b3)

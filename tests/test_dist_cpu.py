@@ -35,6 +35,11 @@ def _worker(rank, world, port, q):
     _, rec_fn = fdist.gather_camera_major(rec, num_cams)
     work.wait()
     ok = torch.equal(tok_fn(), full_tok) and torch.equal(rec_fn(), full_rec)
+    # persistent destination (what ShardedFrame hands the replicated head): gathered in place, twice
+    dst = torch.full((world * per, S, C), -1.0)
+    for _ in range(2):
+        _, fn = fdist.gather_camera_major(tok, num_cams, out=dst)
+        ok = ok and fn().data_ptr() == dst.data_ptr() and torch.equal(dst[:num_cams], full_tok)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -16,7 +16,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def _build(precision="fp32"):
     from far3d_amd import engine, weights
-    z = np.load(os.path.join(GOLD, "far3d_small_3frames.npz"))
+    z = np.load(os.path.join(GOLD, "far3d_small_seq.npz"))
     rc = json.loads(bytes(z["recipe"]).decode())
     spec = weights.detector_spec(rc["backbone"], num_query=rc["num_query"], num_propagated=rc["num_propagated"])
     sd = weights.init_state_dict(spec, seed=rc["weight_seed"])
@@ -37,7 +37,7 @@ def _worker(rank, world, port, q, use_graph, frames):
         runner = fdist.ShardedFrame(eng, use_graph=use_graph)
         outs = []
         for fi in range(frames):
-            data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
+            data, metas = synth.recipe_frame(rc, fi)
             o = runner.forward_frame(data, metas)
             outs.append((o["all_cls_scores"].cpu().numpy(), o["all_bbox_preds"].cpu().numpy()))
         q.put((rank, outs))
@@ -59,7 +59,7 @@ def test_sharded_frame_ranks_match_single_rank(hip_lib, world, use_graph, frames
     eng, rc = _build()
     want = []
     for fi in range(frames):
-        data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
+        data, metas = synth.recipe_frame(rc, fi)
         o = eng.forward_frame(data, metas)
         want.append((o["all_cls_scores"].cpu().numpy(), o["all_bbox_preds"].cpu().numpy()))
     del eng

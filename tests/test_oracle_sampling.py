@@ -42,3 +42,22 @@ def test_aggregation_ref_linear_in_features():
     c2["feat"] = c["feat"] * 2.0
     assert torch.allclose(cases.oracle_aggregate(c2), 2 * a, atol=1e-4)
     assert a.abs().max() > 1e-3  # some camera actually sees the points
+
+
+def test_tent_patch_form_equals_bilinear_corner_form():
+    """The algorithm of the v4 HIP aggregation kernel (merge the bilinear taps of a (camera, level) per token through the
+    tent form of the interpolation weights, clipped bounding patch, per-corner path for wide spreads) restated on the CPU:
+    identical to the reference formulation up to fp32 re-association, for tight, wide and off-image point clouds."""
+    seen = dict(patch=0, wide=0)
+    for seed, std, hw, A in ((0, 4.0, (64, 96), 37), (1, 0.5, (64, 96), 37), (2, 12.0, (64, 96), 37), (3, 6.0, (256, 384), 12)):
+        c = cases.aggregate_case(num_cams=3, pad_hw=hw, A=A, seed=seed, offset_std=std)
+        if seed == 3:   # near the cameras: wide spreads on the fine levels
+            c["ref"] = 0.5 + (torch.rand(A, 3, generator=torch.Generator().manual_seed(9)) - 0.5) * torch.tensor([0.06, 0.06, 0.3])
+        want = cases.oracle_aggregate(c)
+        logits = c["U"][:, None, :] + c["Vc"][None, :, :]
+        got, st = sampling.aggregation_tent(c["feat"], c["ref"], c["offsets"], c["lidar2img"], logits, c["level_hw"], c["level_start"],
+                                            c["pc_range"], c["pad_hw"])
+        assert (got - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item()) + 2e-6
+        for k in seen:
+            seen[k] += st[k]
+    assert seen["patch"] > 0 and seen["wide"] > 0, seen

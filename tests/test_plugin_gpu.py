@@ -16,7 +16,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def _golden():
-    z = np.load(os.path.join(GOLD, "far3d_small_3frames.npz"))
+    z = np.load(os.path.join(GOLD, "far3d_small_seq.npz"))
     return z, json.loads(bytes(z["recipe"]).decode())
 
 
@@ -29,7 +29,7 @@ def test_far3d_detector_from_config_reproduces_reference_boxes(hip_lib):
     det.load_state_dict(weights.init_state_dict(spec, seed=rc["weight_seed"]))
     det.prepare(DEV, precision="fp32")
     for fi in range(rc["frames"]):
-        data, metas = synth.make_frame(rc["num_cams"], tuple(rc["pad_hw"]), seed=rc["data_seed"], frame_index=fi)
+        data, metas = synth.recipe_frame(rc, fi)
         res = det(return_loss=False, rescale=True, img_metas=metas, **data)[0]["pts_bbox"]
         from tests.conftest import assert_detections_match
         assert_detections_match(tuple(res[k].cpu().numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")),

@@ -1,0 +1,131 @@
+"""GPU: the post-processing / calibration kernels of csrc/post.hip (C ABI far3d_topk, far3d_decode_topk, far3d_camera_prep,
+far3d_agg_order, far3d_nan_to_num) and the row-strided variants of far3d_add_cast / far3d_layernorm, against torch on the CPU
+and the oracle's decode."""
+import numpy as np
+import pytest
+import torch
+
+from far3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n,K", [(1544, 256), (37, 5), (40144, 300), (1024, 1024), (3000, 1)])
+def test_topk_matches_torch(hip_lib, n, K):
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(n + K)
+    v = torch.randn(n, generator=g)
+    v[::7] = torch.round(v[::7] * 4) / 4          # ties
+    v[3] = float("inf")
+    v[5] = -float("inf")
+    idx, val = ops.topk(v.to(DEV), K, with_values=True)
+    idx, val = idx.cpu(), val.cpu()
+    want_v, _ = torch.topk(v, K)
+    assert torch.equal(val, want_v)
+    assert torch.equal(v[idx], val)
+    # ties resolved towards the lower index, positions unique
+    order = np.lexsort((np.arange(n), -v.numpy()))[:K]
+    assert np.array_equal(idx.numpy(), order)
+
+
+def test_decode_topk_matches_oracle_decode(hip_lib):
+    from far3d_amd import ops
+    from oracle import far3d_oracle
+    g = torch.Generator().manual_seed(11)
+    A, ncls = 1544, 26
+    cls = torch.randn(1, 1, A, ncls, generator=g) * 2
+    box = torch.randn(1, 1, A, 8, generator=g)
+    box[..., :3] = (torch.rand(1, 1, A, 3, generator=g) - 0.5) * torch.tensor([330.0, 330.0, 12.0])   # some centres out of range
+    orc = far3d_oracle.Far3DOracle({}, far3d_oracle.default_cfg())
+    want = orc.decode(dict(all_cls_scores=cls, all_bbox_preds=box))
+    got = ops.decode_topk(cls[0, 0].to(DEV), box[0, 0].to(DEV), 300, synth.PC_RANGE)
+    keep = got["keep"].cpu()
+    assert got["labels_3d"].dtype == torch.int64 and int(keep.sum()) == want["scores_3d"].numel() < 300
+    assert torch.equal(got["labels_3d"].cpu()[keep], want["labels_3d"])
+    assert (got["scores_3d"].cpu()[keep] - want["scores_3d"]).abs().max().item() < 1e-6
+    assert (got["boxes_3d"].cpu()[keep] - want["boxes_3d"]).abs().max().item() < 1e-4
+    s = got["scores_3d"].cpu()
+    assert (s[:-1] >= s[1:]).all()
+
+
+def test_decode_topk_keeps_velocity_channels(hip_lib):
+    """code_size 10 (the reference nuScenes layout): vx, vy are appended like denormalize_bbox does (core/bbox/util.py:45-50)."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(12)
+    cls, box = torch.randn(50, 10, generator=g), torch.randn(50, 10, generator=g)
+    got = ops.decode_topk(cls.to(DEV), box.to(DEV), 20, [-1e3] * 3 + [1e3] * 3)
+    assert got["boxes_3d"].shape == (20, 9)
+    q = torch.div(torch.topk(cls.flatten(), 20).indices, 10, rounding_mode="floor")
+    assert torch.allclose(got["boxes_3d"].cpu()[:, 7:], box[q][:, 8:])
+    assert torch.allclose(got["boxes_3d"].cpu()[:, 6], torch.atan2(box[q][:, 6], box[q][:, 7]), atol=1e-6)
+
+
+def test_camera_prep_inverse_and_mln_code(hip_lib):
+    from far3d_amd import ops
+    intr, extr, l2i = synth.ring_cameras(7, (640, 960))
+    i2l, c14 = ops.camera_prep(l2i.to(DEV), intr.to(DEV), extr.to(DEV))
+    want = torch.linalg.inv(l2i.double())
+    rel = ((i2l.cpu().double() - want).abs() / (want.abs() + 1e-3)).max().item()
+    assert rel < 1e-5, rel
+    eye = i2l.cpu().double() @ l2i.double()
+    assert (eye - torch.eye(4, dtype=torch.float64)).abs().max().item() < 1e-3     # f32 storage of entries up to ~1e3
+    want14 = torch.cat([intr[:, 0, 0:1] / 1e3, intr[:, 1, 1:2] / 1e3, extr[:, :3, :].flatten(1)], dim=-1)
+    assert torch.allclose(c14.cpu(), want14, atol=1e-6)
+
+
+def test_agg_order_groups_like_camera_sort(hip_lib):
+    from far3d_amd import ops
+    from tests import cases
+    c = cases.config2_aggregate_case(seed=5)
+    ref, l2i = c["ref"].to(DEV), c["lidar2img"].to(DEV)
+    perm = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"]).cpu()
+    assert sorted(perm.tolist()) == list(range(ref.shape[0]))
+    want = ops.camera_sorted_order(ref, l2i, c["pc_range"], c["pad_hw"], spatial=True).cpu()
+    # same (camera, cell) grouping in the same group order; the order inside a group is free
+    pc = torch.tensor(c["pc_range"])
+    pts = c["ref"] * (pc[3:] - pc[:3]) + pc[:3]
+    p = torch.einsum("nij,aj->nai", c["lidar2img"][:, :3, :3], pts) + c["lidar2img"][:, :3, 3][:, None, :]
+    z = p[..., 2]
+    u = p[..., 0] / z.clamp(min=1e-5) / c["pad_hw"][1] - 0.5
+    v = p[..., 1] / z.clamp(min=1e-5) / c["pad_hw"][0] - 0.5
+    cost = torch.where(z > 1e-5, u * u + v * v, torch.full_like(z, 1e9))
+    cam = cost.argmin(0)
+    uu, vv = torch.gather(u, 0, cam[None])[0], torch.gather(v, 0, cam[None])[0]
+    key = (cam * 8 + ((vv + 0.5).clamp(0, 0.999) * 8).long()) * 8 + ((uu + 0.5).clamp(0, 0.999) * 8).long()
+    kp = key[perm.long()]
+    mism = int((kp[1:] < kp[:-1]).sum())
+    assert mism <= 2, mism        # a point on a cell border may round to the neighbouring cell on the device
+    assert torch.equal(torch.sort(key[want.long()]).values, torch.sort(kp).values)
+
+
+def test_nan_to_num_inplace_and_bf16_copy(hip_lib):
+    from far3d_amd import ops
+    x = torch.randn(6, 100, 256)
+    x[0, 0, 0], x[1, 2, 3], x[2, 5, 7] = float("nan"), float("inf"), -float("inf")
+    want = torch.nan_to_num(x)
+    d = x.to(DEV)
+    xb = ops.nan_to_num_(d, bf16_copy=True)
+    assert torch.equal(d.cpu(), want)
+    assert torch.equal(xb.float().cpu(), want.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_add_cast_and_layernorm_write_strided_operand_halves(hip_lib, dt):
+    """[x+pos | x] merged-GEMM operand: both producers write the two halves of one (rows, 2C) buffer."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(77, 256, generator=g), torch.randn(77, 256, generator=g)
+    buf = torch.zeros(77, 512, dtype=dt, device=DEV)
+    ops.add_cast(a.to(DEV), b.to(DEV), dt, out_sum=buf[:, :256], out_a=buf[:, 256:])
+    assert torch.equal(buf[:, :256].float().cpu(), (a + b).to(dt).float())
+    assert torch.equal(buf[:, 256:].float().cpu(), a.to(dt).float())
+    gam, bet = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    buf.zero_()
+    y = torch.empty(77, 256, device=DEV)
+    ops.layernorm(a.to(DEV), gam.to(DEV), bet.to(DEV), out=y, add=b.to(DEV), y2=buf[:, :256], yb=buf[:, 256:])
+    want = torch.nn.functional.layer_norm(a, (256,), gam, bet)
+    assert (y.cpu() - want).abs().max().item() < 1e-5
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert (buf[:, :256].float().cpu() - (want + b)).abs().max().item() < tol
+    assert (buf[:, 256:].float().cpu() - want).abs().max().item() < tol

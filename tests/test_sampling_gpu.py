@@ -44,16 +44,55 @@ def test_msda_empty_queries(hip_lib):
     assert out.shape == (1, 0, 8)
 
 
+VARIANTS = [0, 3, 4]   # far3d_aggregate_forward kernel variants (include/far3d_hip.h): 0 = default (4)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_aggregate_small(hip_lib, dtype):
+def test_aggregate_small(hip_lib, dtype, variant):
     for seed in range(3):
-        assert cases.run_aggregate_case(cases.small_aggregate_case(seed), DEV, dtype) < 2e-5
+        assert cases.run_aggregate_case(cases.small_aggregate_case(seed), DEV, dtype, variant) < 2e-5
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_aggregate_config2_full_size(hip_lib, dtype):
+def test_aggregate_config2_full_size(hip_lib, dtype, variant):
     c = cases.config2_aggregate_case(seed=0)
-    assert cases.run_aggregate_case(c, DEV, dtype) < 5e-5
+    assert cases.run_aggregate_case(c, DEV, dtype, variant) < 5e-5
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aggregate_near_queries_wide_spread(hip_lib, dtype, variant):
+    """Queries close to the cameras: the key points of one query cover many tokens (the per-corner path of the v4 kernel,
+    patches of every aspect ratio, list flushes) and several cameras."""
+    assert cases.run_aggregate_case(cases.near_aggregate_case(seed=1), DEV, dtype, variant) < 5e-5
+    assert cases.run_aggregate_case(cases.aggregate_case(7, (640, 960), 64, seed=3, offset_std=12.0), DEV, dtype, variant) < 5e-5
+
+
+def test_aggregate_strided_operands_and_perm(hip_lib):
+    """U and the key-point offsets as column blocks of one row-strided buffer (the merged-GEMM output the engine passes),
+    bf16 output, and a workgroup order: same rows as the dense call."""
+    from far3d_amd import ops
+    c = cases.config2_aggregate_case(seed=2)
+    A, J = c["U"].shape
+    buf = torch.zeros(A, 512)
+    buf[:, :J] = c["U"]
+    buf[:, J:J + 39] = c["offsets"].reshape(A, 39)
+    buf = buf.to(DEV)
+    d = lambda t: t.to(DEV).contiguous()
+    feat, ref, l2i, Vc = d(c["feat"].to(torch.bfloat16)), d(c["ref"]), d(c["lidar2img"]), d(c["Vc"])
+    dense = cases.hip_aggregate(c, DEV, torch.bfloat16)
+    perm = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"])
+    assert sorted(perm.cpu().tolist()) == list(range(A))
+    for variant in VARIANTS:
+        got = ops.aggregate_forward(feat, ref, buf[:, J:J + 39], l2i, buf[:, :J], Vc, c["level_hw"], c["level_start"], c["pc_range"],
+                                    c["pad_hw"], perm=perm, variant=variant, out_dtype=torch.bfloat16)
+        assert got.dtype == torch.bfloat16
+        assert (got.float() - dense).abs().max().item() < 1e-2 * max(1.0, dense.abs().max().item())
+        got32 = ops.aggregate_forward(feat, ref, buf[:, J:J + 39], l2i, buf[:, :J], Vc, c["level_hw"], c["level_start"], c["pc_range"],
+                                      c["pad_hw"], perm=perm, variant=variant)
+        assert (got32 - dense).abs().max().item() < 5e-5
 
 
 def test_aggregate_equals_unfused_msda_sum(hip_lib):
@@ -85,23 +124,3 @@ def test_aggregate_invisible_queries_are_zero(hip_lib):
     out = cases.hip_aggregate(c, DEV)
     assert out.abs().max().item() == 0.0
     assert cases.oracle_aggregate(c).abs().max().item() == 0.0
-
-
-def test_aggregate_dedup_variant_matches_oracle(hip_lib):
-    """The opt-in de-duplicating gather (FAR3D_AGG_DEDUP=1, read once per process -> run in a child): per-token-row merged
-    weights via an LDS hash table; must equal the oracle like the default gather, incl. the fall-back for crowded queries."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import torch\n"
-            "from tests import cases\n"
-            "e = [cases.run_aggregate_case(cases.small_aggregate_case(s), 'cuda:0', torch.bfloat16) for s in range(2)]\n"
-            "e.append(cases.run_aggregate_case(cases.config2_aggregate_case(seed=0), 'cuda:0', torch.bfloat16))\n"
-            "e.append(cases.run_aggregate_case(cases.aggregate_case(7, (640, 960), 64, seed=3, offset_std=12.0), 'cuda:0', torch.bfloat16))\n"
-            "print('ERR', max(e))\n")
-    env = dict(os.environ, FAR3D_AGG_DEDUP="1", PYTHONPATH=root)
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    err = float([l for l in r.stdout.splitlines() if l.startswith("ERR")][-1].split()[1])
-    assert err < 5e-5, err

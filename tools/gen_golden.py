@@ -5,8 +5,9 @@
 What it does
   1. builds the reference's own Far3D detector (its files, loaded where they lie, oracle/refload.py),
   2. checks far3d_amd.weights.detector_spec() == the reference state-dict schema (names and shapes),
-  3. loads the SAME seeded weights into the reference and into oracle/far3d_oracle.py, runs a 3-frame
-     synthetic sequence through both (streaming memory exercised) and asserts agreement,
+  3. loads the SAME seeded weights into the reference and into oracle/far3d_oracle.py, runs synthetic streaming sequences
+     through both -- 2 cameras with ego motion and a scene change, and the single-camera 256x256 case of BASELINE.json
+     configs[0] -- and asserts agreement,
   4. writes the inputs' recipe (seeds, sizes) and the reference's outputs to tests/golden/.
 Fixtures hold data only (seeds + expected tensors) -- never reference source.
 """
@@ -24,14 +25,25 @@ from far3d_amd import synth, weights  # noqa: E402
 from oracle import far3d_oracle, refload  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-SMALL = dict(num_cams=2, pad_hw=(64, 96), num_query=60, num_propagated=16, memory_len=64, topk_proposals=16,
-             backbone="V-99-eSE", weight_seed=1, data_seed=5, frames=3)
+# streaming sequence with ego motion and a scene change (frames 0-1 scene 0, frames 2-3 scene 1): memory warp, prev_exists
+# masking and the memory reset are all exercised against the reference
+SMALL = dict(name="far3d_small_seq", num_cams=2, pad_hw=(64, 96), num_query=60, num_propagated=16, memory_len=64, topk_proposals=16,
+             backbone="V-99-eSE", weight_seed=1, data_seed=5, frames=4, ego_motion=True, scene_change_at=2)
+# BASELINE.json configs[0] scale: ONE camera, 256x256, 100 fixed queries (84 learned + 16 propagated).  The reference's
+# Far3D.extract_img_feat cannot take a single camera (img.squeeze_() drops the camera axis, detectors/far3d.py:71-72), so its
+# backbone + neck are called directly and everything downstream runs through the reference's own methods.
+C1 = dict(name="far3d_c1_seq", num_cams=1, pad_hw=(256, 256), num_query=84, num_propagated=16, memory_len=64, topk_proposals=16,
+          backbone="V-99-eSE", weight_seed=2, data_seed=9, frames=2, ego_motion=True)
 
 
 def run_reference(model, data, img_metas):
     """The body of Far3D.simple_test / simple_test_pts (detectors/far3d.py:244-277), calling the reference's methods."""
     data = dict(data)
-    data["img_feats"] = model.extract_img_feat(data["img"])
+    if data["img"].shape[1] == 1:      # single camera: see C1 above
+        feats = model.img_neck(model.img_backbone(data["img"][0]))
+        data["img_feats"] = [f[None] for f in feats]
+    else:
+        data["img_feats"] = model.extract_img_feat(data["img"])
     location = model.prepare_location(img_metas, **data)
     outs_roi = model.forward_roi_head(location, **data)
     outs_roi.update(model.img_roi_head.get_bboxes(outs_roi))
@@ -48,9 +60,13 @@ def run_reference(model, data, img_metas):
 
 
 def main():
+    for c in (SMALL, C1):
+        generate(c)
+
+
+def generate(c):
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    c = SMALL
     cfg, _ = refload.reference_model_cfg(num_cams=c["num_cams"], num_query=c["num_query"], num_propagated=c["num_propagated"],
                                          memory_len=c["memory_len"], topk_proposals=c["topk_proposals"])
     model = refload.build_reference_detector(cfg)
@@ -68,9 +84,10 @@ def main():
         assert tuple(spec[k]) == canon[k], (k, spec[k], canon[k])
     print("[golden] schema: %d tensors, %.1f M parameters -- matches the reference" %
           (len(spec), sum(int(np.prod(s)) for s in spec.values()) / 1e6))
-    full = weights.detector_spec("V-99-eSE")
-    manifest = {k: list(v) for k, v in full.items()}
-    json.dump(manifest, open(os.path.join(GOLD, "state_dict_manifest.json"), "w"), indent=0, sort_keys=True)
+    if c is SMALL:
+        full = weights.detector_spec("V-99-eSE")
+        manifest = {k: list(v) for k, v in full.items()}
+        json.dump(manifest, open(os.path.join(GOLD, "state_dict_manifest.json"), "w"), indent=0, sort_keys=True)
 
     # ---- 3. same weights into both
     sd = weights.init_state_dict(spec, seed=c["weight_seed"])
@@ -85,7 +102,7 @@ def main():
     worst = 0.0
     with torch.no_grad():
         for fi in range(c["frames"]):
-            data, metas = synth.make_frame(c["num_cams"], c["pad_hw"], seed=c["data_seed"], frame_index=fi)
+            data, metas = synth.recipe_frame(c, fi)
             metas[0]["box_type_3d"] = refload.LiDARBoxes
             r = run_reference(model, copy.deepcopy(data), metas)
             o = orc.simple_test(copy.deepcopy(data), metas)
@@ -94,16 +111,17 @@ def main():
                       ("bbox2d_scores", r["roi"]["bbox2d_scores"], o["roi"]["bbox2d_scores"]),
                       ("bbox2d", torch.cat(r["roi"]["bbox_list"]), torch.cat(o["roi"]["bbox_list"])),
                       ("all_cls_scores", r["outs"]["all_cls_scores"], o["all_cls_scores"]),
-                      ("all_bbox_preds", r["outs"]["all_bbox_preds"], o["all_bbox_preds"]),
-                      ("boxes_3d", r["result"]["boxes_3d"], o["result"]["boxes_3d"]),
-                      ("scores_3d", r["result"]["scores_3d"], o["result"]["scores_3d"])]
+                      ("all_bbox_preds", r["outs"]["all_bbox_preds"], o["all_bbox_preds"])]
             for name, a, b in pairs:
                 assert a.shape == b.shape, (fi, name, a.shape, b.shape)
                 err = (a - b).abs().max().item() if a.numel() else 0.0
                 worst = max(worst, err)
                 scale = max(1.0, a.abs().max().item()) if a.numel() else 1.0   # box coordinates are metres / pixels
                 assert err < 2e-4 * scale, "frame %d %s: oracle deviates from the reference by %.3e" % (fi, name, err)
-            assert torch.equal(r["result"]["labels_3d"], o["result"]["labels_3d"])
+            # decoded boxes: compared as a set above the top-k bar (the rank of near-tied scores is summation-order noise)
+            from tests.conftest import assert_detections_match
+            assert_detections_match(tuple(o["result"][k].numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")),
+                                    tuple(r["result"][k].numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi)
             assert torch.equal(r["roi"]["valid_indices"], o["roi"]["valid_indices"])
             M = r["roi"]["bbox2d_scores"].shape[0]
             print("[golden] frame %d: M=%d adaptive queries, A=%d, %d boxes, max |oracle-reference| so far %.2e" %
@@ -120,8 +138,9 @@ def main():
             for l in range(4):
                 gold["f%d_fpn%d_sample" % (fi, l)] = r["img_feats"][l][:, ::16, ::2, ::3].numpy()   # sparse sample of the maps
     gold["recipe"] = np.frombuffer(json.dumps(c).encode(), dtype=np.uint8)
-    np.savez_compressed(os.path.join(GOLD, "far3d_small_3frames.npz"), **gold)
-    print("[golden] wrote %s (worst oracle-vs-reference deviation %.2e)" % (os.path.join(GOLD, "far3d_small_3frames.npz"), worst))
+    path = os.path.join(GOLD, c["name"] + ".npz")
+    np.savez_compressed(path, **gold)
+    print("[golden] wrote %s (worst oracle-vs-reference deviation %.2e)" % (path, worst))
 
 
 if __name__ == "__main__":
