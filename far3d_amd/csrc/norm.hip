@@ -97,9 +97,11 @@ extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* 
 // hipGraph-vs-eager results are bit-identical.
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                        int ldx, long img_stride, int rows_per_block) {
+                                                        int ldx, long img_stride, int rows_per_block, float* __restrict__ total,
+                                                        unsigned* __restrict__ ticket) {
   // thread -> 4 consecutive channels; the 256 threads cover rstep = 256*4/C rows per pass; 4 passes are kept in flight.
   __shared__ float red[2][1024];
+  __shared__ unsigned s_last;
   const int n = blockIdx.y;
   const int cq = C / 4;
   const int tcol = threadIdx.x % cq, trow = threadIdx.x / cq;
@@ -124,17 +126,40 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
       q.x += a.x * a.x; q.y += a.y * a.y; q.z += a.z * a.z; q.w += a.w * a.w;
     }
   }
-  // cross-row reduction through LDS: rstep*C = 1024 floats exactly
+  // cross-row reduction through LDS: rstep*C <= 1024 floats
   if (trow < rstep) {
     *reinterpret_cast<float4*>(&red[0][trow * C + tcol * 4]) = s;
     *reinterpret_cast<float4*>(&red[1][trow * C + tcol * 4]) = q;
   }
   __syncthreads();
-  float* dst = part + ((long)n * gridDim.x + blockIdx.x) * C * 2;
+  const int nblk = gridDim.x;
+  float* dst = part + ((long)n * nblk + blockIdx.x) * C * 2;
   for (int c = threadIdx.x; c < C; c += 256) {
     float ss = 0.f, qq = 0.f;
     for (int k = 0; k < rstep; ++k) { ss += red[0][k * C + c]; qq += red[1][k * C + c]; }
     *reinterpret_cast<float2*>(dst + 2 * c) = make_float2(ss, qq);
+  }
+  // The workgroup that finishes LAST for image n adds the nblk partials in index order (a fixed order: the result does not
+  // depend on which workgroup happens to be last) and leaves the totals for the consumer; the ticket only elects it.
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tk = atomicAdd(ticket + n, 1u);
+    s_last = (tk == (unsigned)nblk - 1u) ? 1u : 0u;
+    if (s_last) ticket[n] = 0u;                 // self-cleaning: ready for the next launch on the stream
+  }
+  __syncthreads();
+  if (s_last) {
+    __threadfence();
+    const float* src = part + (long)n * nblk * C * 2;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float ss = 0.f, qq = 0.f;
+      for (int b = 0; b < nblk; ++b) {
+        const volatile float* v = src + ((long)b * C + c) * 2;      // volatile: written by other CUs, read through L2
+        ss += v[0]; qq += v[1];
+      }
+      *reinterpret_cast<float2*>(total + ((long)n * C + c) * 2) = make_float2(ss, qq);
+    }
   }
 }
 
@@ -149,34 +174,29 @@ static int chan_sums_parts(int HW, int C) {
   return (HW + rows_per_block - 1) / rows_per_block;
 }
 
-static int launch_chan_sums(const void* x, int dt, float* part, int N, int HW, int C, int ldx, long img_stride, hipStream_t st) {
+static int launch_chan_sums(const void* x, int dt, float* part, float* total, unsigned* ticket, int N, int HW, int C, int ldx,
+                            long img_stride, hipStream_t st) {
   const int nblk = chan_sums_parts(HW, C);
   const int rstep = 256 / (C / 4);
   int rows_per_block = (HW + nblk - 1) / nblk;
   rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
   dim3 grid(nblk, N), block(256);
   if (dt == FAR3D_DT_F32)
-    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block);
+    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block, total, ticket);
   else
-    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, part, HW, C, ldx, img_stride, rows_per_block);
+    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, part, HW, C, ldx, img_stride, rows_per_block, total, ticket);
   return nblk;
 }
 
 // ---------------------------------------------------------------- eSE
-// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image: it first
-// adds the `nparts` partial sums of every input channel in index order (LDS), then each wave does 4 rows of the mat-vec.
-// partial (p, n, k) lives at sums[p * part_stride + n * img_stride + 2 * k].
-__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ sums, const float* __restrict__ fcw,
+// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image; the
+// channel totals come from the pooling kernel (total[n][k][0]).
+__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ total, const float* __restrict__ fcw,
                                                        const float* __restrict__ fcb, float* __restrict__ gate, int C,
-                                                       float inv_hw, int nparts, long part_stride, long img_stride) {
+                                                       float inv_hw) {
   __shared__ float mean[1024];
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = threadIdx.x; k < C; k += 256) {
-    float sk = 0.f;
-    const float* p = sums + (long)n * img_stride + 2 * k;
-    for (int r = 0; r < nparts; ++r) sk += p[r * part_stride];
-    mean[k] = sk * inv_hw;
-  }
+  for (int k = threadIdx.x; k < C; k += 256) mean[k] = total[((long)n * C + k) * 2] * inv_hw;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -215,22 +235,23 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
   }
 }
 
-// scratch (floats): [N][nparts][C][2] partial sums (nparts <= FAR3D_SUMS_MAX_PARTS), then [N][C] gates at offset
-// N*FAR3D_SUMS_MAX_PARTS*C*2.  Size: N*C*(2*FAR3D_SUMS_MAX_PARTS+1) floats; never needs zeroing.
+// scratch (floats): [N][nparts][C][2] partial sums (nparts <= FAR3D_SUMS_MAX_PARTS), then at offset N*FAR3D_SUMS_MAX_PARTS*C*2:
+// [N][C][2] totals, [N][C] gates, [N] tickets.  Size: far3d_sums_scratch_floats(N, C); the tickets must be zero before the
+// FIRST use (cudaMalloc'ed zeros / one memset at allocation) and clean themselves afterwards.
 extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                               float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
                               long i_img_stride, int ldy, long y_img_stride, void* stream) {
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 1024 % C == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
-                  "far3d_ese_nhwc: bad sizes (C=%d must divide 1024)", C);
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
+                  "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4, <= 1024)", C);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
   float* sums = scratch;
-  float* gate = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
-  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
-  const long part_stride = (long)C * 2, img_stride = (long)nparts * C * 2;
-  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, nparts,
-                     part_stride, img_stride);
+  float* total = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
+  float* gate = total + (long)N * C * 2;
+  unsigned* ticket = reinterpret_cast<unsigned*>(gate + (long)N * C);
+  launch_chan_sums(x, dt, sums, total, ticket, N, HW, C, ldx, x_img_stride, st);
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, total, fcw, fcb, gate, C, 1.f / HW);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -245,16 +266,14 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
 }
 
 // ---------------------------------------------------------------- GroupNorm + ReLU (NHWC)
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int C,
-                                                       int groups, float inv_cnt, float eps, int total, int nparts) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ total, float* __restrict__ stat, int C,
+                                                       int groups, float inv_cnt, float eps, int ntot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
-  if (i >= total) return;
+  if (i >= ntot) return;
   const int n = i / groups, g = i % groups, cpg = C / groups;
   float s = 0.f, q = 0.f;
-  for (int r = 0; r < nparts; ++r) {          // fixed order: deterministic
-    const float* p = part + ((long)n * nparts + r) * C * 2;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += p[2 * c]; q += p[2 * c + 1]; }
-  }
+  const float* p = total + (long)n * C * 2;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += p[2 * c]; q += p[2 * c + 1]; }
   const float mean = s * inv_cnt;
   const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
   stat[2 * i] = mean;
@@ -288,15 +307,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch,
                                     int N, int HW, int C, int groups, float eps, int relu, void* stream) {
   FAR3D_CHECK_ARG(x && gamma && beta && y && scratch, "far3d_groupnorm_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && 1024 % C == 0 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_groupnorm_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
   float* sums = scratch;                                              // [N][nparts][C][2]
-  float* stat = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;     // [N][groups][2]
-  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
+  float* total = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;    // [N][C][2]
+  float* stat = total + (long)N * C * 2;                              // [N][C] (only [N][groups][2] used: same layout as eSE)
+  unsigned* ticket = reinterpret_cast<unsigned*>(stat + (long)N * C);
+  launch_chan_sums(x, dt, sums, total, ticket, N, HW, C, C, (long)HW * C, st);
   const int tot = N * groups;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, sums, stat, C, groups,
-                     1.f / ((float)HW * (C / groups)), eps, tot, nparts);
+  FAR3D_CHECK_ARG(groups * 2 <= C, "far3d_groupnorm_nhwc: groups*2 must be <= C");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, total, stat, C, groups,
+                     1.f / ((float)HW * (C / groups)), eps, tot);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;

@@ -15,9 +15,10 @@
 #include "common.hpp"
 
 // ------------------------------------------------------------------------------------------ block-wide top-K
-// order-preserving map float -> uint (larger float <-> larger uint; -0 < +0; NaNs sort above +inf, like torch.topk)
+// order-preserving map float -> uint (larger float <-> larger uint; -0 == +0; NaNs sort above +inf, like torch.topk)
 __device__ __forceinline__ unsigned ord_key(float f) {
-  const unsigned b = __float_as_uint(f);
+  unsigned b = __float_as_uint(f);
+  if (b == 0x80000000u) b = 0u;      // -0 == +0 (torch.topk compares values)
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 __device__ __forceinline__ float ord_val(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
@@ -64,9 +65,9 @@ __device__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, 
   // ordered compaction (index order), keeping all keys > kth and the first K - n_gt keys == kth
   int base = 0, eq_left = K - n_gt;
 #pragma unroll
-  for (int k = 0; k < TOPK_MAXV; ++k) {
+  for (int k = 0; k < TOPK_MAXV; ++k) {      // fully unrolled (v[] stays in registers); chunks past n are skipped, uniformly
     const int c0 = k * TOPK_THREADS;
-    if (c0 >= n) break;
+    if (c0 < n) {
     const int i = c0 + t;
     const bool in = i < n;
     const bool gt = in && v[k] > kth, eq = in && v[k] == kth;
@@ -91,6 +92,7 @@ __device__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, 
     base += chunk;
     eq_left -= min(eq_left, eq_chunk);
     __syncthreads();
+    }
   }
   // bitonic sort, descending, of the next power of two >= K entries (padding 0 sorts last)
   int Kp = 1;

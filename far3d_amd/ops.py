@@ -202,7 +202,8 @@ SUMS_MAX_PARTS = 64     # FAR3D_SUMS_MAX_PARTS in include/far3d_hip.h
 
 
 def ese_scratch_floats(N, C):
-    return N * C * (2 * SUMS_MAX_PARTS + 1)
+    """FAR3D_SUMS_SCRATCH_FLOATS(N, C): workspace of ese_nhwc / groupnorm_nhwc -- allocate it with torch.zeros ONCE."""
+    return N * C * (2 * SUMS_MAX_PARTS + 3) + N
 
 
 def conv_tile(x, pc):
@@ -335,7 +336,7 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
         ldi, isd = _nhwc_view(identity, "identity")
         ip = _ptr(identity)
     if scratch is None:
-        scratch = torch.empty(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
+        scratch = torch.zeros(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
     if scratch.numel() < ese_scratch_floats(N, C):
         raise ValueError("ese_nhwc: scratch needs %d floats" % ese_scratch_floats(N, C))
     _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
@@ -350,7 +351,7 @@ def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scr
     if out is None:
         out = torch.empty_like(x)
     if scratch is None:
-        scratch = torch.empty(N * C * 2 * SUMS_MAX_PARTS + N * groups * 2, dtype=torch.float32, device=x.device)
+        scratch = torch.zeros(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
     _lib.check(lib.far3d_groupnorm_nhwc(_ptr(x), _dt(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), N, H * W, C,
                                         groups, float(eps), 1 if relu else 0, _stream(x)), "far3d_groupnorm_nhwc")
     return out

@@ -44,7 +44,7 @@ def test_msda_empty_queries(hip_lib):
     assert out.shape == (1, 0, 8)
 
 
-VARIANTS = [0, 3, 4]   # far3d_aggregate_forward kernel variants (include/far3d_hip.h): 0 = default (4)
+VARIANTS = [0, 3, 4, 6, 7]   # far3d_aggregate_forward kernel variants (include/far3d_hip.h): 0 = default (4)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -124,3 +124,15 @@ def test_aggregate_invisible_queries_are_zero(hip_lib):
     out = cases.hip_aggregate(c, DEV)
     assert out.abs().max().item() == 0.0
     assert cases.oracle_aggregate(c).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aggregate_generic_point_and_level_counts(hip_lib, dtype):
+    """P != 13 / L != 4 take the runtime-sized instantiation of the kernel (no quad-level pass)."""
+    c = cases.aggregate_case(num_cams=5, pad_hw=(128, 192), A=45, P=6, seed=8, offset_std=3.0)
+    c["level_hw"], c["level_start"] = c["level_hw"][:3], c["level_start"][:3]
+    S3 = c["level_start"][2] + c["level_hw"][2][0] * c["level_hw"][2][1]
+    g = torch.Generator().manual_seed(8)
+    c["feat"] = c["feat"][:, :S3].contiguous()
+    c["U"], c["Vc"] = torch.randn(45, 3 * 6 * 8, generator=g), torch.randn(5, 3 * 6 * 8, generator=g)
+    assert cases.run_aggregate_case(c, DEV, dtype) < 2e-5

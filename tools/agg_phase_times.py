@@ -1,0 +1,79 @@
+"""Where does one query's time go inside the v6 aggregation kernel?  Builds libfar3d_hip_prof.so (the same sources with
+-DFAR3D_PROFILING: per-wave s_memtime stamps at the phase boundaries), runs the kernel on the config-2 case and prints the
+median per-phase times.  Tools only -- the shipped libfar3d_hip.so has no such hooks."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from far3d_amd import build as fbuild  # noqa: E402
+from far3d_amd import lib as flib  # noqa: E402
+
+PROF = os.path.join(ROOT, "far3d_amd", "libfar3d_hip_prof.so")
+
+
+def build_prof():
+    srcs = [os.path.join(fbuild.CSRC, f) for f in fbuild._sources()]
+    cmd = [fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_PROFILING", "-shared", "-o", PROF] + srcs
+    subprocess.run(cmd, check=True)
+
+
+def main():
+    A = int(sys.argv[1]) if len(sys.argv) > 1 else 1544
+    variant = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    nw = 2 if variant == 7 else 4
+    if not os.path.exists(PROF) or os.path.getmtime(PROF) < os.path.getmtime(os.path.join(fbuild.CSRC, "sampling.hip")):
+        build_prof()
+    flib.LIB_PATH = PROF
+    lib = flib.load()
+    from far3d_amd import ops
+    from tests import cases
+    dev = "cuda:0"
+    c = cases.aggregate_case(num_cams=7, pad_hw=(640, 960), A=A, seed=0)
+    d = lambda t: t.to(dev).contiguous()
+    feat = d(c["feat"].to(torch.bfloat16))
+    args = [d(c[k]) for k in ("ref", "offsets", "lidar2img", "U", "Vc")]
+    perm = ops.aggregation_order(args[0], args[2], c["pc_range"], c["pad_hw"])
+    nblk = 8 * ((A + 7) // 8)
+    ts = torch.zeros(nblk * 4 * 16, dtype=torch.int64, device=dev)
+    run = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=variant)
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    fn = lib.far3d_prof_set_agg_timestamps
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    assert fn(ctypes.c_void_p(ts.data_ptr())) == 0
+    run()
+    torch.cuda.synchronize()
+    t = ts.cpu().numpy().reshape(nblk, 4, 16)[:, :nw]
+    live = t[:, :, 0] != 0
+    t = t[live[:, 0]]
+    if variant == 7:
+        for nm, i, j in (("  issue logit loads", 0, 8), ("  projection+bbox", 8, 9), ("  local max", 9, 1)):
+            dlt = (t[:, :, j] - t[:, :, i]).astype(np.float64)
+            print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
+    t0 = t[:, :, 0].min()
+    names = ["loads+proj+localmax", "B1 wait", "exp+sums+B2", "build", "gather", "reduce+B3"]
+    print("queries %d, workgroups stamped %d; s_memtime ticks (100 MHz constant clock on gfx9: 1 tick = 10 ns)" % (A, len(t)))
+    for i, nm in enumerate(names):
+        dlt = (t[:, :, i + 1] - t[:, :, i]).astype(np.float64)
+        print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
+    tot = (t[:, :, 6] - t[:, :, 0]).astype(np.float64)
+    print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % ("whole wave", np.median(tot), np.percentile(tot, 90), tot.max()))
+    print("  kernel span (first start -> last end): %d ticks; start spread %d ticks" % (t[:, :, 6].max() - t0, t[:, :, 0].max() - t0))
+    busy = t[:, :, 7] > 0
+    bld = (t[:, :, 4] - t[:, :, 3]).astype(np.float64)
+    gth = (t[:, :, 5] - t[:, :, 4]).astype(np.float64)
+    print("  waves with rows: %d of %d; their build median %.0f p90 %.0f; gather median %.0f p90 %.0f" %
+          (busy.sum(), busy.size, np.median(bld[busy]), np.percentile(bld[busy], 90), np.median(gth[busy]), np.percentile(gth[busy], 90)))
+    print("  list entries per wave: median %d  p90 %d  max %d; per query median %d" %
+          (np.median(t[:, :, 7]), np.percentile(t[:, :, 7], 90), t[:, :, 7].max(), np.median(t[:, :, 7].sum(1))))
+
+
+if __name__ == "__main__":
+    main()

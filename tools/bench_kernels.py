@@ -58,10 +58,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--out", default="")
+    ap.add_argument("--A", type=int, default=1544, help="number of queries (1544 = BASELINE configs[1])")
     a = ap.parse_args()
     dev = "cuda:0"
     rows = []
-    c = cases.config2_aggregate_case(seed=0)
+    c = cases.aggregate_case(num_cams=7, pad_hw=(640, 960), A=a.A, seed=0)
     N, S, C = c["feat"].shape
     A = c["ref"].shape[0]
     for dt, ev in ((torch.bfloat16, 2), (torch.float32, 4)):
@@ -72,7 +73,7 @@ def main():
         perm = ops.camera_sorted_order(args[0], args[2], c["pc_range"], c["pad_hw"], spatial=False)
         perm2 = ops.camera_sorted_order(args[0], args[2], c["pc_range"], c["pad_hw"], spatial=True)
         by = agg_bytes(N, S, C, A, 13, 8, 4, ev)
-        for variant in (4, 3):
+        for variant in (7, 6, 3):
             for name, pm in (("aggregate_fwd", None), ("aggregate_fwd+camsort", perm), ("aggregate_fwd+cam+tile", perm2)):
                 fn = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], out=out, perm=pm,
                                                    variant=variant)
