@@ -235,21 +235,23 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
   }
 }
 
-// scratch (floats): [N][nparts][C][2] partial sums (nparts <= FAR3D_SUMS_MAX_PARTS), then at offset N*FAR3D_SUMS_MAX_PARTS*C*2:
-// [N][C][2] totals, [N][C] gates, [N] tickets.  Size: far3d_sums_scratch_floats(N, C); the tickets must be zero before the
-// FIRST use (cudaMalloc'ed zeros / one memset at allocation) and clean themselves afterwards.
+// scratch (floats): [FAR3D_SUMS_MAX_IMAGES] tickets, [N][FAR3D_SUMS_MAX_PARTS][C][2] partial sums, [N][C][2] totals, [N][C]
+// gates.  Size: FAR3D_SUMS_SCRATCH_FLOATS(N, C); the tickets must be zero before the FIRST use (one memset at allocation)
+// and clean themselves afterwards, so one workspace (sized for the widest layer) serves a whole stream of calls.
 extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                               float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
                               long i_img_stride, int ldy, long y_img_stride, void* stream) {
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
+  FAR3D_CHECK_ARG(N > 0 && N <= FAR3D_SUMS_MAX_IMAGES && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
                   "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4, <= 1024)", C);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
-  float* sums = scratch;
-  float* total = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
+  // tickets FIRST, at a position that does not depend on C: one workspace serves layers of different widths, and a ticket
+  // must never land inside another layer's partial sums
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch);
+  float* sums = scratch + FAR3D_SUMS_MAX_IMAGES;
+  float* total = sums + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
   float* gate = total + (long)N * C * 2;
-  unsigned* ticket = reinterpret_cast<unsigned*>(gate + (long)N * C);
   launch_chan_sums(x, dt, sums, total, ticket, N, HW, C, ldx, x_img_stride, st);
   hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, total, fcw, fcb, gate, C, 1.f / HW);
   const long total4 = (long)N * HW * (C / 4);
@@ -307,13 +309,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch,
                                     int N, int HW, int C, int groups, float eps, int relu, void* stream) {
   FAR3D_CHECK_ARG(x && gamma && beta && y && scratch, "far3d_groupnorm_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
+  FAR3D_CHECK_ARG(N > 0 && N <= FAR3D_SUMS_MAX_IMAGES && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_groupnorm_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
-  float* sums = scratch;                                              // [N][nparts][C][2]
-  float* total = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;    // [N][C][2]
-  float* stat = total + (long)N * C * 2;                              // [N][C] (only [N][groups][2] used: same layout as eSE)
-  unsigned* ticket = reinterpret_cast<unsigned*>(stat + (long)N * C);
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch);            // [FAR3D_SUMS_MAX_IMAGES], same layout as far3d_ese_nhwc
+  float* sums = scratch + FAR3D_SUMS_MAX_IMAGES;                      // [N][nparts][C][2]
+  float* total = sums + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;       // [N][C][2]
+  float* stat = total + (long)N * C * 2;                              // [N][C] (only [N][groups][2] used)
   launch_chan_sums(x, dt, sums, total, ticket, N, HW, C, C, (long)HW * C, st);
   const int tot = N * groups;
   FAR3D_CHECK_ARG(groups * 2 <= C, "far3d_groupnorm_nhwc: groups*2 must be <= C");

@@ -546,7 +546,7 @@ class Far3DEngine:
         idx = ops.topk(sc, cfg["topk_proposals"])
         ops.memory_post_update(m, idx, outs_dec[-1], all_box[-1][0], dd["ego_pose"], dd["timestamp"], self.mem)
         outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
-                    reference_points=ref)
+                    reference_points=ref, memory_topk=idx)
         outs["result"] = self.decode(all_cls, all_box)
         return outs
 

@@ -203,7 +203,7 @@ SUMS_MAX_PARTS = 64     # FAR3D_SUMS_MAX_PARTS in include/far3d_hip.h
 
 def ese_scratch_floats(N, C):
     """FAR3D_SUMS_SCRATCH_FLOATS(N, C): workspace of ese_nhwc / groupnorm_nhwc -- allocate it with torch.zeros ONCE."""
-    return N * C * (2 * SUMS_MAX_PARTS + 3) + N
+    return 64 + N * C * (2 * SUMS_MAX_PARTS + 3)
 
 
 def conv_tile(x, pc):

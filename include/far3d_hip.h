@@ -23,8 +23,9 @@ extern "C" {
 #define FAR3D_ESE_REPLICAS 8
 /* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */
 #define FAR3D_SUMS_MAX_PARTS 64
-/* partial sums [N][PARTS][C][2] + totals [N][C][2] + gates/stats [N][C] + tickets [N] */
-#define FAR3D_SUMS_SCRATCH_FLOATS(N, C) ((long)(N) * (C) * (2 * FAR3D_SUMS_MAX_PARTS + 3) + (N))
+#define FAR3D_SUMS_MAX_IMAGES 64   /* images per far3d_ese_nhwc / far3d_groupnorm_nhwc call (ticket slots) */
+/* tickets [MAX_IMAGES] + partial sums [N][PARTS][C][2] + totals [N][C][2] + gates/stats [N][C] */
+#define FAR3D_SUMS_SCRATCH_FLOATS(N, C) (FAR3D_SUMS_MAX_IMAGES + (long)(N) * (C) * (2 * FAR3D_SUMS_MAX_PARTS + 3))
 
 #define FAR3D_OK 0
 #define FAR3D_ERR_ARG (-1)

@@ -38,7 +38,7 @@ def inverse_sigmoid(x, eps=1e-5):  # mmdet.models.utils.transformer.inverse_sigm
 
 def pos2posemb(pos, num_pos_feats, temperature=10000):
     """One coordinate -> interleaved sin/cos (models/utils/positional_encoding.py:13-36)."""
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=pos.device)
+    dim_t = torch.arange(num_pos_feats, dtype=pos.dtype if pos.dtype == torch.float64 else torch.float32, device=pos.device)
     dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
     p = (pos * (2 * math.pi))[..., None] / dim_t
     return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
@@ -56,8 +56,11 @@ def nerf_encoding(t, n=6):   # positional_encoding.py:38-80 (log sampling, no in
 
 
 class Far3DOracle:
-    def __init__(self, state_dict, cfg=None):
-        self.sd = {k: v.detach().float() if v.is_floating_point() else v for k, v in state_dict.items()}
+    def __init__(self, state_dict, cfg=None, dtype=torch.float32):
+        """dtype=torch.float64 runs the same restatement in double precision: the yardstick for how much of a deviation is the
+        fp32 rounding noise of the reference arithmetic itself (tools/error_budget.py); inputs must then be double too."""
+        self.sd = {k: v.detach().to(dtype) if v.is_floating_point() else v for k, v in state_dict.items()}
+        self.dtype = dtype
         self.cfg = cfg or default_cfg()
         self.reset_memory()
         self.prev_scene = None
@@ -143,24 +146,29 @@ class Far3DOracle:
         return dict(enc_cls_scores=cls, enc_bbox_preds=reg, objectnesses=obj, depth_logit=logit, pred_depth=logit.softmax(dim=1))
 
     # ------------------------------------------------------------------ a5: 2D proposals (yolox_head.py:355-501)
-    def get_bboxes(self, outs):
+    def get_bboxes(self, outs, forced_valid=None):
+        """forced_valid: optional (BN,S,1) bool mask that replaces the peak selection (test rigs use it to resolve K-th-place
+        near-ties of the build-defined static top-K mode the same way as the device did; the weights are returned for the check)."""
         cls, reg, obj = outs["enc_cls_scores"], outs["enc_bbox_preds"], outs["objectnesses"]
         n_img = cls[0].shape[0]
-        priors, weights = [], []
+        priors, weights, raws = [], [], []
         for l, c in enumerate(cls):
             h, w = c.shape[2:]
             s = float(self.cfg["strides"][l])
-            xs = torch.arange(w, dtype=torch.float32) * s
-            ys = torch.arange(h, dtype=torch.float32) * s
+            xs = torch.arange(w, dtype=self.dtype) * s
+            ys = torch.arange(h, dtype=self.dtype) * s
             priors.append(torch.stack([xs.repeat(h), ys.view(-1, 1).repeat(1, w).view(-1),
-                                       torch.full((h * w,), s), torch.full((h * w,), s)], dim=-1))
+                                       torch.full((h * w,), s, dtype=self.dtype), torch.full((h * w,), s, dtype=self.dtype)], dim=-1))
             sw = obj[l].sigmoid() * c.topk(1, dim=1).values.sigmoid()
             nms = F.max_pool2d(sw, (3, 3), stride=1, padding=1).permute(0, 2, 3, 1).reshape(n_img, -1, 1)
             sw = sw.permute(0, 2, 3, 1).reshape(n_img, -1, 1)
-            weights.append(sw * (sw == nms).float())
+            raws.append(sw)
+            weights.append(sw * (sw == nms).to(sw.dtype))
         weight = torch.cat(weights, dim=1)                    # (BN, S, 1)
         K = self.cfg["proposal_topk"]
-        if K is None:
+        if forced_valid is not None:
+            valid = forced_valid
+        elif K is None:
             valid = weight > self.cfg["score_thr"]
         else:
             idx = weight[..., 0].topk(K, dim=1).indices
@@ -175,7 +183,8 @@ class Far3DOracle:
         for i in range(n_img):
             b = boxes[i][valid[i].repeat(1, 4)].reshape(-1, 4)
             bbox_list.append(torch.cat([(b[:, :2] + b[:, 2:]) / 2, b[:, 2:] - b[:, :2]], dim=-1))   # cxcywh
-        return dict(bbox_list=bbox_list, bbox2d_scores=weight[valid].reshape(-1, 1), valid_indices=valid)
+        return dict(bbox_list=bbox_list, bbox2d_scores=weight[valid].reshape(-1, 1), valid_indices=valid, peak_weight=weight,
+                    raw_weight=torch.cat(raws, dim=1))
 
     # ------------------------------------------------------------------ FarHead helpers
     def _lin(self, x, name):
@@ -216,7 +225,7 @@ class Far3DOracle:
             pseudo = self.P(h + "pseudo_reference_points.weight") * (pc[3:6] - pc[0:3]) + pc[0:3]
             m = self.mem
             m["ref"] = torch.cat([m["ref"][:, :np_] + (1 - x).view(1, 1, 1) * pseudo, m["ref"][:, np_:]], dim=1)
-            m["pose"] = torch.cat([m["pose"][:, :np_] + (1 - x).view(1, 1, 1, 1) * torch.eye(4), m["pose"][:, np_:]], dim=1)
+            m["pose"] = torch.cat([m["pose"][:, :np_] + (1 - x).view(1, 1, 1, 1) * torch.eye(4, dtype=self.dtype), m["pose"][:, np_:]], dim=1)
 
     @staticmethod
     def _transform_ref(ref, pose):   # misc.py:193-202
@@ -235,7 +244,7 @@ class Far3DOracle:
         nums = [len(b) for b in bbox_list]
         if sum(nums) == 0:
             return None, None
-        boxes = torch.cat(bbox_list, dim=0).float()
+        boxes = torch.cat(bbox_list, dim=0).to(self.dtype)
         ds = int(pad_hw[0] / pred_depth.shape[2])
         hmax, wmax = pred_depth.shape[2:]
         depths = []
@@ -250,7 +259,7 @@ class Far3DOracle:
             flat = c2[:, 1] * (pad_hw[1] / ds) + c2[:, 0]
             depths.append(torch.gather(dm, 0, flat.long().unsqueeze(1)))
         depths = torch.cat(depths, dim=0)                        # (M,1) bin indices (topk = 1 -> argmax bin)
-        thr = torch.tensor([0.1])
+        thr = torch.tensor([0.1], dtype=self.dtype)
         # build-defined static top-K mode may pad a camera with zero-weight cells: keep their log-odds finite.  A peak that
         # passed the reference's `> 0.1` test is never touched by this clamp, so threshold mode is the reference as is.
         scores = scores.clamp(min=1e-6)
@@ -274,23 +283,23 @@ class Far3DOracle:
         temp_pos = self._mlp2(pos2posemb3d(temp_ref), h + "query_embedding")
         temp_mem = m["emb"]
         A = query_pos.size(1)
-        eye = torch.eye(4).unsqueeze(0).unsqueeze(0).repeat(1, A, 1, 1)
+        eye = torch.eye(4, dtype=self.dtype).unsqueeze(0).unsqueeze(0).repeat(1, A, 1, 1)
         rec_motion = nerf_encoding(torch.cat([torch.zeros_like(ref[..., :3]), eye[..., :3, :].flatten(-2)], dim=-1))
         tgt = self._mln(F.layer_norm(tgt, (256,)), rec_motion, h + "ego_pose_memory")
         query_pos = self._mln(F.layer_norm(query_pos, (256,)), rec_motion, h + "ego_pose_pe")
-        mem_motion = nerf_encoding(torch.cat([m["velo"], m["ts"], m["pose"][..., :3, :].flatten(-2)], dim=-1).float())
+        mem_motion = nerf_encoding(torch.cat([m["velo"], m["ts"], m["pose"][..., :3, :].flatten(-2)], dim=-1).to(self.dtype))
         temp_pos = self._mln(F.layer_norm(temp_pos, (256,)), mem_motion, h + "ego_pose_pe")
         temp_mem = self._mln(F.layer_norm(temp_mem, (256,)), mem_motion, h + "ego_pose_memory")
         te = lambda t: F.layer_norm(self._lin(t, h + "time_embedding.0"), (256,), self.P(h + "time_embedding.1.weight"),
                                     self.P(h + "time_embedding.1.bias"))
         query_pos = query_pos + te(pos2posemb(torch.zeros_like(ref[..., 0]), 256))
-        temp_pos = temp_pos + te(pos2posemb(m["ts"][..., 0], 256).float())
+        temp_pos = temp_pos + te(pos2posemb(m["ts"][..., 0], 256).to(self.dtype))
         np_ = c["num_propagated"]
         if np_ > 0:
             tgt = torch.cat([tgt, temp_mem[:, :np_]], dim=1)
             query_pos = torch.cat([query_pos, temp_pos[:, :np_]], dim=1)
             ref = torch.cat([ref, temp_ref[:, :np_]], dim=1)
-            eye = torch.eye(4).unsqueeze(0).unsqueeze(0).repeat(1, A + np_, 1, 1)
+            eye = torch.eye(4, dtype=self.dtype).unsqueeze(0).unsqueeze(0).repeat(1, A + np_, 1, 1)
             temp_mem, temp_pos = temp_mem[:, np_:], temp_pos[:, np_:]
         return tgt, query_pos, ref, temp_mem, temp_pos, eye
 
@@ -336,7 +345,7 @@ class Far3DOracle:
         return torch.stack(outs)
 
     # ------------------------------------------------------------------ a6 + a10 + a11: FarHead.forward (farhead.py:533-693)
-    def head_forward(self, mlvl_feats, outs_roi, data, prev_exists, pad_hw):
+    def head_forward(self, mlvl_feats, outs_roi, data, prev_exists, pad_hw, forced_topk=None):
         h = "pts_bbox_head."
         cfg = self.cfg
         self._pre_update_memory(data, prev_exists)
@@ -379,6 +388,8 @@ class Far3DOracle:
         # post_update_memory (farhead.py:479-508)
         score = all_cls[-1].sigmoid().topk(1, dim=-1).values[..., 0:1]
         _, idx = torch.topk(score, cfg["topk_proposals"], dim=1)
+        if forced_topk is not None:     # test rigs: resolve near-ties of the memory selection the way the device did
+            idx = forced_topk(score[0, :, 0], idx[0, :, 0]).view(1, -1, 1)
         g = lambda t: torch.gather(t, 1, idx.view(1, -1, *([1] * (t.dim() - 2))).repeat(1, 1, *t.shape[2:]))
         m = self.mem
         m["emb"] = torch.cat([g(outs_dec[-1]), m["emb"]], dim=1)
@@ -402,7 +413,7 @@ class Far3DOracle:
         b = box[torch.div(idx, cfg["num_classes"], rounding_mode="floor")]
         rot = torch.atan2(b[..., 6:7], b[..., 7:8])
         b = torch.cat([b[..., 0:3], b[..., 3:6].exp(), rot], dim=-1)
-        rng = torch.tensor(cfg["pc_range"])
+        rng = torch.tensor(cfg["pc_range"], dtype=self.dtype)
         mask = (b[..., :3] >= rng[:3]).all(1) & (b[..., :3] <= rng[3:]).all(1)
         b, scores, labels = b[mask], scores[mask], labels[mask]
         b = b.clone()
@@ -410,21 +421,23 @@ class Far3DOracle:
         return dict(boxes_3d=b, scores_3d=scores, labels_3d=labels)
 
     # ------------------------------------------------------------------ a1: one frame (detectors/far3d.py:64-99,244-277)
-    def simple_test(self, data, img_metas):
+    def simple_test(self, data, img_metas, forced_valid=None, forced_topk=None):
         img = data["img"]
         B, N = img.shape[:2]
         assert B == 1
         pad_hw = img_metas[0]["pad_shape"][0][:2]
         feats = self.fpn(self.backbone(img.reshape(B * N, *img.shape[2:])))
         outs_roi = self.roi_head(feats)
-        outs_roi.update(self.get_bboxes(outs_roi))
+        if callable(forced_valid):
+            forced_valid = forced_valid(self.get_bboxes(outs_roi))
+        outs_roi.update(self.get_bboxes(outs_roi, forced_valid))
         if img_metas[0]["scene_token"] != self.prev_scene:
             self.prev_scene = img_metas[0]["scene_token"]
             prev = img.new_zeros(1)
             self.reset_memory()
         else:
             prev = img.new_ones(1)
-        outs = self.head_forward(feats, outs_roi, data, prev, pad_hw)
+        outs = self.head_forward(feats, outs_roi, data, prev, pad_hw, forced_topk)
         outs["roi"] = outs_roi
         outs["feat_levels"] = feats
         outs["result"] = self.decode(outs)

@@ -21,7 +21,7 @@ def msda_grid_sample(value, spatial_shapes, level_start_index, sampling_location
     _, Q, _, L, P, _ = sampling_locations.shape
     attention_weights = attention_weights.reshape(bs, Q, H, L, P)
     shapes = [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
-    value = value.float()
+    value = value if value.dtype == torch.float64 else value.float()
     grids = 2 * sampling_locations - 1
     out_lv = []
     for l, (h, w) in enumerate(shapes):
@@ -87,7 +87,7 @@ def aggregation_ref(feat_flatten, ref, offsets, lidar2img, logits, level_hw, lev
     N, S, C = feat_flatten.shape
     A, P = offsets.shape[0], offsets.shape[1]
     L, G = len(level_hw), num_groups
-    pc = torch.as_tensor(pc_range, dtype=torch.float32)
+    pc = torch.as_tensor(pc_range, dtype=ref.dtype)
     ref_m = ref * (pc[3:6] - pc[0:3]) + pc[0:3]                                   # get_global_pos :27-29
     key_points = ref_m[None, :, None, :] + offsets[None]                          # :525
     # _get_weights :540-542
