@@ -13,8 +13,7 @@
 #define FAR3D_DT_F32 0
 #define FAR3D_DT_BF16 1
 #define FAR3D_ESE_REPLICAS 8   // mirrors include/far3d_hip.h: per-XCD replicas of the fused eSE channel sums
-#define FAR3D_SUMS_MAX_PARTS 64
-#define FAR3D_SUMS_MAX_IMAGES 64   /* images per far3d_ese_nhwc / far3d_groupnorm_nhwc call (ticket slots) */   // mirrors include/far3d_hip.h
+#define FAR3D_SUMS_MAX_PARTS 32
 
 void far3d_set_error(const char* fmt, ...);
 

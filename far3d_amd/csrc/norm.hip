@@ -97,11 +97,9 @@ extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* 
 // hipGraph-vs-eager results are bit-identical.
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                        int ldx, long img_stride, int rows_per_block, float* __restrict__ total,
-                                                        unsigned* __restrict__ ticket) {
+                                                        int ldx, long img_stride, int rows_per_block) {
   // thread -> 4 consecutive channels; the 256 threads cover rstep = 256*4/C rows per pass; 4 passes are kept in flight.
   __shared__ float red[2][1024];
-  __shared__ unsigned s_last;
   const int n = blockIdx.y;
   const int cq = C / 4;
   const int tcol = threadIdx.x % cq, trow = threadIdx.x / cq;
@@ -139,28 +137,6 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
     for (int k = 0; k < rstep; ++k) { ss += red[0][k * C + c]; qq += red[1][k * C + c]; }
     *reinterpret_cast<float2*>(dst + 2 * c) = make_float2(ss, qq);
   }
-  // The workgroup that finishes LAST for image n adds the nblk partials in index order (a fixed order: the result does not
-  // depend on which workgroup happens to be last) and leaves the totals for the consumer; the ticket only elects it.
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned tk = atomicAdd(ticket + n, 1u);
-    s_last = (tk == (unsigned)nblk - 1u) ? 1u : 0u;
-    if (s_last) ticket[n] = 0u;                 // self-cleaning: ready for the next launch on the stream
-  }
-  __syncthreads();
-  if (s_last) {
-    __threadfence();
-    const float* src = part + (long)n * nblk * C * 2;
-    for (int c = threadIdx.x; c < C; c += 256) {
-      float ss = 0.f, qq = 0.f;
-      for (int b = 0; b < nblk; ++b) {
-        const volatile float* v = src + ((long)b * C + c) * 2;      // volatile: written by other CUs, read through L2
-        ss += v[0]; qq += v[1];
-      }
-      *reinterpret_cast<float2*>(total + ((long)n * C + c) * 2) = make_float2(ss, qq);
-    }
-  }
 }
 
 // number of partial-sum workgroups per image: >= 64 Ki elements per workgroup, at most FAR3D_SUMS_MAX_PARTS
@@ -174,40 +150,66 @@ static int chan_sums_parts(int HW, int C) {
   return (HW + rows_per_block - 1) / rows_per_block;
 }
 
-static int launch_chan_sums(const void* x, int dt, float* part, float* total, unsigned* ticket, int N, int HW, int C, int ldx,
-                            long img_stride, hipStream_t st) {
+static int launch_chan_sums(const void* x, int dt, float* part, int N, int HW, int C, int ldx, long img_stride, hipStream_t st) {
   const int nblk = chan_sums_parts(HW, C);
   const int rstep = 256 / (C / 4);
   int rows_per_block = (HW + nblk - 1) / nblk;
   rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
   dim3 grid(nblk, N), block(256);
   if (dt == FAR3D_DT_F32)
-    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block, total, ticket);
+    hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block);
   else
-    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, part, HW, C, ldx, img_stride, rows_per_block, total, ticket);
+    hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, part, HW, C, ldx, img_stride, rows_per_block);
   return nblk;
 }
 
 // ---------------------------------------------------------------- eSE
-// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image; the
-// channel totals come from the pooling kernel (total[n][k][0]).
-__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ total, const float* __restrict__ fcw,
+// Partial sums of image n, channel c: part[(n * nparts + b) * C + c] (float2: sum, sum of squares), b = 0..nparts-1; added in
+// index order with 8 loads in flight (deterministic).
+__device__ __forceinline__ float2 sum_parts(const float2* __restrict__ src, int nparts, int C, int c) {
+  float ss = 0.f, qq = 0.f;
+  int b = 0;
+  for (; b + 8 <= nparts; b += 8) {
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[(long)(b + k) * C + c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ss += v[k].x; qq += v[k].y; }
+  }
+  for (; b < nparts; ++b) { const float2 v = src[(long)b * C + c]; ss += v.x; qq += v.y; }
+  return make_float2(ss, qq);
+}
+
+// gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image: it first
+// adds the per-workgroup partial channel sums of the pooling kernel (every workgroup of the image does; they are L2 hits), then
+// each wave does 4 rows of the mat-vec.
+__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ part, const float* __restrict__ fcw,
                                                        const float* __restrict__ fcb, float* __restrict__ gate, int C,
-                                                       float inv_hw) {
+                                                       float inv_hw, int nparts) {
   __shared__ float mean[1024];
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = threadIdx.x; k < C; k += 256) mean[k] = total[((long)n * C + k) * 2] * inv_hw;
+  const float2* src = reinterpret_cast<const float2*>(part) + (long)n * nparts * C;
+  for (int k = threadIdx.x; k < C; k += 256) mean[k] = sum_parts(src, nparts, C, k).x * inv_hw;
   __syncthreads();
+  // each wave: 4 output channels at once (4 independent weight-row streams), float4 loads
+  const int c0 = blockIdx.x * 16 + wv * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane * 4; k < C; k += 256) {
+    const float4 m = *reinterpret_cast<const float4*>(mean + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c0 + j < C) {
+        const float4 w = *reinterpret_cast<const float4*>(fcw + (long)(c0 + j) * C + k);
+        acc[j] += (w.x * m.x + w.y * m.y) + (w.z * m.z + w.w * m.w);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int c = blockIdx.x * 16 + wv * 4 + j;
-    if (c >= C) break;   // wave-uniform
-    float acc = 0.f;
-    for (int k = lane; k < C; k += 64) acc += fcw[(long)c * C + k] * mean[k];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float z = acc + fcb[c];
-      gate[(long)n * C + c] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
+    const float a = wave_sum(acc[j]);
+    if (lane == 0 && c0 + j < C) {
+      const float z = a + fcb[c0 + j];
+      gate[(long)n * C + c0 + j] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
     }
   }
 }
@@ -235,25 +237,20 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
   }
 }
 
-// scratch (floats): [FAR3D_SUMS_MAX_IMAGES] tickets, [N][FAR3D_SUMS_MAX_PARTS][C][2] partial sums, [N][C][2] totals, [N][C]
-// gates.  Size: FAR3D_SUMS_SCRATCH_FLOATS(N, C); the tickets must be zero before the FIRST use (one memset at allocation)
-// and clean themselves afterwards, so one workspace (sized for the widest layer) serves a whole stream of calls.
+// scratch (floats): [N][FAR3D_SUMS_MAX_PARTS][C][2] partial sums, then [N][C] gates.  Size FAR3D_SUMS_SCRATCH_FLOATS(N, C); never
+// needs zeroing, and one workspace (sized for the widest layer) serves a whole stream of calls.
 extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                               float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
                               long i_img_stride, int ldy, long y_img_stride, void* stream) {
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && N <= FAR3D_SUMS_MAX_IMAGES && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
                   "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4, <= 1024)", C);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
-  // tickets FIRST, at a position that does not depend on C: one workspace serves layers of different widths, and a ticket
-  // must never land inside another layer's partial sums
-  unsigned* ticket = reinterpret_cast<unsigned*>(scratch);
-  float* sums = scratch + FAR3D_SUMS_MAX_IMAGES;
-  float* total = sums + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
-  float* gate = total + (long)N * C * 2;
-  launch_chan_sums(x, dt, sums, total, ticket, N, HW, C, ldx, x_img_stride, st);
-  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, total, fcw, fcb, gate, C, 1.f / HW);
+  float* sums = scratch;
+  float* gate = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
+  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, nparts);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -268,14 +265,14 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
 }
 
 // ---------------------------------------------------------------- GroupNorm + ReLU (NHWC)
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ total, float* __restrict__ stat, int C,
-                                                       int groups, float inv_cnt, float eps, int ntot) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int C,
+                                                       int groups, float inv_cnt, float eps, int ntot, int nparts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
   if (i >= ntot) return;
   const int n = i / groups, g = i % groups, cpg = C / groups;
+  const float2* src = reinterpret_cast<const float2*>(part) + (long)n * nparts * C;
   float s = 0.f, q = 0.f;
-  const float* p = total + (long)n * C * 2;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += p[2 * c]; q += p[2 * c + 1]; }
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const float2 v = sum_parts(src, nparts, C, c); s += v.x; q += v.y; }
   const float mean = s * inv_cnt;
   const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
   stat[2 * i] = mean;
@@ -309,18 +306,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch,
                                     int N, int HW, int C, int groups, float eps, int relu, void* stream) {
   FAR3D_CHECK_ARG(x && gamma && beta && y && scratch, "far3d_groupnorm_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && N <= FAR3D_SUMS_MAX_IMAGES && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
+  FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_groupnorm_nhwc: unsupported dtype");
   hipStream_t st = (hipStream_t)stream;
-  unsigned* ticket = reinterpret_cast<unsigned*>(scratch);            // [FAR3D_SUMS_MAX_IMAGES], same layout as far3d_ese_nhwc
-  float* sums = scratch + FAR3D_SUMS_MAX_IMAGES;                      // [N][nparts][C][2]
-  float* total = sums + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;       // [N][C][2]
-  float* stat = total + (long)N * C * 2;                              // [N][C] (only [N][groups][2] used)
-  launch_chan_sums(x, dt, sums, total, ticket, N, HW, C, C, (long)HW * C, st);
+  float* sums = scratch;                                              // [N][nparts][C][2]
+  float* stat = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;     // [N][groups][2]
+  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
   const int tot = N * groups;
   FAR3D_CHECK_ARG(groups * 2 <= C, "far3d_groupnorm_nhwc: groups*2 must be <= C");
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, total, stat, C, groups,
-                     1.f / ((float)HW * (C / groups)), eps, tot);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, sums, stat, C, groups,
+                     1.f / ((float)HW * (C / groups)), eps, tot, nparts);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;

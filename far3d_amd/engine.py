@@ -270,14 +270,6 @@ class Far3DEngine:
             self._bufs[key] = b
         return b
 
-    def _zbuf(self, key, shape, dtype):
-        """Like _buf, but zero-filled when (re)allocated (workspaces holding self-cleaning tickets)."""
-        b = self._bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
-            b = torch.zeros(shape, dtype=dtype, device=self.dev)
-            self._bufs[key] = b
-        return b
-
     # ------------------------------------------------------------------------------------------ a2: backbone
     def backbone(self, img):
         """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps."""
@@ -285,7 +277,7 @@ class Far3DEngine:
         N = img.shape[0]
         Lb = spec["layer_per_block"]
         # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
-        scratch = self._zbuf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
+        scratch = self._buf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
         x = ops.stem_im2col(img, act)
         x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
@@ -366,7 +358,7 @@ class Far3DEngine:
             rf = ops.conv2d_nhwc(t0[..., half:], lv["reg"][1], act="swish")
             reg.append(ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32))
         d = raw[0]
-        gscr = self._zbuf(("gn_scratch",), (ops.ese_scratch_floats(d.shape[0], 256),), torch.float32)
+        gscr = self._buf(("gn_scratch",), (ops.ese_scratch_floats(d.shape[0], 256),), torch.float32)
         for i in range(2):
             d = ops.conv2d_nhwc(d, self.depth["convs"][i])
             d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True, scratch=gscr)

@@ -198,12 +198,12 @@ def _nhwc_view(t, name):
 
 
 ESE_REPLICAS = 8        # FAR3D_ESE_REPLICAS in include/far3d_hip.h
-SUMS_MAX_PARTS = 64     # FAR3D_SUMS_MAX_PARTS in include/far3d_hip.h
+SUMS_MAX_PARTS = 32     # FAR3D_SUMS_MAX_PARTS in include/far3d_hip.h
 
 
 def ese_scratch_floats(N, C):
-    """FAR3D_SUMS_SCRATCH_FLOATS(N, C): workspace of ese_nhwc / groupnorm_nhwc -- allocate it with torch.zeros ONCE."""
-    return 64 + N * C * (2 * SUMS_MAX_PARTS + 3)
+    """FAR3D_SUMS_SCRATCH_FLOATS(N, C): workspace of ese_nhwc / groupnorm_nhwc (never needs zeroing)."""
+    return N * C * (2 * SUMS_MAX_PARTS + 1)
 
 
 def conv_tile(x, pc):
@@ -336,7 +336,7 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
         ldi, isd = _nhwc_view(identity, "identity")
         ip = _ptr(identity)
     if scratch is None:
-        scratch = torch.zeros(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
     if scratch.numel() < ese_scratch_floats(N, C):
         raise ValueError("ese_nhwc: scratch needs %d floats" % ese_scratch_floats(N, C))
     _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
@@ -351,7 +351,7 @@ def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scr
     if out is None:
         out = torch.empty_like(x)
     if scratch is None:
-        scratch = torch.zeros(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
     _lib.check(lib.far3d_groupnorm_nhwc(_ptr(x), _dt(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), N, H * W, C,
                                         groups, float(eps), 1 if relu else 0, _stream(x)), "far3d_groupnorm_nhwc")
     return out

@@ -22,10 +22,9 @@ extern "C" {
 /* per-XCD replicas of the channel-sum array written by far3d_conv2d_nhwc(chan_sum) and read by far3d_ese_nhwc */
 #define FAR3D_ESE_REPLICAS 8
 /* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */
-#define FAR3D_SUMS_MAX_PARTS 64
-#define FAR3D_SUMS_MAX_IMAGES 64   /* images per far3d_ese_nhwc / far3d_groupnorm_nhwc call (ticket slots) */
-/* tickets [MAX_IMAGES] + partial sums [N][PARTS][C][2] + totals [N][C][2] + gates/stats [N][C] */
-#define FAR3D_SUMS_SCRATCH_FLOATS(N, C) (FAR3D_SUMS_MAX_IMAGES + (long)(N) * (C) * (2 * FAR3D_SUMS_MAX_PARTS + 3))
+#define FAR3D_SUMS_MAX_PARTS 32
+/* partial sums [N][PARTS][C][2] + gates / group statistics [N][C] */
+#define FAR3D_SUMS_SCRATCH_FLOATS(N, C) ((long)(N) * (C) * (2 * FAR3D_SUMS_MAX_PARTS + 1))
 
 #define FAR3D_OK 0
 #define FAR3D_ERR_ARG (-1)
@@ -131,17 +130,16 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
- * scratch: device workspace of FAR3D_SUMS_SCRATCH_FLOATS(N, C) floats, ZEROED ONCE at allocation (it holds per-image tickets
- * that clean themselves after every use).  The average pool writes per-workgroup partial channel sums with plain stores; the
- * workgroup that finishes last for an image (elected by the ticket) adds them in index order, so the sums are deterministic:
- * no data atomics, bit-identical run to run and hipGraph vs eager.  C a multiple of 4, <= 1024. */
+ * scratch: device workspace of FAR3D_SUMS_SCRATCH_FLOATS(N, C) floats; never needs zeroing.  The average pool writes
+ * per-workgroup partial channel sums with plain stores and the gate kernel adds them in index order, so the sums are
+ * deterministic: no atomics, bit-identical run to run and hipGraph vs eager.  C a multiple of 4, <= 1024. */
 int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
                    int ldy, long y_img_stride, void* stream);
 
 /* GroupNorm(groups, C) (+ReLU) on dense NHWC maps.  Replaces nn.GroupNorm(32, 256)+ReLU of the depth head,
- * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: FAR3D_SUMS_SCRATCH_FLOATS(N, C) floats, zeroed once at
- * allocation (see far3d_ese_nhwc); statistics are reduced deterministically from per-workgroup partial sums. */
+ * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: FAR3D_SUMS_SCRATCH_FLOATS(N, C) floats (no zeroing needed);
+ * statistics are reduced deterministically from per-workgroup partial sums. */
 int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, const float* beta, void* y, float* scratch, int N,
                          int HW, int C, int groups, float eps, int relu, void* stream);
 
