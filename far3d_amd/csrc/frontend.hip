@@ -124,62 +124,71 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
   // buffered and every thread adds the 16 wave partials itself), 31 passes.
   unsigned kth = __float_as_uint(thr);   // mode 0: strict threshold
   int n_gt = 0;
+  constexpr int MAXV = 16;
+  unsigned v[MAXV];
   if (mode == 1) {
-    constexpr int MAXV = 16;
-    unsigned v[MAXV];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) { const int i = t + k * nt; v[k] = i < S ? __float_as_uint(w[i]) : 0u; }   // padding 0 never counts (mid >= 1)
     __shared__ int s_part[2][1024 / 64];
-    auto count_ge = [&](unsigned key, int slot) __attribute__((always_inline)) {
-      int c = 0;
-#pragma unroll
-      for (int k = 0; k < MAXV; ++k) c += (v[k] >= key) ? 1 : 0;
-      for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-      if ((t & 63) == 0) s_part[slot][t >> 6] = c;
-      __syncthreads();
-      int tot = 0;
-      for (int k = 0; k < nt / 64; ++k) tot += s_part[slot][k];
-      return tot;
-    };
-    unsigned lo = 0u, hi = 0x7f800000u;   // invariant: count(w >= lo) >= K, count(w >= hi) < K
     int pass = 0;
+#define PROP_COUNT_GE(dst, keyv)                                           \
+    {                                                                      \
+      int c_ = 0;                                                          \
+      _Pragma("unroll") for (int k = 0; k < MAXV; ++k) c_ += (v[k] >= (keyv)) ? 1 : 0; \
+      for (int o = 32; o >= 1; o >>= 1) c_ += __shfl_xor(c_, o);           \
+      if ((t & 63) == 0) s_part[pass & 1][t >> 6] = c_;                    \
+      __syncthreads();                                                     \
+      int tot_ = 0;                                                        \
+      for (int k = 0; k < nt / 64; ++k) tot_ += s_part[pass & 1][k];       \
+      ++pass;                                                              \
+      dst = tot_;                                                          \
+    }
+    unsigned lo = 0u, hi = 0x7f800000u;   // invariant: count(w >= lo) >= K, count(w >= hi) < K
     while (hi - lo > 1u) {
       const unsigned mid = lo + ((hi - lo) >> 1);
-      if (count_ge(mid, pass & 1) >= cap) lo = mid; else hi = mid;
-      ++pass;
+      int c;
+      PROP_COUNT_GE(c, mid);
+      if (c >= cap) lo = mid; else hi = mid;
     }
     kth = lo;   // value of the K-th largest element
-    n_gt = kth == 0xffffffffu ? 0 : count_ge(kth + 1u, pass & 1);   // strictly greater
+    if (kth != 0xffffffffu) PROP_COUNT_GE(n_gt, kth + 1u);   // strictly greater
+#undef PROP_COUNT_GE
     __syncthreads();
   }
   // --- ordered compaction, chunk by chunk (chunk = workgroup size)
-  // mode 0 keeps w > thr.  mode 1 keeps w > kth first-come AND as many w == kth (in index order) as needed.
+  // mode 0 keeps w > thr.  mode 1 keeps w > kth first-come AND as many w == kth (in index order) as needed; its values are
+  // already in registers (v[k] = chunk k), mode 0 reads each chunk once.
   int base = 0, eq_left = (mode == 1) ? cap - n_gt : 0;
-  for (int c0 = 0; c0 < S; c0 += nt) {
-    const int i = c0 + t;
-    const unsigned bits = i < S ? __float_as_uint(w[i]) : 0u;
-    bool gt = i < S && ((mode == 0) ? (w[i] > thr) : (bits > kth));
-    bool eq = (mode == 1) && i < S && bits == kth;
-    // rank of equal-valued entries inside this chunk (needed to cut ties in index order)
-    const unsigned long long eqm = __ballot(eq);
-    int eq_before = __popcll(eqm & ((1ull << (t & 63)) - 1ull));
-    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(eqm);
-    __syncthreads();
-    int eq_wave_off = 0, eq_chunk = 0;
-    for (int k = 0; k < nt / 64; ++k) { if (k < (t >> 6)) eq_wave_off += s_cnt[k]; eq_chunk += s_cnt[k]; }
-    __syncthreads();
-    const bool keep = gt || (eq && (eq_wave_off + eq_before) < eq_left);
-    const unsigned long long km = __ballot(keep);
-    const int k_before = __popcll(km & ((1ull << (t & 63)) - 1ull));
-    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(km);
-    __syncthreads();
-    int wave_off = 0, chunk = 0;
-    for (int k = 0; k < nt / 64; ++k) { if (k < (t >> 6)) wave_off += s_cnt[k]; chunk += s_cnt[k]; }
-    const int pos = base + wave_off + k_before;
-    if (keep && pos < cap) sel_idx[(long)n * cap + pos] = i;
-    base += chunk;
-    eq_left -= min(eq_left, eq_chunk);
-    __syncthreads();
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c0 = k * nt;
+    if (c0 < S) {                       // block-uniform
+      const int i = c0 + t;
+      unsigned bits;
+      if (mode == 1) bits = v[k]; else bits = i < S ? __float_as_uint(w[i]) : 0u;
+      bool gt = i < S && ((mode == 0) ? (__uint_as_float(bits) > thr) : (bits > kth));
+      bool eq = (mode == 1) && i < S && bits == kth;
+      // rank of equal-valued entries inside this chunk (needed to cut ties in index order)
+      const unsigned long long eqm = __ballot(eq);
+      int eq_before = __popcll(eqm & ((1ull << (t & 63)) - 1ull));
+      if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(eqm);
+      __syncthreads();
+      int eq_wave_off = 0, eq_chunk = 0;
+      for (int q = 0; q < nt / 64; ++q) { if (q < (t >> 6)) eq_wave_off += s_cnt[q]; eq_chunk += s_cnt[q]; }
+      __syncthreads();
+      const bool keep = gt || (eq && (eq_wave_off + eq_before) < eq_left);
+      const unsigned long long km = __ballot(keep);
+      const int k_before = __popcll(km & ((1ull << (t & 63)) - 1ull));
+      if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(km);
+      __syncthreads();
+      int wave_off = 0, chunk = 0;
+      for (int q = 0; q < nt / 64; ++q) { if (q < (t >> 6)) wave_off += s_cnt[q]; chunk += s_cnt[q]; }
+      const int pos = base + wave_off + k_before;
+      if (keep && pos < cap) sel_idx[(long)n * cap + pos] = i;
+      base += chunk;
+      eq_left -= min(eq_left, eq_chunk);
+      __syncthreads();
+    }
   }
   if (t == 0) sel_cnt[n] = min(base, cap);
   (void)s_key;
@@ -275,7 +284,7 @@ extern "C" int far3d_proposal_select(const float* const* cls, const float* const
   PropLevels lv;
   const int S = fill_levels(lv, L, level_hw, strides, cls, reg, ncls, nreg);
   FAR3D_CHECK_ARG(mode == 0 || (mode == 1 && cap <= S), "far3d_proposal_select: bad mode / K > S");
-  FAR3D_CHECK_ARG(mode == 0 || S <= 16 * 1024, "far3d_proposal_select: top-K mode keeps a camera's S=%d weights in registers (S <= 16384)", S);
+  FAR3D_CHECK_ARG(S <= 16 * 1024, "far3d_proposal_select: a camera's S=%d cells are handled as 16 chunks of 1024 (S <= 16384)", S);
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)N * S;
   const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -29,69 +29,72 @@ __device__ __forceinline__ float ord_val(unsigned k) { return __uint_as_float((k
 
 // Selects the K largest of vals[0..n) (ties -> lower index first) and leaves them sorted descending in
 // sel[0..K) as (ord_key << 32) | (0xffffffff - index).  All TOPK_THREADS threads must call; sel is LDS [TOPK_MAXK].
-__device__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, unsigned long long* sel) {
+// The values stay in registers (v[k] is only ever indexed by unrolled loops); a pass of the bisection = register compares,
+// one wave reduction, ONE barrier.  The winners are compacted in arbitrary order (LDS counter) and the bitonic sort on the
+// (key, index) pairs restores the order, so no ordered scan is needed.
+__device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, unsigned long long* sel) {
   const int t = threadIdx.x;
   __shared__ int s_part[2][TOPK_THREADS / 64];
-  __shared__ int s_cnt[TOPK_THREADS / 64];
+  __shared__ int s_cnt;
   unsigned v[TOPK_MAXV];
 #pragma unroll
   for (int k = 0; k < TOPK_MAXV; ++k) {
     const int i = t + k * TOPK_THREADS;
-    v[k] = i < n ? ord_key(vals[i]) : 0u;      // padding slots are excluded by the index test below, not by their value
+    unsigned key = 0u;                              // padding: below every real key (real keys are >= 1)
+    if (i < n) { key = ord_key(vals[i]); key = key < 1u ? 1u : key; }
+    v[k] = key;
   }
-  auto count_ge = [&](unsigned key, int slot) __attribute__((always_inline)) {
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < TOPK_MAXV; ++k) c += (v[k] >= key && (t + k * TOPK_THREADS) < n) ? 1 : 0;
-    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-    if ((t & 63) == 0) s_part[slot][t >> 6] = c;
-    __syncthreads();
-    int tot = 0;
-#pragma unroll
-    for (int k = 0; k < TOPK_THREADS / 64; ++k) tot += s_part[slot][k];
-    return tot;
-  };
-  // invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
-  unsigned long long lo = 0ull, hi = 0x100000000ull;
   int pass = 0;
+#define TOPK_COUNT(dst, pred)                                              \
+  {                                                                        \
+    int c_ = 0;                                                            \
+    _Pragma("unroll") for (int k = 0; k < TOPK_MAXV; ++k) {                \
+      const unsigned key = v[k];                                           \
+      const int idx = t + k * TOPK_THREADS;                                \
+      (void)idx;                                                           \
+      c_ += (pred) ? 1 : 0;                                                \
+    }                                                                      \
+    for (int o = 32; o >= 1; o >>= 1) c_ += __shfl_xor(c_, o);             \
+    if ((t & 63) == 0) s_part[pass & 1][t >> 6] = c_;                      \
+    __syncthreads();                                                       \
+    int tot_ = 0;                                                          \
+    _Pragma("unroll") for (int w = 0; w < TOPK_THREADS / 64; ++w) tot_ += s_part[pass & 1][w]; \
+    ++pass;                                                                \
+    dst = tot_;                                                            \
+  }
+  // K-th largest key by bisection; invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
+  unsigned long long lo = 1ull, hi = 0x100000000ull;
   while (hi - lo > 1ull) {
-    const unsigned long long mid = lo + ((hi - lo) >> 1);
-    if (count_ge((unsigned)mid, pass & 1) >= K) lo = mid; else hi = mid;
-    ++pass;
+    const unsigned mid = (unsigned)(lo + ((hi - lo) >> 1));
+    int c;
+    TOPK_COUNT(c, key >= mid);
+    if (c >= K) lo = mid; else hi = mid;
   }
   const unsigned kth = (unsigned)lo;
-  const int n_gt = kth == 0xffffffffu ? 0 : count_ge(kth + 1u, pass & 1);
+  int n_ge, n_gt = 0;
+  TOPK_COUNT(n_ge, key >= kth);
+  int idx_cut = 0x7fffffff;                           // among the keys == kth, keep indices <= idx_cut
+  if (n_ge > K) {                                     // ties at the cut (block-uniform): keep the lowest indices
+    if (kth != 0xffffffffu) TOPK_COUNT(n_gt, key > kth);
+    const int need = K - n_gt;
+    int ilo = -1, ihi = n - 1;                        // count(idx <= ilo) < need <= count(idx <= ihi)
+    while (ihi - ilo > 1) {
+      const int mid = ilo + ((ihi - ilo) >> 1);
+      int c;
+      TOPK_COUNT(c, key == kth && idx <= mid);
+      if (c >= need) ihi = mid; else ilo = mid;
+    }
+    idx_cut = ihi;
+  }
+#undef TOPK_COUNT
+  if (t == 0) s_cnt = 0;
   __syncthreads();
-  // ordered compaction (index order), keeping all keys > kth and the first K - n_gt keys == kth
-  int base = 0, eq_left = K - n_gt;
 #pragma unroll
-  for (int k = 0; k < TOPK_MAXV; ++k) {      // fully unrolled (v[] stays in registers); chunks past n are skipped, uniformly
-    const int c0 = k * TOPK_THREADS;
-    if (c0 < n) {
-    const int i = c0 + t;
-    const bool in = i < n;
-    const bool gt = in && v[k] > kth, eq = in && v[k] == kth;
-    const unsigned long long eqm = __ballot(eq);
-    const int eq_before = __popcll(eqm & ((1ull << (t & 63)) - 1ull));
-    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(eqm);
-    __syncthreads();
-    int eq_wave_off = 0, eq_chunk = 0;
-#pragma unroll
-    for (int w = 0; w < TOPK_THREADS / 64; ++w) { if (w < (t >> 6)) eq_wave_off += s_cnt[w]; eq_chunk += s_cnt[w]; }
-    __syncthreads();
-    const bool keep = gt || (eq && (eq_wave_off + eq_before) < eq_left);
-    const unsigned long long km = __ballot(keep);
-    const int k_before = __popcll(km & ((1ull << (t & 63)) - 1ull));
-    if ((t & 63) == 0) s_cnt[t >> 6] = __popcll(km);
-    __syncthreads();
-    int wave_off = 0, chunk = 0;
-#pragma unroll
-    for (int w = 0; w < TOPK_THREADS / 64; ++w) { if (w < (t >> 6)) wave_off += s_cnt[w]; chunk += s_cnt[w]; }
-    const int pos = base + wave_off + k_before;
-    if (keep && pos < K) sel[pos] = ((unsigned long long)v[k] << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
-    base += chunk;
-    eq_left -= min(eq_left, eq_chunk);
-    __syncthreads();
+  for (int k = 0; k < TOPK_MAXV; ++k) {
+    const int i = t + k * TOPK_THREADS;
+    if (v[k] > kth || (v[k] == kth && i <= idx_cut)) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)v[k] << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
     }
   }
   // bitonic sort, descending, of the next power of two >= K entries (padding 0 sorts last)

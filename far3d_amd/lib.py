@@ -52,6 +52,9 @@ SIGNATURES = {
     "far3d_decode_topk": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p]),
     "far3d_camera_prep": (c_int, [_p, _p, _p, _p, _p, c_int, _p]),
     "far3d_nan_to_num": (c_int, [_p, _p, c_long, _p]),
+    "far3d_image_resample_h": (c_int, [_p, c_long, c_int, c_int, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p]),
+    "far3d_image_resample_v": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_int, c_int, c_int, c_int, c_int, _p, c_int, c_int, c_int,
+                                       _p, _p, c_int, _p]),
 }
 
 _lib = None

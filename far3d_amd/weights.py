@@ -207,3 +207,52 @@ def fold_bn(conv_w, bn_w, bn_b, mean, var, eps):
     """conv (no bias) + eval-mode BN  ->  conv weight / bias (vovnet.py norm_eval=True; YOLOX BN eps 1e-3)."""
     scale = bn_w / torch.sqrt(var + eps)
     return conv_w * scale.view(-1, 1, 1, 1), bn_b - mean * scale
+
+
+# ------------------------------------------------------------------------------------------ checkpoint compatibility (§8 f2)
+def normalize_state_dict(ckpt, strict_schema=None):
+    """Whatever mmcv's `load_checkpoint(model, path, map_location='cpu')` accepts (ref tools/test.py:208) -> a flat
+    {schema key: tensor} dict: unwraps `{'state_dict': ...}` / `{'model': ...}` containers (mmcv runner checkpoints carry
+    'meta', 'state_dict', 'optimizer'), strips DDP `module.` prefixes (tools/test.py:229-232 wraps the model before saving in
+    training), keeps the '/'-containing VoVNet names (vovnet.py:128-139), resolves the shared cls/reg branch aliases
+    (farhead.py:248-251) after checking that the six copies are identical, and drops BN `num_batches_tracked`.
+    strict_schema: optional detector_spec(); then missing / unexpected / mis-shaped keys raise with the offending names."""
+    sd = ckpt
+    for k in ("state_dict", "model"):
+        if isinstance(sd, dict) and k in sd and isinstance(sd[k], dict):
+            sd = sd[k]
+    if not isinstance(sd, dict) or not all(isinstance(k, str) for k in sd):
+        raise TypeError("checkpoint does not contain a state dict")
+    out = OrderedDict()
+    for k, v in sd.items():
+        if not isinstance(v, torch.Tensor):
+            continue
+        while k.startswith("module."):
+            k = k[len("module."):]
+        ck = canonical_key(k)
+        if ck is None:
+            continue
+        if ck in out:
+            if ck != k and not torch.equal(out[ck], v):
+                raise ValueError("checkpoint key %s disagrees with its shared-branch owner %s" % (k, ck))
+            if ck != k:
+                continue
+        out[ck] = v
+    if strict_schema is not None:
+        missing = [k for k in strict_schema if k not in out]
+        unexpected = [k for k in out if k not in strict_schema]
+        bad = [k for k in strict_schema if k in out and tuple(out[k].shape) != tuple(strict_schema[k])]
+        if missing or unexpected or bad:
+            raise KeyError("checkpoint does not match the Far3D schema: %d missing (e.g. %s), %d unexpected (e.g. %s), %d mis-shaped (e.g. %s)"
+                           % (len(missing), missing[:3], len(unexpected), unexpected[:3], len(bad), bad[:3]))
+    return out
+
+
+def load_checkpoint(path, strict_schema=None, map_location="cpu"):
+    """torch.load + normalize_state_dict.  Works for the released `iter_82548.pth` layout (mmcv runner checkpoint) and for a
+    bare state dict."""
+    try:
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    except TypeError:
+        ckpt = torch.load(path, map_location=map_location)
+    return normalize_state_dict(ckpt, strict_schema)

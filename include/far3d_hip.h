@@ -254,6 +254,25 @@ int far3d_cam_embed_chain(const float* l2i, const float* w0t, const float* b0, c
                           const float* ln_g, const float* ln_b, const float* w3t, const float* b3, float* out, int N, int L,
                           int J, int Hd, float eps, int ld_l2i, void* stream);
 
+/* --- device image pre-processing (far3d_amd/csrc/preproc.hip) ------------------------------------
+ * Pillow-exact 8-bit separable resampling (Image.resize as used by AV2ResizeCropFlipRotImageV2._img_transform,
+ * ref datasets/pipelines/custom_pipeline.py:277-311) restricted to the crop window, then crop / flip / normalise / pad / HWC->CHW
+ * (ref datasets/pipelines/transform_3d.py:89-101, custom_pipeline.py:358-378).  bounds (out_size,2) and coeffs (out_size,ksize)
+ * int32 DEVICE: per output position the first input sample, the sample count and the 22-bit fixed-point filter weights, built on
+ * the host exactly like Pillow's precompute_coeffs + normalize_coeffs_8bpc (far3d_amd/data_pipeline/resample.py).
+ *
+ * far3d_image_resample_h: horizontal pass.  src u8 HWC (in_h,in_w,3), row pitch src_pitch bytes; dst u8 (rows,outw,3) = output
+ *   columns [x0, x0+outw) of input rows [row0, row0+rows).
+ * far3d_image_resample_v: vertical pass over that intermediate for output rows [y0, y0+outh), optional horizontal flip, then
+ *   mode 0: u8 HWC (outh,outw,3) (an intermediate image: the portrait camera is resized twice, custom_pipeline.py:71-92), or
+ *   mode 1: out (3,pad_h,pad_w) f32|bf16 = (pixel - mean[c]) * stdinv[c] inside the crop, 0 in the padding; mean / stdinv 3 floats
+ *   HOST; to_rgb swaps channels 0 and 2 first. */
+int far3d_image_resample_h(const unsigned char* src, long src_pitch, int in_h, int in_w, unsigned char* dst, const int32_t* bounds,
+                           const int32_t* coeffs, int ksize, int row0, int rows, int x0, int outw, void* stream);
+int far3d_image_resample_v(const unsigned char* tmp, int row0, int rows, int outw, const int32_t* bounds, const int32_t* coeffs,
+                           int ksize, int y0, int outh, int flip, int mode, void* out, int out_dt, int pad_h, int pad_w,
+                           const float* mean, const float* stdinv, int to_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -299,8 +299,15 @@ class BaseBBoxCoder:
 
 
 class LiDARBoxes:
+    """mmdet3d LiDARInstance3DBoxes stand-in: (x, y, z_bottom, w, l, h, yaw, ...) rows; gravity_center = bottom centre + h/2."""
+
     def __init__(self, tensor, box_dim=7):
         self.tensor, self.box_dim = tensor, box_dim
+
+    @property
+    def gravity_center(self):
+        t = self.tensor
+        return torch.cat([t[:, :2], t[:, 2:3] + t[:, 5:6] * 0.5], dim=1)
 
 
 def bbox3d2result(bboxes, scores, labels):
@@ -398,6 +405,98 @@ def install():
                      ("projects.mmdet3d_plugin.core.bbox.coders", "core/bbox/coders")):
         _mod(pkg).__path__ = [os.path.normpath(os.path.join(PLUGIN, rel))]
     _installed = True
+
+
+class _AnyMeta(type):
+    def __getattr__(cls, k):      # enum-like members (AffinityType.CENTER, ...) evaluate to their own name
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return k
+
+    def __iter__(cls):            # constants used as sequences at import time (ORDERED_CUBOID_COL_NAMES, ...)
+        return iter(())
+
+
+class _AnyModule(types.ModuleType):
+    """A module whose every attribute exists (a throw-away class): for packages the reference's dataset files import names from
+    but whose functions the fixture generator never calls (av2, kornia, refile)."""
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        v = _AnyMeta(k, (), {})
+        setattr(self, k, v)
+        return v
+
+
+_data_installed = False
+
+
+def install_data_stubs(class_names):
+    """Stand-ins for what the reference's pipeline / dataset / sampler files import (mmcv image ops restated from mmcv 1.6.2's
+    published semantics; av2 0.2.1 / kornia / refile as name-only shells).  Test-only, build container only."""
+    global _data_installed
+    install()
+    if _data_installed:
+        return
+    import enum
+    import numpy as np
+
+    def imnormalize(img, mean, std, to_rgb=True):      # mmcv.image.photometric.imnormalize: float32 image, float64 scalars via cv2
+        img = img.copy().astype(np.float32)
+        mean32 = np.float64(mean.reshape(1, -1)).astype(np.float32)
+        stdinv32 = (1 / np.float64(std.reshape(1, -1))).astype(np.float32)
+        if to_rgb:
+            img = img[..., ::-1]
+        return ((img - mean32) * stdinv32).astype(np.float32)
+
+    def impad(img, *, shape=None, padding=None, pad_val=0, padding_mode="constant"):   # mmcv.image.geometric.impad (shape mode)
+        out = np.full((shape[0], shape[1]) + img.shape[2:], pad_val, dtype=img.dtype)
+        out[:img.shape[0], :img.shape[1]] = img
+        return out
+
+    class _DC:      # mmcv.parallel.DataContainer
+        def __init__(self, data, **kw):
+            self.data = data
+
+    _mod("mmcv", imnormalize=imnormalize, impad=impad, imread=None, track_iter_progress=lambda it: it,
+         mkdir_or_exist=lambda p: os.makedirs(p, exist_ok=True))
+    _mod("mmcv.parallel", DataContainer=_DC)
+    _mod("mmcv.utils.registry", Registry=Registry, build_from_cfg=build_from_cfg)
+    PIPELINES, DATASETS = Registry("pipeline"), Registry("dataset")
+    _mod("mmdet.datasets", DATASETS=DATASETS)
+    _mod("mmdet.datasets.builder", PIPELINES=PIPELINES)
+    _mod("mmdet3d.datasets")
+    _mod("mmdet3d.datasets.builder", PIPELINES=PIPELINES)
+    _mod("mmdet3d.datasets.custom_3d", Custom3DDataset=type("Custom3DDataset", (), {}))
+    _mod("mmdet3d.core.points", BasePoints=object, get_points_type=lambda *a: None)
+    _mod("mmdet3d.core.bbox", LiDARInstance3DBoxes=LiDARBoxes)
+    import importlib.abc
+    import importlib.machinery
+
+    class _ShellFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):    # any av2.* / kornia.* / refile import -> name-only shell
+        def find_spec(self, fullname, path=None, target=None):
+            if fullname.split(".")[0] in ("av2", "kornia", "refile"):
+                return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            m = _AnyModule(spec.name)
+            m.__path__ = []
+            return m
+
+        def exec_module(self, module):
+            pass
+    sys.meta_path.insert(0, _ShellFinder())
+    cats = enum.Enum("CompetitionCategories", {c: c for c in class_names}, type=str)
+    consts = importlib.import_module("av2.evaluation.detection.constants")
+    consts.CompetitionCategories = cats
+    for k in ("MAX_NORMALIZED_ASE", "MAX_SCALE_ERROR", "MAX_YAW_RAD_ERROR", "MIN_AP", "MIN_CDS", "NUM_DECIMALS", "EPS"):
+        setattr(consts, k, 0.0)
+    for pkg, rel in (("projects.mmdet3d_plugin.datasets", "datasets"), ("projects.mmdet3d_plugin.datasets.pipelines", "datasets/pipelines"),
+                     ("projects.mmdet3d_plugin.datasets.samplers", "datasets/samplers")):
+        _mod(pkg).__path__ = [os.path.normpath(os.path.join(PLUGIN, rel))]
+    _data_installed = True
 
 
 def ref(module):

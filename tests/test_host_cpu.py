@@ -46,3 +46,37 @@ def test_cam_embed_chain_packing_is_transposed_and_stacked():
     assert p["w0t"].shape == (3, 12, 128) and p["w2t"].shape == (3, 128, 256) and p["w3t"].shape == (3, 256, 416)
     assert torch.equal(p["w2t"][1], layers[1][2].t()) and torch.equal(p["b3"][2], layers[2][7])
     assert all(v.is_contiguous() and v.dtype == torch.float32 for v in p.values())
+
+
+def test_load_checkpoint_unwraps_runner_layout_ddp_prefix_and_shared_branches(tmp_path):
+    """§8(f2): a synthetic checkpoint in the layout mmcv's runner writes for the reference (meta + state_dict, DDP `module.`
+    prefixes, six copies of the shared cls/reg branches, BN bookkeeping) loads into the schema unchanged."""
+    import pytest
+    import torch
+    from far3d_amd import weights
+    spec = weights.detector_spec("V-tiny-eSE", num_query=8, num_propagated=4)
+    sd = weights.init_state_dict(spec, seed=3)
+    ck = {}
+    for k, v in sd.items():
+        ck["module." + k] = v.clone()
+        for i in range(1, 6):
+            for br in ("cls_branches", "reg_branches"):
+                if k.startswith("pts_bbox_head.%s.0." % br):
+                    ck["module." + k.replace("%s.0." % br, "%s.%d." % (br, i))] = v.clone()
+    ck["module.img_backbone.stem.stem_1/norm.num_batches_tracked"] = torch.tensor(5)
+    path = str(tmp_path / "iter_1.pth")
+    torch.save(dict(meta=dict(iter=1), state_dict=ck, optimizer={}), path)
+    got = weights.load_checkpoint(path, strict_schema=spec)
+    assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert "img_backbone.stem.stem_1/conv.weight" in got
+    # bare state dict, no prefixes
+    torch.save(sd, path)
+    assert list(weights.load_checkpoint(path, strict_schema=spec)) == list(sd)
+    # a diverging shared-branch copy and a missing key are loud
+    bad = dict(ck)
+    bad["module.pts_bbox_head.cls_branches.3.6.bias"] = bad["module.pts_bbox_head.cls_branches.3.6.bias"] + 1
+    with pytest.raises(ValueError):
+        weights.normalize_state_dict(dict(state_dict=bad))
+    del ck["module.pts_bbox_head.reference_points.weight"]
+    with pytest.raises(KeyError):
+        weights.normalize_state_dict(dict(state_dict=ck), strict_schema=spec)
