@@ -173,7 +173,7 @@ class ImagePreprocessor:
         ida_mats = []
         for i, p in enumerate(plans):
             results["intrinsics"][i][:3, :3] = np.asarray(p[4]) @ results["intrinsics"][i][:3, :3]
-            ida_mats.append(np.array(p[4]))
+            ida_mats.append(p[4].numpy().copy())
         results["cam2img"] = results["intrinsics"]
         results["lidar2img"] = [results["intrinsics"][i] @ results["extrinsics"][i] for i in range(N)]
         results["ida_mat"] = ida_mats

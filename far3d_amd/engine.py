@@ -122,7 +122,9 @@ class Far3DEngine:
         if "backbone" in self.parts:
             self._prepare_backbone()
         if "neck" in self.parts:
-            self._prepare_neck_roi()
+            self._prepare_neck()
+        if "roi" in self.parts or ("neck" in self.parts and "head" in self.parts):
+            self._prepare_roi()
         if "head" in self.parts:
             self._prepare_head()
         torch.cuda.synchronize(self.dev)
@@ -151,14 +153,17 @@ class Far3DEngine:
         bb["stages"] = stages
         self.bb = bb
 
-    def _prepare_neck_roi(self):
+    def _prepare_neck(self):
         sd, cfg, dev = self.sd, self.cfg, self.dev
-        f32 = lambda t: t.to(dev).float().contiguous()
         # ---- FPN (a3)
         nl = len(self.spec["stage_out_ch"]) - 1
         self.fpn_lat = [self._pack(sd["img_neck.lateral_convs.%d.conv.weight" % i], sd["img_neck.lateral_convs.%d.conv.bias" % i]) for i in range(nl)]
         self.fpn_out = [self._pack(sd["img_neck.fpn_convs.%d.conv.weight" % i], sd["img_neck.fpn_convs.%d.conv.bias" % i],
                                    stride=2 if i == nl else 1, pad=1) for i in range(nl + 1)]
+
+    def _prepare_roi(self):
+        sd, cfg, dev = self.sd, self.cfg, self.dev
+        f32 = lambda t: t.to(dev).float().contiguous()
         # ---- 2D head + depth (a4)
         r = "img_roi_head."
         self.roi = []
@@ -174,6 +179,8 @@ class Far3DEngine:
             lv["cls_head"] = self._pack(sd[r + "multi_level_conv_cls.%d.weight" % l], sd[r + "multi_level_conv_cls.%d.bias" % l])
             lv["reg_head"] = self._pack(torch.cat([sd[r + "multi_level_conv_reg.%d.weight" % l], sd[r + "multi_level_conv_obj.%d.weight" % l]]),
                                         torch.cat([sd[r + "multi_level_conv_reg.%d.bias" % l], sd[r + "multi_level_conv_obj.%d.bias" % l]]))
+            if r + "multi_level_conv_centers2d.%d.weight" % l in sd:     # only the stand-alone module forward returns it (loss input)
+                lv["ctr_head"] = self._pack(sd[r + "multi_level_conv_centers2d.%d.weight" % l], sd[r + "multi_level_conv_centers2d.%d.bias" % l])
             self.roi.append(lv)
         self.depth = dict(
             convs=[self._pack(sd[r + "depthnet.depth_head.%d.0.weight" % i], sd[r + "depthnet.depth_head.%d.0.bias" % i], pad=1) for i in range(2)],
@@ -346,8 +353,9 @@ class Far3DEngine:
         return raw, tokens, hw, starts
 
     # ------------------------------------------------------------------------------------------ a4: 2D head + depth
-    def roi_head(self, raw):
-        """YOLOX towers + depth head on the raw FPN maps."""
+    def roi_head(self, raw, centers2d=None):
+        """YOLOX towers + depth head on the raw FPN maps.  centers2d: optional list that receives the (N,h,w,2) centre-offset maps
+        (a loss input the inference path never reads; the stand-alone YOLOXHeadCustom.forward returns them like the reference)."""
         cls, reg = [], []
         for l, x in enumerate(raw):
             lv = self.roi[l]
@@ -357,6 +365,8 @@ class Far3DEngine:
             cls.append(ops.conv2d_nhwc(cf, lv["cls_head"], out_dtype=torch.float32))
             rf = ops.conv2d_nhwc(t0[..., half:], lv["reg"][1], act="swish")
             reg.append(ops.conv2d_nhwc(rf, lv["reg_head"], out_dtype=torch.float32))
+            if centers2d is not None:
+                centers2d.append(ops.conv2d_nhwc(rf, lv["ctr_head"], out_dtype=torch.float32))
         d = raw[0]
         gscr = self._buf(("gn_scratch",), (ops.ese_scratch_floats(d.shape[0], 256),), torch.float32)
         for i in range(2):
@@ -453,6 +463,14 @@ class Far3DEngine:
         raw, tokens, hw, starts = self.fpn(feats, mln_scale, mln_shift)
         st = dict(tokens=tokens, hw=hw, starts=starts, raw=raw, lidar2img=lidar2img)
         cls, reg, depth_logit = self.roi_head(raw)
+        st.update(self.proposals(cls, reg, depth_logit, img2lidar, tokens))
+        return st
+
+    def proposals(self, cls, reg, depth_logit, img2lidar, tokens):
+        """a5 + the adaptive-query part of a6: peak selection and 3D proposal construction for n cameras."""
+        cfg = self.cfg
+        n = tokens.shape[0]
+        E = cfg["embed_dims"]
         K = cfg["proposal_topk"]
         cap = K if K is not None else min(cfg["proposal_cap"], tokens.shape[1])
         while True:
@@ -471,8 +489,7 @@ class Far3DEngine:
         ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, wgt, depth_logit,
                                                          cfg["depthnet"]["stride"], cfg["depthnet"], img2lidar, tokens,
                                                          cfg["pc_range"], score_thr=0.1, out=out)
-        st.update(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit)
-        return st
+        return dict(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit, peak_weight=wgt)
 
     def head_stage(self, tokens, ref2d, ctx, M, dd, img_metas, hw, starts, pad_hw):
         """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12)."""

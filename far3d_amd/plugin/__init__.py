@@ -88,6 +88,28 @@ class _SchemaModule(nn.Module):
     def init_weights(self):
         pass
 
+    # stand-alone use of one module (a maintainer swapping in a single registry class): a private engine holding only this
+    # module's parts, rebuilt when the weights, device or precision change
+    precision = "bf16"
+    _eng = None
+
+    def _part_engine(self, device, parts, cfg, extra_sd=None):
+        ver = (sum(int(p._version) for p in self.parameters()), str(device), self.precision)
+        if self._eng is None or self._eng_ver != ver:
+            sd = {self.prefix + k: v for k, v in self.state_dict().items()}
+            sd.update(extra_sd or {})
+            self._eng = _engine.Far3DEngine(sd, cfg, device=device, precision=self.precision, parts=parts)
+            self._eng_ver = ver
+        return self._eng
+
+
+def _to_nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def _to_nchw(x):
+    return x.float().permute(0, 3, 1, 2).contiguous()
+
 
 # ------------------------------------------------------------------------------------------------ operator drop-in
 class MultiScaleDeformableAttnFunction:
@@ -180,8 +202,45 @@ class MultiheadAttention(nn.Module):
         kwargs.pop("dropout", None)
         self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
         self.attn = nn.MultiheadAttention(embed_dims, num_heads, 0.0)   # parameter holder: in_proj_*, out_proj.*
+        self.precision = "bf16"
+        self._packed = None
         for p in self.parameters():
             p.requires_grad_(False)
+
+    @torch.no_grad()
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        """mmcv semantics (in-tree statement models/utils/petr_transformer.py:286-326): key/value default to query, identity to
+        query, key_pos to query_pos when shapes agree; positions are added to q and k only; out = identity + out_proj(attn).
+        One sample (the reference tests with B=1), no masks (inference)."""
+        _lib.require_device()
+        if attn_mask is not None or key_padding_mask is not None:
+            raise NotImplementedError("far3d_amd MultiheadAttention: masks are a training-time (denoising) feature")
+        key = query if key is None else key
+        value = key if value is None else value
+        identity = query if identity is None else identity
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        sq = (lambda t: t[0] if self.batch_first else t[:, 0])
+        if (query.shape[0] if self.batch_first else query.shape[1]) != 1:
+            raise NotImplementedError("far3d_amd MultiheadAttention runs one sample per call")
+        q = sq(query) + (sq(query_pos) if query_pos is not None else 0)
+        k = sq(key) + (sq(key_pos) if key_pos is not None else 0)
+        v, idn = sq(value), sq(identity).float().contiguous()
+        dev, E = q.device, self.embed_dims
+        dw = _engine.PRECISIONS[self.precision]["dec"]
+        ver = (int(self.attn.in_proj_weight._version), str(dev), self.precision)
+        if self._packed is None or self._packed[0] != ver:
+            w, b = self.attn.in_proj_weight.data, self.attn.in_proj_bias.data
+            pk = lambda ww, bb: ops.PackedConv(ww, bb, dtype=dw, device=dev)
+            self._packed = (ver, pk(w[:E], b[:E]), pk(w[E:2 * E], b[E:2 * E]), pk(w[2 * E:], b[2 * E:]),
+                            pk(self.attn.out_proj.weight.data, self.attn.out_proj.bias.data))
+        _, pq, pkk, pv, po = self._packed
+        cast = lambda t: t.to(dw).contiguous()
+        Q, K_, V = ops.linear(cast(q), pq, out_dtype=dw), ops.linear(cast(k), pkk, out_dtype=dw), ops.linear(cast(v), pv, out_dtype=dw)
+        att = ops.attention_forward(Q, K_, V, num_heads=self.num_heads, out_dtype=dw)
+        out = ops.linear(att, po, res=idn)
+        return out[None] if self.batch_first else out[:, None]
 
 
 # ------------------------------------------------------------------------------------------------ transformer containers
@@ -308,6 +367,22 @@ class FPN(_SchemaModule):
             spec["img_neck.fpn_convs.%d.conv.bias" % i] = (out_channels,)
         self._init_schema(spec)
 
+    @torch.no_grad()
+    def forward(self, inputs):
+        """inputs: the backbone's stage maps (NCHW, the first one is skipped by start_level=1) -> tuple of num_outs NCHW maps,
+        computed by the engine's FPN stage (laterals + fused nearest-upsample add + 3x3 output convs + stride-2 extra level)."""
+        _lib.require_device()
+        assert len(inputs) == len(self.in_channels)
+        dev = inputs[0].device
+        name = next(k for k, v in weights.VOV_SPECS.items() if tuple(v["stage_out_ch"]) == tuple(self.in_channels))
+        eng = self._part_engine(dev, ("neck",), _engine.default_cfg(backbone=name))
+        act = eng.prec["act"]
+        feats = [_to_nhwc(x, act) for x in inputs]
+        n = feats[0].shape[0]
+        one, zero = torch.ones(n, self.out_channels, device=dev), torch.zeros(n, self.out_channels, device=dev)
+        raw, _, _, _ = eng.fpn(feats, one, zero)
+        return tuple(_to_nchw(r) for r in raw)
+
 
 @HEADS.register_module()
 class YOLOXHeadCustom(_SchemaModule):
@@ -325,6 +400,65 @@ class YOLOXHeadCustom(_SchemaModule):
         full = weights.detector_spec(num_classes=num_classes, embed=in_channels, fpn_levels=len(strides),
                                      depth_bins=self.depthnet_config.get("num_depth_bins", 50))
         self._init_schema(full)
+
+    def _engine_for(self, dev):
+        cfg = _engine.default_cfg(num_classes=self.num_classes, strides=tuple(self.strides), score_thr=self.threshold_score,
+                                  proposal_topk=self.topk_proposal,
+                                  depthnet=dict(num_depth_bins=self.depthnet_config.get("num_depth_bins", 50),
+                                                depth_min=self.depthnet_config.get("depth_min", 0.1),
+                                                depth_max=self.depthnet_config.get("depth_max", 110.0),
+                                                stride=self.depthnet_config.get("stride", 8)))
+        return self._part_engine(dev, ("roi",), cfg)
+
+    @torch.no_grad()
+    def forward(self, locations, **data):
+        """ref yolox_head.py:260-341.  data['img_feats']: list of (B,N,C,h,w) FPN maps.  Returns the reference's dict
+        (enc_cls_scores / enc_bbox_preds / objectnesses / pred_centers2d_offset lists of (BN,c,h,w), depth_logit, pred_depth,
+        topk_indexes=None); the NHWC device maps the HIP proposal kernels consume ride along under '_far3d'."""
+        _lib.require_device()
+        feats = data["img_feats"]
+        dev = feats[0].device
+        eng = self._engine_for(dev)
+        raw = [_to_nhwc(f.flatten(0, 1), eng.prec["act"]) for f in feats]
+        ctr = []
+        cls, reg, depth_logit = eng.roi_head(raw, centers2d=ctr)
+        out = dict(enc_cls_scores=[_to_nchw(c) for c in cls], enc_bbox_preds=[_to_nchw(r[..., :4]) for r in reg],
+                   pred_centers2d_offset=[_to_nchw(c) for c in ctr], objectnesses=[_to_nchw(r[..., 4:5]) for r in reg],
+                   topk_indexes=None, depth_logit=_to_nchw(depth_logit))
+        out["pred_depth"] = out["depth_logit"].softmax(dim=1)
+        out["_far3d"] = dict(cls=cls, reg=reg, depth_logit=depth_logit)
+        return out
+
+    @torch.no_grad()
+    def get_bboxes(self, preds_dicts):
+        """ref yolox_head.py:355-489: peak test, score threshold, 2D box decode.  Returns bbox_list (per camera (M_i,4) cxcywh),
+        bbox2d_scores (M,1), valid_indices (BN,S,1) bool -- built from the device-side ordered selection."""
+        st = preds_dicts.get("_far3d")
+        if st is None:
+            raise NotImplementedError("YOLOXHeadCustom.get_bboxes needs the dict returned by this module's forward")
+        dev = st["cls"][0].device
+        eng = self._engine_for(dev)
+        cfg = eng.cfg
+        n = st["cls"][0].shape[0]
+        S = sum(c.shape[1] * c.shape[2] for c in st["cls"])
+        K = cfg["proposal_topk"]
+        cap = K if K is not None else S
+        wgt, sel_idx, sel_cnt = ops.proposal_select(st["cls"], st["reg"], cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
+        cnt = sel_cnt.cpu().tolist()
+        valid = torch.zeros((n, S, 1), dtype=torch.bool, device=dev)
+        for i in range(n):
+            valid[i, sel_idx[i, :cnt[i]].long(), 0] = True
+        # 2D boxes: the gather kernel decodes them (identity img2lidar / dummy tokens: only box2d and score are read here)
+        eye = torch.eye(4, device=dev)[None].repeat(n, 1, 1).contiguous()
+        tok = torch.zeros((n, S, cfg["embed_dims"]), device=dev)
+        _, _, box2d, score2d = ops.proposal_gather(st["reg"], cfg["strides"], sel_idx, sel_cnt, wgt, st["depth_logit"], cfg["depthnet"]["stride"],
+                                                   cfg["depthnet"], eye, tok, cfg["pc_range"], score_thr=0.1)
+        M = sum(cnt)
+        off = [0]
+        for c in cnt:
+            off.append(off[-1] + c)
+        st.update(sel_idx=sel_idx, sel_cnt=sel_cnt, peak_weight=wgt)
+        return dict(bbox_list=[box2d[off[i]:off[i + 1]] for i in range(n)], bbox2d_scores=score2d[:M, None], valid_indices=valid)
 
 
 @HEADS.register_module()
@@ -358,6 +492,79 @@ class FarHead(_SchemaModule):
             self.code_weights.fill_(1.0); self.match_costs.fill_(1.0)
         self.agg_cfg = dict(num_cams=agg.num_cams, num_groups=agg.num_groups, num_levels=agg.num_levels, num_pts=agg.num_pts,
                             num_heads=layer0.attentions[0].num_heads, ffn_dim=layer0.ffn_dim)
+
+    def engine_cfg(self, **over):
+        a = self.agg_cfg
+        cfg = dict(embed_dims=self.embed_dims, num_classes=self.num_classes, num_cams=a["num_cams"], num_query=self.num_query,
+                   num_propagated=self.num_propagated, memory_len=self.memory_len, topk_proposals=self.topk_proposals,
+                   num_layers=self.num_layers, num_heads=a["num_heads"], num_groups=a["num_groups"], num_levels=a["num_levels"],
+                   num_pts=a["num_pts"], ffn_dim=a["ffn_dim"], pc_range=list(self.bbox_coder.pc_range), code_size=self.code_size,
+                   max_num=self.bbox_coder.max_num,
+                   depthnet=dict(num_depth_bins=self.depthnet_config.get("num_depth_bins", 50), depth_min=self.depthnet_config.get("depth_min", 0.1),
+                                 depth_max=self.depthnet_config.get("depth_max", 110.0), stride=self.depthnet_config.get("stride", 8)))
+        cfg.update(over)
+        return _engine.default_cfg(**cfg)
+
+    def reset_memory(self):
+        if self._eng is not None:
+            self._eng.reset_memory()
+
+    @torch.no_grad()
+    def forward(self, img_metas, outs_roi=None, **data):
+        """ref farhead.py:533-693 (inference branch): data['img_feats'] list of (1,N,C,h,w) FPN maps, intrinsics / extrinsics /
+        lidar2img (1,N,4,4), ego_pose / ego_pose_inv (1,4,4), timestamp (1,), prev_exists (1,); outs_roi = the dict built by this
+        package's YOLOXHeadCustom forward + get_bboxes.  Returns all_cls_scores (layers,1,A,classes), all_bbox_preds
+        (layers,1,A,code) and dn_mask_dict=None like the reference; the streaming memory lives in the module's engine."""
+        _lib.require_device()
+        feats = data["img_feats"]
+        dev = feats[0].device
+        if outs_roi is None or "_far3d" not in outs_roi or "sel_idx" not in outs_roi["_far3d"]:
+            raise NotImplementedError("FarHead.forward needs outs_roi from far3d_amd's YOLOXHeadCustom (forward + get_bboxes): the "
+                                      "adaptive queries are built by the HIP proposal kernels from its device-side selection")
+        st = outs_roi["_far3d"]
+        eng = self._part_engine(dev, ("head",), self.engine_cfg(strides=tuple(2 ** (3 + i) for i in range(len(feats)))))
+        N = feats[0].shape[1]
+        E = self.embed_dims
+        f32 = lambda t: t.to(dev).float().contiguous()
+        dd = dict(lidar2img=f32(data["lidar2img"]), intrinsics=f32(data["intrinsics"]), extrinsics=f32(data["extrinsics"]),
+                  ego_pose=f32(data["ego_pose"]), ego_pose_inv=f32(data["ego_pose_inv"]), timestamp=data["timestamp"].to(dev).double().contiguous())
+        if "prev_exists" in data and float(data["prev_exists"].flatten()[0]) == 0.0:
+            eng.reset_memory()
+        # camera-aware MLN of every token (farhead.py:553-563) -> token-major value maps
+        img2lidar, c14 = ops.camera_prep(dd["lidar2img"][0], dd["intrinsics"][0], dd["extrinsics"][0])
+        hh = eng.sa["reduce"](c14, act="relu")
+        gamma, beta = eng.sa["gamma"](hh), eng.sa["beta"](hh)
+        hw = [(f.shape[3], f.shape[4]) for f in feats]
+        from ..synth import level_starts
+        starts, S = level_starts(hw)
+        tokens = torch.empty((N, S, E), dtype=torch.float32, device=dev)
+        for l, f in enumerate(feats):
+            x = f[0].float().permute(0, 2, 3, 1).contiguous()          # (N,h,w,C)
+            for n in range(N):
+                ops.row_affine_ln(x[n].view(-1, E), gamma[n:n + 1], beta[n:n + 1], do_ln=False,
+                                  out=tokens[n, starts[l]:starts[l] + hw[l][0] * hw[l][1]])
+        tokens = tokens.to(eng.prec["value"])
+        M = int(st["sel_cnt"].sum().item())
+        pr = ops.proposal_gather(st["reg"], eng.cfg["strides"], st["sel_idx"], st["sel_cnt"], st["peak_weight"], st["depth_logit"],
+                                 eng.cfg["depthnet"]["stride"], eng.cfg["depthnet"], img2lidar, tokens, eng.cfg["pc_range"], score_thr=0.1)
+        pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
+        outs = eng.head_stage(tokens, pr[0], pr[1], M, dd, img_metas, hw, starts, pad_hw)
+        self.last_outs = outs
+        return dict(all_cls_scores=outs["all_cls_scores"], all_bbox_preds=outs["all_bbox_preds"], dn_mask_dict=None,
+                    reference_points2d=pr[0][:M][None], _far3d_result=outs["result"])
+
+    @torch.no_grad()
+    def get_bboxes(self, preds_dicts, img_metas, rescale=False):
+        """ref farhead.py:1224-1245 -> [[boxes, scores, labels]] (boxes wrapped in img_metas[0]['box_type_3d'] when given)."""
+        r = preds_dicts.get("_far3d_result")
+        if r is None:
+            r = self._eng.decode(preds_dicts["all_cls_scores"], preds_dicts["all_bbox_preds"])
+        keep = r["keep"]
+        boxes, scores, labels = r["boxes_3d"][keep], r["scores_3d"][keep], r["labels_3d"][keep]
+        box_type = img_metas[0].get("box_type_3d")
+        if box_type is not None:
+            boxes = box_type(boxes, boxes.size(-1))
+        return [[boxes, scores, labels]]
 
 
 # ------------------------------------------------------------------------------------------------ detector
