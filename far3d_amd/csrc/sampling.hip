@@ -418,6 +418,78 @@ __device__ __forceinline__ void agg4_gather(const TV* __restrict__ feat, const i
   }
 }
 
+// Software-pipelined gather: batch k+1's row loads are issued before batch k is consumed, so a list of any length costs about
+// one memory round trip plus its FMA time (the plain loop above pays one round trip per batch).  bf16: UNR loads = 2*UNR rows.
+template <typename TV, int UNR>
+__device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const int* off_s, const float* wt_s, int cnt, int lane,
+                                            float (&acc)[8]) {
+  if (cnt <= 0) return;
+  if constexpr (sizeof(TV) == 2) {
+    typedef unsigned g4_u32x4 __attribute__((ext_vector_type(4)));
+    const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
+    const bf16_t* fb = reinterpret_cast<const bf16_t*>(feat) + l31 * 8;
+    g4_u32x4 va[UNR], vb[UNR];
+    float wa[UNR], wb[UNR];
+    auto issue = [&](int k0, g4_u32x4 (&v)[UNR], float (&w)[UNR]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        const int e = k0 + 2 * i + hi;
+        const bool ok = e < cnt;
+        v[i] = *reinterpret_cast<const g4_u32x4*>(fb + off_s[ok ? e : 0]);
+        w[i] = ok ? wt_s[e * 8 + g] : 0.f;
+      }
+    };
+    auto consume = [&](const g4_u32x4 (&v)[UNR], const float (&w)[UNR]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[2 * k] += w[i] * __uint_as_float(v[i][k] << 16);
+          acc[2 * k + 1] += w[i] * __uint_as_float(v[i][k] & 0xffff0000u);
+        }
+      }
+    };
+    issue(0, va, wa);
+    for (int k0 = 2 * UNR; ; k0 += 4 * UNR) {
+      if (k0 < cnt) issue(k0, vb, wb);
+      consume(va, wa);
+      if (k0 >= cnt) break;
+      if (k0 + 2 * UNR < cnt) issue(k0 + 2 * UNR, va, wa);
+      consume(vb, wb);
+      if (k0 + 2 * UNR >= cnt) break;
+    }
+  } else {
+    const int g = lane >> 3;
+    const float* fb = reinterpret_cast<const float*>(feat) + lane * 4;
+    float4 va[UNR], vb[UNR];
+    float wa[UNR], wb[UNR];
+    auto issue = [&](int k0, float4 (&v)[UNR], float (&w)[UNR]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        const int e = k0 + i;
+        const bool ok = e < cnt;
+        v[i] = *reinterpret_cast<const float4*>(fb + off_s[ok ? e : 0]);
+        w[i] = ok ? wt_s[e * 8 + g] : 0.f;
+      }
+    };
+    auto consume = [&](const float4 (&v)[UNR], const float (&w)[UNR]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        acc[0] += w[i] * v[i].x; acc[1] += w[i] * v[i].y; acc[2] += w[i] * v[i].z; acc[3] += w[i] * v[i].w;
+      }
+    };
+    issue(0, va, wa);
+    for (int k0 = UNR; ; k0 += 2 * UNR) {
+      if (k0 < cnt) issue(k0, vb, wb);
+      consume(va, wa);
+      if (k0 >= cnt) break;
+      if (k0 + UNR < cnt) issue(k0 + UNR, va, wa);
+      consume(vb, wb);
+      if (k0 + UNR >= cnt) break;
+    }
+  }
+}
+
 __device__ __forceinline__ int agg4_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // PT / LT: compile-time point / level counts (0 = take them from the launch parameters).  PT in [1,16] lays the projection
@@ -1044,7 +1116,7 @@ __global__ __launch_bounds__(256, 4) void aggregate_v6_kernel(const TV* __restri
 // fall back to per-corner entries), and invisible (camera, level) pairs cost nothing: the projection phase leaves a per-camera
 // level-visibility mask and the build loop walks its set bits.
 // ------------------------------------------------------------------------------------------
-#define AGG7_CAPW 64
+#define AGG7_CAPW 128     // list entries per wave between flushes (2 x 128 x 36 B; 7 workgroups of 22.1 KB fit a CU's 160 KB)
 
 template <typename TV, int PT>
 __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
@@ -1217,7 +1289,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
     const unsigned long long m = __ballot(hit);
     const int c = __popcll(m);
     if (cnt + c > AGG7_CAPW) {            // wave-uniform; the list is private to the wave (LDS is in order per wave)
-      agg4_gather<TV, 4>(feat, off_s, wt_s, cnt, lane, acc);
+      agg7_gather<TV, 4>(feat, off_s, wt_s, cnt, lane, acc);
       cnt = 0;
     }
     if (hit) {
@@ -1294,7 +1366,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
     }
   }
   AGG_TS(4);
-  agg4_gather<TV, (sizeof(TV) == 2 ? 16 : 8)>(feat, off_s, wt_s, cnt, lane, acc);
+  agg7_gather<TV, 4>(feat, off_s, wt_s, cnt, lane, acc);
   AGG_TS(5);
 #ifdef FAR3D_PROFILING
   if (g_agg_ts && lane == 0) g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 7] = cnt;

@@ -185,6 +185,8 @@ def init_state_dict(spec, seed=0, pc_range=(-152.4, -152.4, -5.0, 152.4, 152.4, 
             v = torch.rand(shape, generator=g) * 0.5 + 0.75
         elif len(shape) == 1 and leaf == "weight":           # BN / LN / GN scale
             v = torch.rand(shape, generator=g) * 0.5 + 0.75
+        elif leaf == "bias" and "learnable_fc" in k:
+            v = (torch.rand(shape, generator=g) * 2 - 1) * 2.0   # U(-2, 2) metres, see the weight branch below
         elif leaf == "bias" or leaf == "in_proj_bias":
             v = torch.randn(shape, generator=g) * 0.05
         else:                                                 # conv / linear weight
@@ -194,7 +196,10 @@ def init_state_dict(spec, seed=0, pc_range=(-152.4, -152.4, -5.0, 152.4, 152.4, 
             gain = 1.0 if ("attn" in k or "weights_fc" in k or "learnable_fc" in k or "branches" in k) else math.sqrt(2.0)
             v = torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
             if "learnable_fc" in k:
-                v = v * 4.0                                   # metres-scale key-point offsets
+                # the reference's own initialiser for the key-point offsets (detr3d_transformer.py:505,517-520): nn.Linear's
+                # default weight U(-1/sqrt(fan_in), 1/sqrt(fan_in)); the bias (below) U(-bias, bias) with bias = 2 m from the
+                # config (projects/configs/far3d.py:117-125).  Round 1 used N(0, 4/sqrt(fan_in)) weights, i.e. ~3x wider clouds.
+                v = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
             if k.startswith("img_neck."):
                 v = v * 0.5                                   # no ReLU/BN in the FPN: keep its outputs O(1)
             if "multi_level_conv_" in k:

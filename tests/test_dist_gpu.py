@@ -49,7 +49,7 @@ def _worker(rank, world, port, q, use_graph, frames):
 # 3 cameras on 2 ranks -> (2, 1 + padding slot).  use_graph: frame 0 runs eagerly, frame 1 captures the two per-rank hipGraphs,
 # frames 2-3 replay them (streaming memory updated in place).  FAR3D_TEST_RANKS=4 adds the idle-rank layout (1 camera each + a
 # rank with none: the 8-GPU / 7-camera case); it is off by default because four engine builds take minutes on the one-GPU box.
-_CASES = [(2, False, 2), (2, True, 4)] + ([(4, False, 2), (4, True, 3)] if os.environ.get("FAR3D_TEST_RANKS") == "4" else [])
+_CASES = [(2, False, 2), (2, True, 5)] + ([(4, False, 2), (4, True, 3)] if os.environ.get("FAR3D_TEST_RANKS") == "4" else [])
 
 
 @pytest.mark.parametrize("world,use_graph,frames", _CASES)
@@ -88,3 +88,57 @@ def test_sharded_frame_ranks_match_single_rank(hip_lib, world, use_graph, frames
     for fi in range(frames):
         for r in range(1, world):
             assert np.array_equal(res[0][fi][0], res[r][fi][0])
+
+
+def _nccl_worker(port, q):
+    import torch.distributed as dist
+    from far3d_amd import synth
+    from far3d_amd import dist as fdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng, rc = _build()
+        runner = fdist.ShardedFrame(eng, use_graph=True)
+        outs = []
+        for fi in range(4):
+            data, metas = synth.recipe_frame(rc, fi)
+            o = runner.forward_frame(data, metas)
+            outs.append(o["all_cls_scores"].cpu().numpy())
+        # the RCCL branch of gather_camera_major itself, into a persistent destination
+        t = torch.arange(24, dtype=torch.float32, device="cuda:0").view(2, 3, 4)
+        dst = torch.empty_like(t)
+        work, fn = fdist.gather_camera_major(t, 2, async_op=True, out=dst)
+        work.wait()
+        q.put((outs, bool(torch.equal(fn(), t)) and fn().data_ptr() == dst.data_ptr(), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_frame_over_rccl_world_of_one(hip_lib):
+    """The `nccl` (= RCCL) branch of the exchange executes for real: one rank, device-side all_gather_into_tensor into the
+    persistent head-input buffers, both per-rank hipGraphs captured while the RCCL watchdog thread is alive, a scene change in
+    the sequence.  Multi-rank RCCL over xGMI is the driver's 8-GPU run; 2-rank logic runs above over gloo."""
+    import torch.multiprocessing as mp
+    from far3d_amd import synth
+    eng, rc = _build()
+    want = []
+    for fi in range(4):
+        data, metas = synth.recipe_frame(rc, fi)
+        want.append(eng.forward_frame(data, metas)["all_cls_scores"].cpu().numpy())
+    del eng
+    torch.cuda.empty_cache()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    try:
+        outs, gather_ok, backend = q.get(timeout=300)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    assert backend == "nccl" and gather_ok
+    for fi in range(4):
+        assert np.array_equal(outs[fi], want[fi]), "frame %d: sharded-over-RCCL (world 1) differs from the plain engine" % fi

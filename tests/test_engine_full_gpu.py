@@ -171,10 +171,12 @@ def _pct(d):
 def test_fp32_engine_matches_oracle_at_full_size(hip_lib, oracle_run):
     """North-star tolerance 1e-3 on logits, at the benchmarked size, 3 streaming frames with ego motion.
 
-    At this size the reference arithmetic is not conditioned well enough for a blanket max-norm bound: the oracle itself, run in
-    fp32 and in fp64 on the same inputs, differs by up to ~2e-3 on a handful of logits (key points that project next to a
-    camera plane -- the reference has no behind-camera mask, detr3d_transformer.py:550 -- turn 1e-7 input noise into O(1)
-    sampling changes).  So the bar is stated against that yardstick:
+    With key-point offsets initialised like the reference does (weights.init_state_dict) every logit of all three frames is
+    within 1e-3 (asserted below).  The test additionally reports a yardstick that explains what happens when the computation is
+    conditioned worse (e.g. 3x wider key-point clouds, the round-1 weights: key points that project next to a camera plane --
+    the reference has no behind-camera mask, detr3d_transformer.py:550 -- turn 1e-7 input noise into O(1) sampling changes and
+    the oracle run in fp32 and in fp64 then differs by ~2e-3 itself): errors are also bounded relative to the oracle's own
+    fp32-vs-fp64 deviation:
       * the discrete decisions of the path (K-th 2D peak per camera, top-256 memory selection) are near-ties at rounding-noise
         level; the fixture lets the oracle adopt the device's choice after checking that it IS a near-tie (without that, frames
         1+ of the oracle in fp32 and in fp64 already disagree by O(1) on whole rows);
@@ -208,6 +210,8 @@ def test_fp32_engine_matches_oracle_at_full_size(hip_lib, oracle_run):
     for fi, rep in enumerate(report):
         assert rep["value_maps_rel_max"] < 2e-5 and all(rep["fpn%d_rel_max" % l] < 2e-5 for l in range(4)), rep
         e, nz = rep["logit_abs_err_vs_oracle32"], rep["oracle32_vs_oracle64"]
+        # the north-star bar itself, on every frame of the streaming sequence (observed max: 4e-5 / 3e-4 / 3e-4)
+        assert e["max"] < 1e-3, "frame %d: max abs logit error %.3e (north-star tolerance 1e-3); %s" % (fi, e["max"], e)
         if fi == 0:
             assert e["p999"] < 1e-3, (fi, e)
             assert rep["well_conditioned_fraction"] > 0.99 and rep["well_conditioned_max_err"] < 1e-3, (fi, rep["well_conditioned_fraction"], rep["well_conditioned_max_err"])
