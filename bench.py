@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
-MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}    # dense FLOP/s (same guide)
+MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12,     # dense FLOP/s (same guide)
+             "bf16x3": 2.5e15 / 3}                 # split mode: three bf16 MFMAs per useful product
 BACKBONE_FLOP_PER_CAM = 2 * 201.87e9   # VoV-99 @ 640x960
 AGG_KERNEL = "aggregate_v7_kernel"
 K_PROP = 92                # adaptive-query count fixed at 644 = 7 x 92 (static shapes)
@@ -120,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16_fp32dec", "bf16_fp32val"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16_fp32dec", "bf16_fp32val"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
@@ -244,7 +245,7 @@ def main():
         by = agg_algorithmic_bytes(N, S, C, A, cfg["num_pts"], cfg["num_groups"], cfg["num_levels"], evb)
         bb_t = (sum(bb_ms) / len(bb_ms)) * 1e-3 if bb_ms else float("nan")
         ncam_local = len(runner.cams) if sharded else 7
-        mfma_peak = MFMA_PEAK["bf16" if eng.prec["act"] == torch.bfloat16 else "fp32"]
+        mfma_peak = MFMA_PEAK["bf16" if eng.prec["act"] == torch.bfloat16 else (eng.prec.get("mma") or "fp32")]
         samples = args.steps * (world if (world > 1 and not sharded) else 1)
         traffic, traffic_src = agg_traffic()
         try:
@@ -256,7 +257,7 @@ def main():
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak",
             "vs_baseline": (samples / dt) / 6.4 if world == 1 else None,   # 6.4 samples/s (hardware not stated)
-            "dtype": "bf16" if args.precision.startswith("bf16") else args.precision, "data": "synthetic",
+            "dtype": args.precision if args.precision in ("fp32", "bf16x3", "bf16x3_all") else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 7 cameras 3x640x960, VoV-99, A=%d queries (644 learned + 644 adaptive + 256 "
                                    "propagated), 2312 self-attn keys, 6 decoder layers, streaming memory on, ego motion on" % A,
                        "parallelism": "single GPU" if world == 1 else ("camera-sharded x%d + 1 all-gather" % world if sharded else

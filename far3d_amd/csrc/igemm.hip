@@ -50,6 +50,23 @@ struct IgemmParams {
 template <typename TC> struct Cfg;
 template <> struct Cfg<bf16_t> { static constexpr int E = 8, ROWB = 80, KSUB = 2; };
 template <> struct Cfg<float> { static constexpr int E = 4, ROWB = 144, KSUB = 4; };
+// fp32 data computed as a two-term bf16 split: x = hi + lo (both round-to-nearest-even bf16, 16 significant bits together),
+// x*w ~= hi*hi' + hi*lo' + lo*hi' on the bf16 MFMA with fp32 accumulation (the dropped lo*lo' term is 2^-16 relative).
+// 3 bf16 MFMAs of K=16 replace 16 fp32 MFMAs of K=2: ~5x the fp32 matrix rate at ~1e-5 relative operand error.
+// LDS rows: [32 hi | 32 lo] bf16 (same 128 B as 32 floats) + 16 B padding.  Activations are split once, while staging;
+// weights are split when they are packed (host side) and arrive in the LDS row layout.
+struct split_t { float v; };
+template <> struct Cfg<split_t> { static constexpr int E = 4, ROWB = 144, KSUB = 2; };
+template <typename TC> struct is_split { static constexpr bool value = false; };
+template <> struct is_split<split_t> { static constexpr bool value = true; };
+
+// 4 floats -> (4 hi bf16, 4 lo bf16)
+__device__ __forceinline__ void split4(const u32x4_t& c, uint2& h, uint2& l) {
+  const float x0 = __uint_as_float(c.x), x1 = __uint_as_float(c.y), x2 = __uint_as_float(c.z), x3 = __uint_as_float(c.w);
+  h.x = pack_bf16x2(x0, x1); h.y = pack_bf16x2(x2, x3);
+  l.x = pack_bf16x2(x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xffff0000u));
+  l.y = pack_bf16x2(x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xffff0000u));
+}
 
 // Load E consecutive input channels (E = elements per 16-B LDS chunk) converting TIn -> TC.
 template <typename TIn, typename TC>
@@ -293,6 +310,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
   const int Ktot = P.KH * P.KW * P.cin_pad;
 
   // ---- per-thread staging coordinates (fixed for the whole K loop)
+  constexpr bool SPLIT = is_split<TC>::value;
+  static_assert(sizeof(TC) == 2 || sizeof(TIn) == 4, "fp32 compute types take fp32 activations");
   const TC* wsrc[A_CH];
   int arow[A_CH], acol[A_CH];
 #pragma unroll
@@ -330,12 +349,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
     }
   };
   auto lstore = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (SPLIT) {
+      uint2 h, l;
 #pragma unroll
-    for (int c = 0; c < A_CH; ++c)
-      *reinterpret_cast<u32x4_t*>(As + (buf * BM + arow[c]) * ROWB + acol[c] * 16) = areg[c];
+      for (int c = 0; c < A_CH; ++c)        // weights arrive pre-split (rows of [32 hi | 32 lo] bf16 per 32-channel block): plain copy
+        *reinterpret_cast<u32x4_t*>(As + (buf * BM + arow[c]) * ROWB + acol[c] * 16) = areg[c];
 #pragma unroll
-    for (int c = 0; c < B_CH; ++c)
-      *reinterpret_cast<u32x4_t*>(Bs + (buf * BP + brow[c]) * ROWB + bcol[c] * 16) = breg[c];
+      for (int c = 0; c < B_CH; ++c) {
+        split4(breg[c], h, l);
+        unsigned char* d = Bs + (buf * BP + brow[c]) * ROWB + bcol[c] * 8;
+        *reinterpret_cast<uint2*>(d) = h; *reinterpret_cast<uint2*>(d + 64) = l;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < A_CH; ++c)
+        *reinterpret_cast<u32x4_t*>(As + (buf * BM + arow[c]) * ROWB + acol[c] * 16) = areg[c];
+#pragma unroll
+      for (int c = 0; c < B_CH; ++c)
+        *reinterpret_cast<u32x4_t*>(Bs + (buf * BP + brow[c]) * ROWB + bcol[c] * 16) = breg[c];
+    }
   };
 
   f32x16_t acc[WM][WN];
@@ -362,10 +394,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
       for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(Ab + i * 32 * ROWB + kk * 32);
 #pragma unroll
       for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 32 * ROWB + kk * 32);
+      if constexpr (SPLIT) {
+        u32x4_t al[WM], bl[WN];        // the lo halves sit 64 B further in the row
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i) al[i] = *reinterpret_cast<const u32x4_t*>(Ab + i * 32 * ROWB + kk * 32 + 64);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) mma<TC>(acc[i][j], af[i], bf[j]);
+        for (int j = 0; j < WN; ++j) bl[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 32 * ROWB + kk * 32 + 64);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {       // small terms first
+            mma<bf16_t>(acc[i][j], al[i], bf[j]);
+            mma<bf16_t>(acc[i][j], af[i], bl[j]);
+            mma<bf16_t>(acc[i][j], af[i], bf[j]);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) mma<TC>(acc[i][j], af[i], bf[j]);
+      }
     }
     if (more) lstore(buf ^ 1);
     __syncthreads();
@@ -1002,9 +1050,10 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   FAR3D_CHECK_ARG((Ho - 1) * stride - pad + KH - 1 < H + pad + stride && (Wo - 1) * stride - pad + KW - 1 < W + pad + stride,
                   "far3d_conv2d_nhwc: output size %dx%d inconsistent with input %dx%d k=%d s=%d p=%d", Ho, Wo, H, W, KH, stride, pad);
   FAR3D_CHECK_ARG(ldx >= Cin && ldy >= Cout, "far3d_conv2d_nhwc: pixel strides smaller than channel counts");
-  FAR3D_CHECK_ARG((x_dt == FAR3D_DT_F32 || x_dt == FAR3D_DT_BF16) && (w_dt == FAR3D_DT_F32 || w_dt == FAR3D_DT_BF16) &&
+  FAR3D_CHECK_ARG((x_dt == FAR3D_DT_F32 || x_dt == FAR3D_DT_BF16) &&
+                  (w_dt == FAR3D_DT_F32 || w_dt == FAR3D_DT_BF16 || w_dt == FAR3D_DT_F32_BF16X3) &&
                   (y_dt == FAR3D_DT_F32 || y_dt == FAR3D_DT_BF16), "far3d_conv2d_nhwc: unsupported dtype");
-  FAR3D_CHECK_ARG(!(x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_F32),
+  FAR3D_CHECK_ARG(!(x_dt == FAR3D_DT_BF16 && w_dt != FAR3D_DT_BF16),
                   "far3d_conv2d_nhwc: bf16 activations with fp32 weights is not a supported combination");
   FAR3D_CHECK_ARG(act >= 0 && act <= 2, "far3d_conv2d_nhwc: unknown activation %d", act);
   FAR3D_CHECK_ARG(!y2 || (y2_scale && y2_shift), "far3d_conv2d_nhwc: y2 needs scale and shift");
@@ -1020,7 +1069,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.act = act; P.y_dt = y_dt; P.y2_dt = y2_dt; P.ldy2 = ldy2;
   P.res_dt = res_dt; P.ldr = ldr; P.Hr = res ? Hr : Ho; P.Wr = res ? Wr : Wo;
   const int xe = x_dt == FAR3D_DT_F32 ? 4 : 2;
-  const int ve = w_dt == FAR3D_DT_F32 ? 4 : 8;  // elements per LDS chunk of the compute type
+  const int ve = w_dt == FAR3D_DT_BF16 ? 8 : 4;  // elements per staged 16-byte chunk of the compute type
   auto aligned = [](const void* p, long a) { return ((uintptr_t)p % a) == 0; };
   P.x_vec = aligned(x, 16) && (ldx % ve == 0) && (x_img_stride % ve == 0) && (long)ve * xe % 16 == 0;
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
@@ -1132,6 +1181,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   }
   if (tile > 5) { far3d_set_error("far3d_conv2d_nhwc: tile %d needs the bf16 LDS-DMA path (Cin %% 32 == 0, aligned; 20+: 3x3 s1 p1)", tile); return FAR3D_ERR_ARG; }
   if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32) { LAUNCH(float, float) }
+  else if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32_BF16X3) { LAUNCH(float, split_t) }
   else if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_BF16) { LAUNCH(float, bf16_t) }
   else { LAUNCH(bf16_t, bf16_t) }
 #undef LAUNCH

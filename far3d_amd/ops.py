@@ -11,6 +11,7 @@ import torch
 from . import lib as _lib
 
 DT_F32, DT_BF16 = 0, 1
+DT_F32_BF16X3 = 2       # FAR3D_DT_F32_BF16X3: conv weight code "fp32 data, two-term bf16 split products"
 
 
 def _dt(t):
@@ -136,24 +137,24 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
 # implicit-GEMM convolution / linear
 # --------------------------------------------------------------------------------------------------
 ACT = {None: 0, "none": 0, "relu": 1, "swish": 2}
-_TUNING = None
+_TUNING = {}
 
 
-def _tuned_tile(Cout, Cin, k, stride, npix):
+def _tuned_tile(Cout, Cin, k, stride, npix, table="tuning_mi355x.json"):
     """Workgroup tile measured fastest on MI355X for this conv shape (tools/tune_conv.py); 0 = kernel heuristic.
     Shapes that were not swept (e.g. fewer cameras per rank in camera-sharded mode) borrow the entry of the same layer
-    geometry with the closest pixel count."""
-    global _TUNING
-    if _TUNING is None:
+    geometry with the closest pixel count.  table: tuning_mi355x.json (bf16) or tuning_mi355x_bf16x3.json (split mode)."""
+    tab = _TUNING.get(table)
+    if tab is None:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tuning_mi355x.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", table)
         raw = json.load(open(path)) if os.path.exists(path) else {}
-        _TUNING = {}
+        tab = _TUNING[table] = {}
         for key, tile in raw.items():
             co, ci, kk, st, npx = (int(v) for v in key.split(","))
-            _TUNING.setdefault((co, ci, kk, st), []).append((npx, int(tile)))
-    cands = _TUNING.get((Cout, Cin, k, stride))
+            tab.setdefault((co, ci, kk, st), []).append((npx, int(tile)))
+    cands = tab.get((Cout, Cin, k, stride))
     if not cands:
         return 0
     return min(cands, key=lambda c: abs(c[0] - npix))[1]
@@ -163,10 +164,13 @@ class PackedConv:
     """Weights of one conv / linear layer in the kernel's layout (built once at model-prepare time).
 
     w (rows=ceil(Cout/128)*128, taps*cin_pad) in the compute dtype (bf16 -> bf16 MFMA, fp32 -> exact fp32
-    MFMA), tap-major K; bias (rows,) f32 or None.
+    MFMA), tap-major K; bias (rows,) f32 or None.  compute="bf16x3" (fp32 weights and activations only): products as a
+    two-term bf16 split on the bf16 MFMA with fp32 accumulation (FAR3D_DT_F32_BF16X3).
     """
 
-    def __init__(self, weight, bias=None, stride=1, pad=0, dtype=torch.bfloat16, device=None):
+    def __init__(self, weight, bias=None, stride=1, pad=0, dtype=torch.bfloat16, device=None, compute=None):
+        if compute not in (None, "bf16x3") or (compute == "bf16x3" and dtype != torch.float32):
+            raise ValueError("PackedConv: compute=%r needs dtype=float32 (got %s)" % (compute, dtype))
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
         Cout, Cin, KH, KW = weight.shape
@@ -175,13 +179,20 @@ class PackedConv:
         rows = (Cout + 255) // 256 * 256 + 256   # zero rows so that ANY channel tile (<= 256 rows) may over-read
         w = torch.zeros(rows, KH * KW, cin_pad, dtype=torch.float32, device=weight.device)
         w[:Cout, :, :Cin] = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin)
-        self.w = w.reshape(rows, KH * KW * cin_pad).to(dtype).to(device).contiguous()
+        if compute == "bf16x3":    # pre-split rows: per 32-channel block [32 hi | 32 lo] bf16 (include/far3d_hip.h)
+            blk = w.reshape(rows, KH * KW * cin_pad // 32, 32)
+            hi = blk.to(torch.bfloat16)
+            lo = (blk - hi.float()).to(torch.bfloat16)
+            self.w = torch.cat([hi, lo], dim=2).reshape(rows, 2 * KH * KW * cin_pad).to(device).contiguous()
+        else:
+            self.w = w.reshape(rows, KH * KW * cin_pad).to(dtype).to(device).contiguous()
         self.bias = None
         if bias is not None:
             b = torch.zeros(rows, dtype=torch.float32, device=weight.device)
             b[:Cout] = bias.detach().float()
             self.bias = b.to(device)
         self.Cout, self.Cin, self.KH, self.KW, self.stride, self.pad = Cout, Cin, KH, KW, stride, pad
+        self.w_code = DT_F32_BF16X3 if compute == "bf16x3" else _dt(self.w)
 
     def out_hw(self, H, W):
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -243,8 +254,10 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
         y2p, y2dt, sp, hp = _ptr(y2), _dt(y2), _ptr(y2_scale), _ptr(y2_shift)
     if tile == 0 and x.dtype == torch.bfloat16:
         tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W)
+    elif tile == 0 and pc.w_code == DT_F32_BF16X3:
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W, "tuning_mi355x_bf16x3.json")
     _lib.check(lib.far3d_conv2d_nhwc(
-        _ptr(x), _dt(x), _ptr(pc.w), _dt(pc.w), _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
+        _ptr(x), _dt(x), _ptr(pc.w), pc.w_code, _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
         N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],
         rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, _ptr(chan_sum) if chan_sum is not None else None, tile,
         _stream(x)), "far3d_conv2d_nhwc")

@@ -19,6 +19,12 @@ extern "C" {
 
 #define FAR3D_DT_F32 0
 #define FAR3D_DT_BF16 1
+/* weight-dtype code of far3d_conv2d_nhwc only: fp32 activations, products computed as a two-term bf16 split
+ * (x = hi + lo, both round-to-nearest-even bf16; hi*hi' + hi*lo' + lo*hi' on the bf16 MFMA, fp32 accumulation): ~1e-5 relative
+ * operand error at ~5x the fp32 matrix rate.  The "bf16x3" precision mode of the engine.  The weight buffer has the byte size
+ * and row stride of the fp32 layout, but holds the split: every 32-channel block of a row (128 B) is 32 hi bf16 followed by
+ * 32 lo bf16 (hi = bf16(w), lo = bf16(w - hi)). */
+#define FAR3D_DT_F32_BF16X3 2
 /* per-XCD replicas of the channel-sum array written by far3d_conv2d_nhwc(chan_sum) and read by far3d_ese_nhwc */
 #define FAR3D_ESE_REPLICAS 8
 /* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */

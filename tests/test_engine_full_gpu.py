@@ -14,6 +14,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F  # noqa: F401
 
 from far3d_amd import synth, weights
 from tests.conftest import ROOT, assert_detections_match
@@ -28,24 +29,46 @@ def _frames(device="cpu"):
     return [synth.make_frame(7, (640, 960), seed=0, frame_index=fi, device=device, ego_motion=True) for fi in range(FRAMES)]
 
 
-def _resolve_topk_ties(sel, tag):
-    """The static top-K proposal mode picks the K best 2D peaks per camera; a K-th / (K+1)-th pair closer than fp32 rounding
-    noise can come out either way.  Returns a callback for the oracle: it checks that the device's set differs from the oracle's
-    own only by such near-ties and then selects exactly the device's peaks (so that the frames stay comparable row by row)."""
+LEVEL_HW = [(80, 120), (40, 60), (20, 30), (10, 15)]      # 640x960 at strides 8, 16, 32, 64
+
+
+def _neighbour_max(raw):
+    """(N,S) -> (N,S): the largest score among the 8 neighbours of every cell (per pyramid level, borders clipped)."""
+    out, st = [], 0
+    for h, w in LEVEL_HW:
+        seg = F.pad(raw[:, st:st + h * w].view(-1, h, w), (1, 1, 1, 1), value=-1.0)
+        shifts = [seg[:, 1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dy, dx) != (0, 0)]
+        out.append(torch.stack(shifts).max(dim=0).values.reshape(-1, h * w))
+        st += h * w
+    return torch.cat(out, dim=1)
+
+
+def _resolve_topk_ties(sel, tag, tol=2e-5):
+    """The static top-K proposal mode keeps the K best 2D peaks per camera (peak: score == maxpool3x3(score)); both the peak test
+    and the K-th place are decisions on near-equal numbers that rounding noise can turn either way -- and one flipped peak test
+    shifts the K-th place by a whole rank.  Returns a callback for the oracle: it checks that the device's set D is one the
+    oracle's own scores allow when relative differences below `tol` may go either way, and then selects exactly D so that the
+    frames stay comparable row by row.  In the oracle's scores a cell is a ROBUST peak if it exceeds its 8 neighbours by more
+    than tol, a NON-peak if it is below their maximum by more than tol, FRAGILE otherwise.  D is allowed iff
+      * |D| = K and D contains no non-peak;
+      * every robust peak outside D scores no higher than the lowest score in D (up to tol)."""
     def pick(own):
         raw = own["raw_weight"][..., 0]                      # (N,S) score before the 3x3 peak test
+        N = raw.shape[0]
+        assert raw.shape[1] == sum(h * w for h, w in LEVEL_HW)
+        nb = _neighbour_max(raw)
+        robust, nonpeak = raw > (1 + tol) * nb, raw < (1 - tol) * nb
         mask = torch.zeros_like(own["valid_indices"])
         for n, i in sel:
             mask[n, i, 0] = True
-        mine, theirs = (mask & ~own["valid_indices"])[..., 0], (~mask & own["valid_indices"])[..., 0]
-        for n in range(raw.shape[0]):
-            a, b = raw[n][mine[n]], raw[n][theirs[n]]
-            assert a.numel() == b.numel(), "%s camera %d: %d vs %d peaks" % (tag, n, a.numel(), b.numel())
-            if a.numel():
-                # every peak only the device picked pairs with one only the oracle picked: either two neighbours that tie in
-                # the `score == maxpool3x3(score)` test, or the K-th / (K+1)-th place -- equal scores up to rounding noise
-                gap = ((a.sort().values - b.sort().values).abs() / b.sort().values).max().item()
-                assert gap < 2e-5, "%s camera %d: proposal sets differ beyond a near-tie (relative gap %.2e)" % (tag, n, gap)
+        D = mask[..., 0]
+        for n in range(N):
+            assert int(D[n].sum()) == int(own["valid_indices"][n].sum()), "%s camera %d: %d peaks" % (tag, n, int(D[n].sum()))
+            bad = (D[n] & nonpeak[n]).nonzero().flatten().tolist()
+            assert not bad, "%s camera %d: the device selected cells %s that are not peaks (beyond a relative %.0e)" % (tag, n, bad, tol)
+            low = raw[n][D[n]].min().item()
+            miss = (robust[n] & ~D[n] & (raw[n] > (1 + tol) * low)).nonzero().flatten().tolist()
+            assert not miss, "%s camera %d: the device skipped robust peaks %s that outscore its lowest pick %.6f" % (tag, n, miss, low)
         return mask
     return pick
 
@@ -69,14 +92,9 @@ def _resolve_memory_ties(idx_dev, tag, tol=1e-2):
     return pick
 
 
-@pytest.fixture(scope="module")
-def oracle_run(hip_lib):
-    """The fp32 engine on 3 streaming frames, then the oracle in fp32 AND fp64 on the same frames (~15-25 s per fp32 frame on
-    the box's host cores).  The fp64 run is the yardstick for the fp32 rounding noise of the reference arithmetic itself."""
-    from oracle import far3d_oracle
-    torch.set_num_threads(min(64, os.cpu_count() or 1))
-    sd = weights.init_state_dict(weights.detector_spec("V-99-eSE"), seed=0)
-    eng = _engine(sd, "fp32")
+def _run_engine(sd, precision):
+    """3 streaming frames through the engine; everything the comparisons need, on the host."""
+    eng = _engine(sd, precision)
     got = []
     for data, metas in _frames():
         o = eng.forward_frame(data, metas)
@@ -89,22 +107,40 @@ def oracle_run(hip_lib):
                         result={k: v.cpu().clone() for k, v in o["result"].items()}))
     del eng
     torch.cuda.empty_cache()
+    return got
+
+
+def _run_oracle(sd, got, with_f64, tie_tol=2e-5):
+    """The oracle on the same frames, adopting the device's near-tie decisions (checked to BE near-ties: 2D scores within a
+    relative `tie_tol`, the rounding-noise level of the mode under test)."""
+    from oracle import far3d_oracle
     keep = lambda o: dict(logits=o["all_cls_scores"].clone(), boxes=o["all_bbox_preds"].clone(), outs_dec=o["outs_dec"].clone(),
                           feat_flatten=o["feat_flatten"].clone(), fpn=[f.clone() for f in o["feat_levels"]],
                           valid=o["roi"]["valid_indices"].clone(), ref=o["reference_points"].clone(),
                           result={k: v.clone() for k, v in o["result"].items()})
     orc = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K))
-    o64 = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K), dtype=torch.float64)
+    o64 = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K), dtype=torch.float64) if with_f64 else None
     outs = []
     with torch.no_grad():
         for fi, (data, metas) in enumerate(_frames()):
-            w = keep(orc.simple_test(data, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d" % fi),
+            w = keep(orc.simple_test(data, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d" % fi, tie_tol),
                                      forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d" % fi)))
-            d64 = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
-            w["f64"] = keep(o64.simple_test(d64, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d (fp64)" % fi),
-                                            forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d (fp64)" % fi)))
+            if with_f64:
+                d64 = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
+                w["f64"] = keep(o64.simple_test(d64, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d (fp64)" % fi, tie_tol),
+                                                forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d (fp64)" % fi)))
             outs.append(w)
-    return sd, outs, got
+    return outs
+
+
+@pytest.fixture(scope="module")
+def oracle_run(hip_lib):
+    """The fp32 engine on 3 streaming frames, then the oracle in fp32 AND fp64 on the same frames (~15-25 s per fp32 frame on
+    the box's host cores).  The fp64 run is the yardstick for the fp32 rounding noise of the reference arithmetic itself."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    sd = weights.init_state_dict(weights.detector_spec("V-99-eSE"), seed=0)
+    got = _run_engine(sd, "fp32")
+    return sd, _run_oracle(sd, got, with_f64=True), got
 
 
 def _engine(sd, precision, use_graph=False):
@@ -230,6 +266,49 @@ def test_fp32_engine_matches_oracle_at_full_size(hip_lib, oracle_run):
         assert_detections_match(tuple(r[k].numpy()[keep] for k in ("labels_3d", "boxes_3d", "scores_3d")),
                                 tuple(want[fi]["result"][k].numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi,
                                 score_tol=tol, box_tol=100 * tol)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_all"])
+def test_split_bf16_modes_against_the_logit_tolerance(hip_lib, oracle_run, precision):
+    """The split-bf16 modes (fp32 data; conv products -- and in bf16x3_all also the decoder GEMMs -- as hi*hi' + hi*lo' + lo*hi'
+    on the bf16 MFMA with fp32 accumulation; far3d_hip.h FAR3D_DT_F32_BF16X3) against the oracle at the benchmarked size.
+
+    What holds (asserted): on a single frame (frame 0, what the north star describes) EVERY logit is within 2e-4, five times
+    inside the 1e-3 bar.  On the streaming frames the propagated queries feed each frame's rounding noise into the next one; the
+    reference arithmetic itself (oracle fp32 vs fp64) disagrees by 4.6e-4 there, the exact-fp32 engine by 3e-4, and the split
+    modes stay within 1e-3 at the 99.9th percentile with the worst logits at 1-2e-3 (asserted: < 4e-3), i.e. 2-4x the
+    reference's own rounding ambiguity.  Where the near-tie decisions (K-th 2D peak, memory top-256 cut) coincide with the fp32
+    engine's, the fixture's oracle run is reused; otherwise the oracle is run again on this engine's decisions."""
+    sd, want, got32 = oracle_run
+    got = _run_engine(sd, precision)
+    same = all(sorted(got[fi]["sel"]) == sorted(got32[fi]["sel"]) and torch.equal(got[fi]["memory_topk"], got32[fi]["memory_topk"])
+               for fi in range(FRAMES))
+    if not same:
+        want = _run_oracle(sd, got, with_f64=False, tie_tol=5e-4)     # 2D scores carry ~2e-5 mean / 2e-4 max relative noise in this mode
+    report = []
+    for fi in range(FRAMES):
+        o, w = got[fi], want[fi]
+        rep = _stage_errors(o, w)
+        rep.update(frame=fi, precision=precision, decisions_equal_fp32_engine=same,
+                   logit_abs_err_vs_oracle32=_pct((o["all_cls_scores"] - w["logits"]).abs()),
+                   logit_abs_diff_vs_fp32_engine=_pct((o["all_cls_scores"] - got32[fi]["all_cls_scores"]).abs()) if same else None)
+        report.append(rep)
+        print("\n%s engine vs oracle, frame %d: %s" % (precision, fi, json.dumps(rep)))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_full_%s.json" % precision), "w") as f:
+        json.dump(report, f, indent=1)
+    for fi, rep in enumerate(report):
+        assert rep["value_maps_rel_max"] < 2e-4 and all(rep["fpn%d_rel_max" % l] < 2e-4 for l in range(4)), rep
+        e = rep["logit_abs_err_vs_oracle32"]
+        if fi == 0:
+            assert e["max"] < 2e-4, "frame 0: max abs logit error %.3e; %s" % (e["max"], e)
+        else:
+            assert e["p999"] < 1e-3 and e["max"] < 4e-3, "frame %d: %s" % (fi, e)
+        r = got[fi]["result"]
+        keep = r["keep"].numpy()
+        assert_detections_match(tuple(r[k].numpy()[keep] for k in ("labels_3d", "boxes_3d", "scores_3d")),
+                                tuple(want[fi]["result"][k].numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi,
+                                score_tol=1e-2, box_tol=1.0)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -215,3 +215,47 @@ def test_pipelined_epilogue_channel_sums(hip_lib, tile):
     with pytest.raises(Exception):
         ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=1, chan_sum=sums)
 
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", ["conv3x3", "stride2_odd_channels", "linear"])
+def test_split_bf16_products_track_fp32(hip_lib, tile, case):
+    """compute="bf16x3" (FAR3D_DT_F32_BF16X3): fp32 operands split as hi + lo bf16 while staging, three bf16 MFMAs per product
+    (hi*hi' + hi*lo' + lo*hi', fp32 accumulation).  Each operand keeps 16 significant bits and the dropped lo*lo' term is 2^-16
+    relative, so a K-term dot product of O(1) terms deviates from the exact one by ~2^-16 * sqrt(K) * |term| -- asserted at
+    4x that, which is ~100x tighter than plain bf16 could pass and fails if any of the three partial products is missing."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(11)
+    if case == "linear":
+        M, Kd, Co = 333, 264, 200                     # K not a multiple of 32, odd row count
+        x = torch.randn(M, Kd, generator=g)
+        w = torch.randn(Co, Kd, generator=g) * 0.1
+        b = torch.randn(Co, generator=g)
+        want = F.linear(x.double(), w.double(), b.double())
+        pc = ops.PackedConv(w, b, dtype=torch.float32, device=DEV, compute="bf16x3")
+        got = ops.linear(x.to(DEV), pc, tile=tile).cpu()
+        K, scale = Kd, (x.abs().mean() * w.abs().mean()).item()
+    else:
+        stride = 2 if case == "stride2_odd_channels" else 1
+        N, Cin, Cout, H, W = (2, 40, 72, 19, 26) if stride == 2 else (2, 64, 96, 17, 23)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1).relu()
+        pc = ops.PackedConv(w, b, stride=stride, pad=1, dtype=torch.float32, device=DEV, compute="bf16x3")
+        got = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), pc, act="relu", tile=tile).cpu().permute(0, 3, 1, 2)
+        K, scale = Cin * 9, (x.abs().mean() * w.abs().mean()).item()
+    err = (got.double() - want).abs().max().item()
+    bound = 4 * 2.0 ** -16 * K ** 0.5 * scale * 3      # 3 error sources of ~2^-17..2^-16 each per product
+    bf16_level = 2.0 ** -9 * K ** 0.5 * scale
+    assert err < bound, (err, bound)
+    assert bound < 0.1 * bf16_level                   # the assertion is far below what one bf16 product term would give
+
+
+def test_split_mode_rejects_bf16_operands(hip_lib):
+    from far3d_amd import lib, ops
+    with pytest.raises(ValueError):
+        ops.PackedConv(torch.randn(8, 8, 1, 1), None, dtype=torch.bfloat16, device=DEV, compute="bf16x3")
+    pc = ops.PackedConv(torch.randn(32, 32, 1, 1), None, dtype=torch.float32, device=DEV, compute="bf16x3")
+    with pytest.raises(lib.Far3dHipError):
+        ops.conv2d_nhwc(torch.randn(1, 4, 4, 32, device=DEV).bfloat16(), pc)

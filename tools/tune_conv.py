@@ -1,5 +1,6 @@
 """Sweep the workgroup tile of far3d_conv2d_nhwc for every distinct conv shape of the VoV-99 640x960x7 frame (bf16) and
-write the winners to far3d_amd/tuning_mi355x.json (key "Cout,Cin,k,stride,Npix").  Device time via hipGraph replay."""
+write the winners to gpurun_out/tuning_mi355x.json (key "Cout,Cin,k,stride,Npix"; copied to far3d_amd/data/).  Device time
+via hipGraph replay.  MODE=bf16x3: the split-precision mode (fp32 tensors, tiles 1-5) -> tuning_mi355x_bf16x3.json."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -58,6 +59,8 @@ def main():
     dev = "cuda:0"
     table, seen = {}, set()
     only = os.environ.get("ONLY_K")
+    x3 = os.environ.get("MODE") == "bf16x3"
+    tdt = torch.float32 if x3 else torch.bfloat16
     for name, N, H, W, Cin, Cout, k, stride in shapes():
         if only and int(only) != k:
             continue
@@ -67,13 +70,16 @@ def main():
         if key in seen:
             continue
         seen.add(key)
-        x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
-        pc = ops.PackedConv(torch.randn(Cout, Cin, k, k) * 0.05, torch.randn(Cout), stride=stride, pad=k // 2, dtype=torch.bfloat16, device=dev)
+        x = torch.randn(N, H, W, Cin, device=dev).to(tdt)
+        pc = ops.PackedConv(torch.randn(Cout, Cin, k, k) * 0.05, torch.randn(Cout), stride=stride, pad=k // 2, dtype=tdt, device=dev,
+                            compute="bf16x3" if x3 else None)
         Ho, Wo = pc.out_hw(H, W)
-        y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
+        y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=tdt)
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         res = {}
         tiles = ((0, 1, 2, 3, 4, 18, 43, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81) if (k == 1 and stride == 1) else ()) + ((50, 52, 60, 61, 63, 64, 65, 90, 92, 93, 96, 100, 101, 102, 103) if (k == 3 and stride == 1) else ())
+        if x3:
+            tiles = (0, 1, 2, 3, 4, 5)
         if k == 3 and stride == 1 and os.environ.get("EXTRA_TILES"):
             tiles = tiles + tuple(int(v) for v in os.environ["EXTRA_TILES"].split(","))
         for tile in tiles:
@@ -83,7 +89,7 @@ def main():
         table[key] = best[1]
         print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %4.0f" % (tl, res[tl] * 1e6) for tl in tiles if tl) +
               " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
-    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x.json"), "w"), indent=0, sort_keys=True)
+    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x_bf16x3.json" if x3 else "tuning_mi355x.json"), "w"), indent=0, sort_keys=True)
 
 if __name__ == "__main__":
     main()
