@@ -252,6 +252,7 @@ def main():
             commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
         except Exception:   # noqa: BLE001
             commit = None
+        commit = commit or os.environ.get("FAR3D_COMMIT")     # the GPU box gets a snapshot without .git
         line = {
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -13,7 +13,6 @@
 #define FAR3D_DT_F32 0
 #define FAR3D_DT_BF16 1
 #define FAR3D_DT_F32_BF16X3 2   // far3d_conv2d_nhwc weight code: fp32 data, two-term bf16 split products (include/far3d_hip.h)
-#define FAR3D_ESE_REPLICAS 8   // mirrors include/far3d_hip.h: per-XCD replicas of the fused eSE channel sums
 #define FAR3D_SUMS_MAX_PARTS 32
 
 void far3d_set_error(const char* fmt, ...);

@@ -25,7 +25,6 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define ACT_RELU 1
 #define ACT_SWISH 2
 
-#define FAR3D_SUM_REPLICAS FAR3D_ESE_REPLICAS   // = XCDs of an MI355X; see epilogue_rows16
 struct IgemmParams {
   const void* x;        // input activations (TIn), NHWC with pixel stride ldx, channel offset pre-applied
   const void* w;        // packed weights (TC) [Cout_pad][taps][cin_pad]
@@ -43,7 +42,6 @@ struct IgemmParams {
   int act, y_dt, y2_dt, ldy2;
   int res_dt, ldr, Hr, Wr;
   int x_vec, y_vec, y2_vec, res_vec;
-  float* chan_sum;      // optional [N][Cout][2] f32: [n][m][0] += sum over pixels of the stored y (rows16 epilogue only)
   int y_rows16;         // plain bf16 output whose pixel rows take 16-byte stores (LDS-transposed coalesced epilogue)
 };
 
@@ -214,9 +212,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&
 // that cover whole pixel rows (the MFMA layout alone gives 8-byte pieces 2*ldy bytes apart).  pix_off(pl) -> element
 // offset of local pixel pl in y, or -1.  smem must hold BPX * (2*BM + 16) bytes and is free once every wave has passed
 // the first barrier.
-template <int NW, int WM, int WN, int BM, int BPX, typename PixFn, typename ImgFn>
+template <int NW, int WM, int WN, int BM, int BPX, typename PixFn>
 __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned char* smem, f32x16_t (&acc)[WM][WN], int m0,
-                                                int wm, int wn, int l31, int hi, PixFn pix_off, ImgFn img_of) {
+                                                int wm, int wn, int l31, int hi, PixFn pix_off) {
   constexpr int RS = BM * 2 + 16, CPP = BM / 8, NT = 64 * NW;
   __syncthreads();
 #pragma unroll
@@ -253,40 +251,6 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
     const long off = pix_off(pl);
     if (off < 0) continue;
     *reinterpret_cast<u32x4_t*>(y + off + m0 + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
-  }
-  if (P.chan_sum) {
-    // per-image channel sums of the tile (eSE average pool, models/backbones/vovnet.py:95-101) from the staged bf16 values:
-    // thread = (channel pair, pixel phase); img_of(pl) -> image of local pixel pl or -1.
-    // Accumulation target: replica [xcc][n][c][2] where xcc = the XCD this workgroup runs on (hardware XCC_ID register), so
-    // every writer of a replica shares ONE L2 and the adds can be L2-local (workgroup-scope: no sc1, not sent to the
-    // memory side like an agent-scope atomic, which is what made a single shared array slower than a separate pooling
-    // kernel).  The kernel-end writeback publishes the replicas; the eSE gate kernel adds the FAR3D_SUM_REPLICAS copies.
-    constexpr int CP = BM / 2, G = NT / CP > 0 ? NT / CP : 1;
-    const int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & (FAR3D_SUM_REPLICAS - 1);   // HW_REG_XCC_ID[3:0]
-    float* rep = P.chan_sum + (long)xcc * P.N * P.Cout * 2;
-    const int cp = threadIdx.x % CP, ph = threadIdx.x / CP;
-    if (ph < G && m0 + 2 * cp < P.Cout) {
-      int cur = -1;
-      float s0 = 0.f, s1 = 0.f;
-      for (int pl = ph; pl < BPX; pl += G) {
-        const int n = img_of(pl);
-        if (n != cur) {
-          if (cur >= 0) {
-            __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          cur = n; s0 = 0.f; s1 = 0.f;
-        }
-        if (n >= 0) {
-          const unsigned u = *reinterpret_cast<const unsigned*>(smem + pl * RS + cp * 4);
-          s0 += __uint_as_float(u << 16); s1 += __uint_as_float(u & 0xffff0000u);
-        }
-      }
-      if (cur >= 0) {
-        __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp) * 2, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(rep + ((long)cur * P.Cout + m0 + 2 * cp + 1) * 2, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
   }
 }
 
@@ -577,7 +541,7 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
   constexpr size_t lds = (size_t)NS * KPS * (BM + BP) * 64;
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), grid, dim3(256), lds, st, P);
@@ -822,7 +786,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     epilogue_rows16<NW, WM, WN, BM, TH * 32>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
       return (y < P.H && x < P.W) ? (long)n * P.y_img_stride + ((long)y * P.W + x) * P.ldy : -1L;
-    }, [&](int pl) -> int { return (y0 + (pl >> 5) < P.H && x0 + (pl & 31) < P.W) ? n : -1; });
+    });
     return;
   }
   int pn[WN], ppix[WN];
@@ -1007,11 +971,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
       if (p >= Npix) return -1L;
       const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
-    }, [&, n0 = (int)((long)p0 / HoWo)](int pl) -> int {
-      const long p = (long)p0 + pl;
-      if (p >= Npix) return -1;
-      const long nb = (long)(n0 + 1) * HoWo;          // first pixel of the next image
-      return p < nb ? n0 : n0 + 1 + (int)((p - nb) / HoWo);
     });
     return;
   }
@@ -1042,7 +1001,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
                                  int Wo, int Cout, int ldy, long y_img_stride, int KH, int KW, int stride,
                                  int pad, int act, const void* res, int res_dt, int ldr, long res_img_stride,
                                  int Hr, int Wr, void* y2, int y2_dt, int ldy2, long y2_img_stride,
-                                 const float* y2_scale, const float* y2_shift, float* chan_sum, int tile, void* stream) {
+                                 const float* y2_scale, const float* y2_shift, int tile, void* stream) {
   FAR3D_CHECK_ARG(x && w && y, "far3d_conv2d_nhwc: null x/w/y");
   FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0,
                   "far3d_conv2d_nhwc: bad sizes N=%d H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d", N, H, W, Cin, Ho, Wo, Cout);
@@ -1074,7 +1033,6 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.x_vec = aligned(x, 16) && (ldx % ve == 0) && (x_img_stride % ve == 0) && (long)ve * xe % 16 == 0;
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
-  P.chan_sum = chan_sum;
   P.y_rows16 = y_dt == FAR3D_DT_BF16 && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   const long Npix = (long)N * Ho * Wo;
@@ -1085,10 +1043,6 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     else if (big >= 512) tile = 1;
     else if (((Npix + 63) / 64) * ((Cout + 127) / 128) >= 512) tile = 4;
     else tile = 3;
-  }
-  if (chan_sum && !(P.y_rows16 && tile >= 50 && x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && (Cin % 32) == 0 && P.x_vec)) {
-    far3d_set_error("far3d_conv2d_nhwc: chan_sum needs a pipelined tile (>= 50) with a plain, 16-byte-row bf16 output");
-    return FAR3D_ERR_ARG;
   }
 #define LAUNCH(TIN, TCC)                                                        \
   switch (tile) {                                                               \

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// v4 of the fused aggregation: ONE WAVE PER QUERY, no block-wide phases, taps merged per token row without atomics.
+// Tap-merging aggregation (default kernel, `aggregate_v7_kernel`): two waves per query, no atomics.
 //
 // Why: the v3 counters (profiles/r1) showed no HBM over-fetch at all -- the kernel sat on (i) ~11 us of block-wide fixed
 // phases (3 barriers per query for the scan / softmax statistics) and (ii) L2 -> CU gather volume: every visible sample moved
@@ -364,62 +364,17 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
 // accumulates W[T][g] = sum_p softmax_w[p][g] * tent(p, T) in registers: dense, branch-free, no sort, no atomics.  Tokens with
 // a non-zero weight are appended (ballot + mbcnt) to a per-wave LDS list of {row offset, 8 group weights}; a (camera, level)
 // whose points spread wider falls back to one list entry per (point, corner).  The gather then walks the list: one 16-byte
-// load per lane = two 512-byte bf16 token rows per instruction (one 1-KiB fp32 row), 8 (4) channels per lane, UNR loads in
-// flight.  Same arithmetic as the reference up to fp32 re-association.
+// load per lane = two 512-byte bf16 token rows per instruction (one 1-KiB fp32 row), 8 (4) channels per lane, several loads in
+// flight.  Same arithmetic as the reference up to fp32 re-association.  The softmax normaliser 1/S[g] is applied ONCE to the
+// final sums (every merged weight of group g carries it), so the weights are stored un-normalised.
+//
+// Two earlier shapes of the same algorithm were measured and removed (git history has them): one wave per query
+// (2990 VALU instructions per query but 53 % of the wave cycles in s_waitcnt at ~1.5 waves per SIMD: 28 us vs 22 us for v3) and
+// four waves per query with wave = camera (82 VGPRs -> 5 workgroups per CU, a second round of workgroups, one wave building a
+// visible camera for ~20k cycles while three wait: 26 us).
 // ------------------------------------------------------------------------------------------
-#define AGG4_CAP 192     // list entries per flush
-#define AGG4_UNR 8       // row loads in flight per lane in the gather (16 bf16 rows / 8 fp32 rows per batch)
 #define AGG4_MAX_N 16
 
-template <typename TV, int UNR = AGG4_UNR>
-__device__ __forceinline__ void agg4_gather(const TV* __restrict__ feat, const int* off_s, const float* wt_s, int cnt, int lane,
-                                            float (&acc)[8]) {
-  if constexpr (sizeof(TV) == 2) {
-    typedef unsigned g4_u32x4 __attribute__((ext_vector_type(4)));
-    const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
-    const bf16_t* fb = reinterpret_cast<const bf16_t*>(feat) + l31 * 8;
-    for (int k0 = 0; k0 < cnt; k0 += 2 * UNR) {
-      g4_u32x4 v[UNR];
-      float w[UNR];
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        const int e = k0 + 2 * i + hi;
-        const bool ok = e < cnt;
-        v[i] = *reinterpret_cast<const g4_u32x4*>(fb + off_s[ok ? e : 0]);
-        w[i] = ok ? wt_s[e * 8 + g] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          acc[2 * k] += w[i] * __uint_as_float(v[i][k] << 16);
-          acc[2 * k + 1] += w[i] * __uint_as_float(v[i][k] & 0xffff0000u);
-        }
-      }
-    }
-  } else {
-    const int g = lane >> 3;
-    const float* fb = reinterpret_cast<const float*>(feat) + lane * 4;
-    for (int k0 = 0; k0 < cnt; k0 += UNR) {
-      float4 v[UNR];
-      float w[UNR];
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        const int e = k0 + i;
-        const bool ok = e < cnt;
-        v[i] = *reinterpret_cast<const float4*>(fb + off_s[ok ? e : 0]);
-        w[i] = ok ? wt_s[e * 8 + g] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        acc[0] += w[i] * v[i].x; acc[1] += w[i] * v[i].y; acc[2] += w[i] * v[i].z; acc[3] += w[i] * v[i].w;
-      }
-    }
-  }
-}
-
-// Software-pipelined gather: batch k+1's row loads are issued before batch k is consumed, so a list of any length costs about
-// one memory round trip plus its FMA time (the plain loop above pays one round trip per batch).  bf16: UNR loads = 2*UNR rows.
 template <typename TV, int UNR>
 __device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const int* off_s, const float* wt_s, int cnt, int lane,
                                             float (&acc)[8]) {
@@ -492,309 +447,8 @@ __device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const i
 
 __device__ __forceinline__ int agg4_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// PT / LT: compile-time point / level counts (0 = take them from the launch parameters).  PT in [1,16] lays the projection
-// out as 4 cameras x 16 lanes (bounding boxes by shuffles); LT == 4 builds all four levels of a camera in one pass.
-template <typename TV, int PT, int LT, int PU = 13>   // PU: unroll factor of the point loop of the quad-level build
-__global__ __launch_bounds__(64) void aggregate_v4_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
-                                                          const float* __restrict__ offs, const float* __restrict__ l2i,
-                                                          const float* __restrict__ U, const float* __restrict__ Vc,
-                                                          const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
-  // XCD-aware query mapping: workgroup b lands on XCD b%8; each XCD gets a contiguous run of the camera-sorted order
-  int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
-  if (a >= prm.A) return;
-  if (perm) a = perm[a];
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int P = PT ? PT : prm.P, L = LT ? LT : prm.L, N = prm.N;
-  const int NP = N * P, J = L * P, NLP = NP * L;
-  float* w_s = reinterpret_cast<float*>(smem);                            // [NLP][8] softmax weights, index = ((n*L+l)*P+p)*8+g
-  float2* uv_s = reinterpret_cast<float2*>(w_s + NLP * 8);                // [NP] normalised image coordinates
-  float4* bb_s = reinterpret_cast<float4*>(uv_s + ((NP + 1) & ~1));       // [AGG4_MAX_N] (umin, umax, vmin, vmax) per camera
-  int* off_s = reinterpret_cast<int*>(bb_s + AGG4_MAX_N);                 // [CAP] element offset of the token row
-  float* wt_s = reinterpret_cast<float*>(off_s + AGG4_CAP);               // [CAP][8] merged weight of the row, per group
-
-  // ---- logits: issue the loads first (their latency hides under the projection).  float4 index i4 covers logits
-  // 4*i4 .. 4*i4+3 of the flattened (camera, level*P+point, group) array: groups (i4&1)*4 .. +3.
-  constexpr int NV = AGG_MAX_NLP * 2 / 64;     // 12 float4 per lane
-  const int n4 = NLP * 2, J2 = J * 2;
-  float4 lg[NV];
-  {
-    int cam = lane / J2, rem = lane - cam * J2;
-    const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
-    const float4* V4 = reinterpret_cast<const float4*>(Vc);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int i4 = i * 64 + lane;
-      lg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      if (i4 < n4) {
-        const float4 u = U4[rem], v = V4[i4];
-        lg[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
-      }
-      rem += 64;
-      while (rem >= J2) { rem -= J2; ++cam; }
-    }
-  }
-
-  // ---- projection of the P key points into the N cameras (detr3d_transformer.py:524-525,547-552) + per-camera bounding box
-  {
-    const float r0 = ref[a * 3] * prm.pc_span[0] + prm.pc_lo[0], r1 = ref[a * 3 + 1] * prm.pc_span[1] + prm.pc_lo[1],
-                r2 = ref[a * 3 + 2] * prm.pc_span[2] + prm.pc_lo[2];
-    auto project = [&](int n, int p, float& u, float& v) __attribute__((always_inline)) {
-      const float* o = offs + (long)a * prm.ldO + p * 3;
-      const float k0 = r0 + o[0], k1 = r1 + o[1], k2 = r2 + o[2];
-      const float* m = l2i + n * 16;
-      const float x = m[0] * k0 + m[1] * k1 + m[2] * k2 + m[3];
-      const float y = m[4] * k0 + m[5] * k1 + m[6] * k2 + m[7];
-      const float z = m[8] * k0 + m[9] * k1 + m[10] * k2 + m[11];
-      const float zc = fmaxf(z, 1e-5f);
-      u = (x / zc) / prm.pad_w; v = (y / zc) / prm.pad_h;
-    };
-    if constexpr (PT >= 1 && PT <= 16) {
-      for (int c0 = 0; c0 < N; c0 += 4) {          // 4 cameras x 16 lanes per pass
-        const int n = c0 + (lane >> 4), p = lane & 15;
-        const bool act = n < N && p < P;
-        float u = 0.f, v = 0.f;
-        if (act) { project(n, p, u, v); uv_s[n * P + p] = make_float2(u, v); }
-        float umin = act ? u : INFINITY, umax = act ? u : -INFINITY, vmin = act ? v : INFINITY, vmax = act ? v : -INFINITY;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
-          vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        }
-        if (p == 0 && n < N) bb_s[n] = make_float4(umin, umax, vmin, vmax);
-      }
-    } else {
-      for (int idx = lane; idx < NP; idx += 64) {
-        float u, v;
-        project(idx / P, idx % P, u, v);
-        uv_s[idx] = make_float2(u, v);
-      }
-      __syncthreads();
-      if (lane < N) {
-        float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-        for (int p = 0; p < P; ++p) {
-          const float2 q = uv_s[lane * P + p];
-          umin = fminf(umin, q.x); umax = fmaxf(umax, q.x);
-          vmin = fminf(vmin, q.y); vmax = fmaxf(vmax, q.y);
-        }
-        bb_s[lane] = make_float4(umin, umax, vmin, vmax);
-      }
-    }
-  }
-
-  // ---- softmax over cameras x levels x points per group (detr3d_transformer.py:539-540), all in registers + shuffles
-  {
-    float4 mx = lg[0];
-#pragma unroll
-    for (int i = 1; i < NV; ++i) {
-      mx.x = fmaxf(mx.x, lg[i].x); mx.y = fmaxf(mx.y, lg[i].y); mx.z = fmaxf(mx.z, lg[i].z); mx.w = fmaxf(mx.w, lg[i].w);
-    }
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) {      // lanes with equal (lane & 1) hold the same 4 groups
-      mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o));
-      mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o));
-    }
-    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const bool ok = i * 64 + lane < n4;
-      lg[i].x = ok ? __expf(lg[i].x - mx.x) : 0.f; lg[i].y = ok ? __expf(lg[i].y - mx.y) : 0.f;
-      lg[i].z = ok ? __expf(lg[i].z - mx.z) : 0.f; lg[i].w = ok ? __expf(lg[i].w - mx.w) : 0.f;
-      sm.x += lg[i].x; sm.y += lg[i].y; sm.z += lg[i].z; sm.w += lg[i].w;
-    }
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) {
-      sm.x += __shfl_xor(sm.x, o); sm.y += __shfl_xor(sm.y, o); sm.z += __shfl_xor(sm.z, o); sm.w += __shfl_xor(sm.w, o);
-    }
-    const float4 inv = make_float4(1.f / sm.x, 1.f / sm.y, 1.f / sm.z, 1.f / sm.w);
-    float4* w4 = reinterpret_cast<float4*>(w_s);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int i4 = i * 64 + lane;
-      if (i4 < n4) w4[i4] = make_float4(lg[i].x * inv.x, lg[i].y * inv.y, lg[i].z * inv.z, lg[i].w * inv.w);
-    }
-  }
-  __syncthreads();
-
-  // ---- build the merged row list and gather it
-  float acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  int cnt = 0;
-  auto make_room = [&](int c) __attribute__((always_inline)) {      // wave-uniform
-    if (cnt + c > AGG4_CAP) {
-      __syncthreads();
-      agg4_gather<TV>(feat, off_s, wt_s, cnt, lane, acc);
-      __syncthreads();
-      cnt = 0;
-    }
-  };
-  auto append = [&](bool hit, int off, const float (&wa)[8]) __attribute__((always_inline)) {
-    const unsigned long long m = __ballot(hit);
-    const int c = __popcll(m);
-    make_room(c);
-    if (hit) {
-      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-      off_s[pos] = off;
-      *reinterpret_cast<float4*>(wt_s + pos * 8) = make_float4(wa[0], wa[1], wa[2], wa[3]);
-      *reinterpret_cast<float4*>(wt_s + pos * 8 + 4) = make_float4(wa[4], wa[5], wa[6], wa[7]);
-    }
-    cnt += c;
-  };
-  // one (camera, level) whose points span more than 16 tokens: a 64-token patch (lane = token), else one entry per
-  // (point, corner) with mmcv's bilinear arithmetic as is
-  auto wide_combo = [&](int n, int l, float4 bb) __attribute__((always_inline)) {
-    const int Wl = prm.W[l], Hl = prm.H[l];
-    const float Wf = (float)Wl, Hf = (float)Hl;
-    const float fx0 = fmaxf(floorf(bb.x * Wf - 0.5f), 0.f), fx1 = fminf(floorf(bb.y * Wf - 0.5f) + 1.f, Wf - 1.f);
-    const float fy0 = fmaxf(floorf(bb.z * Hf - 0.5f), 0.f), fy1 = fminf(floorf(bb.w * Hf - 0.5f) + 1.f, Hf - 1.f);
-    if (!agg4_uni((fx1 >= fx0 && fy1 >= fy0) ? 1 : 0)) return;   // false for NaN / empty
-    const int x0 = agg4_uni((int)fx0), y0 = agg4_uni((int)fy0);
-    const int spanx = agg4_uni((int)(fx1 - fx0)) + 1, spany = agg4_uni((int)(fy1 - fy0)) + 1;
-    const int rowbase = n * prm.S + prm.start[l];
-    const float* wrow = w_s + ((n * L + l) * P) * 8;
-    int lw = 0;
-    while ((1 << lw) < spanx) ++lw;
-    if (lw <= 6 && spany <= (64 >> lw)) {
-      const int tx = x0 + (lane & ((1 << lw) - 1)), ty = y0 + (lane >> lw);
-      const bool active = tx < x0 + spanx && ty < y0 + spany;
-      const float ftx = (float)tx, fty = (float)ty;
-      float wa[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) wa[k] = 0.f;
-      float any = 0.f;
-      for (int p = 0; p < P; ++p) {
-        const float2 q = uv_s[n * P + p];
-        const float px = q.x * Wf - 0.5f, py = q.y * Hf - 0.5f;
-        const float w = fmaxf(1.f - fabsf(px - ftx), 0.f) * fmaxf(1.f - fabsf(py - fty), 0.f);
-        const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
-        any = fmaxf(any, w);
-        wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
-        wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
-      }
-      append(active && any > 0.f, (rowbase + ty * Wl + tx) * 256, wa);
-    } else {
-      for (int i0 = 0; i0 < P * 4; i0 += 64) {
-        const int idx = i0 + lane;
-        bool hit = false;
-        int off = 0;
-        float wa[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wa[k] = 0.f;
-        if (idx < P * 4) {
-          const int p = idx >> 2, tap = idx & 3;
-          const float2 q = uv_s[n * P + p];
-          const float h_im = q.y * Hf - 0.5f, w_im = q.x * Wf - 0.5f;
-          if (h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf) {
-            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const float lh = h_im - h_low, lw_ = w_im - w_low;
-            const int ty = h_low + (tap >> 1), tx = w_low + (tap & 1);
-            const float bw = ((tap >> 1) ? lh : 1.f - lh) * ((tap & 1) ? lw_ : 1.f - lw_);
-            hit = ty >= 0 && ty <= Hl - 1 && tx >= 0 && tx <= Wl - 1 && bw != 0.f;
-            off = (rowbase + ty * Wl + tx) * 256;
-            const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
-            wa[0] = bw * a0.x; wa[1] = bw * a0.y; wa[2] = bw * a0.z; wa[3] = bw * a0.w;
-            wa[4] = bw * a1.x; wa[5] = bw * a1.y; wa[6] = bw * a1.z; wa[7] = bw * a1.w;
-          }
-        }
-        append(hit, off, wa);
-      }
-    }
-  };
-
-  if constexpr (LT == 4) {
-    // lane = level * 16 + token: all four levels of a camera are built in ONE pass over the P points; a level whose points
-    // span more than 16 tokens (pw x ph, pw * ph = 16) goes through wide_combo afterwards
-    const int lq = lane >> 4, T = lane & 15;
-    const int Wq = lq == 0 ? prm.W[0] : lq == 1 ? prm.W[1] : lq == 2 ? prm.W[2] : prm.W[3];
-    const int Hq = lq == 0 ? prm.H[0] : lq == 1 ? prm.H[1] : lq == 2 ? prm.H[2] : prm.H[3];
-    const int startq = lq == 0 ? prm.start[0] : lq == 1 ? prm.start[1] : lq == 2 ? prm.start[2] : prm.start[3];
-    const float Wf = (float)Wq, Hf = (float)Hq;
-    for (int n = 0; n < N; ++n) {
-      const float4 bb = bb_s[n];
-      const float fx0 = fmaxf(floorf(bb.x * Wf - 0.5f), 0.f), fx1 = fminf(floorf(bb.y * Wf - 0.5f) + 1.f, Wf - 1.f);
-      const float fy0 = fmaxf(floorf(bb.z * Hf - 0.5f), 0.f), fy1 = fminf(floorf(bb.w * Hf - 0.5f) + 1.f, Hf - 1.f);
-      const bool vis = fx1 >= fx0 && fy1 >= fy0;          // per level (same in the 16 lanes of a level); false for NaN / empty
-      const unsigned long long vmask = __ballot(vis);
-      if (vmask == 0ull) continue;                          // camera does not see the query at all (the common case)
-      const int x0 = vis ? (int)fx0 : 0, y0 = vis ? (int)fy0 : 0;
-      const int spanx = vis ? (int)(fx1 - fx0) + 1 : 1, spany = vis ? (int)(fy1 - fy0) + 1 : 1;
-      const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8);     // pw = 1 << lw >= spanx (when spanx <= 16)
-      const bool fits = vis && spanx <= 16 && spany <= (16 >> lw);
-      const int tx = x0 + (T & ((1 << lw) - 1)), ty = y0 + (T >> lw);
-      const bool active = fits && tx < x0 + spanx && ty < y0 + spany;
-      if (__ballot(active) != 0ull) {
-        const float ftx = (float)tx, fty = (float)ty;
-        const float* wrow = w_s + ((n * 4 + lq) * P) * 8;
-        float wa[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wa[k] = 0.f;
-        float any = 0.f;
-#pragma unroll PU
-        for (int p = 0; p < P; ++p) {
-          const float2 q = uv_s[n * P + p];
-          const float px = q.x * Wf - 0.5f, py = q.y * Hf - 0.5f;
-          const float w = fmaxf(1.f - fabsf(px - ftx), 0.f) * fmaxf(1.f - fabsf(py - fty), 0.f);
-          const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
-          any = fmaxf(any, w);
-          wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
-          wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
-        }
-        append(active && any > 0.f, ((n * prm.S + startq) + ty * Wq + tx) * 256, wa);
-      }
-      const unsigned long long wmask = __ballot(vis && !fits);
-      if (wmask != 0ull) {
-#pragma unroll 1
-        for (int l = 0; l < 4; ++l)
-          if ((wmask >> (16 * l)) & 1ull) wide_combo(n, l, bb);
-      }
-    }
-  } else {
-    for (int n = 0; n < N; ++n) {
-      const float4 bb = bb_s[n];
-      for (int l = 0; l < L; ++l) wide_combo(n, l, bb);
-    }
-  }
-  __syncthreads();
-  agg4_gather<TV>(feat, off_s, wt_s, cnt, lane, acc);
-
-  // ---- store (the cross-camera sum already happened in the accumulators)
-  if constexpr (sizeof(TV) == 2) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], 32);      // two token rows per load: add the halves
-    if (lane < 32) {
-      if (prm.out_dt == FAR3D_DT_F32) {
-        float* o = reinterpret_cast<float*>(out) + (long)a * 256 + lane * 8;
-        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-      } else {
-        bf16_t* o = reinterpret_cast<bf16_t*>(out) + (long)a * 256 + lane * 8;
-        *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
-                                                  pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
-      }
-    }
-  } else {
-    if (prm.out_dt == FAR3D_DT_F32)
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)a * 256 + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    else
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + lane * 4) =
-          make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// v6: the v4 algorithm (tent-form tap merge, quad-level build, LDS row lists) on FOUR waves per query.
-//
-// SQ counters of v4 (gpurun_out/c3, bf16, 1544 queries): 2990 VALU instructions per query and 53 % of the wave cycles parked on
-// s_waitcnt -- with one wave per query there are only ~1.5 waves per SIMD and nothing hides the LDS / L2 latencies, so it ran
-// SLOWER (28 us) than v3 (22 us) although v3 issues 1.8x more instructions.  v6 keeps v4's instruction count and spreads one
-// query over 4 waves without duplicating work: the 728 logit float4s, the (camera, point) projections (16 cameras x 16 lanes in
-// one pass) and the cameras of the build loop (wave w owns cameras w, w+4, ...) are split; each wave gathers its own row list;
-// the softmax normaliser 1/S[g] is applied ONCE to the final sums (every merged weight of group g carries it), so the weights
-// are stored un-normalised and the kernel needs three barriers: max, sum, cross-wave reduction.
-// ------------------------------------------------------------------------------------------
 #ifdef FAR3D_PROFILING
-// tools/agg_phase_times.py: per-wave s_memtime stamps at the phase boundaries of the v6 kernel (never in libfar3d_hip.so)
+// tools/agg_phase_times.py: per-wave s_memtime stamps at the phase boundaries of the kernel (never in libfar3d_hip.so)
 __device__ long long* g_agg_ts = nullptr;
 extern "C" int far3d_prof_set_agg_timestamps(long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_agg_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
@@ -803,318 +457,14 @@ extern "C" int far3d_prof_set_agg_timestamps(long long* buf) {
 #else
 #define AGG_TS(i) do { } while (0)
 #endif
-#define AGG6_CAPW 64      // list entries per wave between flushes: one pass appends at most 64; the region also holds the wave's 256 partial sums
-
-// (82 VGPRs: 6 workgroups = 24 waves per CU.  Forcing 72 VGPRs for a 7th workgroup spills, and the spilling build faulted on the GPU.)
-template <typename TV, int PT, int LT>
-__global__ __launch_bounds__(256, 4) void aggregate_v6_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
-                                                           const float* __restrict__ offs, const float* __restrict__ l2i,
-                                                           const float* __restrict__ U, const float* __restrict__ Vc,
-                                                           const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
-  int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
-  if (a >= prm.A) return;
-  if (perm) a = perm[a];
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave index: scalar
-  const int P = PT ? PT : prm.P, L = LT ? LT : prm.L, N = prm.N;
-  const int NP = N * P, J = L * P, NLP = NP * L;
-  float* w_s = reinterpret_cast<float*>(smem);                            // [NLP][8] exp(logit - max): UN-normalised weights
-  float2* uv_s = reinterpret_cast<float2*>(w_s + NLP * 8);                // [NP] normalised image coordinates
-  float4* bb_s = reinterpret_cast<float4*>(uv_s + ((NP + 1) & ~1));       // [AGG4_MAX_N] (umin, umax, vmin, vmax) per camera
-  float* stat_s = reinterpret_cast<float*>(bb_s + AGG4_MAX_N);            // [2][4][8]: per-wave max, per-wave sum, by group
-  int* off_all = reinterpret_cast<int*>(stat_s + 64);                     // [4][CAPW] row offsets, then [4][CAPW][8] weights
-  float* wt_all = reinterpret_cast<float*>(off_all + 4 * AGG6_CAPW);
-  int* off_s = off_all + wv * AGG6_CAPW;
-  float* wt_s = wt_all + wv * AGG6_CAPW * 8;
-
-  AGG_TS(0);
-  // ---- logits (float4 index i4 covers groups (i4&1)*4..+3 of one (camera, level*P+point) row); loads issued first
-  constexpr int NV = AGG_MAX_NLP * 2 / 256;     // 3 float4 per thread
-  const int n4 = NLP * 2, J2 = J * 2;
-  float4 lg[NV];
-  {
-    int cam = t / J2, rem = t - cam * J2;
-    const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
-    const float4* V4 = reinterpret_cast<const float4*>(Vc);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int i4 = i * 256 + t;
-      lg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      if (i4 < n4) {
-        const float4 u = U4[rem], v = V4[i4];
-        lg[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
-      }
-      rem += 256;
-      while (rem >= J2) { rem -= J2; ++cam; }
-    }
-  }
-
-  // ---- projection (detr3d_transformer.py:524-525,547-552) + per-camera bounding box of the P points
-  {
-    const float r0 = ref[a * 3] * prm.pc_span[0] + prm.pc_lo[0], r1 = ref[a * 3 + 1] * prm.pc_span[1] + prm.pc_lo[1],
-                r2 = ref[a * 3 + 2] * prm.pc_span[2] + prm.pc_lo[2];
-    auto project = [&](int n, int p, float& u, float& v) __attribute__((always_inline)) {
-      const float* o = offs + (long)a * prm.ldO + p * 3;
-      const float k0 = r0 + o[0], k1 = r1 + o[1], k2 = r2 + o[2];
-      const float* m = l2i + n * 16;
-      const float x = m[0] * k0 + m[1] * k1 + m[2] * k2 + m[3];
-      const float y = m[4] * k0 + m[5] * k1 + m[6] * k2 + m[7];
-      const float z = m[8] * k0 + m[9] * k1 + m[10] * k2 + m[11];
-      const float zc = fmaxf(z, 1e-5f);
-      u = (x / zc) / prm.pad_w; v = (y / zc) / prm.pad_h;
-    };
-    if constexpr (PT >= 1 && PT <= 16) {          // 16 cameras x 16 lanes in one pass
-      const int n = t >> 4, p = t & 15;
-      const bool act = n < N && p < P;
-      float u = 0.f, v = 0.f;
-      if (act) { project(n, p, u, v); uv_s[n * P + p] = make_float2(u, v); }
-      float umin = act ? u : INFINITY, umax = act ? u : -INFINITY, vmin = act ? v : INFINITY, vmax = act ? v : -INFINITY;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
-        vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-      }
-      if (p == 0 && n < N) bb_s[n] = make_float4(umin, umax, vmin, vmax);
-    } else {
-      for (int idx = t; idx < NP; idx += 256) {
-        float u, v;
-        project(idx / P, idx % P, u, v);
-        uv_s[idx] = make_float2(u, v);
-      }
-    }
-  }
-
-  // ---- softmax statistics (detr3d_transformer.py:539-540): wave-local by shuffles, across waves through LDS
-  const int gh = (lane & 1) * 4;          // this lane's 4 groups
-  {
-    float4 mx = lg[0];
-#pragma unroll
-    for (int i = 1; i < NV; ++i) {
-      mx.x = fmaxf(mx.x, lg[i].x); mx.y = fmaxf(mx.y, lg[i].y); mx.z = fmaxf(mx.z, lg[i].z); mx.w = fmaxf(mx.w, lg[i].w);
-    }
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) {      // lanes with equal (lane & 1) hold the same 4 groups
-      mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o));
-      mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o));
-    }
-    if (lane < 2) *reinterpret_cast<float4*>(stat_s + wv * 8 + gh) = mx;
-  }
-  AGG_TS(1);
-  __syncthreads();                                                                        // B1: maxima, uv_s, bb_s
-  AGG_TS(2);
-  if constexpr (!(PT >= 1 && PT <= 16)) {
-    if (t < N) {
-      float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-      for (int p = 0; p < P; ++p) {
-        const float2 q = uv_s[t * P + p];
-        umin = fminf(umin, q.x); umax = fmaxf(umax, q.x);
-        vmin = fminf(vmin, q.y); vmax = fmaxf(vmax, q.y);
-      }
-      bb_s[t] = make_float4(umin, umax, vmin, vmax);
-    }
-  }
-  {
-    float4 mx = *reinterpret_cast<const float4*>(stat_s + gh);
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float4 o = *reinterpret_cast<const float4*>(stat_s + w * 8 + gh);
-      mx.x = fmaxf(mx.x, o.x); mx.y = fmaxf(mx.y, o.y); mx.z = fmaxf(mx.z, o.z); mx.w = fmaxf(mx.w, o.w);
-    }
-    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* w4 = reinterpret_cast<float4*>(w_s);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int i4 = i * 256 + t;
-      if (i4 < n4) {
-        const float4 e = make_float4(__expf(lg[i].x - mx.x), __expf(lg[i].y - mx.y), __expf(lg[i].z - mx.z), __expf(lg[i].w - mx.w));
-        sm.x += e.x; sm.y += e.y; sm.z += e.z; sm.w += e.w;
-        w4[i4] = e;
-      }
-    }
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) {
-      sm.x += __shfl_xor(sm.x, o); sm.y += __shfl_xor(sm.y, o); sm.z += __shfl_xor(sm.z, o); sm.w += __shfl_xor(sm.w, o);
-    }
-    if (lane < 2) *reinterpret_cast<float4*>(stat_s + 32 + wv * 8 + gh) = sm;
-  }
-  __syncthreads();                                                                        // B2: weights, sums (and bb_s, generic P)
-  AGG_TS(3);
-
-  // ---- per wave: build the merged row list of cameras wv, wv+4, ... and gather it
-  float acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  int cnt = 0;
-  auto append = [&](bool hit, int off, const float (&wa)[8]) __attribute__((always_inline)) {
-    const unsigned long long m = __ballot(hit);
-    const int c = __popcll(m);
-    if (cnt + c > AGG6_CAPW) {            // wave-uniform; the list is private to the wave: no barrier, LDS is in order per wave
-      agg4_gather<TV, 2>(feat, off_s, wt_s, cnt, lane, acc);
-      cnt = 0;
-    }
-    if (hit) {
-      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < AGG6_CAPW) {
-        off_s[pos] = off;
-        *reinterpret_cast<float4*>(wt_s + pos * 8) = make_float4(wa[0], wa[1], wa[2], wa[3]);
-        *reinterpret_cast<float4*>(wt_s + pos * 8 + 4) = make_float4(wa[4], wa[5], wa[6], wa[7]);
-      }
-    }
-    cnt += c;
-  };
-  auto wide_combo = [&](int n, int l, float4 bb) __attribute__((always_inline)) {
-    const int Wl = prm.W[l], Hl = prm.H[l];
-    const float Wf = (float)Wl, Hf = (float)Hl;
-    const float fx0 = fmaxf(floorf(bb.x * Wf - 0.5f), 0.f), fx1 = fminf(floorf(bb.y * Wf - 0.5f) + 1.f, Wf - 1.f);
-    const float fy0 = fmaxf(floorf(bb.z * Hf - 0.5f), 0.f), fy1 = fminf(floorf(bb.w * Hf - 0.5f) + 1.f, Hf - 1.f);
-    if (!agg4_uni((fx1 >= fx0 && fy1 >= fy0) ? 1 : 0)) return;   // false for NaN / empty
-    const int x0 = agg4_uni((int)fx0), y0 = agg4_uni((int)fy0);
-    const int spanx = agg4_uni((int)(fx1 - fx0)) + 1, spany = agg4_uni((int)(fy1 - fy0)) + 1;
-    const int rowbase = n * prm.S + prm.start[l];
-    const float* wrow = w_s + ((n * L + l) * P) * 8;
-    int lw = 0;
-    while ((1 << lw) < spanx) ++lw;
-    if (lw <= 6 && spany <= (64 >> lw)) {
-      const int tx = x0 + (lane & ((1 << lw) - 1)), ty = y0 + (lane >> lw);
-      const bool active = tx < x0 + spanx && ty < y0 + spany;
-      const float ftx = (float)tx, fty = (float)ty;
-      float wa[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) wa[k] = 0.f;
-      float any = 0.f;
-      for (int p = 0; p < P; ++p) {
-        const float2 q = uv_s[n * P + p];
-        const float px = q.x * Wf - 0.5f, py = q.y * Hf - 0.5f;
-        const float w = fmaxf(1.f - fabsf(px - ftx), 0.f) * fmaxf(1.f - fabsf(py - fty), 0.f);
-        const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
-        any = fmaxf(any, w);
-        wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
-        wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
-      }
-      append(active && any > 0.f, (rowbase + ty * Wl + tx) * 256, wa);
-    } else {
-      for (int i0 = 0; i0 < P * 4; i0 += 64) {
-        const int idx = i0 + lane;
-        bool hit = false;
-        int off = 0;
-        float wa[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wa[k] = 0.f;
-        if (idx < P * 4) {
-          const int p = idx >> 2, tap = idx & 3;
-          const float2 q = uv_s[n * P + p];
-          const float h_im = q.y * Hf - 0.5f, w_im = q.x * Wf - 0.5f;
-          if (h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf) {
-            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const float lh = h_im - h_low, lw_ = w_im - w_low;
-            const int ty = h_low + (tap >> 1), tx = w_low + (tap & 1);
-            const float bw = ((tap >> 1) ? lh : 1.f - lh) * ((tap & 1) ? lw_ : 1.f - lw_);
-            hit = ty >= 0 && ty <= Hl - 1 && tx >= 0 && tx <= Wl - 1 && bw != 0.f;
-            off = (rowbase + ty * Wl + tx) * 256;
-            const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
-            wa[0] = bw * a0.x; wa[1] = bw * a0.y; wa[2] = bw * a0.z; wa[3] = bw * a0.w;
-            wa[4] = bw * a1.x; wa[5] = bw * a1.y; wa[6] = bw * a1.z; wa[7] = bw * a1.w;
-          }
-        }
-        append(hit, off, wa);
-      }
-    }
-  };
-
-  if constexpr (LT == 4) {
-    // lane = level * 16 + token: all four levels of a camera in ONE pass over the P points; a level whose points span more than
-    // 16 tokens goes through wide_combo afterwards
-    int lane2 = lane;
-    asm volatile("" : "+v"(lane2));        // keep the per-lane level constants out of the (register-hungry) softmax section
-    const int lq = lane2 >> 4, T = lane2 & 15;
-    const int Wq = lq == 0 ? prm.W[0] : lq == 1 ? prm.W[1] : lq == 2 ? prm.W[2] : prm.W[3];
-    const int Hq = lq == 0 ? prm.H[0] : lq == 1 ? prm.H[1] : lq == 2 ? prm.H[2] : prm.H[3];
-    const int startq = lq == 0 ? prm.start[0] : lq == 1 ? prm.start[1] : lq == 2 ? prm.start[2] : prm.start[3];
-    const float Wf = (float)Wq, Hf = (float)Hq;
-    for (int n = wv; n < N; n += 4) {
-      const float4 bb = bb_s[n];
-      const float fx0 = fmaxf(floorf(bb.x * Wf - 0.5f), 0.f), fx1 = fminf(floorf(bb.y * Wf - 0.5f) + 1.f, Wf - 1.f);
-      const float fy0 = fmaxf(floorf(bb.z * Hf - 0.5f), 0.f), fy1 = fminf(floorf(bb.w * Hf - 0.5f) + 1.f, Hf - 1.f);
-      const bool vis = fx1 >= fx0 && fy1 >= fy0;          // per level; false for NaN / empty
-      if (__ballot(vis) == 0ull) continue;                  // the camera does not see the query at all (the common case)
-      const int x0 = vis ? (int)fx0 : 0, y0 = vis ? (int)fy0 : 0;
-      const int spanx = vis ? (int)(fx1 - fx0) + 1 : 1, spany = vis ? (int)(fy1 - fy0) + 1 : 1;
-      const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8);     // pw = 1 << lw >= spanx (when spanx <= 16)
-      const bool fits = vis && spanx <= 16 && spany <= (16 >> lw);
-      const int tx = x0 + (T & ((1 << lw) - 1)), ty = y0 + (T >> lw);
-      const bool active = fits && tx < x0 + spanx && ty < y0 + spany;
-      if (__ballot(active) != 0ull) {
-        const float ftx = (float)tx, fty = (float)ty;
-        const float* wrow = w_s + ((n * 4 + lq) * P) * 8;
-        float wa[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wa[k] = 0.f;
-        float any = 0.f;
-#pragma unroll 1
-        for (int p = 0; p < P; ++p) {
-          const float2 q = uv_s[n * P + p];
-          const float px = q.x * Wf - 0.5f, py = q.y * Hf - 0.5f;
-          const float w = fmaxf(1.f - fabsf(px - ftx), 0.f) * fmaxf(1.f - fabsf(py - fty), 0.f);
-          const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
-          any = fmaxf(any, w);
-          wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
-          wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
-        }
-        append(active && any > 0.f, ((n * prm.S + startq) + ty * Wq + tx) * 256, wa);
-      }
-      const unsigned long long wmask = __ballot(vis && !fits);
-      if (wmask != 0ull) {
-#pragma unroll 1
-        for (int l = 0; l < 4; ++l)
-          if ((wmask >> (16 * l)) & 1ull) wide_combo(n, l, bb);
-      }
-    }
-  } else {
-    for (int n = wv; n < N; n += 4) {
-      const float4 bb = bb_s[n];
-      for (int l = 0; l < L; ++l) wide_combo(n, l, bb);
-    }
-  }
-  AGG_TS(4);
-  agg4_gather<TV, 4>(feat, off_s, wt_s, cnt, lane, acc);
-  AGG_TS(5);
-
-  // ---- cross-wave (= cross-camera) sum: partial sums go into the wave's own (now dead) list region
-  float* red = wt_s;                       // 256 floats: CAPW * 8 >= 256
-  if constexpr (sizeof(TV) == 2) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], 32);      // two token rows per load: add the halves
-    if (lane < 32) {
-      *reinterpret_cast<float4*>(red + lane * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<float4*>(red + lane * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    }
-  } else {
-    *reinterpret_cast<float4*>(red + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  }
-  __syncthreads();                                                                        // B3
-  AGG_TS(6);
-#ifdef FAR3D_PROFILING
-  if (g_agg_ts && lane == 0) g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 7] = cnt;
-#endif
-  {
-    const int g = t >> 5;                  // channel t belongs to group t / 32
-    const float S = (stat_s[32 + g] + stat_s[40 + g]) + (stat_s[48 + g] + stat_s[56 + g]);
-    const float r = ((wt_all[t] + wt_all[AGG6_CAPW * 8 + t]) + (wt_all[2 * AGG6_CAPW * 8 + t] + wt_all[3 * AGG6_CAPW * 8 + t])) / S;
-    if (prm.out_dt == FAR3D_DT_F32) reinterpret_cast<float*>(out)[(long)a * 256 + t] = r;
-    else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + t] = f32_to_bf16(r);
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // v7: TWO waves per query, wave w owns pyramid levels w, w+2 (64-token patches).
 //
-// s_memtime stamps of v6 (tools/agg_phase_times.py): the wave that builds a visible camera needs ~20k cycles (13 serial
-// point iterations per pass with exposed LDS latency, plus extra passes for levels wider than 16 tokens) while the other three
-// waves sit in the final barrier; and 4-wave workgroups at 82 VGPRs leave only 5 workgroups per CU (1280 < 1544 queries: a
-// second round).  v7: 128 threads per query -> 7+ workgroups per CU at a 128-VGPR budget, so the point loop is fully unrolled
-// (its 39 LDS reads pipeline), both waves build (2 levels each, lane = token of a 64-token patch, so only spreads > 64 tokens
-// fall back to per-corner entries), and invisible (camera, level) pairs cost nothing: the projection phase leaves a per-camera
-// level-visibility mask and the build loop walks its set bits.
+// 128 threads per query -> 8 workgroups per CU at 120 VGPRs (every query of a frame resident in one round), both waves build
+// (2 levels each, lane = token of a 64-token patch, so only spreads > 64 tokens fall back to per-corner entries), and
+// invisible (camera, level) pairs cost nothing: the projection phase leaves a per-camera level-visibility mask and the build
+// loop walks its set bits.  Barriers: B1 maxima, B2 sums, B3 cross-wave reduction.
 // ------------------------------------------------------------------------------------------
 #define AGG7_CAPW 128     // list entries per wave between flushes (2 x 128 x 36 B; 7 workgroups of 22.1 KB fit a CU's 160 KB)
 
@@ -1411,7 +761,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || (variant >= 3 && variant <= 7), "far3d_aggregate_forward: unknown kernel variant %d (0 auto, 3..7)", variant);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7, "far3d_aggregate_forward: unknown kernel variant %d (0 = 7 = default, 3 = round-1 kernel)", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -1450,30 +800,6 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
     } else {
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    }
-  } else if (variant == 6) {     // 4 waves per query
-    const int NP = N * P;
-    const size_t lds6 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + 64 * 4 + (size_t)4 * AGG6_CAPW * 36;
-    const bool fastpl = P == 13 && L == 4;
-    if (feat_dtype == FAR3D_DT_F32) {
-      if (fastpl) hipLaunchKernelGGL((aggregate_v6_kernel<float, 13, 4>), grid, dim3(256), lds6, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v6_kernel<float, 0, 0>), grid, dim3(256), lds6, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    } else {
-      if (fastpl) hipLaunchKernelGGL((aggregate_v6_kernel<bf16_t, 13, 4>), grid, dim3(256), lds6, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v6_kernel<bf16_t, 0, 0>), grid, dim3(256), lds6, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    }
-  } else {
-    const int NP = N * P;
-    const size_t lds4 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + AGG4_CAP * 4 + (size_t)AGG4_CAP * 32;
-    const bool fastpl = P == 13 && L == 4;      // the reference's configuration (projects/configs/far3d.py:117-125)
-    if (feat_dtype == FAR3D_DT_F32) {
-      if (fastpl && variant == 5) hipLaunchKernelGGL((aggregate_v4_kernel<float, 13, 4, 4>), grid, dim3(64), lds4, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-      else if (fastpl) hipLaunchKernelGGL((aggregate_v4_kernel<float, 13, 4>), grid, dim3(64), lds4, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v4_kernel<float, 0, 0>), grid, dim3(64), lds4, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-    } else {
-      if (fastpl && variant == 5) hipLaunchKernelGGL((aggregate_v4_kernel<bf16_t, 13, 4, 4>), grid, dim3(64), lds4, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-      else if (fastpl) hipLaunchKernelGGL((aggregate_v4_kernel<bf16_t, 13, 4>), grid, dim3(64), lds4, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v4_kernel<bf16_t, 0, 0>), grid, dim3(64), lds4, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
   }
   FAR3D_CHECK_LAUNCH("far3d_aggregate_forward");

@@ -208,7 +208,6 @@ def _nhwc_view(t, name):
     return t.stride(2), t.stride(0)
 
 
-ESE_REPLICAS = 8        # FAR3D_ESE_REPLICAS in include/far3d_hip.h
 SUMS_MAX_PARTS = 32     # FAR3D_SUMS_MAX_PARTS in include/far3d_hip.h
 
 
@@ -223,8 +222,7 @@ def conv_tile(x, pc):
     return _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W) if x.dtype == torch.bfloat16 else 0
 
 
-def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0,
-                chan_sum=None):
+def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0):
     """x: (N,H,W,Cin) NHWC view (f32|bf16).  pc: PackedConv.  out: optional (N,Ho,Wo,Cout) NHWC view to write
     into (e.g. a channel slice of an OSA concat buffer).  Returns out."""
     lib = _lib.require_device()
@@ -259,7 +257,7 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
     _lib.check(lib.far3d_conv2d_nhwc(
         _ptr(x), _dt(x), _ptr(pc.w), pc.w_code, _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
         N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],
-        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, _ptr(chan_sum) if chan_sum is not None else None, tile,
+        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, tile,
         _stream(x)), "far3d_conv2d_nhwc")
     return out
 

@@ -25,8 +25,6 @@ extern "C" {
  * and row stride of the fp32 layout, but holds the split: every 32-channel block of a row (128 B) is 32 hi bf16 followed by
  * 32 lo bf16 (hi = bf16(w), lo = bf16(w - hi)). */
 #define FAR3D_DT_F32_BF16X3 2
-/* per-XCD replicas of the channel-sum array written by far3d_conv2d_nhwc(chan_sum) and read by far3d_ese_nhwc */
-#define FAR3D_ESE_REPLICAS 8
 /* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */
 #define FAR3D_SUMS_MAX_PARTS 32
 /* partial sums [N][PARTS][C][2] + gates / group statistics [N][C] */
@@ -72,8 +70,8 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) of dtype out_dt (f32 | bf16).  perm: optional (A) int32 DEVICE permutation giving
  * the order in which queries are assigned to workgroups (camera-sorted order keeps one XCD's L2 on 1-2 cameras); it never
  * changes results (row a of `out` is always query a).  Requires C=256, G=8, L<=4, N<=16,
- * N*P<=256, N*P*L<=384.  variant: 0 = default kernel (4); 4 = one wave per query, bilinear taps merged per token row through
- * the tent form of the interpolation weights (no atomics), LDS row list, 16-byte row gathers; 3 = round-1 kernel (workgroup
+ * N*P<=256, N*P*L<=384.  variant: 0 (= 7) default kernel: two waves per query, bilinear taps merged per token row through
+ * the tent form of the interpolation weights (no atomics), LDS row lists, 16-byte row gathers; 3 = round-1 kernel (workgroup
  * per query, one gather per sample corner pair) kept for A/B measurements.  Both give the same result up to fp32
  * re-association. */
 int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
@@ -99,10 +97,6 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  * y2 (optional, y2_dt): second output y2 = y2_scale[n][m] * v + y2_shift[n][m] (FarHead's camera-aware MLN,
  *    ref: models/utils/misc.py:182-190, models/dense_heads/farhead.py:553-563) so that the FPN output conv writes
  *    the modulated token-major value maps directly.
- * chan_sum (optional): [FAR3D_ESE_REPLICAS][N][Cout][2] f32 (caller zeroes it); element [r][n][m][0] += sum over the pixels
- *    handled on XCD r of the stored y (an average pool riding on a conv epilogue; measured slower than the separate
- *    pooling pass for eSE and not used by the engine).  Needs a pipelined tile (>= 50), bf16 y,
- *    no res / y2, 16-byte aligned rows (ldy, Cout multiples of 8).
  * tile: 0 auto (host callers pass the measured choice of far3d_amd/data/tuning_mi355x.json).  Any dtype: 1 128x128, 2 64x128,
  *    3 64x64, 4 128x64, 5 64x256 (channels x pixels).  bf16 with Cin % 32 == 0 only: 18, 43, 46, 48 (LDS-DMA ring variants, any
  *    kernel size / stride); 50-67, 90-97, 100-103 pipelined 3x3/s1/p1 kernel (channels x rows of 32 pixels, 4/8/16 waves, 2- or 3-deep
@@ -111,7 +105,7 @@ int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const fl
                       int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
                       long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,
                       int ldr, long res_img_stride, int Hr, int Wr, void* y2, int y2_dt, int ldy2,
-                      long y2_img_stride, const float* y2_scale, const float* y2_shift, float* chan_sum, int tile, void* stream);
+                      long y2_img_stride, const float* y2_scale, const float* y2_shift, int tile, void* stream);
 
 /* Multi-head self-attention core: out = softmax(q k^T * scale) v per head (flash-style, no score tensor in HBM).
  * Replaces the bmm/softmax/bmm inside torch.nn.MultiheadAttention as wrapped by mmcv's MultiheadAttention

@@ -193,30 +193,6 @@ def test_pipelined_kernels_bf16_output_coalesced_rows(hip_lib, tile):
         assert (buf[..., :8] == 7.0).all() and (buf[..., 8 + Cout:] == 7.0).all()
 
 
-@pytest.mark.parametrize("tile", [60, 65, 70, 75, 79, 80, 81])
-def test_pipelined_epilogue_channel_sums(hip_lib, tile):
-    """chan_sum: the pipelined kernels' row-store epilogue also accumulates per-image channel sums of the stored bf16
-    values (the eSE average pool); pixel tiles straddle images and the ragged edges must not contribute."""
-    from far3d_amd import ops
-    g = torch.Generator().manual_seed(900 + tile)
-    k = 3 if tile < 70 else 1
-    N, Cin, Cout, H, W = 3, 64, 168, 15, 37
-    x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
-    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
-    b = torch.randn(Cout, generator=g)
-    pc = ops.PackedConv(w, b, stride=1, pad=k // 2, dtype=torch.bfloat16, device=DEV)
-    sums = torch.zeros(ops.ESE_REPLICAS, N, Cout, 2, device=DEV)       # one replica per XCD
-    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=tile, chan_sum=sums)
-    want = y.float().sum(dim=(1, 2)).cpu()            # sums of the values actually stored
-    got = sums.sum(dim=0)
-    err = (got[..., 0].cpu() - want).abs().max().item()
-    assert err < 1e-4 * max(1.0, want.abs().max().item()), err
-    assert got[..., 1].abs().max().item() == 0.0
-    with pytest.raises(Exception):
-        ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), pc, act="relu", tile=1, chan_sum=sums)
-
-
-
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", ["conv3x3", "stride2_odd_channels", "linear"])
 def test_split_bf16_products_track_fp32(hip_lib, tile, case):

@@ -1,4 +1,4 @@
-"""Where does one query's time go inside the v6 aggregation kernel?  Builds libfar3d_hip_prof.so (the same sources with
+"""Where does one query's time go inside the aggregation kernel?  Builds libfar3d_hip_prof.so (the same sources with
 -DFAR3D_PROFILING: per-wave s_memtime stamps at the phase boundaries), runs the kernel on the config-2 case and prints the
 median per-phase times.  Tools only -- the shipped libfar3d_hip.so has no such hooks."""
 import ctypes
@@ -25,8 +25,7 @@ def build_prof():
 
 def main():
     A = int(sys.argv[1]) if len(sys.argv) > 1 else 1544
-    variant = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-    nw = 2 if variant == 7 else 4
+    variant, nw = 7, 2
     if not os.path.exists(PROF) or os.path.getmtime(PROF) < os.path.getmtime(os.path.join(fbuild.CSRC, "sampling.hip")):
         build_prof()
     flib.LIB_PATH = PROF
