@@ -55,24 +55,3 @@ def pil_resample_coeffs(in_size, out_size, filter="bicubic"):
         bounds[xx] = (xmin, xmax)
     fixed = np.where(kk < 0, np.trunc(-0.5 + kk * (1 << PRECISION_BITS)), np.trunc(0.5 + kk * (1 << PRECISION_BITS))).astype(np.int32)
     return bounds, fixed, ksize
-
-
-def resample_u8_reference(img, out_w, out_h, filter="bicubic"):
-    """numpy statement of the two-pass resize (horizontal to an 8-bit intermediate, then vertical): what the HIP kernels compute.
-    img (H,W,3) uint8 -> (out_h,out_w,3) uint8.  Used by the CPU tests to pin the tables against Pillow itself."""
-    H, W, _ = img.shape
-    bh, kh, _ = pil_resample_coeffs(W, out_w, filter)
-    bv, kv, _ = pil_resample_coeffs(H, out_h, filter)
-    tmp = np.zeros((H, out_w, 3), dtype=np.uint8)
-    src = img.astype(np.int64)
-    for x in range(out_w):
-        x0, n = bh[x]
-        acc = (1 << (PRECISION_BITS - 1)) + (src[:, x0:x0 + n, :] * kh[x, :n].astype(np.int64)[None, :, None]).sum(1)
-        tmp[:, x, :] = np.clip(acc >> PRECISION_BITS, 0, 255)
-    out = np.zeros((out_h, out_w, 3), dtype=np.uint8)
-    t64 = tmp.astype(np.int64)
-    for y in range(out_h):
-        y0, n = bv[y]
-        acc = (1 << (PRECISION_BITS - 1)) + (t64[y0:y0 + n] * kv[y, :n].astype(np.int64)[:, None, None]).sum(0)
-        out[y] = np.clip(acc >> PRECISION_BITS, 0, 255)
-    return out
