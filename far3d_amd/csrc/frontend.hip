@@ -148,9 +148,10 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
       const unsigned mid = lo + ((hi - lo) >> 1);
       int c;
       PROP_COUNT_GE(c, mid);
-      if (c >= cap) lo = mid; else hi = mid;
+      if (c == cap) { lo = mid; break; }     // `w >= mid` keeps exactly K: the cut need not be an element itself
+      if (c > cap) lo = mid; else hi = mid;
     }
-    kth = lo;   // value of the K-th largest element
+    kth = lo;   // the K-th largest element, or a cut between the K-th and the (K+1)-th
     if (kth != 0xffffffffu) PROP_COUNT_GE(n_gt, kth + 1u);   // strictly greater
 #undef PROP_COUNT_GE
     __syncthreads();

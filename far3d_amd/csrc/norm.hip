@@ -165,19 +165,28 @@ static int launch_chan_sums(const void* x, int dt, float* part, int N, int HW, i
 
 // ---------------------------------------------------------------- eSE
 // Partial sums of image n, channel c: part[(n * nparts + b) * C + c] (float2: sum, sum of squares), b = 0..nparts-1; added in
-// index order with 8 loads in flight (deterministic).
-__device__ __forceinline__ float2 sum_parts(const float2* __restrict__ src, int nparts, int C, int c) {
-  float ss = 0.f, qq = 0.f;
-  int b = 0;
-  for (; b + 8 <= nparts; b += 8) {
-    float2 v[8];
+// index order (deterministic).  A thread sums NCH channels (c0, c0 + cstep, ...) at once with 8 partials of each in flight:
+// nparts <= 32 costs 4 dependent round trips for all of them (summing them one channel / one tail element at a time cost ~20 round
+// trips and made the 16 gate launches of a frame 15 us each).  Slots past nparts / C load nothing and add +0.0.
+template <int NCH>
+__device__ __forceinline__ void sum_parts(const float2* __restrict__ src, int nparts, int C, int c0, int cstep, float2 (&out)[NCH]) {
+  float ss[NCH], qq[NCH];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = src[(long)(b + k) * C + c];
+  for (int j = 0; j < NCH; ++j) { ss[j] = 0.f; qq[j] = 0.f; }
+  for (int b = 0; b < nparts; b += 8) {
+    float2 v[NCH][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { ss += v[k].x; qq += v[k].y; }
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        v[j][k] = (c0 + j * cstep < C && b + k < nparts) ? src[(long)(b + k) * C + c0 + j * cstep] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { ss[j] += v[j][k].x; qq[j] += v[j][k].y; }
   }
-  for (; b < nparts; ++b) { const float2 v = src[(long)b * C + c]; ss += v.x; qq += v.y; }
-  return make_float2(ss, qq);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) out[j] = make_float2(ss[j], qq[j]);
 }
 
 // gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image: it first
@@ -189,7 +198,13 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
   __shared__ float mean[1024];
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float2* src = reinterpret_cast<const float2*>(part) + (long)n * nparts * C;
-  for (int k = threadIdx.x; k < C; k += 256) mean[k] = sum_parts(src, nparts, C, k).x * inv_hw;
+  {
+    float2 sm[4];                                  // C <= 1024: channels t, t + 256, t + 512, t + 768
+    sum_parts<4>(src, nparts, C, threadIdx.x, 256, sm);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (threadIdx.x + j * 256 < C) mean[threadIdx.x + j * 256] = sm[j].x * inv_hw;
+  }
   __syncthreads();
   // each wave: 4 output channels at once (4 independent weight-row streams), float4 loads
   const int c0 = blockIdx.x * 16 + wv * 4;
@@ -266,17 +281,26 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
 
 // ---------------------------------------------------------------- GroupNorm + ReLU (NHWC)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int C,
-                                                       int groups, float inv_cnt, float eps, int ntot, int nparts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, group)
-  if (i >= ntot) return;
-  const int n = i / groups, g = i % groups, cpg = C / groups;
+                                                       int groups, float inv_cnt, float eps, int nparts) {
+  // one workgroup per image: per-channel sums first (all partial loads in flight), then thread g adds its group's channels in
+  // ascending order -- the same additions in the same order as a per-group serial loop
+  __shared__ float2 cs[1024];
+  const int n = blockIdx.x, cpg = C / groups;
   const float2* src = reinterpret_cast<const float2*>(part) + (long)n * nparts * C;
-  float s = 0.f, q = 0.f;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const float2 v = sum_parts(src, nparts, C, c); s += v.x; q += v.y; }
-  const float mean = s * inv_cnt;
-  const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
-  stat[2 * i] = mean;
-  stat[2 * i + 1] = 1.f / sqrtf(var + eps);
+  float2 sm[4];
+  sum_parts<4>(src, nparts, C, threadIdx.x, 256, sm);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (threadIdx.x + j * 256 < C) cs[threadIdx.x + j * 256] = sm[j];
+  __syncthreads();
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += cs[c].x; q += cs[c].y; }
+    const float mean = s * inv_cnt;
+    const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
+    stat[2 * ((long)n * groups + g)] = mean;
+    stat[2 * ((long)n * groups + g) + 1] = 1.f / sqrtf(var + eps);
+  }
 }
 
 template <typename T>
@@ -312,10 +336,9 @@ extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, c
   float* sums = scratch;                                              // [N][nparts][C][2]
   float* stat = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;     // [N][groups][2]
   const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
-  const int tot = N * groups;
   FAR3D_CHECK_ARG(groups * 2 <= C, "far3d_groupnorm_nhwc: groups*2 must be <= C");
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, sums, stat, C, groups,
-                     1.f / ((float)HW * (C / groups)), eps, tot, nparts);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(N), dim3(256), 0, st, sums, stat, C, groups,
+                     1.f / ((float)HW * (C / groups)), eps, nparts);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;

@@ -32,13 +32,14 @@ __device__ __forceinline__ float ord_val(unsigned k) { return __uint_as_float((k
 // The values stay in registers (v[k] is only ever indexed by unrolled loops); a pass of the bisection = register compares,
 // one wave reduction, ONE barrier.  The winners are compacted in arbitrary order (LDS counter) and the bitonic sort on the
 // (key, index) pairs restores the order, so no ordered scan is needed.
+template <int MAXV>      // values per thread held in registers: n <= TOPK_THREADS * MAXV
 __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, unsigned long long* sel) {
   const int t = threadIdx.x;
   __shared__ int s_part[2][TOPK_THREADS / 64];
   __shared__ int s_cnt;
-  unsigned v[TOPK_MAXV];
+  unsigned v[MAXV];
 #pragma unroll
-  for (int k = 0; k < TOPK_MAXV; ++k) {
+  for (int k = 0; k < MAXV; ++k) {
     const int i = t + k * TOPK_THREADS;
     unsigned key = 0u;                              // padding: below every real key (real keys are >= 1)
     if (i < n) { key = ord_key(vals[i]); key = key < 1u ? 1u : key; }
@@ -48,7 +49,7 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
 #define TOPK_COUNT(dst, pred)                                              \
   {                                                                        \
     int c_ = 0;                                                            \
-    _Pragma("unroll") for (int k = 0; k < TOPK_MAXV; ++k) {                \
+    _Pragma("unroll") for (int k = 0; k < MAXV; ++k) {                     \
       const unsigned key = v[k];                                           \
       const int idx = t + k * TOPK_THREADS;                                \
       (void)idx;                                                           \
@@ -64,15 +65,17 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
   }
   // K-th largest key by bisection; invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
   unsigned long long lo = 1ull, hi = 0x100000000ull;
+  int n_ge = -1;
   while (hi - lo > 1ull) {
     const unsigned mid = (unsigned)(lo + ((hi - lo) >> 1));
     int c;
     TOPK_COUNT(c, key >= mid);
-    if (c >= K) lo = mid; else hi = mid;
+    if (c == K) { lo = mid; n_ge = K; break; }        // `key >= mid` selects exactly K: the cut need not be a key itself
+    if (c > K) lo = mid; else hi = mid;
   }
   const unsigned kth = (unsigned)lo;
-  int n_ge, n_gt = 0;
-  TOPK_COUNT(n_ge, key >= kth);
+  int n_gt = 0;
+  if (n_ge < 0) TOPK_COUNT(n_ge, key >= kth);
   int idx_cut = 0x7fffffff;                           // among the keys == kth, keep indices <= idx_cut
   if (n_ge > K) {                                     // ties at the cut (block-uniform): keep the lowest indices
     if (kth != 0xffffffffu) TOPK_COUNT(n_gt, key > kth);
@@ -90,7 +93,7 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
   if (t == 0) s_cnt = 0;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < TOPK_MAXV; ++k) {
+  for (int k = 0; k < MAXV; ++k) {
     const int i = t + k * TOPK_THREADS;
     if (v[k] > kth || (v[k] == kth && i <= idx_cut)) {
       const int pos = atomicAdd(&s_cnt, 1);
@@ -117,10 +120,11 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
   }
 }
 
+template <int MAXV>
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ vals, int n, int K, long* __restrict__ idx_out,
                                                             float* __restrict__ val_out) {
   __shared__ unsigned long long sel[TOPK_MAXK];
-  block_topk_sorted(vals, n, K, sel);
+  block_topk_sorted<MAXV>(vals, n, K, sel);
   for (int i = threadIdx.x; i < K; i += TOPK_THREADS) {
     const unsigned long long e = sel[i];
     idx_out[i] = (long)(0xffffffffu - (unsigned)(e & 0xffffffffull));
@@ -132,7 +136,10 @@ extern "C" int far3d_topk(const float* vals, int n, int K, int64_t* idx_out, flo
   FAR3D_CHECK_ARG(vals && idx_out, "far3d_topk: null pointer argument");
   FAR3D_CHECK_ARG(n > 0 && n <= TOPK_THREADS * TOPK_MAXV && K > 0 && K <= n && K <= TOPK_MAXK,
                   "far3d_topk: need 0 < K <= min(n, %d), n <= %d (got n=%d K=%d)", TOPK_MAXK, TOPK_THREADS * TOPK_MAXV, n, K);
-  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
+  if (n <= TOPK_THREADS * 4)      // the memory update ranks A ~ 1.5k scores: 4 registers per thread instead of 40
+    hipLaunchKernelGGL(topk_kernel<4>, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
+  else
+    hipLaunchKernelGGL(topk_kernel<TOPK_MAXV>, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
   FAR3D_CHECK_LAUNCH("far3d_topk");
   return FAR3D_OK;
 }
@@ -152,7 +159,7 @@ struct DecodeParams {
 __global__ __launch_bounds__(TOPK_THREADS) void decode_topk_kernel(DecodeParams p) {
   __shared__ unsigned long long sel[TOPK_MAXK];
   // sigmoid is monotone: the top-K of sigmoid(logits) is the top-K of the logits
-  block_topk_sorted(p.cls, p.A * p.ncls, p.K, sel);
+  block_topk_sorted<TOPK_MAXV>(p.cls, p.A * p.ncls, p.K, sel);
   for (int i = threadIdx.x; i < p.K; i += TOPK_THREADS) {
     const unsigned long long e = sel[i];
     const int idx = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
