@@ -98,7 +98,7 @@ extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                         int ldx, long img_stride, int rows_per_block) {
-  // thread -> 4 consecutive channels; the 256 threads cover rstep = 256*4/C rows per pass; 4 passes are kept in flight.
+  // thread -> 4 consecutive channels; the 256 threads cover rstep = 256*4/C rows per pass; 8 passes are kept in flight.
   __shared__ float red[2][1024];
   const int n = blockIdx.y;
   const int cq = C / 4;
@@ -110,13 +110,18 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
   if (trow < rstep) {
     const T* base = x + (long)n * img_stride + tcol * 4;
     int r = r0 + trow;
-    for (; r + 3 * rstep < r1; r += 4 * rstep) {
-      const float4 a = load4(base + (long)r * ldx), b = load4(base + (long)(r + rstep) * ldx);
-      const float4 c = load4(base + (long)(r + 2 * rstep) * ldx), d = load4(base + (long)(r + 3 * rstep) * ldx);
-      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
-      s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
-      q.x += (a.x * a.x + b.x * b.x) + (c.x * c.x + d.x * d.x); q.y += (a.y * a.y + b.y * b.y) + (c.y * c.y + d.y * d.y);
-      q.z += (a.z * a.z + b.z * b.z) + (c.z * c.z + d.z * d.z); q.w += (a.w * a.w + b.w * b.w) + (c.w * c.w + d.w * d.w);
+    for (; r + 7 * rstep < r1; r += 8 * rstep) {          // 8 row loads in flight per thread: the loop is latency bound
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = load4(base + (long)(r + k * rstep) * ldx);
+      s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+      s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+      s.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+      s.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+      q.x += ((v[0].x * v[0].x + v[1].x * v[1].x) + (v[2].x * v[2].x + v[3].x * v[3].x)) + ((v[4].x * v[4].x + v[5].x * v[5].x) + (v[6].x * v[6].x + v[7].x * v[7].x));
+      q.y += ((v[0].y * v[0].y + v[1].y * v[1].y) + (v[2].y * v[2].y + v[3].y * v[3].y)) + ((v[4].y * v[4].y + v[5].y * v[5].y) + (v[6].y * v[6].y + v[7].y * v[7].y));
+      q.z += ((v[0].z * v[0].z + v[1].z * v[1].z) + (v[2].z * v[2].z + v[3].z * v[3].z)) + ((v[4].z * v[4].z + v[5].z * v[5].z) + (v[6].z * v[6].z + v[7].z * v[7].z));
+      q.w += ((v[0].w * v[0].w + v[1].w * v[1].w) + (v[2].w * v[2].w + v[3].w * v[3].w)) + ((v[4].w * v[4].w + v[5].w * v[5].w) + (v[6].w * v[6].w + v[7].w * v[7].w));
     }
     for (; r < r1; r += rstep) {
       const float4 a = load4(base + (long)r * ldx);
@@ -146,7 +151,7 @@ static int chan_sums_parts(int HW, int C) {
   if (n > FAR3D_SUMS_MAX_PARTS) n = FAR3D_SUMS_MAX_PARTS;
   const int rstep = 256 / (C / 4);
   int rows_per_block = (int)((HW + n - 1) / n);
-  rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
+  rows_per_block = ((rows_per_block + 8 * rstep - 1) / (8 * rstep)) * (8 * rstep);
   return (HW + rows_per_block - 1) / rows_per_block;
 }
 
@@ -154,7 +159,7 @@ static int launch_chan_sums(const void* x, int dt, float* part, int N, int HW, i
   const int nblk = chan_sums_parts(HW, C);
   const int rstep = 256 / (C / 4);
   int rows_per_block = (HW + nblk - 1) / nblk;
-  rows_per_block = ((rows_per_block + 4 * rstep - 1) / (4 * rstep)) * (4 * rstep);
+  rows_per_block = ((rows_per_block + 8 * rstep - 1) / (8 * rstep)) * (8 * rstep);
   dim3 grid(nblk, N), block(256);
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block);
@@ -198,6 +203,20 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
   __shared__ float mean[1024];
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float2* src = reinterpret_cast<const float2*>(part) + (long)n * nparts * C;
+  // each wave: 4 output channels at once (4 independent weight-row streams), float4 loads.  The weight rows do not depend on the
+  // pooled means: their loads (C <= 1024: at most 4 per row and lane) go out first and overlap the partial-sum round trips.
+  const int c0 = blockIdx.x * 16 + wv * 4;
+  float4 w[4][4];
+  float bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = c0 + j < C ? fcb[c0 + j] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane * 4 + i * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      w[i][j] = (k < C && c0 + j < C) ? *reinterpret_cast<const float4*>(fcw + (long)(c0 + j) * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   {
     float2 sm[4];                                  // C <= 1024: channels t, t + 256, t + 512, t + 768
     sum_parts<4>(src, nparts, C, threadIdx.x, 256, sm);
@@ -206,24 +225,21 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
       if (threadIdx.x + j * 256 < C) mean[threadIdx.x + j * 256] = sm[j].x * inv_hw;
   }
   __syncthreads();
-  // each wave: 4 output channels at once (4 independent weight-row streams), float4 loads
-  const int c0 = blockIdx.x * 16 + wv * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = lane * 4; k < C; k += 256) {
-    const float4 m = *reinterpret_cast<const float4*>(mean + k);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (c0 + j < C) {
-        const float4 w = *reinterpret_cast<const float4*>(fcw + (long)(c0 + j) * C + k);
-        acc[j] += (w.x * m.x + w.y * m.y) + (w.z * m.z + w.w * m.w);
-      }
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane * 4 + i * 256;
+    if (k < C) {
+      const float4 m = *reinterpret_cast<const float4*>(mean + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += (w[i][j].x * m.x + w[i][j].y * m.y) + (w[i][j].z * m.z + w[i][j].w * m.w);
     }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float a = wave_sum(acc[j]);
     if (lane == 0 && c0 + j < C) {
-      const float z = a + fcb[c0 + j];
+      const float z = a + bias[j];
       gate[(long)n * C + c0 + j] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
     }
   }
