@@ -459,7 +459,7 @@ extern "C" int far3d_prof_set_agg_timestamps(long long* buf) {
 #endif
 
 // ------------------------------------------------------------------------------------------
-// v7: TWO waves per query, wave w owns pyramid levels w, w+2 (64-token patches).
+// v7: TWO waves per query, wave 0 owns pyramid levels 0 and 3, wave 1 levels 1 and 2 (64-token patches).
 //
 // 128 threads per query -> 8 workgroups per CU at 120 VGPRs (every query of a frame resident in one round), both waves build
 // (2 levels each, lane = token of a 64-token patch, so only spreads > 64 tokens fall back to per-corner entries), and
@@ -651,7 +651,8 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
     cnt += c;
   };
   const int myvis = lane < N ? vis_s[lane] : 0;
-  for (int l = wv; l < L; l += 2) {
+  for (int l = 0; l < L; ++l) {
+    if (((l ^ (l >> 1)) & 1) != wv) continue;       // wave 0: levels 0, 3; wave 1: levels 1, 2 (finest + coarsest together)
     const int Wl = prm.W[l], Hl = prm.H[l];
     const float Wf = (float)Wl, Hf = (float)Hl;
     unsigned long long cams = __ballot((myvis >> l) & 1);          // cameras whose points touch level l: walk the set bits

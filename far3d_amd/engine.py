@@ -24,7 +24,7 @@ PRECISIONS = {
     # projections and every accumulation are fp32 in all modes.
     "bf16": dict(act=torch.bfloat16, value=torch.bfloat16, dec=torch.bfloat16),
     "fp32": dict(act=torch.float32, value=torch.float32, dec=torch.float32),          # parity mode (exact-fp32 MFMA)
-    # mixed assignments measured by tools/error_budget.py
+    # mixed assignments measured by tests/test_engine_full_gpu.py::test_bf16_error_budget_is_measured_and_bounded
     "bf16_fp32dec": dict(act=torch.bfloat16, value=torch.bfloat16, dec=torch.float32),
     "bf16_fp32val": dict(act=torch.bfloat16, value=torch.float32, dec=torch.float32),
     # fp32 data everywhere; conv products (backbone / FPN / 2D head: 95 % of the FLOPs) as a two-term bf16 split on the bf16 MFMA

@@ -58,7 +58,7 @@ def nerf_encoding(t, n=6):   # positional_encoding.py:38-80 (log sampling, no in
 class Far3DOracle:
     def __init__(self, state_dict, cfg=None, dtype=torch.float32):
         """dtype=torch.float64 runs the same restatement in double precision: the yardstick for how much of a deviation is the
-        fp32 rounding noise of the reference arithmetic itself (tools/error_budget.py); inputs must then be double too."""
+        fp32 rounding noise of the reference arithmetic itself (tests/test_engine_full_gpu.py); inputs must then be double too."""
         self.sd = {k: v.detach().to(dtype) if v.is_floating_point() else v for k, v in state_dict.items()}
         self.dtype = dtype
         self.cfg = cfg or default_cfg()
