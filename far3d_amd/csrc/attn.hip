@@ -43,26 +43,30 @@ __device__ __forceinline__ int vt_pos(int key) {
   return (key & ~15) | (sw << 2) | (key & 3);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
-                                                       const T* __restrict__ V, void* __restrict__ O, int out_dt, int Aq,
-                                                       int Nk, int ldq, int ldk, int ldv, int ldo, float scale) {
-  // Workgroup = 64 queries of one head.  Waves 0,1 walk the first half of the keys for queries [0,32) / [32,64), waves 2,3 the
-  // second half for the same queries (flash-decoding style split); the two partial (max, sum, O) states are merged through
-  // LDS at the end.  Twice as many workgroups (fills the 256 CUs) and half as many serial key tiles per wave.
+template <typename T, int NS>     // NS: key-range parts per workgroup (2 waves each)
+__global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                            const T* __restrict__ V, void* __restrict__ O, int out_dt, int Aq,
+                                                            int Nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+  // Workgroup = 64 queries of one head, 2*NS waves.  Waves 2p, 2p+1 walk part p of the keys for queries [0,32) / [32,64)
+  // (flash-decoding style split); the NS partial (max, sum, O) states are merged through LDS at the end.  The loop is a chain
+  // of latencies (global load -> LDS -> MFMA -> exp -> MFMA, ~1.7 us per 64-key tile), and 200 workgroups of 4 waves leave most
+  // SIMDs with a single wave: more parts = fewer serial tiles per wave and more waves per SIMD (bf16: NS = 4, 9 tiles per wave
+  // at 2312 keys; fp32 keeps NS = 2, its tiles do not fit four times into the static LDS budget).
+  constexpr int NT = 128 * NS;
   constexpr int KROW = ACfg<T>::KROW, VROW = ACfg<T>::VROW, KSUB = ACfg<T>::KSUB, CH = ACfg<T>::CH;
   constexpr int E = 16 / sizeof(T);
   constexpr int KBYTES = ATT_KT * KROW, VBYTES = (sizeof(T) == 2 ? ATT_D : ATT_KT) * VROW;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KBYTES + 2 * VBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * KBYTES + NS * VBYTES];
+  static_assert((NS - 1) * 2 * 18 * 64 * 4 <= NS * (KBYTES + VBYTES), "merge buffer must fit the tile buffers");
   unsigned char* KsAll = smem;
-  unsigned char* VsAll = smem + 2 * KBYTES;
+  unsigned char* VsAll = smem + NS * KBYTES;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int half = wv >> 1;
+  const int half = wv >> 1;                     // key part of this wave, 0..NS-1
   const int head = blockIdx.y;
   const int q = blockIdx.x * 64 + (wv & 1) * 32 + l31;
   const bool q_ok = q < Aq;
   const int ntiles = (Nk + ATT_KT - 1) / ATT_KT;
-  const int htiles = (ntiles + 1) / 2;          // tiles per half; half 1 may have one fewer (or none)
+  const int htiles = (ntiles + NS - 1) / NS;    // tiles per part; the last parts may have fewer (or none)
   unsigned char* Ks = KsAll + half * KBYTES;
   unsigned char* Vs = VsAll + half * VBYTES;
 
@@ -83,14 +87,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
     }
   }
 
-  // cooperative staging of TWO K/V tiles per iteration (one per half): chunk id -> (half, key, 16-B piece)
+  // cooperative staging of NS K/V tiles per iteration (one per part): chunk id -> (part, key, 16-B piece)
   constexpr int CPK = ATT_D * sizeof(T) / 16;  // 16-B chunks per key row: 4 (bf16) / 8 (f32)
   constexpr int CH2 = 2 * CH;
   u32x4_t kreg[CH2], vreg[CH2];
   auto gload = [&](int it) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CH2; ++c) {
-      const int id = t + c * 256, h = id / (ATT_KT * CPK), rem = id % (ATT_KT * CPK), key = rem / CPK, ck = rem % CPK;
+      const int id = t + c * NT, h = id / (ATT_KT * CPK), rem = id % (ATT_KT * CPK), key = rem / CPK, ck = rem % CPK;
       const int tl = it + h * htiles;
       const int gk = tl * ATT_KT + key;
       kreg[c] = u32x4_t{0u, 0u, 0u, 0u};
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CH2; ++c) {
-      const int id = t + c * 256, h = id / (ATT_KT * CPK), rem = id % (ATT_KT * CPK), key = rem / CPK, ck = rem % CPK;
+      const int id = t + c * NT, h = id / (ATT_KT * CPK), rem = id % (ATT_KT * CPK), key = rem / CPK, ck = rem % CPK;
       *reinterpret_cast<u32x4_t*>(KsAll + h * KBYTES + key * KROW + ck * 16) = kreg[c];
       unsigned char* vs = VsAll + h * VBYTES;
       if constexpr (sizeof(T) == 2) {
@@ -208,11 +212,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
     __syncthreads();
   }
 
-  // ---- merge the two key halves: waves 2,3 publish (m, l, O) per lane, waves 0,1 combine and store
+  // ---- merge the key parts: waves of parts 1..NS-1 publish (m, l, O) per lane, waves 0,1 combine in part order and store
   float l_tot = l_run + __shfl_xor(l_run, 32);   // both lane halves of a query share m_run
-  float* mb = reinterpret_cast<float*>(smem);    // [2 waves][18][64 lanes]
-  if (half == 1) {
-    float* dst = mb + (wv & 1) * 18 * 64 + lane;
+  float* mb = reinterpret_cast<float*>(smem);    // [NS-1 parts][2 waves][18][64 lanes]
+  if (half >= 1) {
+    float* dst = mb + ((half - 1) * 2 + (wv & 1)) * 18 * 64 + lane;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[r * 64] = o[r];
     dst[16 * 64] = m_run;
@@ -220,20 +224,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
   }
   __syncthreads();
   if (half == 0 && q_ok) {
-    const float* src = mb + (wv & 1) * 18 * 64 + lane;
-    const float m2 = src[16 * 64], l2 = src[17 * 64];
-    const float m = fmaxf(m_run, m2);
+    float m = m_run;
+#pragma unroll
+    for (int p = 1; p < NS; ++p) m = fmaxf(m, mb[((p - 1) * 2 + (wv & 1)) * 18 * 64 + lane + 16 * 64]);
     const float mu = (m == -INFINITY) ? 0.f : m;
-    const float a1 = expf(m_run - mu), a2 = expf(m2 - mu);   // a half that saw no key has m = -inf -> weight 0
-    const float inv = 1.f / (l_tot * a1 + l2 * a2);
+    float ap[NS];                                  // a part that saw no key has m = -inf -> weight 0
+    ap[0] = expf(m_run - mu);
+    float den = l_tot * ap[0];
+#pragma unroll
+    for (int p = 1; p < NS; ++p) {
+      const float* src = mb + ((p - 1) * 2 + (wv & 1)) * 18 * 64 + lane;
+      ap[p] = expf(src[16 * 64] - mu);
+      den += src[17 * 64] * ap[p];
+    }
+    const float inv = 1.f / den;
     const long off = (long)q * ldo + head * ATT_D + 4 * hi;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      float4 r;
-      r.x = (o[4 * qd] * a1 + src[(4 * qd) * 64] * a2) * inv;
-      r.y = (o[4 * qd + 1] * a1 + src[(4 * qd + 1) * 64] * a2) * inv;
-      r.z = (o[4 * qd + 2] * a1 + src[(4 * qd + 2) * 64] * a2) * inv;
-      r.w = (o[4 * qd + 3] * a1 + src[(4 * qd + 3) * 64] * a2) * inv;
+      float acc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = o[4 * qd + e] * ap[0];
+#pragma unroll
+      for (int p = 1; p < NS; ++p) {
+        const float* src = mb + ((p - 1) * 2 + (wv & 1)) * 18 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += src[(4 * qd + e) * 64] * ap[p];
+      }
+      const float4 r = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
       if (out_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off + 8 * qd) = r;
       else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(O) + off + 8 * qd) = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
     }
@@ -252,13 +269,13 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
                   (ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && ldo % 4 == 0 &&
                   (out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16),
                   "far3d_attention_forward: pointers / row strides must be 16-byte aligned");
-  dim3 grid((Aq + 63) / 64, heads), block(256);
+  dim3 grid((Aq + 63) / 64, heads);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FAR3D_DT_F32)
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
+    hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                        Aq, Nk, ldq, ldk, ldv, ldo, scale);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+    hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale);
   FAR3D_CHECK_LAUNCH("far3d_attention_forward");
   return FAR3D_OK;
