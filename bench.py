@@ -247,7 +247,8 @@ def main():
         ncam_local = len(runner.cams) if sharded else 7
         mfma_peak = MFMA_PEAK["bf16" if eng.prec["act"] == torch.bfloat16 else (eng.prec.get("mma") or "fp32")]
         samples = args.steps * (world if (world > 1 and not sharded) else 1)
-        traffic, traffic_src = agg_traffic()
+        # the committed PMC passes measured the bf16-row kernel: no traffic figure for the fp32-row modes
+        traffic, traffic_src = agg_traffic() if eng.prec["value"] == torch.bfloat16 else (None, None)
         try:
             commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
         except Exception:   # noqa: BLE001
