@@ -488,7 +488,14 @@ class Far3DEngine:
                 break
             cap = min(2 * cap, tokens.shape[1])
         M = n * cap
-        out = (self._buf(("ref2d",), (M, 3), torch.float32), self._buf(("ctx",), (M, E + 1), torch.float32),
+        if K is not None and n == cfg["num_cams"] and "head" in self.parts:
+            # every camera is local and M is static: the reference points land directly in the adaptive-query rows of the
+            # head's query-major buffer (head_stage then has nothing to copy)
+            nq = cfg["num_query"]
+            ref_out = self._buf(("rf",), (nq + M + cfg["memory_len"], 3), torch.float32)[nq:nq + M]
+        else:
+            ref_out = self._buf(("ref2d",), (M, 3), torch.float32)
+        out = (ref_out, self._buf(("ctx",), (M, E + 1), torch.float32),
                self._buf(("box2d",), (M, 4), torch.float32), self._buf(("score2d",), (M,), torch.float32))
         # the log-odds threshold is the reference's hard-coded 0.1 (farhead.py:577), not cfg score_thr
         ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, wgt, depth_logit,
@@ -524,7 +531,7 @@ class Far3DEngine:
         # ---- a6: memory pre-update + temporal codes (one kernel)
         m, _, mem_code, tpos = ops.memory_prepare(self.mem, dd["ego_pose_inv"], dd["timestamp"], self.pseudo_ref, self.dim_t256,
                                                   0.0 if fresh else 1.0, fresh, cfg["pc_range"], P_, temp_ref_out=RF[nq + M:])
-        if M > 0:
+        if M > 0 and ref2d.data_ptr() != RF[nq:nq + M].data_ptr():     # already in place in the single-rank static-M path
             RF[nq:nq + M].copy_(ref2d[:M])
         # position codes of the adaptive queries and the memory slots in one pass (rows [nq, Kt))
         qp_raw = self._query_pos(RF[nq:])
