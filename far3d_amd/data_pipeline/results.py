@@ -3,9 +3,8 @@
 Mirrors Argoverse2Dataset.format_results / box_to_av2 (ref datasets/argoverse2_dataset.py:267-341) and yaw_to_quat / xyz_to_quat
 (ref datasets/av2_utils.py:240-283).  The boxes handed over are what the detector returns (bbox3d2result of
 LiDARInstance3DBoxes, ref detectors/far3d.py:262-265): (x, y, z_bottom, w, l, h, yaw[, vx, vy]) rows -- the engine's `boxes_3d`
-already carries the bottom-centre z (ref farhead.py:1236-1238).  The AV2 metric itself (av2_eval_util.evaluate) needs the `av2`
-package and the ground-truth feather files, neither of which exists offline; its input is exactly the frame produced here."""
-import numpy as np
+already carries the bottom-centre z (ref farhead.py:1236-1238).  The frame produced here is the input of the AV2 metric
+(av2_metric.evaluate in this package)."""
 import torch
 
 LABEL_ATTR = ("tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz")   # ref argoverse2_dataset.py:15-17

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import lib as _lib
 from . import ops, weights
-from .synth import level_shapes, level_starts
+from .synth import level_starts
 
 PRECISIONS = {
     # act: activations/weights of the backbone / FPN / 2D-head convs; value: the token-major value maps the decoder samples;

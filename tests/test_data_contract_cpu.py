@@ -1,6 +1,5 @@
 """CPU: the data contract around the hot path (SURVEY.md §8 f1 host part, f3, f4) against fixtures produced by the reference's
 own classes (tools/gen_golden_data.py -> tests/golden/far3d_data_contract.npz), and the Pillow resampling tables against Pillow."""
-import copy
 import os
 
 import numpy as np
@@ -8,7 +7,7 @@ import pytest
 import torch
 
 from far3d_amd import data_pipeline as dp
-from far3d_amd.data_pipeline import resample, results, streaming
+from far3d_amd.data_pipeline import results, streaming
 from tests.conftest import ROOT
 
 Z = np.load(os.path.join(ROOT, "tests", "golden", "far3d_data_contract.npz"))

@@ -28,7 +28,7 @@ def _build(precision="fp32"):
 
 def _worker(rank, world, port, q, use_graph, frames):
     import torch.distributed as dist
-    from far3d_amd import build, synth
+    from far3d_amd import synth
     from far3d_amd import dist as fdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -1,5 +1,5 @@
 """Probe: what the vendor libraries reach on this model's GEMM / conv shapes (targets for the hand-written kernels)."""
-import torch, time
+import torch
 import torch.nn.functional as F
 dev = "cuda:0"
 def timeit(fn, n=20):
