@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true", help="single GPU: do not overlap the camera stages of frame i+1 with the head of frame i")
     ap.add_argument("--agg-variant", type=int, default=0, help="far3d_aggregate_forward kernel variant (A/B timing)")
     args = ap.parse_args()
 
@@ -157,6 +158,8 @@ def main():
     # N > 1 sharded: per-rank hipGraphs for the per-camera stages and the replicated head, collectives eager in between
     runner = fdist.ShardedFrame(eng, use_graph=not args.eager) if sharded else eng
     eng.use_graph = (not sharded) and not args.eager   # whole steady-state frame as ONE hipGraph (no host launch gaps)
+    # frames of one stream are software-pipelined: the per-camera stages of frame i+1 overlap the head of frame i (engine.py)
+    eng.pipeline = eng.use_graph and not args.no_pipeline
 
     def sync():
         if world > 1:
@@ -167,6 +170,7 @@ def main():
     eng_frames = []
     for fi in range(2):
         o = runner.forward_frame(*frames[fi])
+        eng.wait_outputs()
         cnt = o["sel_cnt"].cpu().numpy() if "sel_cnt" in o else None
         sel = [(n, int(i)) for n in range(7) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()] if cnt is not None else []
         eng_frames.append(dict(logits=o["all_cls_scores"].float().cpu().clone(), sel=sel,
@@ -178,10 +182,10 @@ def main():
     sync()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    evs[0].record()
+    evs[0].record(eng.output_stream())
     for k in range(args.steps):
         out = runner.forward_frame(*frames[step_i % len(frames)])
-        evs[k + 1].record()
+        evs[k + 1].record(eng.output_stream())      # completion of frame k (the head's stream in pipeline mode)
         step_i += 1
     sync()
     dt = time.perf_counter() - t0
@@ -234,7 +238,8 @@ def main():
         agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
                                                             num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
                                                             variant=args.agg_variant), 24)]
-        img_local = eng._in["img"] if not sharded else eng._in["img"][runner.cams[0]:runner.cams[-1] + 1] if runner.cams else eng._in["img"][:0]
+        img_in = eng._ins[0]["img"]
+        img_local = img_in if not sharded else img_in[runner.cams[0]:runner.cams[-1] + 1] if runner.cams else img_in[:0]
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
@@ -267,7 +272,10 @@ def main():
                        "precision_assignment": {k: str(v).replace("torch.", "") for k, v in eng.prec.items()},
                        "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)", "commit": commit},
             "protocol": {"pipelined": {"frames": args.steps, "mean_ms": dt / args.steps * 1e3, "p50_ms_device_events": dev_ms[len(dev_ms) // 2],
-                                       "what": "frames issued back to back, one sync at each end (this file's contract -> `value`)"},
+                                       "what": "frames issued back to back, one sync at each end (this file's contract -> `value`)",
+                                       "frame_overlap": bool(eng.pipeline),
+                                       "frame_overlap_what": "per-camera stages of frame i+1 run on their own stream while the head of frame i is in flight "
+                                                             "(two buffer sets, head graphs ordered on one stream: results identical to the unpipelined engine)"},
                          "sync_per_frame": {"frames": len(per_frame), "mean_ms": sum(per_frame) / len(per_frame), "p50_ms": per_frame[len(per_frame) // 2],
                                             "samples_per_s_mean": 1e3 * len(per_frame) / sum(per_frame),
                                             "what": "reference protocol (tools/analysis_tools/benchmark.py:84-111): device sync before and after every frame"}},

@@ -103,10 +103,22 @@ class Far3DEngine:
                 self.sd[ck] = v.detach().float()
         self.spec = weights.VOV_SPECS[self.cfg["backbone"]]
         self._bufs = {}
-        self._in = None             # static input buffers (graph replay reads them)
+        self._ins = {}              # static input buffers per buffer-set parity (graph replay reads them)
         self._graph = None
         self._graph_outs = None
         self.use_graph = False      # set True to capture the steady-state frame into one hipGraph (static proposal mode only)
+        # pipeline (with use_graph): consecutive frames of a stream are software-pipelined -- the per-camera stages of frame
+        # i+1 (which do not depend on the streaming memory) run on their own HIP stream while the head of frame i is still in
+        # flight.  Two complete buffer sets (parity = frame index & 1) and two graphs per parity (camera stages, head); the
+        # head graphs are ordered on one stream, so the memory updates stay sequential and the results are bit-identical to
+        # the unpipelined engine.  Throughput only: the latency of a single frame does not change.  In this mode the outputs of
+        # forward_frame are ready on `output_stream()`; a caller that reads them on its own stream calls `wait_outputs()` first
+        # (ordering the caller's stream after every head automatically would serialise the next frame's camera stages again).
+        self.pipeline = False
+        self._ready = None          # event of the latest pipelined head (None: outputs are on the caller's stream)
+        self._par = 0               # buffer-set parity currently in use (always 0 without pipelining)
+        self._fidx = 0
+        self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
         self.mem = None
         self.prev_scene = None
@@ -276,6 +288,7 @@ class Far3DEngine:
         return self.qe[1](self.qe[0](ops.posemb3d(ref, self.dim_t128), act="relu"))
 
     def _buf(self, key, shape, dtype):
+        key = (self._par,) + tuple(key)
         b = self._bufs.get(key)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
             b = torch.empty(shape, dtype=dtype, device=self.dev)
@@ -329,7 +342,7 @@ class Far3DEngine:
                 ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out, scratch=scratch)
                 if not last:
                     cat, cur_in = nxt, oc
-            stage_in = self._bufs[("stage", si)]
+            stage_in = self._bufs[(self._par, "stage", si)]
             outs.append(stage_in)
             in_ch = oc
         return outs
@@ -522,7 +535,7 @@ class Far3DEngine:
         # query-major state buffers: rows [0,nq) learned queries (constant), [nq,nq+M) adaptive queries, then the Lm memory
         # slots, whose first P_ are the propagated queries and whose rest are the extra self-attention keys
         # (farhead.py:305-311) -- so tgt = TQ[:A], memory = TQ[A:], with no concatenation copies
-        old = self._bufs.get(("tq",))
+        old = self._bufs.get((self._par, "tq"))
         TQ = self._buf(("tq",), (Kt, E), torch.float32)
         QP = self._buf(("qp",), (Kt, E), torch.float32)
         RF = self._buf(("rf",), (Kt, 3), torch.float32)
@@ -579,27 +592,96 @@ class Far3DEngine:
             assert img.shape[0] == 1, "batch 1 per engine (one scene stream per GPU)"
             img = img[0]
         keys = ("lidar2img", "intrinsics", "extrinsics", "ego_pose", "ego_pose_inv", "timestamp")
-        if self._in is None or tuple(self._in["img"].shape) != tuple(img.shape):
-            self._in = dict(img=torch.empty(tuple(img.shape), dtype=torch.float32, device=dev))
+        cur = self._ins.get(self._par)
+        if cur is None or tuple(cur["img"].shape) != tuple(img.shape):
+            cur = dict(img=torch.empty(tuple(img.shape), dtype=torch.float32, device=dev))
             for k in keys:
-                self._in[k] = torch.empty(tuple(data[k].shape), dtype=torch.float64 if k == "timestamp" else torch.float32, device=dev)
+                cur[k] = torch.empty(tuple(data[k].shape), dtype=torch.float64 if k == "timestamp" else torch.float32, device=dev)
+            self._ins[self._par] = cur
             self._graph = None
-        self._in["img"].copy_(img, non_blocking=True)
+            self._pipe = None
+        cur["img"].copy_(img, non_blocking=True)
         for k in keys:
-            self._in[k].copy_(data[k], non_blocking=True)
-        return self._in
+            cur[k].copy_(data[k], non_blocking=True)
+        return cur
 
     def _frame_body(self, dd, img_metas, pad_hw):
-        cfg = self.cfg
+        return self._head_part(self._camera_part(dd, pad_hw), dd, img_metas, pad_hw)
+
+    def _camera_part(self, dd, pad_hw):
         img = dd["img"]
-        N = img.shape[0]
-        st = self.camera_stage(img, dd, range(N), pad_hw)
+        return self.camera_stage(img, dd, range(img.shape[0]), pad_hw)
+
+    def _head_part(self, st, dd, img_metas, pad_hw):
+        cfg = self.cfg
+        N = dd["img"].shape[0]
         K = cfg["proposal_topk"]
         M = N * K if K is not None else int(st["sel_cnt"].sum().item())   # the reference's data-dependent M: one host sync
         outs = self.head_stage(st["tokens"], st["ref2d"], st["ctx"], M, dd, img_metas, st["hw"], st["starts"], pad_hw)
         outs.update(fpn=st["raw"], depth_logit=st["depth_logit"], bbox2d=st["box2d"][:M], bbox2d_scores=st["score2d"][:M],
                     sel_idx=st["sel_idx"], sel_cnt=st["sel_cnt"])
         return outs
+
+    def _pipelined_frame(self, data, img_metas, pad_hw):
+        """One steady-state frame in pipeline mode (see __init__).  Stream s_cam: [wait until the head that last used this
+        buffer set is done] -> input staging -> camera-stage graph.  Stream s_head: [wait for the camera stages] -> head graph."""
+        if self._pipe is None:
+            self._pipe = dict(s_cam=torch.cuda.Stream(self.dev), s_head=torch.cuda.Stream(self.dev), g_cam={}, g_head={}, outs={},
+                              cam_done={}, head_done={})
+        P = self._pipe
+        p = self._par
+        cur = torch.cuda.current_stream(self.dev)
+        here = torch.cuda.Event()
+        here.record(cur)                                  # the caller's stream up to this call: inputs, eager scene starts
+        if p not in P["g_cam"]:
+            # first steady frame on this buffer set: capture its two graphs with the device quiet
+            torch.cuda.synchronize(self.dev)
+            dd = self._stage_inputs(data)
+            if (p, "tq") not in self._bufs:      # the query-major buffers and their constant rows exist before the capture
+                self._alloc_query_buffers(dd["img"].shape[0])
+            gc, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gc):
+                st = self._camera_part(dd, pad_hw)
+            with torch.cuda.graph(gh):
+                outs = self._head_part(st, dd, img_metas, pad_hw)
+            P["g_cam"][p], P["g_head"][p], P["outs"][p] = gc, gh, outs
+            P["cam_done"][p], P["head_done"][p] = torch.cuda.Event(), torch.cuda.Event()
+            torch.cuda.synchronize(self.dev)
+            first = True
+        else:
+            first = False
+        P["s_cam"].wait_event(here)
+        with torch.cuda.stream(P["s_cam"]):
+            if not first:
+                P["s_cam"].wait_event(P["head_done"][p])  # head(i-2) read this buffer set (inputs included)
+            self._stage_inputs(data)
+            P["g_cam"][p].replay()
+            P["cam_done"][p].record(P["s_cam"])
+        with torch.cuda.stream(P["s_head"]):
+            P["s_head"].wait_event(here)
+            P["s_head"].wait_event(P["cam_done"][p])
+            P["g_head"][p].replay()
+            P["head_done"][p].record(P["s_head"])
+        self._ready = P["head_done"][p]
+        return P["outs"][p]
+
+    def output_stream(self):
+        """The stream the latest forward_frame's outputs are produced on."""
+        return self._pipe["s_head"] if (self.pipeline and self._pipe is not None and self._ready is not None) else torch.cuda.current_stream(self.dev)
+
+    def wait_outputs(self):
+        """Order the caller's current stream after the latest frame's outputs (a no-op outside pipeline mode)."""
+        if self._ready is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._ready)
+
+    def _alloc_query_buffers(self, ncam):
+        cfg = self.cfg
+        E, nq = cfg["embed_dims"], cfg["num_query"]
+        Kt = nq + ncam * cfg["proposal_topk"] + cfg["memory_len"]
+        TQ = self._buf(("tq",), (Kt, E), torch.float32)
+        QP = self._buf(("qp",), (Kt, E), torch.float32)
+        RF = self._buf(("rf",), (Kt, 3), torch.float32)
+        TQ[:nq].copy_(self.tgt_fixed); QP[:nq].copy_(self.qpos_fixed); RF[:nq].copy_(self.ref_fixed)
 
     @torch.no_grad()
     def forward_frame(self, data, img_metas):
@@ -608,9 +690,19 @@ class Far3DEngine:
         steady-state frame (same scene, static proposal mode) is captured once into a hipGraph and replayed; the first
         frame of every scene runs eagerly (it resets the streaming memory in place, so the captured graph stays valid).
         Outputs live in engine-owned buffers that the next frame overwrites: clone what must outlive it."""
-        dd = self._stage_inputs(data)
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
+        if self.pipeline and self.use_graph and self.cfg["proposal_topk"] is not None:
+            self._par = self._fidx & 1
+            self._fidx += 1
+            if steady:
+                return self._pipelined_frame(data, img_metas, pad_hw)
+            if self._pipe is not None:       # scene start: runs eagerly on the caller's stream, after everything in flight
+                cur = torch.cuda.current_stream(self.dev)
+                cur.wait_stream(self._pipe["s_cam"]); cur.wait_stream(self._pipe["s_head"])
+            self._ready = None
+            return self._frame_body(self._stage_inputs(data), img_metas, pad_hw)
+        dd = self._stage_inputs(data)
         if self.use_graph and steady and self.cfg["proposal_topk"] is not None:
             if self._graph is None:
                 g = torch.cuda.CUDAGraph()

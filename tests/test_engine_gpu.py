@@ -89,22 +89,50 @@ def test_engine_graph_mode_with_scene_change_is_bitwise_eager(hip_lib, precision
     scene runs eagerly and resets the streaming memory IN PLACE, so the graph captured in scene 0 stays valid in scene 1
     (the old engine re-allocated the memory and replayed on freed buffers)."""
     res = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "pipeline"):
         eng, z, rc = _golden_engine(precision, proposal_topk=12)
-        eng.use_graph = mode == "graph"
+        eng.use_graph = mode != "eager"
+        eng.pipeline = mode == "pipeline"
         out = []
         for fi in list(range(rc["frames"])) + [3, 3]:      # 2 extra steady frames of scene 1
             data, metas = synth.recipe_frame(rc, fi)
             o = eng.forward_frame(data, metas)
+            eng.wait_outputs()                             # pipeline mode: outputs are produced on the head stream
             out.append((o["all_cls_scores"].clone(), o["all_bbox_preds"].clone(), {k: v.clone() for k, v in eng.mem.items()}))
         if mode == "graph":
             assert eng._graph is not None
+        if mode == "pipeline":
+            assert sorted(eng._pipe["g_head"]) == [0, 1]    # both buffer sets captured their camera / head graphs
         res[mode] = out
-    for fi, (a, b) in enumerate(zip(res["eager"], res["graph"])):
-        assert torch.isfinite(a[0]).all()
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "frame %d: graph replay differs from eager" % fi
-        for k in a[2]:
-            assert torch.equal(a[2][k], b[2][k]), "frame %d: streaming memory '%s' differs" % (fi, k)
+    for mode in ("graph", "pipeline"):
+        for fi, (a, b) in enumerate(zip(res["eager"], res[mode])):
+            assert torch.isfinite(a[0]).all()
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "frame %d: %s differs from eager" % (fi, mode)
+            for k in a[2]:
+                assert torch.equal(a[2][k], b[2][k]), "frame %d (%s): streaming memory '%s' differs" % (fi, mode, k)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pipelined_frames_in_flight_end_in_the_same_state(hip_lib, precision):
+    """Pipeline mode with frames submitted back to back and NO wait in between (camera stages of frame i+1 really overlap the
+    head of frame i; a scene change in the middle): the last frame's outputs and the streaming memory equal the eager engine's."""
+    seq = [0, 1, 1, 1, 2, 3, 3, 3, 3]
+    fin = {}
+    for mode in ("eager", "pipeline"):
+        eng, z, rc = _golden_engine(precision, proposal_topk=12)
+        eng.use_graph = eng.pipeline = mode == "pipeline"
+        frames = [synth.recipe_frame(rc, fi, device=DEV) for fi in range(rc["frames"])]
+        for fi in seq:
+            o = eng.forward_frame(*frames[fi])
+        torch.cuda.synchronize()
+        fin[mode] = (o["all_cls_scores"].clone(), o["all_bbox_preds"].clone(), {k: v.clone() for k, v in eng.mem.items()},
+                     {k: v.clone() for k, v in o["result"].items()})
+    a, b = fin["eager"], fin["pipeline"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
 
 
 def test_threshold_mode_grows_the_proposal_capacity(hip_lib):
