@@ -651,6 +651,9 @@ class Far3DEngine:
         else:
             first = False
         P["s_cam"].wait_event(here)
+        for v in data.values():                           # the caller may free its input tensors right after this call
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(P["s_cam"])
         with torch.cuda.stream(P["s_cam"]):
             if not first:
                 P["s_cam"].wait_event(P["head_done"][p])  # head(i-2) read this buffer set (inputs included)
