@@ -639,6 +639,7 @@ class Far3D(nn.Module):
         if self.engine is None:
             raise _lib.Far3dHipError("call Far3D.prepare(device, precision) before inference")
         outs = self.engine.forward_frame(data, img_metas)
+        self.engine.wait_outputs()       # pipeline mode produces the outputs on the head stream (no-op otherwise)
         r = outs["result"]
         keep = r["keep"]
         res = dict(boxes_3d=r["boxes_3d"][keep], scores_3d=r["scores_3d"][keep], labels_3d=r["labels_3d"][keep])
