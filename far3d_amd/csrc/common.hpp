@@ -13,6 +13,7 @@
 #define FAR3D_DT_F32 0
 #define FAR3D_DT_BF16 1
 #define FAR3D_DT_F32_BF16X3 2   // far3d_conv2d_nhwc weight code: fp32 data, two-term bf16 split products (include/far3d_hip.h)
+#define FAR3D_DT_BF16_PAIR 3    // activation storage: fp32 values kept as [32 hi | 32 lo] bf16 per 32-channel block (include/far3d_hip.h)
 #define FAR3D_SUMS_MAX_PARTS 32
 
 void far3d_set_error(const char* fmt, ...);
@@ -67,6 +68,42 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
   o.z = __uint_as_float(r.y << 16);
   o.w = __uint_as_float(r.y & 0xffff0000u);
   return o;
+}
+
+// ---- "pair" storage (FAR3D_DT_BF16_PAIR): a tensor of C logical channels (C % 32 == 0) is stored as 2C bf16 per pixel; every
+// 32-channel block is 32 hi = bf16(x) followed by 32 lo = bf16(x - hi).  hi + lo is exact in fp32 (both are pieces of x's own
+// mantissa), so the format carries 16 significant bits at fp32's byte size and its 64-byte hi / lo runs are what the LDS-DMA
+// conv kernels stream.  Pointers / strides of pair tensors count bf16 elements; chan_off maps a logical channel to its hi.
+struct pair_t { uint16_t v; };
+template <typename T> __device__ __forceinline__ int chan_off(int c) { return c; }
+template <> __device__ __forceinline__ int chan_off<pair_t>(int c) { return ((c >> 5) << 6) | (c & 31); }
+template <typename T> struct ChanScale { static constexpr int v = 1; };
+template <> struct ChanScale<pair_t> { static constexpr int v = 2; };      // stored elements per logical channel
+__device__ __forceinline__ float4 load4(const pair_t* p) {   // p -> hi of 4 consecutive channels (same 32-block); lo 32 elements on
+  const uint2 h = *reinterpret_cast<const uint2*>(p);
+  const uint2 l = *reinterpret_cast<const uint2*>(p + 32);
+  float4 o;
+  o.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+  o.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+  o.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+  o.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+  return o;
+}
+// 4 floats -> (4 hi bf16, 4 lo bf16)
+__device__ __forceinline__ void split4f(float x0, float x1, float x2, float x3, uint2& h, uint2& l) {
+  h.x = pack_bf16x2(x0, x1); h.y = pack_bf16x2(x2, x3);
+  l.x = pack_bf16x2(x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xffff0000u));
+  l.y = pack_bf16x2(x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xffff0000u));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+__device__ __forceinline__ void store4(pair_t* p, const float4& v) {
+  uint2 h, l;
+  split4f(v.x, v.y, v.z, v.w, h, l);
+  *reinterpret_cast<uint2*>(p) = h;
+  *reinterpret_cast<uint2*>(p + 32) = l;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

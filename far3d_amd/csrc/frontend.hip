@@ -34,6 +34,18 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[tap * 3 + c] = ok ? img[(((long)n * 3 + c) * H + iy) * W + ix] : 0.f;
     }
+    if constexpr (ChanScale<T>::v == 2) {     // pair storage: 32 hi bf16 then 32 lo bf16 (one 128-byte row)
+      uint2 h[8], l[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) split4f(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], h[k], l[k]);
+      uint4* dst = reinterpret_cast<uint4*>(out + i * 64);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dst[k] = make_uint4(h[2 * k].x, h[2 * k].y, h[2 * k + 1].x, h[2 * k + 1].y);
+        dst[4 + k] = make_uint4(l[2 * k].x, l[2 * k].y, l[2 * k + 1].x, l[2 * k + 1].y);
+      }
+      continue;
+    }
     T* dst = out + i * 32;
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -49,7 +61,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
 
 extern "C" int far3d_stem_im2col(const float* img, void* out, int out_dt, int N, int H, int W, void* stream) {
   FAR3D_CHECK_ARG(img && out && N > 0 && H > 0 && W > 0, "far3d_stem_im2col: bad arguments");
-  FAR3D_CHECK_ARG(out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16, "far3d_stem_im2col: unsupported dtype");
+  FAR3D_CHECK_ARG(out_dt == FAR3D_DT_F32 || out_dt == FAR3D_DT_BF16 || out_dt == FAR3D_DT_BF16_PAIR, "far3d_stem_im2col: unsupported dtype");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * Ho * Wo;
   long blocks = (total + 255) / 256;
@@ -57,6 +69,8 @@ extern "C" int far3d_stem_im2col(const float* img, void* out, int out_dt, int N,
   hipStream_t st = (hipStream_t)stream;
   if (out_dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, img, (float*)out, N, H, W, Ho, Wo);
+  else if (out_dt == FAR3D_DT_BF16_PAIR)
+    hipLaunchKernelGGL(stem_im2col_kernel<pair_t>, dim3((unsigned)blocks), dim3(256), 0, st, img, (pair_t*)out, N, H, W, Ho, Wo);
   else
     hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, img, (bf16_t*)out, N, H, W, Ho, Wo);
   FAR3D_CHECK_LAUNCH("far3d_stem_im2col");

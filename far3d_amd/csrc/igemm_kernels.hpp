@@ -1,0 +1,1120 @@
+// Implicit-GEMM convolution / linear layer on the CDNA4 matrix cores.
+//
+//   Out[m][p] = epilogue( sum_k W[m][k] * X[p][k] )      m: output channel, p: output pixel (n,oy,ox),
+//                                                        k: (tap, input channel), tap-major.
+// One kernel serves the VoVNet 3x3 / 1x1 convolutions (folded BN + ReLU), the FPN, the YOLOX towers and
+// every nn.Linear of the decoder (a Linear is a 1x1 "conv" over rows).  Activations are NHWC so that a
+// K-slice of one pixel is contiguous; reading / writing through (pointer, pixel-stride) pairs lets an OSA
+// block's five 3x3 convs write straight into their channel slice of the concat buffer (no torch.cat).
+//
+// gfx950 mapping: 256 threads = 4 waves in a 2x2 grid; each wave owns WM x WN tiles of 32x32 computed with
+// v_mfma_f32_32x32x16_bf16 (TC = bf16) or the exact-fp32 v_mfma_f32_32x32x2_f32 (TC = float, parity mode).
+// The weight tile is the MFMA A operand (rows -> output channels) so every lane ends up holding 4
+// consecutive channels of one pixel per accumulator quad -> 8/16-byte stores.  BK = 32; LDS rows are padded
+// by 16 B which makes the 16-lane ds_read_b128 groups conflict-free (row stride 80 B / 144 B).
+// Global -> register -> LDS staging with the next tile's loads in flight during the MFMAs, two LDS buffers,
+// one barrier per K step.
+#pragma once
+#include "common.hpp"
+#include <stdlib.h>
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_SWISH 2
+
+struct IgemmParams {
+  const void* x;        // input activations (TIn), NHWC with pixel stride ldx, channel offset pre-applied
+  const void* w;        // packed weights (TC) [Cout_pad][taps][cin_pad]
+  const float* bias;    // [Cout_pad] or null
+  void* y;              // output, dtype y_dt, pixel stride ldy
+  void* y2;             // optional second output: y2 = scale[n][m]*v + shift[n][m]  (camera-aware MLN)
+  const float* y2_scale;
+  const float* y2_shift;
+  const void* res;      // optional residual, NHWC (Hr x Wr, nearest-neighbour upsampled to Ho x Wo)
+  long x_img_stride, y_img_stride, y2_img_stride, res_img_stride;  // elements between images
+  int N, H, W, Cin, ldx;
+  int Ho, Wo, Cout, ldy;
+  int KH, KW, stride, pad;
+  int cin_pad, nsteps;
+  int act, y_dt, y2_dt, ldy2;
+  int res_dt, ldr, Hr, Wr;
+  int x_vec, y_vec, y2_vec, res_vec;
+  int y_rows16;         // plain bf16 output whose pixel rows take 16-byte stores (LDS-transposed coalesced epilogue)
+};
+
+template <typename TC> struct Cfg;
+template <> struct Cfg<bf16_t> { static constexpr int E = 8, ROWB = 80, KSUB = 2; };
+template <> struct Cfg<float> { static constexpr int E = 4, ROWB = 144, KSUB = 4; };
+// fp32 data computed as a two-term bf16 split: x = hi + lo (both round-to-nearest-even bf16, 16 significant bits together),
+// x*w ~= hi*hi' + hi*lo' + lo*hi' on the bf16 MFMA with fp32 accumulation (the dropped lo*lo' term is 2^-16 relative).
+// 3 bf16 MFMAs of K=16 replace 16 fp32 MFMAs of K=2: ~5x the fp32 matrix rate at ~1e-5 relative operand error.
+// LDS rows: [32 hi | 32 lo] bf16 (same 128 B as 32 floats) + 16 B padding.  Activations are split once, while staging;
+// weights are split when they are packed (host side) and arrive in the LDS row layout.
+struct split_t { float v; };
+template <> struct Cfg<split_t> { static constexpr int E = 4, ROWB = 144, KSUB = 2; };
+template <typename TC> struct is_split { static constexpr bool value = false; };
+template <> struct is_split<split_t> { static constexpr bool value = true; };
+template <typename T> struct is_pair { static constexpr bool value = false; };
+template <> struct is_pair<pair_t> { static constexpr bool value = true; };   // activations already stored split (common.hpp)
+
+// 4 floats -> (4 hi bf16, 4 lo bf16)
+__device__ __forceinline__ void split4(const u32x4_t& c, uint2& h, uint2& l) {
+  const float x0 = __uint_as_float(c.x), x1 = __uint_as_float(c.y), x2 = __uint_as_float(c.z), x3 = __uint_as_float(c.w);
+  h.x = pack_bf16x2(x0, x1); h.y = pack_bf16x2(x2, x3);
+  l.x = pack_bf16x2(x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xffff0000u));
+  l.y = pack_bf16x2(x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xffff0000u));
+}
+
+// Load E consecutive input channels (E = elements per 16-B LDS chunk) converting TIn -> TC.
+template <typename TIn, typename TC>
+__device__ __forceinline__ u32x4_t load_chunk(const TIn* src, int nvalid, bool vec) {
+  constexpr int E = Cfg<TC>::E;
+  u32x4_t r = {0u, 0u, 0u, 0u};
+  if (nvalid <= 0) return r;
+  if (vec && nvalid >= E) {
+    if constexpr (sizeof(TIn) == sizeof(TC)) {
+      r = *reinterpret_cast<const u32x4_t*>(src);
+    } else {  // float -> bf16
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 b = *reinterpret_cast<const float4*>(src + 4);
+      r.x = pack_bf16x2(a.x, a.y); r.y = pack_bf16x2(a.z, a.w);
+      r.z = pack_bf16x2(b.x, b.y); r.w = pack_bf16x2(b.z, b.w);
+    }
+    return r;
+  }
+  float v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = e < nvalid ? LoadCvt<TIn>::ld(src + e) : 0.f;
+  if constexpr (sizeof(TC) == 4) {
+    r.x = __float_as_uint(v[0]); r.y = __float_as_uint(v[1]); r.z = __float_as_uint(v[2]); r.w = __float_as_uint(v[3]);
+  } else {
+    r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+  }
+  return r;
+}
+
+template <typename TC>
+__device__ __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  if constexpr (sizeof(TC) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+}
+
+// off: element offset of the pixel in the output; m: logical channel of v[0].  Pair storage (FAR3D_DT_BF16_PAIR: strides count
+// bf16 elements, Cout % 32 == 0 so nv == 4): hi at chan_off(m), lo 32 elements further.
+__device__ __forceinline__ void store4(void* base, int dt, long off, int m, const float* v, int nv, bool vec) {
+  if (dt == FAR3D_DT_F32) {
+    float* p = reinterpret_cast<float*>(base) + off + m;
+    if (vec && nv == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) p[e] = v[e];
+    }
+  } else if (dt == FAR3D_DT_BF16_PAIR) {
+    store4(reinterpret_cast<pair_t*>(base) + off + chan_off<pair_t>(m), make_float4(v[0], v[1], v[2], v[3]));
+  } else {
+    bf16_t* p = reinterpret_cast<bf16_t*>(base) + off + m;
+    if (vec && nv == 4) *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) p[e] = f32_to_bf16(v[e]);
+    }
+  }
+}
+
+// Shared epilogue: lane (l31, hi) of wave (wm, wn) holds, per 32x32 tile (i, j), 4 consecutive channels x 1 pixel per quad.
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_px(const IgemmParams& P, f32x16_t (&acc)[WM][WN], const int (&pn)[WN],
+                                                  const int (&ppix)[WN], int m0, int wm, int hi) {
+  // ---- epilogue: bias -> activation -> residual -> store (+ optional modulated second output)
+  // pn[j] / ppix[j]: image index and linear pixel index (oy*Wo+ox) of this lane's pixel in tile column j (pn < 0: none)
+  long yoff[WN], roff[WN], y2off[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = pn[j] < 0 ? 0 : pn[j], pix = ppix[j];
+    yoff[j] = (long)n * P.y_img_stride + (long)pix * P.ldy;
+    y2off[j] = (long)n * P.y2_img_stride + (long)pix * P.ldy2;
+    roff[j] = 0;
+    if (P.res && pn[j] >= 0) {
+      const int oy = pix / P.Wo, ox = pix - oy * P.Wo;
+      const int ry = (P.Hr == P.Ho) ? oy : min((int)floorf(oy * ((float)P.Hr / P.Ho)), P.Hr - 1);
+      const int rx = (P.Wr == P.Wo) ? ox : min((int)floorf(ox * ((float)P.Wr / P.Wo)), P.Wr - 1);
+      roff[j] = (long)n * P.res_img_stride + ((long)ry * P.Wr + rx) * P.ldr;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + (wm * WM + i) * 32 + 8 * q + 4 * hi;
+      if (m >= P.Cout) continue;
+      const int nv = min(4, P.Cout - m);
+      // bias rows are padded (include/far3d_hip.h) and 16-byte aligned: one vector load, hoisted out of the pixel loop
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + m);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        if (pn[j] < 0) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (P.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (P.act == ACT_SWISH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
+        }
+        if (P.res) {
+          if (P.res_dt == FAR3D_DT_F32) {
+            const float* rp = reinterpret_cast<const float*>(P.res) + roff[j] + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += rp[e];
+          } else if (P.res_dt == FAR3D_DT_BF16_PAIR) {
+            const float4 r4 = load4(reinterpret_cast<const pair_t*>(P.res) + roff[j] + chan_off<pair_t>(m));
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          } else {
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(P.res) + roff[j] + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf16_to_f32(rp[e]);
+          }
+        }
+        store4(P.y, P.y_dt, yoff[j], m, v, nv, P.y_vec != 0);
+        if (P.y2) {
+          const long so = (long)pn[j] * P.Cout + m;
+          float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) u[e] = P.y2_scale[so + e] * v[e] + P.y2_shift[so + e];
+          store4(P.y2, P.y2_dt, y2off[j], m, u, nv, P.y2_vec != 0);
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&acc)[WM][WN], int p0, int m0, int wm, int wn,
+                                               int l31, int hi, int HoWo, long Npix) {
+  int pn[WN], ppix[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const long p = (long)p0 + (wn * WN + j) * 32 + l31;
+    pn[j] = -1; ppix[j] = 0;
+    if (p < Npix) { pn[j] = (int)(p / HoWo); ppix[j] = (int)(p - (long)pn[j] * HoWo); }
+  }
+  igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
+}
+
+// Coalesced epilogue for plain bf16 outputs: the workgroup's BM x BPX tile is transposed through LDS (rows of BM channels,
+// +16 B of padding: conflict-free 8-byte writes from the MFMA layout, 16-byte row reads) and leaves as 16-byte stores
+// that cover whole pixel rows (the MFMA layout alone gives 8-byte pieces 2*ldy bytes apart).  pix_off(pl) -> element
+// offset of local pixel pl in y, or -1.  smem must hold BPX * (2*BM + 16) bytes and is free once every wave has passed
+// the first barrier.
+template <int NW, int WM, int WN, int BM, int BPX, bool PO = false, typename PixFn>   // PO: pair-storage output ([32 hi | 32 lo] blocks)
+__device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned char* smem, f32x16_t (&acc)[WM][WN], int m0,
+                                                int wm, int wn, int l31, int hi, PixFn pix_off) {
+  constexpr int EB = PO ? 4 : 2;                       // bytes per logical channel of a staged row
+  constexpr int RS = BM * EB + 16, CPP = BM * EB / 16, NT = 64 * NW;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cl = (wm * WM + i) * 32 + 8 * q + 4 * hi;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + m0 + cl);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int pl = (wn * WN + j) * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (P.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (P.act == ACT_SWISH) {
+          if constexpr (PO) {              // 16 significant bits are kept: full-precision exp / divide
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
+          } else {                         // bf16 output: hardware exp2 / rcp (rel. error ~1e-6, far below the bf16 rounding)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * __frcp_rn(1.f + __expf(-v[e]));
+          }
+        }
+        if constexpr (PO) {
+          uint2 h, l;
+          split4f(v[0], v[1], v[2], v[3], h, l);
+          unsigned char* d = smem + pl * RS + (cl >> 5) * 128 + (cl & 31) * 2;
+          *reinterpret_cast<uint2*>(d) = h;
+          *reinterpret_cast<uint2*>(d + 64) = l;
+        } else {
+          *reinterpret_cast<uint2*>(smem + pl * RS + cl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  bf16_t* y = reinterpret_cast<bf16_t*>(P.y);
+  constexpr int ES = EB / 2;                            // stored bf16 elements per logical channel
+#pragma unroll 2
+  for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
+    const int pl = idx / CPP, c = idx - pl * CPP;
+    if (m0 * ES + c * 8 >= P.Cout * ES) continue;
+    const long off = pix_off(pl);
+    if (off < 0) continue;
+    *reinterpret_cast<u32x4_t*>(y + off + m0 * ES + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+  }
+}
+
+// WGM x WGN: arrangement of the 4 waves over (channels, pixels); WM x WN: 32x32 MFMA tiles per wave.
+template <typename TIn, typename TC, int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int E = Cfg<TC>::E, ROWB = Cfg<TC>::ROWB, KSUB = Cfg<TC>::KSUB;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int CPR = 32 / E;                 // 16-B chunks per tile row
+  constexpr int A_CH = BM * CPR / 256;        // weight chunks per thread
+  constexpr int B_CH = BP * CPR / 256;        // pixel chunks per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                               // [2][BM][ROWB]
+  unsigned char* Bs = smem + 2 * BM * ROWB;               // [2][BP][ROWB]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  const int p0 = blockIdx.x * BP, m0 = blockIdx.y * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int Ktot = P.KH * P.KW * P.cin_pad;
+
+  // ---- per-thread staging coordinates (fixed for the whole K loop)
+  constexpr bool SPLIT = is_split<TC>::value;
+  constexpr bool PAIR_IN = is_pair<TIn>::value;
+  static_assert(sizeof(TC) == 2 || sizeof(TIn) == 4 || (PAIR_IN && SPLIT), "fp32 compute types take fp32 (or pair-stored) activations");
+  static_assert(!PAIR_IN || SPLIT, "pair-stored activations feed the split products");
+  const TC* wsrc[A_CH];
+  int arow[A_CH], acol[A_CH];
+#pragma unroll
+  for (int c = 0; c < A_CH; ++c) {
+    const int id = t + c * 256;
+    arow[c] = id / CPR; acol[c] = id % CPR;
+    wsrc[c] = reinterpret_cast<const TC*>(P.w) + (long)(m0 + arow[c]) * Ktot + acol[c] * E;
+  }
+  int brow[B_CH], bcol[B_CH], bn[B_CH], boy[B_CH], box[B_CH];
+#pragma unroll
+  for (int c = 0; c < B_CH; ++c) {
+    const int id = t + c * 256;
+    brow[c] = id / CPR; bcol[c] = id % CPR;
+    const long p = (long)p0 + brow[c];
+    if (p < Npix) {
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      bn[c] = n; boy[c] = (rem / P.Wo) * P.stride - P.pad; box[c] = (rem % P.Wo) * P.stride - P.pad;
+    } else {
+      bn[c] = -1; boy[c] = 0; box[c] = 0;
+    }
+  }
+  u32x4_t areg[A_CH], breg[B_CH];
+  auto gload = [&](int step) __attribute__((always_inline)) {
+    const int kb = step * 32;
+    const int tap = kb / P.cin_pad, c0 = kb - tap * P.cin_pad;
+    const int ky = tap / P.KW, kx = tap - ky * P.KW;
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) areg[c] = *reinterpret_cast<const u32x4_t*>(wsrc[c] + kb);
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int iy = boy[c] + ky, ix = box[c] + kx, ch = c0 + bcol[c] * E;
+      const bool ok = bn[c] >= 0 && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      if constexpr (PAIR_IN) {      // 4 hi + 4 lo bf16 of 4 logical channels, already split (Cin % 32 == 0: no ragged chunk)
+        u32x4_t r = {0u, 0u, 0u, 0u};
+        if (ok && ch < P.Cin) {
+          const pair_t* src = reinterpret_cast<const pair_t*>(P.x) + (long)bn[c] * P.x_img_stride + ((long)iy * P.W + ix) * P.ldx + chan_off<pair_t>(ch);
+          const uint2 h = *reinterpret_cast<const uint2*>(src), l = *reinterpret_cast<const uint2*>(src + 32);
+          r.x = h.x; r.y = h.y; r.z = l.x; r.w = l.y;
+        }
+        breg[c] = r;
+      } else {
+        const TIn* src = reinterpret_cast<const TIn*>(P.x) + (long)bn[c] * P.x_img_stride + ((long)iy * P.W + ix) * P.ldx + ch;
+        breg[c] = load_chunk<TIn, TC>(src, ok ? P.Cin - ch : 0, P.x_vec != 0);
+      }
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (SPLIT) {
+      uint2 h, l;
+#pragma unroll
+      for (int c = 0; c < A_CH; ++c)        // weights arrive pre-split (rows of [32 hi | 32 lo] bf16 per 32-channel block): plain copy
+        *reinterpret_cast<u32x4_t*>(As + (buf * BM + arow[c]) * ROWB + acol[c] * 16) = areg[c];
+#pragma unroll
+      for (int c = 0; c < B_CH; ++c) {
+        if constexpr (PAIR_IN) { h = make_uint2(breg[c].x, breg[c].y); l = make_uint2(breg[c].z, breg[c].w); }
+        else split4(breg[c], h, l);
+        unsigned char* d = Bs + (buf * BP + brow[c]) * ROWB + bcol[c] * 8;
+        *reinterpret_cast<uint2*>(d) = h; *reinterpret_cast<uint2*>(d + 64) = l;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < A_CH; ++c)
+        *reinterpret_cast<u32x4_t*>(As + (buf * BM + arow[c]) * ROWB + acol[c] * 16) = areg[c];
+#pragma unroll
+      for (int c = 0; c < B_CH; ++c)
+        *reinterpret_cast<u32x4_t*>(Bs + (buf * BP + brow[c]) * ROWB + bcol[c] * 16) = breg[c];
+    }
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int step = 0; step < P.nsteps; ++step) {
+    const bool more = step + 1 < P.nsteps;
+    if (more) gload(step + 1);
+    const unsigned char* Ab = As + (buf * BM + wm * WM * 32 + l31) * ROWB + hi * 16;
+    const unsigned char* Bb = Bs + (buf * BP + wn * WN * 32 + l31) * ROWB + hi * 16;
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk) {
+      u32x4_t af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(Ab + i * 32 * ROWB + kk * 32);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 32 * ROWB + kk * 32);
+      if constexpr (SPLIT) {
+        u32x4_t al[WM], bl[WN];        // the lo halves sit 64 B further in the row
+#pragma unroll
+        for (int i = 0; i < WM; ++i) al[i] = *reinterpret_cast<const u32x4_t*>(Ab + i * 32 * ROWB + kk * 32 + 64);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bl[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 32 * ROWB + kk * 32 + 64);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {       // small terms first
+            mma<bf16_t>(acc[i][j], al[i], bf[j]);
+            mma<bf16_t>(acc[i][j], af[i], bl[j]);
+            mma<bf16_t>(acc[i][j], af[i], bf[j]);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) mma<TC>(acc[i][j], af[i], bf[j]);
+      }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
+}
+
+template <typename TIn, typename TC, int WGM, int WGN, int WM, int WN>
+static int launch_igemm(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
+  const size_t lds = (size_t)2 * (BM + BP) * Cfg<TC>::ROWB;
+  hipLaunchKernelGGL((igemm_kernel<TIn, TC, WGM, WGN, WM, WN>), grid, dim3(256), lds, st, P);
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast path: same tiling / epilogue, but the operands stream global -> LDS directly (LDS-DMA, `global_load_lds`
+// 16 B per lane, no VGPR staging) through an NS-deep ring, issued NS-1 K-steps ahead with counted `s_waitcnt vmcnt` and ONE
+// raw `s_barrier` per step.  An LDS-DMA instruction writes 1 KiB = 16 rows x 64 B linearly, so the 64-byte (BK = 32 bf16)
+// rows are unpadded; bank conflicts of the 16-lane `ds_read_b128` groups are removed by an XOR swizzle applied on the
+// SOURCE side: the lane that fills physical 16-B chunk pc of row r fetches logical chunk pc ^ ((r>>2)&3), and fragment
+// reads use the same involution.  Out-of-image taps read a 64-B zero page instead of branching.
+// ------------------------------------------------------------------------------------------------------------------
+static __device__ __attribute__((aligned(64))) unsigned int g_zero_page[32];
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WGM, int WGN, int WM, int WN, int NS, int KPS = 1>   // KPS: 32-channel K chunks per barrier step
+__global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int GA = BM / 16, GB = BP / 16, GT = GA + GB;      // 16-row groups = LDS-DMA instructions per chunk
+  constexpr int GLW = (GT + 3) / 4;                              // per wave (slots past GT re-fetch an earlier group: benign)
+  constexpr int CHUNK = (BM + BP) * 64, STAGE = CHUNK * KPS;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  const int p0 = blockIdx.x * BP, m0 = blockIdx.y * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int Ktot = P.KH * P.KW * P.cin_pad;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // lane -> (row within the 16-row group, physical chunk) -> logical chunk it must fetch
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);          // group bases are multiples of 16 rows, so (row>>2)&3 == (rg>>2)&3
+  const bf16_t* sbase_[GLW];                     // A slot: weight row pointer; B slot: image base (nullptr = past the end)
+  int soy[GLW], sox[GLW], sdst[GLW];
+  bool sisA[GLW];
+#pragma unroll
+  for (int i = 0; i < GLW; ++i) {
+    int q = wv + 4 * i;
+    if (q >= GT) q -= GT;
+    sisA[i] = q < GA;
+    if (sisA[i]) {
+      const int row = q * 16 + rg;
+      sbase_[i] = reinterpret_cast<const bf16_t*>(P.w) + (long)(m0 + row) * Ktot + lc * 8;
+      soy[i] = 0; sox[i] = 0;
+      sdst[i] = q * 1024;
+    } else {
+      const int row = (q - GA) * 16 + rg;
+      const long p = (long)p0 + row;
+      sdst[i] = BM * 64 + (q - GA) * 1024;
+      if (p < Npix) {
+        const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+        sbase_[i] = reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + lc * 8;
+        soy[i] = (rem / P.Wo) * P.stride - P.pad; sox[i] = (rem % P.Wo) * P.stride - P.pad;
+      } else {
+        sbase_[i] = nullptr; soy[i] = 0; sox[i] = 0;
+      }
+    }
+  }
+  int i_tap = 0, i_c0 = 0;   // (tap, first channel) of the next K chunk to be issued
+  const int ntaps = P.KH * P.KW;
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kc = 0; kc < KPS; ++kc) {
+      const bool live = i_tap < ntaps;     // chunks past the end of K (last, partial step) are fed from the zero page
+      const int ky = i_tap / P.KW, kx = i_tap - ky * P.KW;
+      const int kb = i_tap * P.cin_pad + i_c0;
+      unsigned char* sb = smem + stage * STAGE + kc * CHUNK;
+#pragma unroll
+      for (int i = 0; i < GLW; ++i) {
+        const bf16_t* src;
+        if (sisA[i]) {
+          src = live ? sbase_[i] + kb : zero;
+        } else {
+          const int iy = soy[i] + ky, ix = sox[i] + kx;
+          const bool ok = live && sbase_[i] != nullptr && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+          src = ok ? sbase_[i] + ((long)iy * P.W + ix) * P.ldx + i_c0 : zero;
+        }
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sb + sdst[i]), 16, 0, 0);
+      }
+      i_c0 += 32;
+      if (i_c0 >= P.cin_pad) { i_c0 = 0; ++i_tap; }
+    }
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (P.nsteps + KPS - 1) / KPS;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nsteps) issue(s);
+  // fragment read addresses: row r = tile row, logical chunk (kk*2 + hi) -> physical chunk ^ ((r>>2)&3)
+  int aoff[WM], boff[WN], aswz[WM], bswz[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) { const int r = (wm * WM + i) * 32 + l31; aoff[i] = r * 64; aswz[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) { const int r = (wn * WN + j) * 32 + l31; boff[j] = BM * 64 + r * 64; bswz[j] = (r >> 2) & 3; }
+
+  int stage = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    if (NS > 2 && step + NS - 1 <= nsteps) wait_vmcnt<GLW * KPS * (NS > 2 ? NS - 2 : 0)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (step + NS - 1 < nsteps) {
+      int st2 = stage + NS - 1; if (st2 >= NS) st2 -= NS;
+      issue(st2);
+    }
+#pragma unroll
+    for (int kc = 0; kc < KPS; ++kc) {
+      const unsigned char* sb = smem + stage * STAGE + kc * CHUNK;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4_t af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(sb + aoff[i] + (((kk * 2 + hi) ^ aswz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(sb + boff[j] + (((kk * 2 + hi) ^ bswz[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[i], bf[j]);
+      }
+    }
+    if (++stage == NS) stage = 0;
+  }
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
+}
+
+template <int WGM, int WGN, int WM, int WN, int NS, int KPS = 1>
+static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
+  constexpr size_t lds = (size_t)NS * KPS * (BM + BP) * 64;
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), grid, dim3(256), lds, st, P);
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 bf16 convolution with an LDS-resident input patch, software pipelined.
+// A workgroup owns a TH x 32 pixel rectangle of one image: for every 32-channel slice of Cin the (TH+2) x 34 halo patch is
+// DMA'd to LDS ONCE (double buffered) and the 9 taps are shifted LDS reads of it; only the weights stream, one kernel row
+// (3 taps) per barrier step, through a 2- or 3-deep ring.  The first version of this kernel (global_load_lds, addresses
+// recomputed per tap) ran the matrix pipe 30 % busy with waves parked 42 % of the time: the compiler issued each tap's
+// `ds_read_b128`s, then `s_waitcnt lgkmcnt(0)`, then the MFMAs, six times per step, and spent ~9 VALU per MFMA on swizzled
+// LDS addresses (profiles/r1).  Here
+//   * every fragment address is a per-lane VGPR computed once + a compile-time immediate (chunk parity, ring stage, tap
+//     are compile-time: the loop body is two chunks = six steps, fully unrolled),
+//   * fragments are double-buffered in registers: the reads of tap/k-half i+1 are issued before the MFMAs of i,
+//   * the next chunk's patch is issued AFTER the next step's weights so that `vmcnt(GPL)` keeps it in flight for two steps.
+// ------------------------------------------------------------------------------------------------------------------
+// Pair-stored activations (FAR3D_DT_BF16_PAIR, common.hpp) and pre-split weights run through the same pipeline: a 32-channel
+// chunk is then TWO 64-byte planes (hi, lo) of every patch pixel / weight row, and every (tap, k-half) does the three products
+// lo*hi' + hi*lo' + hi*hi' (NT = 3) from four fragment sets -- 3 MFMAs per 2+2 fragment reads instead of 1 per 1+1, so the
+// split mode is LESS LDS-bound than plain bf16.  NT = 1 with PAIR reads only the hi planes (a single-bf16 layer inside a
+// pair-stored network; the per-layer precision sweep of tools/precision_sweep.py).
+template <int WM, int WN, int KY, int POFF, int WOFF, int TAPB, int NTAPS, int NT, int PPS, int WPS, typename Dma>   // NTAPS: 3 = one kernel row, 9 = all taps
+__device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
+                                                     const int (&baddr)[2][WN + 2][3], f32x16_t (&acc)[WM][WN], Dma dma) {
+  constexpr int PL = NT == 3 ? 2 : 1;          // planes read per chunk: [0] hi (or plain bf16), [1] lo
+  u32x4_t af[2][PL][WM], bf[2][PL][WN];
+#pragma unroll
+  for (int pl = 0; pl < PL; ++pl) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + pl * WPS + aaddr[0][i]);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bf[0][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + pl * PPS + baddr[0][j + KY][0]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < 2 * NTAPS; ++it) {
+    const int cur = it & 1, nxt = cur ^ 1;
+    if (it + 1 < 2 * NTAPS) {
+      const int tp = (it + 1) >> 1, kk = (it + 1) & 1;     // tap tp of this step = kernel row KY + tp / 3, column tp % 3
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[nxt][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + tp * TAPB + pl * WPS + aaddr[kk][i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[nxt][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + pl * PPS + baddr[kk][j + KY + tp / 3][tp % 3]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next fragments' reads ahead of this iteration's MFMAs
+    if constexpr (NT == 3) {               // small terms first; term-major so that consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][PL - 1][i], bf[cur][0][j]);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][0][i], bf[cur][PL - 1][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][0][i], bf[cur][0][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    dma(it);        // this iteration's share of the next step's LDS-DMA pieces: their issue cost hides under the MFMAs above
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// NSW: weight ring depth (steps prefetched ahead + 1).  RPS: kernel rows per barrier step -- 1 (3 taps) or 3 (the whole 32-channel
+// chunk, 9 taps: a third of the barriers, for the layers too small to fill the chip with more than one workgroup per CU).
+// NT / PAIR: see patch_step_pipelined; with PAIR the pointers / strides of x, w (and of y when y_dt is the pair code) count bf16
+// elements of the 2C-wide stored rows.
+template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParams P, int tiles_x, int tiles_y) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
+  constexpr int NW = WGM * WGN;                      // waves per workgroup (4, 8 or 16)
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
+  constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + NW - 1) / NW;
+  constexpr int TPSN = 3 * RPS;                      // taps per barrier step
+  constexpr int GA = BM / 16, WSLOTS = TPSN * GA, GWL = (WSLOTS + NW - 1) / NW, WST = BM * 64;
+  constexpr int PLD = NT == 3 ? 2 : 1;               // 64-byte planes of a chunk brought to LDS
+  constexpr int PLS = PAIR ? 2 : 1;                  // planes a chunk occupies in memory
+  constexpr int TAPB = PLD * WST;                    // one tap of a weight stage: [plane][BM rows x 64 B]
+  static_assert(NSW == 2 || NSW == 3, "weight ring of 2 or 3 steps");
+  static_assert(RPS == 1 || (RPS == 3 && NSW == 2), "whole-chunk steps use the 2-deep ring");
+  static_assert(NT == 1 || (NT == 3 && PAIR && RPS == 1), "split products need pair-stored operands and one kernel row per step");
+  constexpr int WBASE = 2 * PLD * PATCH_B;           // patches: [2 buffers][PLD planes][PATCH_B]; then the weight ring [NSW][TPSN][TAPB]
+  static_assert(WBASE + NSW * TPSN * TAPB <= 163840, "LDS budget");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int x0 = tx * 32, y0 = ty * TH, m0 = blockIdx.y * BM;
+  const int Ktot = 9 * P.cin_pad * PLS;
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);
+
+  // LDS-DMA through buffer descriptors (`buffer_load_dwordx4 ... offen lds`): per-lane byte offset in a VGPR computed once,
+  // the K position in an SGPR, out-of-image halo pixels get an out-of-range offset and the hardware writes zeros.
+  // (MUBUF rather than `global_load_lds`: the compiler treats the latter as a FLAT access that may touch LDS and
+  // then degrades every `s_waitcnt lgkmcnt(n)` to lgkmcnt(0), which serialises the fragment pipeline below.)
+  constexpr unsigned OOB = 0x80000000u;
+  const long img_bytes = (long)P.H * P.W * P.ldx * 2;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride), 0, (int)(img_bytes < 0x7fffffffL ? img_bytes : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+  unsigned pvoff[GPL], wvoff[GWL];
+  int pdst[GPL], wdst[GWL];
+#pragma unroll
+  for (int i = 0; i < GPL; ++i) {       // every wave issues exactly GPL patch slots (slots past PG re-fetch an earlier one)
+    int q = wv + NW * i;
+    if (q >= PG) q -= PG;
+    pdst[i] = q * 1024;
+    const int idx = q * 16 + rg;
+    const int py = idx / PW, px = idx - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = idx < PPIX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    pvoff[i] = ok ? (unsigned)((((long)iy * P.W + ix) * P.ldx + lc * 8) * 2) : OOB;
+  }
+  int wtap[GWL];                        // weight slot = (tap of the kernel row, 16-row group); slots past WSLOTS are skipped
+#pragma unroll
+  for (int i = 0; i < GWL; ++i) {
+    const int q = wv + NW * i;
+    wtap[i] = q < WSLOTS ? q / GA : -1;
+    const int g = q % GA;
+    wdst[i] = (q / GA) * TAPB + g * 1024;
+    wvoff[i] = (unsigned)(((g * 16 + rg) * Ktot + lc * 8) * 2);
+  }
+  // a slot = PLD pieces (the chunk's planes are 64 bytes apart in memory, PATCH_B / WST apart in LDS)
+  auto patch_piece = [&](int i, int pl, int chunk, int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + (buf * PLD + pl) * PATCH_B + pdst[i]), 16, pvoff[i],
+                                             chunk * (64 * PLS) + pl * 64, 0, 0);
+  };
+  auto w_piece = [&](int i, int pl, int chunk, int ky, int stage) __attribute__((always_inline)) {   // kernel row ky: taps 3*ky .. 3*ky+2
+    if (wtap[i] < 0) return;            // wave-uniform
+    const int kb = ((ky * 3 + wtap[i]) * P.cin_pad + chunk * 32) * PLS;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + WBASE + stage * TPSN * TAPB + wdst[i] + pl * WST), 16, wvoff[i],
+                                             kb * 2 + pl * 64, 0, 0);
+  };
+  auto issue_patch = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < GPL; ++i)
+#pragma unroll
+      for (int pl = 0; pl < PLD; ++pl) patch_piece(i, pl, chunk, buf);
+  };
+  auto issue_w = [&](int chunk, int ky, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < GWL; ++i)
+#pragma unroll
+      for (int pl = 0; pl < PLD; ++pl) w_piece(i, pl, chunk, ky, stage);
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addresses (bytes from the plane base): [k-half][...]; the k-half flips bit 5 of the swizzled chunk
+  int aaddr[2][WM], baddr[2][WN + 2][3];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    aaddr[0][i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+    aaddr[1][i] = aaddr[0][i] ^ 32;
+  }
+#pragma unroll
+  for (int r = 0; r < WN + 2; ++r)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int idx = (wn * WN + r) * PW + l31 + kx;
+      baddr[0][r][kx] = idx * 64 + ((hi ^ ((idx >> 2) & 3)) << 4);
+      baddr[1][r][kx] = baddr[0][r][kx] ^ 32;
+    }
+
+  const int nchunks = P.cin_pad / 32;
+  // `s_waitcnt vmcnt` counts this wave's own pieces, oldest first: PLD * nwv weight pieces per step (nwv = GWL or GWL-1 slots),
+  // PLD * GPL patch pieces
+  const int nwv = (WSLOTS - wv + NW - 1) / NW;
+  const bool wfull = nwv == GWL;
+#define FAR3D_WAITC(NWS, PA)                                                                                          \
+  {                                                                                                                    \
+    if (wfull) { if (PA) wait_vmcnt<PLD * ((NWS) * GWL + GPL)>(); else wait_vmcnt<PLD * (NWS) * GWL>(); }              \
+    else       { if (PA) wait_vmcnt<PLD * ((NWS) * (GWL - 1) + GPL)>(); else wait_vmcnt<PLD * (NWS) * (GWL - 1)>(); }  \
+  }
+#define FAR3D_DMA_PIECES(DO_W, WCALL, DO_P, PCALL)                                                                     \
+        _Pragma("unroll")                                                                                              \
+        for (int k = it * PPI; k < (it + 1) * PPI && k < PIECES; ++k) {                                                \
+          if (k < GWL * PLD) { if (DO_W) { const int sl = k / PLD, pl = k % PLD; WCALL; } }                            \
+          else if (DO_P) { const int sl = (k - GWL * PLD) / PLD, pl = (k - GWL * PLD) % PLD; PCALL; }                  \
+        }
+  if constexpr (RPS == 3) {
+    // whole-chunk steps: step c reads patch buffer / weight stage c & 1 (all 9 taps); both were issued during step c - 1
+    // (weights first, then the patch), so the top of every step waits for everything (vmcnt 0)
+    issue_patch(0, 0);
+    issue_w(0, 0, 0);
+#define FAR3D_PIPE_CHUNK(PAR, CH)                                                                                      \
+  {                                                                                                                    \
+    const bool more = (CH) + 1 < nchunks;                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    wait_vmcnt<0>();                                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    asm volatile("" ::: "memory");                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    constexpr int PIECES = (GWL + GPL) * PLD, PPI = (PIECES + 17) / 18;                                                \
+    patch_step_pipelined<WM, WN, 0, (PAR) * PLD * PATCH_B, WBASE + (PAR) * TPSN * TAPB, TAPB, 9, NT, PATCH_B, WST>(    \
+      smem, aaddr, baddr, acc, [&](int it) __attribute__((always_inline)) {                                            \
+        FAR3D_DMA_PIECES(more, w_piece(sl, pl, (CH) + 1, 0, (PAR) ^ 1), more, patch_piece(sl, pl, (CH) + 1, (PAR) ^ 1)) \
+      });                                                                                                              \
+  }
+    for (int c = 0; c < nchunks; c += 2) {
+      FAR3D_PIPE_CHUNK(0, c)
+      if (c + 1 < nchunks) FAR3D_PIPE_CHUNK(1, c + 1)
+    }
+#undef FAR3D_PIPE_CHUNK
+  } else {
+  if (NSW == 2) {
+    issue_patch(0, 0);
+    issue_w(0, 0, 0);
+  } else {
+    issue_w(0, 0, 0);
+    issue_patch(0, 0);
+    issue_w(0, 1, 1);
+  }
+  // step s = 3c + ky reads weight stage s % NSW and patch buffer c & 1; after its barrier it issues the weights of step
+  // s + NSW - 1 and (ky == 0) the next chunk's patch.  Pieces issued after W(s), which may stay in flight at the top of
+  // step s:  NSW 2: the patch when ky == 1;  NSW 3: W(s+1), plus the patch when ky != 0.
+#define FAR3D_PIPE_STEP(PAR, KY, CH)                                                                                   \
+  {                                                                                                                    \
+    constexpr int STG = NSW == 2 ? ((PAR * 3 + KY) & 1) : KY;                                                          \
+    const bool more = (CH) + 1 < nchunks;                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (NSW == 2) {                                                                                                    \
+      if (KY == 1 && more) wait_vmcnt<PLD * GPL>(); else wait_vmcnt<0>();                                              \
+    } else {                                                                                                           \
+      const bool have_next = KY < 2 || more, patch_after = KY != 0 && more;                                            \
+      if (have_next) FAR3D_WAITC(1, patch_after) else wait_vmcnt<0>();                                                 \
+    }                                                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    asm volatile("" ::: "memory");                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    /* next pieces: weights of step s + NSW - 1 (chunk wc, row wk, stage ws) first, then (ky == 0) the next patch */   \
+    const int wc = (NSW == 2 ? (KY < 2) : (KY == 0)) ? (CH) : (CH) + 1;                                                \
+    constexpr int wk = (KY + NSW - 1) % 3, ws = NSW == 2 ? (STG ^ 1) : wk;                                             \
+    const bool do_w = wc < nchunks, do_p = KY == 0 && more;                                                            \
+    constexpr int PIECES = (GWL + GPL) * PLD, PPI = (PIECES + 5) / 6;                                                  \
+    patch_step_pipelined<WM, WN, KY, (PAR) * PLD * PATCH_B, WBASE + STG * 3 * TAPB, TAPB, 3, NT, PATCH_B, WST>(        \
+      smem, aaddr, baddr, acc, [&](int it) __attribute__((always_inline)) {                                            \
+        FAR3D_DMA_PIECES(do_w, w_piece(sl, pl, wc, wk, ws), do_p, patch_piece(sl, pl, (CH) + 1, (PAR) ^ 1))            \
+      });                                                                                                              \
+  }
+  for (int c = 0; c < nchunks; c += 2) {
+    FAR3D_PIPE_STEP(0, 0, c)
+    FAR3D_PIPE_STEP(0, 1, c)
+    FAR3D_PIPE_STEP(0, 2, c)
+    if (c + 1 < nchunks) {
+      FAR3D_PIPE_STEP(1, 0, c + 1)
+      FAR3D_PIPE_STEP(1, 1, c + 1)
+      FAR3D_PIPE_STEP(1, 2, c + 1)
+    }
+  }
+#undef FAR3D_PIPE_STEP
+  }   // RPS == 1
+#undef FAR3D_WAITC
+#undef FAR3D_DMA_PIECES
+  if (P.y_rows16) {
+    epilogue_rows16<NW, WM, WN, BM, TH * 32, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
+      const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
+      return (y < P.H && x < P.W) ? (long)n * P.y_img_stride + ((long)y * P.W + x) * P.ldy : -1L;
+    });
+    return;
+  }
+  int pn[WN], ppix[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int y = y0 + wn * WN + j, x = x0 + l31;
+    pn[j] = (y < P.H && x < P.W) ? n : -1;
+    ppix[j] = y * P.W + x;
+  }
+  igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
+#endif
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false>
+static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PLD = NT == 3 ? 2 : 1;
+  constexpr int PG = (34 * (TH + 2) + 15) / 16;
+  constexpr size_t lds_ring = (size_t)2 * PLD * PG * 1024 + (size_t)NSW * 3 * RPS * PLD * BM * 64;
+  constexpr size_t lds_out = (size_t)TH * 32 * (BM * (PAIR ? 4 : 2) + 16);
+  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
+  static_assert(lds <= 163840, "LDS budget");
+  const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
+  dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 convolution (= GEMM  y[pix][ch] = sum_k x[pix][k] w[ch][k]) with the same pipeline as conv3x3_pipe_kernel:
+// buffer-descriptor LDS-DMA (one VGPR offset per piece, K position in an SGPR, pixels past the end read as zeros),
+// 64 channels of K per barrier step (two 32-channel sub-tiles in the proven 64-byte-row XOR-swizzled layout), 2-deep ring,
+// fragments double-buffered in registers with counted lgkmcnt, 4 / 8 / 16 waves per workgroup.
+// Workgroups are numbered so that one XCD (round-robin dispatch: id % 8) owns a pixel tile for ALL of its channel tiles
+// back to back: the activation tile is fetched from HBM once and re-read from that XCD's L2.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int SOFF, int BM, int SUBB, int NIT>
+__device__ __forceinline__ void gemm_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
+                                                    const int (&baddr)[2][WN], f32x16_t (&acc)[WM][WN]) {
+  // iteration it = (sub-tile it>>1, k-half it&1); sub-tile s lives at SOFF + s * SUBB, activations after the BM weight rows
+  u32x4_t af[2][WM], bf[2][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + aaddr[0][i]);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bf[0][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + baddr[0][j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int cur = it & 1, nxt = cur ^ 1;
+    if (it + 1 < NIT) {
+      const int sb = ((it + 1) >> 1) * SUBB, kk = (it + 1) & 1;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[nxt][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + sb + aaddr[kk][i]);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + sb + baddr[kk][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][i], bf[cur][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Split products on pair-stored operands: the two 64-byte sub-tiles of a step are the hi and the lo plane of ONE 32-channel block
+// (the DMA pattern is that of the bf16 kernel); per k-half: lo*hi' + hi*lo' + hi*hi'.
+template <int WM, int WN, int SOFF, int BM, int SUBB>
+__device__ __forceinline__ void gemm_step_split(const unsigned char* smem, const int (&aaddr)[2][WM], const int (&baddr)[2][WN],
+                                                f32x16_t (&acc)[WM][WN]) {
+  u32x4_t af[2][2][WM], bf[2][2][WN];       // [register buffer][plane][tile]
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + pl * SUBB + aaddr[0][i]);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bf[0][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + pl * SUBB + baddr[0][j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    if (kk == 0) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[1][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + pl * SUBB + aaddr[1][i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[1][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + pl * SUBB + baddr[1][j]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[kk][1][i], bf[kk][0][j]);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[kk][0][i], bf[kk][1][j]);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[kk][0][i], bf[kk][0][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// NT / PAIR as in conv3x3_pipe_kernel: pair-stored activations + pre-split weights; NT = 3 split products, NT = 1 hi planes only.
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int GA = BM / 16, GB = BP / 16;                     // 1 KB DMA pieces per 32-channel sub-tile
+  constexpr int AW = (GA + NW - 1) / NW, BW = (GB + NW - 1) / NW;
+  constexpr bool A_EXACT = GA % NW == 0, B_EXACT = GB % NW == 0;
+  constexpr int SUB = (BM + BP) * 64, STAGE = 2 * SUB;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  // XCD-aware numbering: id % 8 = XCD; inside an XCD channel tiles are consecutive for a fixed pixel tile
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= npt) return;
+  const int p0 = pt * BP, m0 = ct * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  static_assert(NT == 1 || (NT == 3 && PAIR), "split products need pair-stored operands");
+  constexpr int PLS = PAIR ? 2 : 1;
+  constexpr int KSTR = (PAIR && NT == 1) ? 128 : 64;      // bytes along K between the sub-tiles this kernel consumes
+  const int Ktot = P.cin_pad * PLS;
+  const int rg = lane >> 2, pc = lane & 3;
+  const int lc = pc ^ ((rg >> 2) & 3);
+  constexpr unsigned OOB = 0x80000000u;
+  const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)(x_bytes < 0x7fffffffL ? x_bytes : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+  unsigned avoff[AW], bvoff[BW];
+#pragma unroll
+  for (int i = 0; i < AW; ++i) {
+    const int g = wv + NW * i;
+    avoff[i] = (unsigned)(((g * 16 + rg) * Ktot + lc * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < BW; ++i) {
+    const int g = wv + NW * i;
+    const long p = (long)p0 + g * 16 + rg;
+    if (p < Npix) {
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      bvoff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + lc * 8) * 2);
+    } else {
+      bvoff[i] = OOB;
+    }
+  }
+  // one step = NSUBS 32-channel sub-tiles starting at sub-tile index 2*step
+  auto issue = [&](int step, int stage_off, int nsubs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      if (sidx >= nsubs) break;
+      const int kb = (2 * step + sidx) * KSTR;               // bytes along K
+#pragma unroll
+      for (int i = 0; i < AW; ++i) {
+        const int g = wv + NW * i;
+        if (A_EXACT || g < GA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + stage_off + sidx * SUB + g * 1024), 16, avoff[i], kb, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BW; ++i) {
+        const int g = wv + NW * i;
+        if (B_EXACT || g < GB)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + stage_off + sidx * SUB + BM * 64 + g * 1024), 16, bvoff[i], kb, 0, 0);
+      }
+    }
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aaddr[2][WM], baddr[2][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    aaddr[0][i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+    aaddr[1][i] = aaddr[0][i] ^ 32;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int r = (wn * WN + j) * 32 + l31;
+    baddr[0][j] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+    baddr[1][j] = baddr[0][j] ^ 32;
+  }
+  // sub-tiles of 64 bytes along K: NT 1: one per 32 channels, a step takes two; NT 3: the hi and lo plane of one 32-channel block
+  const int nsub = NT == 3 ? P.cin_pad / 16 : P.cin_pad / 32, nfull = nsub >> 1, tail = nsub & 1;   // full steps + an optional half one
+  if (nfull > 0) issue(0, 0, 2); else issue(0, 0, 1);
+#define FAR3D_GEMM_SYNC()                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    wait_vmcnt<0>();                                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define FAR3D_GEMM_STEP(STG, S)                                                                              \
+  {                                                                                                          \
+    FAR3D_GEMM_SYNC()                                                                                        \
+    if ((S) + 1 < nfull) issue((S) + 1, ((STG) ^ 1) * STAGE, 2);                                             \
+    else if (tail) issue((S) + 1, ((STG) ^ 1) * STAGE, 1);                                                   \
+    if constexpr (NT == 3) gemm_step_split<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);         \
+    else gemm_step_pipelined<WM, WN, (STG) * STAGE, BM, SUB, 4>(smem, aaddr, baddr, acc);                    \
+  }
+  for (int s2 = 0; s2 < nfull; s2 += 2) {
+    FAR3D_GEMM_STEP(0, s2)
+    if (s2 + 1 < nfull) FAR3D_GEMM_STEP(1, s2 + 1)
+  }
+  if (tail) {
+    FAR3D_GEMM_SYNC()
+    if (nfull & 1) gemm_step_pipelined<WM, WN, STAGE, BM, SUB, 2>(smem, aaddr, baddr, acc);
+    else           gemm_step_pipelined<WM, WN, 0, BM, SUB, 2>(smem, aaddr, baddr, acc);
+  }
+#undef FAR3D_GEMM_STEP
+#undef FAR3D_GEMM_SYNC
+  if (P.y_rows16) {
+    epilogue_rows16<NW, WM, WN, BM, BP, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
+      const long p = (long)p0 + pl;
+      if (p >= Npix) return -1L;
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      return (long)n * P.y_img_stride + (long)rem * P.ldy;
+    });
+    return;
+  }
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
+#endif
+}
+
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false>
+static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
+  constexpr size_t lds_ring = (size_t)2 * 2 * (BM + BP) * 64, lds_out = (size_t)BP * (BM * (PAIR ? 4 : 2) + 16);
+  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
+  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
+  return 0;
+}
+

@@ -1,0 +1,83 @@
+// Instantiations of the conv / GEMM kernels for pair-stored activations (FAR3D_DT_BF16_PAIR, common.hpp): the fast path of the
+// "bf16x3" precision mode.  Separate translation unit so that it compiles in parallel with igemm.hip.
+// Tile ids (far3d_conv2d_nhwc `tile` with x_dt = FAR3D_DT_BF16_PAIR), t = the bf16 id of the same workgroup shape:
+//   100 + t  split products (3 MFMAs per product, NT = 3): 3x3/s1/p1 t in 50..67, 90..97; 1x1/s1 t in 70..81
+//   200 + t  hi planes only (one bf16 product, NT = 1), a subset of the shapes
+//   1..5     register-staged kernel (any kernel size / stride), split products
+#include "igemm_kernels.hpp"
+
+int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
+  const bool k3 = P.KH == 3 && P.KW == 3 && P.stride == 1 && P.pad == 1 && P.Ho == P.H && P.Wo == P.W;
+  const bool k1 = P.KH == 1 && P.KW == 1 && P.stride == 1 && P.pad == 0;
+  if (tile == 0) tile = k3 ? 160 : (k1 ? 179 : 0);
+  if (tile == 0) {   // strided / odd kernels: the heuristic of the register-staged kernel
+    const long Npix = (long)P.N * P.Ho * P.Wo;
+    const long big = ((Npix + 127) / 128) * ((P.Cout + 127) / 128);
+    if (P.Cout <= 64) tile = (Npix >= 128 * 512) ? 2 : 3;
+    else if (big >= 512) tile = 1;
+    else if (((Npix + 63) / 64) * ((P.Cout + 127) / 128) >= 512) tile = 4;
+    else tile = 3;
+  }
+  if (tile <= 5) {
+    switch (tile) {
+      case 1: launch_igemm<pair_t, split_t, 2, 2, 2, 2>(P, st); break;
+      case 2: launch_igemm<pair_t, split_t, 2, 2, 1, 2>(P, st); break;
+      case 3: launch_igemm<pair_t, split_t, 2, 2, 1, 1>(P, st); break;
+      case 4: launch_igemm<pair_t, split_t, 2, 2, 2, 1>(P, st); break;
+      case 5: launch_igemm<pair_t, split_t, 1, 4, 2, 2>(P, st); break;
+      default: far3d_set_error("far3d_conv2d_nhwc: unknown tile %d", tile); return FAR3D_ERR_ARG;
+    }
+    return FAR3D_OK;
+  }
+  if (k1) {
+    switch (tile) {
+      case 170: launch_gemm1x1_pipe<2, 2, 2, 2, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 4 waves
+      case 171: launch_gemm1x1_pipe<2, 4, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 8 waves
+      case 172: launch_gemm1x1_pipe<2, 4, 2, 2, 3, true>(P, st); return FAR3D_OK;   // 128 x 256, 8 waves
+      case 173: launch_gemm1x1_pipe<4, 2, 2, 2, 3, true>(P, st); return FAR3D_OK;   // 256 x 128, 8 waves
+      case 174: launch_gemm1x1_pipe<2, 2, 1, 2, 3, true>(P, st); return FAR3D_OK;   // 64 x 128, 4 waves
+      case 175: launch_gemm1x1_pipe<2, 4, 1, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 128, 8 waves
+      case 176: launch_gemm1x1_pipe<2, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 64, 4 waves
+      case 177: launch_gemm1x1_pipe<4, 4, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 256 x 128, 16 waves
+      case 178: launch_gemm1x1_pipe<2, 4, 1, 2, 3, true>(P, st); return FAR3D_OK;   // 64 x 256, 8 waves
+      case 179: launch_gemm1x1_pipe<4, 2, 1, 2, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 8 waves (1x2 tiles per wave)
+      case 180: launch_gemm1x1_pipe<2, 2, 1, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 64, 4 waves
+      case 181: launch_gemm1x1_pipe<4, 4, 1, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 16 waves
+      case 279: launch_gemm1x1_pipe<4, 2, 1, 2, 1, true>(P, st); return FAR3D_OK;   // hi only: 128 x 128, 8 waves
+      case 280: launch_gemm1x1_pipe<2, 2, 1, 1, 1, true>(P, st); return FAR3D_OK;   // hi only: 64 x 64, 4 waves
+      default: break;
+    }
+  }
+  if (k3) {
+    switch (tile) {
+      case 150: launch_conv3x3_pipe<2, 2, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 4 rows
+      case 152: launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 4 rows
+      case 153: launch_conv3x3_pipe<2, 2, 2, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows
+      case 154: launch_conv3x3_pipe<1, 4, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 8 rows
+      case 155: launch_conv3x3_pipe<2, 2, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 2 rows
+      case 157: launch_conv3x3_pipe<2, 2, 1, 4, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 4 waves
+      case 159: launch_conv3x3_pipe<1, 4, 3, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 96 x 4 rows
+      case 160: launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 8 waves
+      case 161: launch_conv3x3_pipe<2, 4, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 4 rows, 8 waves
+      case 162: launch_conv3x3_pipe<4, 2, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows, 8 waves
+      case 163: launch_conv3x3_pipe<2, 8, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 16 waves
+      case 164: launch_conv3x3_pipe<1, 8, 2, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
+      case 165: launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 8 rows, 8 waves
+      case 166: launch_conv3x3_pipe<4, 4, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows, 16 waves
+      case 167: launch_conv3x3_pipe<4, 2, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 2 rows, 8 waves
+      case 168: launch_conv3x3_pipe<2, 4, 2, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows, 8 waves of 64 ch x 1 row
+      // 3-deep weight ring
+      case 191: launch_conv3x3_pipe<2, 4, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 4 rows, 8 waves
+      case 192: launch_conv3x3_pipe<1, 8, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 8 rows, 8 waves
+      case 193: launch_conv3x3_pipe<1, 4, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 4 rows, 4 waves
+      case 197: launch_conv3x3_pipe<2, 2, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 2 rows, 4 waves
+      // hi planes only
+      case 260: launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 1, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 8 waves
+      case 265: launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 1, true>(P, st); return FAR3D_OK;   // 32 x 8 rows, 8 waves
+      case 252: launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 1, true>(P, st); return FAR3D_OK;   // 32 x 4 rows, 4 waves
+      default: break;
+    }
+  }
+  far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for pair-stored activations with k=%d stride=%d", tile, P.KH, P.stride);
+  return FAR3D_ERR_ARG;
+}

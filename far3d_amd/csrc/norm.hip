@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
   const int r1 = min(HW, r0 + rows_per_block);
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
   if (trow < rstep) {
-    const T* base = x + (long)n * img_stride + tcol * 4;
+    const T* base = x + (long)n * img_stride + chan_off<T>(tcol * 4);
     int r = r0 + trow;
     for (; r + 7 * rstep < r1; r += 8 * rstep) {          // 8 row loads in flight per thread: the loop is latency bound
       float4 v[8];
@@ -163,6 +163,8 @@ static int launch_chan_sums(const void* x, int dt, float* part, int N, int HW, i
   dim3 grid(nblk, N), block(256);
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(chan_sums_kernel<float>, grid, block, 0, st, (const float*)x, part, HW, C, ldx, img_stride, rows_per_block);
+  else if (dt == FAR3D_DT_BF16_PAIR)
+    hipLaunchKernelGGL(chan_sums_kernel<pair_t>, grid, block, 0, st, (const pair_t*)x, part, HW, C, ldx, img_stride, rows_per_block);
   else
     hipLaunchKernelGGL(chan_sums_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, part, HW, C, ldx, img_stride, rows_per_block);
   return nblk;
@@ -255,16 +257,15 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
     const long pr = i / cq;
     const int n = (int)(pr / HW);
     const long pix = pr - (long)n * HW;
-    float4 v = load4(x + n * xs + pix * ldx + c);
+    const int co = chan_off<T>(c);
+    float4 v = load4(x + n * xs + pix * ldx + co);
     const float4 g = *reinterpret_cast<const float4*>(gate + (long)n * C + c);
     v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
     if (idn) {
-      const float4 d = load4(idn + n * is + pix * ldi + c);
+      const float4 d = load4(idn + n * is + pix * ldi + co);
       v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
     }
-    T* dst = y + n * ys + pix * ldy + c;
-    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = v;
-    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    store4(y + n * ys + pix * ldy + co, v);
   }
 }
 
@@ -276,7 +277,8 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
   FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
                   "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4, <= 1024)", C);
-  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_ese_nhwc: unsupported dtype");
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16 || dt == FAR3D_DT_BF16_PAIR, "far3d_ese_nhwc: unsupported dtype");
+  FAR3D_CHECK_ARG(dt != FAR3D_DT_BF16_PAIR || C % 32 == 0, "far3d_ese_nhwc: pair storage needs C %% 32 == 0");
   hipStream_t st = (hipStream_t)stream;
   float* sums = scratch;
   float* gate = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
@@ -288,6 +290,9 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(ese_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, gate,
                        (const float*)identity, (float*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
+  else if (dt == FAR3D_DT_BF16_PAIR)
+    hipLaunchKernelGGL(ese_apply_kernel<pair_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const pair_t*)x, gate,
+                       (const pair_t*)identity, (pair_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
   else
     hipLaunchKernelGGL(ese_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, gate,
                        (const bf16_t*)identity, (bf16_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int c = (int)(i % cq) * 4;
     const long pr = i / cq;
     const int n = (int)(pr / HW);
-    float4 v = load4(x + pr * C + c);
+    const long eo = pr * (C * ChanScale<T>::v) + chan_off<T>(c);
+    float4 v = load4(x + eo);
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -337,9 +343,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       o[e] = (o[e] - mean) * rstd * gamma[c + e] + beta[c + e];
       if (relu) o[e] = fmaxf(o[e], 0.f);
     }
-    T* dst = y + pr * C + c;
-    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    store4(y + eo, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -347,11 +351,12 @@ extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, c
                                     int N, int HW, int C, int groups, float eps, int relu, void* stream) {
   FAR3D_CHECK_ARG(x && gamma && beta && y && scratch, "far3d_groupnorm_nhwc: null pointer argument");
   FAR3D_CHECK_ARG(N > 0 && HW > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "far3d_groupnorm_nhwc: bad sizes C=%d groups=%d", C, groups);
-  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_groupnorm_nhwc: unsupported dtype");
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16 || (dt == FAR3D_DT_BF16_PAIR && C % 32 == 0), "far3d_groupnorm_nhwc: unsupported dtype");
+  const int cs = dt == FAR3D_DT_BF16_PAIR ? 2 : 1;      // stored elements per logical channel
   hipStream_t st = (hipStream_t)stream;
   float* sums = scratch;                                              // [N][nparts][C][2]
   float* stat = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;     // [N][groups][2]
-  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, C, (long)HW * C, st);
+  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, C * cs, (long)HW * C * cs, st);
   FAR3D_CHECK_ARG(groups * 2 <= C, "far3d_groupnorm_nhwc: groups*2 must be <= C");
   hipLaunchKernelGGL(gn_stats_kernel, dim3(N), dim3(256), 0, st, sums, stat, C, groups,
                      1.f / ((float)HW * (C / groups)), eps, nparts);
@@ -361,6 +366,9 @@ extern "C" int far3d_groupnorm_nhwc(const void* x, int dt, const float* gamma, c
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, stat, gamma, beta,
                        (float*)y, total4, C, groups, HW, relu);
+  else if (dt == FAR3D_DT_BF16_PAIR)
+    hipLaunchKernelGGL(gn_apply_kernel<pair_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const pair_t*)x, stat, gamma, beta,
+                       (pair_t*)y, total4, C, groups, HW, relu);
   else
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, stat, gamma, beta,
                        (bf16_t*)y, total4, C, groups, HW, relu);
@@ -388,31 +396,31 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * 2 + kx;
         if (ix >= W) continue;
-        const float4 v = load4(x + (((long)n * H + iy) * W + ix) * C + c);
+        const float4 v = load4(x + (((long)n * H + iy) * W + ix) * (C * ChanScale<T>::v) + chan_off<T>(c));
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    T* dst = y + (long)n * ys + ((long)oy * Wo + ox) * ldy + c;
-    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = m;
-    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w));
+    store4(y + (long)n * ys + ((long)oy * Wo + ox) * ldy + chan_off<T>(c), m);
   }
 }
 
 extern "C" int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W, int C, int Ho, int Wo, int ldy,
                                        long y_img_stride, void* stream) {
   FAR3D_CHECK_ARG(x && y, "far3d_maxpool3x3s2_nhwc: null pointer argument");
-  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldy >= C && ldy % 4 == 0, "far3d_maxpool3x3s2_nhwc: bad sizes");
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16 || (dt == FAR3D_DT_BF16_PAIR && C % 32 == 0), "far3d_maxpool3x3s2_nhwc: unsupported dtype");
+  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldy >= C * (dt == FAR3D_DT_BF16_PAIR ? 2 : 1) && ldy % 4 == 0, "far3d_maxpool3x3s2_nhwc: bad sizes");
   // ceil_mode output size: ceil((H-3)/2)+1, last window must start inside the input
   int eh = (H - 3 + 1) / 2 + 1; if ((eh - 1) * 2 >= H) --eh;
   int ew = (W - 3 + 1) / 2 + 1; if ((ew - 1) * 2 >= W) --ew;
   FAR3D_CHECK_ARG(Ho == eh && Wo == ew, "far3d_maxpool3x3s2_nhwc: output %dx%d != ceil-mode size %dx%d", Ho, Wo, eh, ew);
-  FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16, "far3d_maxpool3x3s2_nhwc: unsupported dtype");
   const long total4 = (long)N * Ho * Wo * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, total4, C, H, W, Ho, Wo, ldy, y_img_stride);
+  else if (dt == FAR3D_DT_BF16_PAIR)
+    hipLaunchKernelGGL(maxpool_kernel<pair_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const pair_t*)x, (pair_t*)y, total4, C, H, W, Ho, Wo, ldy, y_img_stride);
   else
     hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, total4, C, H, W, Ho, Wo, ldy, y_img_stride);
   FAR3D_CHECK_LAUNCH("far3d_maxpool3x3s2_nhwc");

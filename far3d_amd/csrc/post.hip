@@ -15,13 +15,17 @@
 #include "common.hpp"
 
 // ------------------------------------------------------------------------------------------ block-wide top-K
-// order-preserving map float -> uint (larger float <-> larger uint; -0 == +0; NaNs sort above +inf, like torch.topk)
+// order-preserving map float -> uint (larger float <-> larger uint; -0 == +0; every NaN, whatever its sign bit, maps to the
+// largest key and so sorts above +inf, like torch.topk)
 __device__ __forceinline__ unsigned ord_key(float f) {
+  if (f != f) return 0xffffffffu;
   unsigned b = __float_as_uint(f);
   if (b == 0x80000000u) b = 0u;      // -0 == +0 (torch.topk compares values)
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__device__ __forceinline__ float ord_val(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ float ord_val(unsigned k) {     // inverse of ord_key (the NaN key comes back as a NaN)
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
 
 #define TOPK_THREADS 1024
 #define TOPK_MAXV 40          // values per thread held in registers: n <= 40960
@@ -156,13 +160,19 @@ struct DecodeParams {
   float lo[3], hi[3];
 };
 
-__global__ __launch_bounds__(TOPK_THREADS) void decode_topk_kernel(DecodeParams p) {
+// cand_idx: null = the K winners' positions are indices into cls (A * ncls <= TOPK_THREADS * TOPK_MAXV, one launch);
+// otherwise cls points at candidate logits (the per-chunk winners of decode_chunk_kernel, chunk-major, each chunk sorted) and
+// cand_idx maps a position to the original index.  Equal logits keep their original index order in that layout, so the tie rule
+// (lowest index first) is the single-launch one.
+template <int MAXV>
+__global__ __launch_bounds__(TOPK_THREADS) void decode_topk_kernel(DecodeParams p, int n, const int* __restrict__ cand_idx) {
   __shared__ unsigned long long sel[TOPK_MAXK];
   // sigmoid is monotone: the top-K of sigmoid(logits) is the top-K of the logits
-  block_topk_sorted<TOPK_MAXV>(p.cls, p.A * p.ncls, p.K, sel);
+  block_topk_sorted<MAXV>(p.cls, n, p.K, sel);
   for (int i = threadIdx.x; i < p.K; i += TOPK_THREADS) {
     const unsigned long long e = sel[i];
-    const int idx = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    int idx = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    if (cand_idx) idx = cand_idx[idx];
     const float logit = ord_val((unsigned)(e >> 32));
     const int q = idx / p.ncls;
     p.labels[i] = (long)(idx - q * p.ncls);
@@ -179,18 +189,59 @@ __global__ __launch_bounds__(TOPK_THREADS) void decode_topk_kernel(DecodeParams 
   }
 }
 
+// Large inputs (A * ncls > TOPK_THREADS * TOPK_MAXV: the reference's threshold proposal mode on a busy frame): workgroup c
+// ranks chunk c of the logits and leaves its K best (value, original index) in the workspace; decode_topk_kernel then ranks
+// the nchunks * K candidates.  Exact: the global top-K is a subset of the union of the per-chunk top-K.
+#define DECODE_CHUNK (TOPK_THREADS * TOPK_MAXV)
+__global__ __launch_bounds__(TOPK_THREADS) void decode_chunk_kernel(const float* __restrict__ cls, int n, int K, float* __restrict__ cand_val,
+                                                                    int* __restrict__ cand_idx) {
+  __shared__ unsigned long long sel[TOPK_MAXK];
+  const int c = blockIdx.x, base = c * DECODE_CHUNK;
+  const int cn = min(DECODE_CHUNK, n - base), Kc = min(K, cn);
+  block_topk_sorted<TOPK_MAXV>(cls + base, cn, Kc, sel);
+  for (int i = threadIdx.x; i < K; i += TOPK_THREADS) {
+    float v = -INFINITY;      // a short last chunk pads with -inf pointing at its own first element (never beats a real candidate
+    int idx = base;           // on value; on an all -inf tie the padding sits after the real entries of the same chunk)
+    if (i < Kc) {
+      const unsigned long long e = sel[i];
+      v = ord_val((unsigned)(e >> 32));
+      idx = base + (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    }
+    cand_val[c * K + i] = v;
+    cand_idx[c * K + i] = idx;
+  }
+}
+
 extern "C" int far3d_decode_topk(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
                                  const float* post_center_range, float* boxes, float* scores, int64_t* labels,
-                                 unsigned char* keep, void* stream) {
+                                 unsigned char* keep, void* workspace, long workspace_bytes, void* stream) {
   FAR3D_CHECK_ARG(cls_last && box_last && post_center_range && boxes && scores && labels && keep, "far3d_decode_topk: null pointer argument");
-  FAR3D_CHECK_ARG(A > 0 && num_classes > 0 && code_size >= 8 && K > 0 && K <= TOPK_MAXK && (long)A * num_classes <= TOPK_THREADS * TOPK_MAXV &&
-                  K <= A * num_classes, "far3d_decode_topk: bad sizes A=%d ncls=%d code=%d K=%d (A*ncls <= %d, K <= %d)", A, num_classes,
-                  code_size, K, TOPK_THREADS * TOPK_MAXV, TOPK_MAXK);
+  const long n = (long)A * num_classes;
+  FAR3D_CHECK_ARG(A > 0 && num_classes > 0 && code_size >= 8 && K > 0 && K <= TOPK_MAXK && n < (1L << 30) && K <= n,
+                  "far3d_decode_topk: bad sizes A=%d ncls=%d code=%d K=%d (K <= %d)", A, num_classes, code_size, K, TOPK_MAXK);
   DecodeParams p;
   p.cls = cls_last; p.box = box_last; p.boxes = boxes; p.scores = scores; p.labels = (long*)labels; p.keep = keep;
   p.A = A; p.ncls = num_classes; p.code = code_size; p.K = K;
   for (int k = 0; k < 3; ++k) { p.lo[k] = post_center_range[k]; p.hi[k] = post_center_range[3 + k]; }
-  hipLaunchKernelGGL(decode_topk_kernel, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= DECODE_CHUNK) {
+    hipLaunchKernelGGL(decode_topk_kernel<TOPK_MAXV>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)n, (const int*)nullptr);
+  } else {
+    const int nchunks = (int)((n + DECODE_CHUNK - 1) / DECODE_CHUNK);
+    const long ncand = (long)nchunks * K;
+    FAR3D_CHECK_ARG(ncand <= DECODE_CHUNK, "far3d_decode_topk: A*num_classes=%ld needs %d chunks x K=%d candidates > %d", n, nchunks, K, DECODE_CHUNK);
+    FAR3D_CHECK_ARG(workspace && workspace_bytes >= ncand * 8 && ((uintptr_t)workspace % 8) == 0,
+                    "far3d_decode_topk: A*num_classes=%ld > %d needs a workspace of FAR3D_DECODE_WS_BYTES = %ld bytes (got %ld)", n, DECODE_CHUNK,
+                    ncand * 8, workspace ? workspace_bytes : 0L);
+    float* cand_val = (float*)workspace;
+    int* cand_idx = (int*)(cand_val + ncand);
+    hipLaunchKernelGGL(decode_chunk_kernel, dim3(nchunks), dim3(TOPK_THREADS), 0, st, cls_last, (int)n, K, cand_val, cand_idx);
+    p.cls = cand_val;
+    if (ncand <= TOPK_THREADS * 4)
+      hipLaunchKernelGGL(decode_topk_kernel<4>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)ncand, (const int*)cand_idx);
+    else
+      hipLaunchKernelGGL(decode_topk_kernel<TOPK_MAXV>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)ncand, (const int*)cand_idx);
+  }
   FAR3D_CHECK_LAUNCH("far3d_decode_topk");
   return FAR3D_OK;
 }

@@ -30,8 +30,12 @@ PRECISIONS = {
     # fp32 data everywhere; conv products (backbone / FPN / 2D head: 95 % of the FLOPs) as a two-term bf16 split on the bf16 MFMA
     # with fp32 accumulation (far3d_hip.h FAR3D_DT_F32_BF16X3), decoder + FarHead GEMMs on the exact fp32 MFMA: the cheapest
     # assignment that keeps single-frame logits within the north-star 1e-3
-    "bf16x3": dict(act=torch.float32, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma=None),
-    "bf16x3_all": dict(act=torch.float32, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma="bf16x3"),
+    # Activations of the conv stages are PAIR-STORED (ops.pair_from_float: [32 hi | 32 lo] bf16 per 32-channel block, fp32's byte
+    # size, 16 significant bits) so that the split products run on the LDS-DMA pipelined kernels (csrc/igemm_pair.hip).
+    "bf16x3": dict(act=torch.bfloat16, pair=True, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma=None),
+    "bf16x3_all": dict(act=torch.bfloat16, pair=True, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma="bf16x3"),
+    # the same arithmetic on plain fp32 activations (split while staging, register-staged kernel): round 2's form, kept for A/B
+    "bf16x3_f32act": dict(act=torch.float32, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma=None),
 }
 
 
@@ -96,6 +100,8 @@ class Far3DEngine:
         self.dev = torch.device(device)
         self.prec = dict(PRECISIONS[precision]) if isinstance(precision, str) else dict(precision)
         self.precision = precision if isinstance(precision, str) else "custom"
+        self.pair = bool(self.prec.get("pair"))     # conv-stage activations in pair storage
+        self.cs = 2 if self.pair else 1             # stored elements per logical channel of those maps
         self.sd = {}
         for k, v in state_dict.items():
             ck = weights.canonical_key(k)
@@ -133,7 +139,8 @@ class Far3DEngine:
         return w, b, stride, pad
 
     def _pack(self, w, b, stride=1, pad=0):
-        return ops.PackedConv(w, b, stride=stride, pad=pad, dtype=self.prec["act"], device=self.dev, compute=self.prec.get("mma"))
+        wdt = torch.float32 if self.prec.get("mma") == "bf16x3" else self.prec["act"]
+        return ops.PackedConv(w, b, stride=stride, pad=pad, dtype=wdt, device=self.dev, compute=self.prec.get("mma"))
 
     def _prepare(self):
         if "backbone" in self.parts:
@@ -287,6 +294,16 @@ class Far3DEngine:
     def _query_pos(self, ref):
         return self.qe[1](self.qe[0](ops.posemb3d(ref, self.dim_t128), act="relu"))
 
+    def act_from_nchw(self, x):
+        """(N,C,H,W) float map -> the engine's NHWC activation storage (bf16 / f32 / pair-stored bf16)."""
+        y = x.permute(0, 2, 3, 1).contiguous()
+        return ops.pair_from_float(y) if self.pair else y.to(self.prec["act"])
+
+    def act_to_nchw(self, y):
+        """An NHWC activation map of this engine (or an f32 head output) -> (N,C,H,W) f32."""
+        y = ops.pair_to_float(y) if (self.pair and y.dtype == torch.bfloat16) else y.float()
+        return y.permute(0, 3, 1, 2).contiguous()
+
     def _buf(self, key, shape, dtype):
         key = (self._par,) + tuple(key)
         b = self._bufs.get(key)
@@ -297,13 +314,13 @@ class Far3DEngine:
 
     # ------------------------------------------------------------------------------------------ a2: backbone
     def backbone(self, img):
-        """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps."""
-        act, spec = self.prec["act"], self.spec
+        """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps (pair mode: 2C stored bf16 channels each)."""
+        act, spec, cs, pair = self.prec["act"], self.spec, self.cs, self.pair
         N = img.shape[0]
         Lb = spec["layer_per_block"]
         # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
         scratch = self._buf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
-        x = ops.stem_im2col(img, act)
+        x = ops.stem_im2col(img, act, pair=pair)
         x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
         H, W = self.bb["stem3"].out_hw(x.shape[1], x.shape[2])
@@ -319,27 +336,28 @@ class Far3DEngine:
                     H -= 1
                 if (W - 1) * 2 >= Wp:
                     W -= 1
-            cat = self._buf(("cat", si, 0), (N, H, W, in_ch + Lb * sc), act)
+            cat = self._buf(("cat", si, 0), (N, H, W, (in_ch + Lb * sc) * cs), act)
             if si == 0:
-                ops.conv2d_nhwc(x, self.bb["stem3"], out=cat[..., :in_ch], act="relu")
+                ops.conv2d_nhwc(x, self.bb["stem3"], out=cat[..., :in_ch * cs], act="relu")
             else:
-                ops.maxpool3x3s2_nhwc(stage_in, out=cat[..., :in_ch])
+                ops.maxpool3x3s2_nhwc(stage_in, out=cat[..., :in_ch * cs], pair=pair)
             cur_in = in_ch
             for bi, blk in enumerate(blocks):
                 last = bi == len(blocks) - 1
-                src = cat[..., :cur_in]
+                src = cat[..., :cur_in * cs]
                 for i, pc in enumerate(blk["convs"]):
-                    dst = cat[..., cur_in + i * sc: cur_in + (i + 1) * sc]
+                    dst = cat[..., (cur_in + i * sc) * cs: (cur_in + (i + 1) * sc) * cs]
                     ops.conv2d_nhwc(src, pc, out=dst, act="relu")
                     src = dst
-                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc), act), act="relu")
+                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc * cs), act), act="relu")
                 if last:
-                    out = self._buf(("stage", si), (N, H, W, oc), act)
+                    out = self._buf(("stage", si), (N, H, W, oc * cs), act)
                     nxt = None
                 else:
-                    nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, oc + Lb * sc), act)
-                    out = nxt[..., :oc]
-                ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in] if bi > 0 else None, out=out, scratch=scratch)
+                    nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, (oc + Lb * sc) * cs), act)
+                    out = nxt[..., :oc * cs]
+                ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in * cs] if bi > 0 else None, out=out, scratch=scratch,
+                             pair=pair)
                 if not last:
                     cat, cur_in = nxt, oc
             stage_in = self._bufs[(self._par, "stage", si)]
@@ -349,7 +367,7 @@ class Far3DEngine:
 
     # ------------------------------------------------------------------------------------------ a3 + MLN: FPN
     def fpn(self, feats, mln_scale, mln_shift):
-        """Returns (raw levels [NHWC act], feat_flatten (N,S,256) value dtype, level_hw, level_start)."""
+        """Returns (raw levels [NHWC act; pair mode: 512 stored channels], feat_flatten (N,S,256) value dtype, level_hw, level_start)."""
         act, val = self.prec["act"], self.prec["value"]
         ins = feats[1:]
         N = ins[0].shape[0]
@@ -360,13 +378,13 @@ class Far3DEngine:
         tokens = self._buf(("tokens",), (N, S, 256), val)
         lat = [None] * n
         for i in range(n - 1, -1, -1):   # top-down: laterals[i-1] += nearest_upsample(laterals[i])
-            lat[i] = ops.conv2d_nhwc(ins[i], self.fpn_lat[i], out=self._buf(("lat", i), (N, hw[i][0], hw[i][1], 256), act),
+            lat[i] = ops.conv2d_nhwc(ins[i], self.fpn_lat[i], out=self._buf(("lat", i), (N, hw[i][0], hw[i][1], 256 * self.cs), act),
                                      res=lat[i + 1] if i + 1 < n else None)
         raw = []
         for i in range(n + 1):
             src = lat[i] if i < n else raw[n - 1]
             y2 = tokens[:, starts[i]: starts[i] + hw[i][0] * hw[i][1]].view(N, hw[i][0], hw[i][1], 256)
-            raw.append(ops.conv2d_nhwc(src, self.fpn_out[i], out=self._buf(("fpn", i), (N, hw[i][0], hw[i][1], 256), act),
+            raw.append(ops.conv2d_nhwc(src, self.fpn_out[i], out=self._buf(("fpn", i), (N, hw[i][0], hw[i][1], 256 * self.cs), act),
                                        y2=y2, y2_scale=mln_scale, y2_shift=mln_shift))
         return raw, tokens, hw, starts
 
@@ -386,10 +404,10 @@ class Far3DEngine:
             if centers2d is not None:
                 centers2d.append(ops.conv2d_nhwc(rf, lv["ctr_head"], out_dtype=torch.float32))
         d = raw[0]
-        gscr = self._buf(("gn_scratch",), (ops.ese_scratch_floats(d.shape[0], 256),), torch.float32)
+        gscr = self._buf(("gn_scratch",), (ops.ese_scratch_floats(d.shape[0], d.shape[-1] // self.cs),), torch.float32)
         for i in range(2):
             d = ops.conv2d_nhwc(d, self.depth["convs"][i])
-            d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True, scratch=gscr)
+            d = ops.groupnorm_nhwc(d, *self.depth["gn"][i], groups=32, relu=True, scratch=gscr, pair=self.pair)
         return cls, reg, ops.conv2d_nhwc(d, self.depth["cls"], out_dtype=torch.float32)
 
     # ------------------------------------------------------------------------------------------ memory (a6/a11)
@@ -594,12 +612,14 @@ class Far3DEngine:
         keys = ("lidar2img", "intrinsics", "extrinsics", "ego_pose", "ego_pose_inv", "timestamp")
         cur = self._ins.get(self._par)
         if cur is None or tuple(cur["img"].shape) != tuple(img.shape):
+            # (re)allocation: graphs captured on the old buffers of THIS parity are stale.  The single-graph mode drops its graph
+            # here; the pipeline's per-parity graphs are dropped by _pipelined_frame BEFORE it decides to replay (it checks the
+            # shape itself), and its streams / events are never dropped, so a scene start can always wait for heads in flight.
             cur = dict(img=torch.empty(tuple(img.shape), dtype=torch.float32, device=dev))
             for k in keys:
                 cur[k] = torch.empty(tuple(data[k].shape), dtype=torch.float64 if k == "timestamp" else torch.float32, device=dev)
             self._ins[self._par] = cur
             self._graph = None
-            self._pipe = None
         cur["img"].copy_(img, non_blocking=True)
         for k in keys:
             cur[k].copy_(data[k], non_blocking=True)
@@ -633,6 +653,12 @@ class Far3DEngine:
         cur = torch.cuda.current_stream(self.dev)
         here = torch.cuda.Event()
         here.record(cur)                                  # the caller's stream up to this call: inputs, eager scene starts
+        img = data["img"][0] if data["img"].dim() == 5 else data["img"]
+        if p in P["g_cam"] and tuple(self._ins[p]["img"].shape) != tuple(img.shape):
+            # input shape changed: this parity's graphs replay on buffers that are about to be replaced
+            torch.cuda.synchronize(self.dev)
+            for k in ("g_cam", "g_head", "outs", "cam_done", "head_done"):
+                P[k].pop(p, None)
         if p not in P["g_cam"]:
             # first steady frame on this buffer set: capture its two graphs with the device quiet
             torch.cuda.synchronize(self.dev)

@@ -12,6 +12,27 @@ from . import lib as _lib
 
 DT_F32, DT_BF16 = 0, 1
 DT_F32_BF16X3 = 2       # FAR3D_DT_F32_BF16X3: conv weight code "fp32 data, two-term bf16 split products"
+DT_BF16_PAIR = 3        # FAR3D_DT_BF16_PAIR: activations stored split, [32 hi | 32 lo] bf16 per 32-channel block
+
+
+# ---- pair storage (include/far3d_hip.h FAR3D_DT_BF16_PAIR): a map of C logical channels (C % 32 == 0) is a bf16 tensor with 2C
+# channels; every 32-channel block is 32 hi = bf16(x) then 32 lo = bf16(x - hi), so hi + lo carries 16 significant bits.
+def pair_from_float(t):
+    """(..., C) f32 -> (..., 2C) bf16 pair storage."""
+    C = t.shape[-1]
+    if C % 32:
+        raise ValueError("pair storage needs C %% 32 == 0 (got %d)" % C)
+    b = t.float().reshape(t.shape[:-1] + (C // 32, 32))
+    hi = b.to(torch.bfloat16)
+    lo = (b - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).reshape(t.shape[:-1] + (2 * C,)).contiguous()
+
+
+def pair_to_float(t):
+    """(..., 2C) bf16 pair storage -> (..., C) f32 (exact: hi + lo)."""
+    C2 = t.shape[-1]
+    b = t.reshape(t.shape[:-1] + (C2 // 64, 2, 32)).float()
+    return (b[..., 0, :] + b[..., 1, :]).reshape(t.shape[:-1] + (C2 // 2,))
 
 
 def _dt(t):
@@ -193,6 +214,9 @@ class PackedConv:
             self.bias = b.to(device)
         self.Cout, self.Cin, self.KH, self.KW, self.stride, self.pad = Cout, Cin, KH, KW, stride, pad
         self.w_code = DT_F32_BF16X3 if compute == "bf16x3" else _dt(self.w)
+        # pair-stored inputs only: 3 = split products (default); 1 = hi halves only, i.e. a single-bf16 layer inside a pair-stored
+        # network (the per-layer precision assignment measured by tools/precision_sweep.py)
+        self.terms = 3
 
     def out_hw(self, H, W):
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -216,46 +240,77 @@ def ese_scratch_floats(N, C):
     return N * C * (2 * SUMS_MAX_PARTS + 1)
 
 
+def _is_pair_input(x, pc):
+    return pc.w_code == DT_F32_BF16X3 and x.dtype == torch.bfloat16
+
+
+_HI_ONLY_TILE = {160: 260, 165: 265, 152: 252, 179: 279, 180: 280}
+
+
+def _pair_tile(pc, Cin, npix, tile):
+    """Tile id for a pair-stored input: the measured split-product tile (far3d_amd/data/tuning_mi355x_pair.json, ids 150+, 0 = the
+    library default), mapped to a hi-planes-only kernel when the layer is assigned a single bf16 product (pc.terms == 1)."""
+    fast = pc.stride == 1 and ((pc.KH == 3 and pc.pad == 1) or (pc.KH == 1 and pc.pad == 0))
+    if tile == 0:
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, "tuning_mi355x_pair.json")
+    if pc.terms == 1 and fast and (tile == 0 or 150 <= tile < 200):
+        tile = _HI_ONLY_TILE.get(tile, 260 if pc.KH == 3 else 279)
+    return tile
+
+
 def conv_tile(x, pc):
     """The tile conv2d_nhwc(tile=0) will use for this input (0 = kernel heuristic)."""
     N, H, W, Cin = x.shape
+    if _is_pair_input(x, pc):
+        return _pair_tile(pc, Cin // 2, N * H * W, 0)
     return _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W) if x.dtype == torch.bfloat16 else 0
 
 
 def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0):
     """x: (N,H,W,Cin) NHWC view (f32|bf16).  pc: PackedConv.  out: optional (N,Ho,Wo,Cout) NHWC view to write
-    into (e.g. a channel slice of an OSA concat buffer).  Returns out."""
+    into (e.g. a channel slice of an OSA concat buffer).  Returns out.
+    Pair storage: with split weights (compute="bf16x3") a bf16 `x` is a pair-stored map (N,H,W,2*Cin) (pair_from_float); a bf16
+    `out` / `res` is then pair-stored too ((..., 2*Cout)), an f32 `out` / `y2` is plain."""
     lib = _lib.require_device()
-    N, H, W, Cin = x.shape
-    if Cin != pc.Cin:
+    N, H, W, Cx = x.shape
+    pair_in = _is_pair_input(x, pc)
+    Cin = Cx // 2 if pair_in else Cx
+    if Cin != pc.Cin or (pair_in and Cx % 64):
         raise ValueError("conv2d_nhwc: input has %d channels, layer expects %d" % (Cin, pc.Cin))
     ldx, xs = _nhwc_view(x, "x")
     Ho, Wo = pc.out_hw(H, W)
     if out is None:
-        out = torch.empty((N, Ho, Wo, pc.Cout), dtype=out_dtype or x.dtype, device=x.device)
-    if tuple(out.shape) != (N, Ho, Wo, pc.Cout):
-        raise ValueError("conv2d_nhwc: out shape %s != %s" % (tuple(out.shape), (N, Ho, Wo, pc.Cout)))
+        odt = out_dtype or x.dtype
+        out = torch.empty((N, Ho, Wo, pc.Cout * (2 if pair_in and odt == torch.bfloat16 else 1)), dtype=odt, device=x.device)
+    pair_out = pair_in and out.dtype == torch.bfloat16
+    cso = 2 if pair_out else 1
+    if tuple(out.shape) != (N, Ho, Wo, pc.Cout * cso):
+        raise ValueError("conv2d_nhwc: out shape %s != %s" % (tuple(out.shape), (N, Ho, Wo, pc.Cout * cso)))
     ldy, ys = _nhwc_view(out, "out")
     rp, rdt, ldr, rs, Hr, Wr = None, 0, 0, 0, Ho, Wo
     if res is not None:
         ldr, rs = _nhwc_view(res, "res")
-        if res.shape[0] != N or res.shape[3] != pc.Cout:
+        pair_res = pair_in and res.dtype == torch.bfloat16
+        if res.shape[0] != N or res.shape[3] != pc.Cout * (2 if pair_res else 1):
             raise ValueError("conv2d_nhwc: residual shape %s incompatible" % (tuple(res.shape),))
-        rp, rdt, Hr, Wr = _ptr(res), _dt(res), res.shape[1], res.shape[2]
+        rp, rdt, Hr, Wr = _ptr(res), DT_BF16_PAIR if pair_res else _dt(res), res.shape[1], res.shape[2]
     y2p, y2dt, ldy2, y2s, sp, hp = None, 0, 0, 0, None, None
     if y2 is not None:
         ldy2, y2s = _nhwc_view(y2, "y2")
         _chk(y2_scale, "y2_scale", torch.float32)
         _chk(y2_shift, "y2_shift", torch.float32)
-        if y2_scale.numel() != N * pc.Cout or y2_shift.numel() != N * pc.Cout or tuple(y2.shape) != tuple(out.shape):
+        if y2_scale.numel() != N * pc.Cout or y2_shift.numel() != N * pc.Cout or tuple(y2.shape) != (N, Ho, Wo, pc.Cout):
             raise ValueError("conv2d_nhwc: y2/scale/shift shapes inconsistent")
         y2p, y2dt, sp, hp = _ptr(y2), _dt(y2), _ptr(y2_scale), _ptr(y2_shift)
-    if tile == 0 and x.dtype == torch.bfloat16:
+    if pair_in:
+        tile = _pair_tile(pc, Cin, N * H * W, tile)
+    elif tile == 0 and x.dtype == torch.bfloat16:
         tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W)
     elif tile == 0 and pc.w_code == DT_F32_BF16X3:
         tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W, "tuning_mi355x_bf16x3.json")
     _lib.check(lib.far3d_conv2d_nhwc(
-        _ptr(x), _dt(x), _ptr(pc.w), pc.w_code, _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), _dt(out),
+        _ptr(x), DT_BF16_PAIR if pair_in else _dt(x), _ptr(pc.w), pc.w_code, _ptr(pc.bias) if pc.bias is not None else None, _ptr(out),
+        DT_BF16_PAIR if pair_out else _dt(out),
         N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],
         rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, tile,
         _stream(x)), "far3d_conv2d_nhwc")
@@ -333,14 +388,19 @@ def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=
     return res if len(res) > 1 else y
 
 
-def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
+def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, pair=False):
     """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride).  scratch: optional
-    ese_scratch_floats(N, C) f32 workspace (never needs zeroing; the pooling is deterministic)."""
+    ese_scratch_floats(N, C) f32 workspace (never needs zeroing; the pooling is deterministic).  pair: x / identity / out are
+    pair-stored bf16 maps (2C stored channels)."""
     lib = _lib.require_device()
     N, H, W, C = x.shape
+    if pair:
+        if x.dtype != torch.bfloat16 or C % 64:
+            raise ValueError("ese_nhwc: pair storage is bf16 with a multiple of 64 stored channels")
+        C //= 2
     ldx, xs = _nhwc_view(x, "x")
     if out is None:
-        out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+        out = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
     ldy, ys = _nhwc_view(out, "out")
     ldi, isd, ip = 0, 0, None
     if identity is not None:
@@ -350,37 +410,46 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None):
         scratch = torch.empty(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
     if scratch.numel() < ese_scratch_floats(N, C):
         raise ValueError("ese_nhwc: scratch needs %d floats" % ese_scratch_floats(N, C))
-    _lib.check(lib.far3d_ese_nhwc(_ptr(x), _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
+    _lib.check(lib.far3d_ese_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
                                   ldx, xs, ldi, isd, ldy, ys, _stream(x)), "far3d_ese_nhwc")
     return out
 
 
-def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scratch=None):
+def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scratch=None, pair=False):
     lib = _lib.require_device()
     _chk(x, "x", ndim=4)
     N, H, W, C = x.shape
+    if pair:
+        if x.dtype != torch.bfloat16 or C % 64:
+            raise ValueError("groupnorm_nhwc: pair storage is bf16 with a multiple of 64 stored channels")
+        C //= 2
     if out is None:
         out = torch.empty_like(x)
     if scratch is None:
         scratch = torch.empty(ese_scratch_floats(N, C), dtype=torch.float32, device=x.device)
-    _lib.check(lib.far3d_groupnorm_nhwc(_ptr(x), _dt(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), N, H * W, C,
+    _lib.check(lib.far3d_groupnorm_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch), N, H * W, C,
                                         groups, float(eps), 1 if relu else 0, _stream(x)), "far3d_groupnorm_nhwc")
     return out
 
 
-def maxpool3x3s2_nhwc(x, out=None):
+def maxpool3x3s2_nhwc(x, out=None, pair=False):
     lib = _lib.require_device()
     _chk(x, "x", ndim=4)
     N, H, W, C = x.shape
+    Cs = C
+    if pair:
+        if x.dtype != torch.bfloat16 or C % 64:
+            raise ValueError("maxpool3x3s2_nhwc: pair storage is bf16 with a multiple of 64 stored channels")
+        C //= 2
     Ho, Wo = -(-(H - 3) // 2) + 1, -(-(W - 3) // 2) + 1
     if (Ho - 1) * 2 >= H:
         Ho -= 1
     if (Wo - 1) * 2 >= W:
         Wo -= 1
     if out is None:
-        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        out = torch.empty((N, Ho, Wo, Cs), dtype=x.dtype, device=x.device)
     ldy, ys = _nhwc_view(out, "out")
-    _lib.check(lib.far3d_maxpool3x3s2_nhwc(_ptr(x), _dt(x), _ptr(out), N, H, W, C, Ho, Wo, ldy, ys, _stream(x)),
+    _lib.check(lib.far3d_maxpool3x3s2_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(out), N, H, W, C, Ho, Wo, ldy, ys, _stream(x)),
                "far3d_maxpool3x3s2_nhwc")
     return out
 
@@ -388,8 +457,8 @@ def maxpool3x3s2_nhwc(x, out=None):
 # --------------------------------------------------------------------------------------------------
 # front-end glue: stem im2col, 2D proposals, MLN apply
 # --------------------------------------------------------------------------------------------------
-def stem_im2col(img, out_dtype=torch.bfloat16, out=None):
-    """(N,3,H,W) f32 NCHW -> (N,Ho,Wo,32) NHWC im2col of the stride-2 3x3 stem conv."""
+def stem_im2col(img, out_dtype=torch.bfloat16, out=None, pair=False):
+    """(N,3,H,W) f32 NCHW -> (N,Ho,Wo,32) NHWC im2col of the stride-2 3x3 stem conv (pair: (N,Ho,Wo,64) bf16 pair storage)."""
     lib = _lib.require_device()
     _chk(img, "img", torch.float32, 4)
     N, C, H, W = img.shape
@@ -397,8 +466,8 @@ def stem_im2col(img, out_dtype=torch.bfloat16, out=None):
         raise ValueError("stem_im2col expects 3 input channels")
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
-        out = torch.empty((N, Ho, Wo, 32), dtype=out_dtype, device=img.device)
-    _lib.check(lib.far3d_stem_im2col(_ptr(img), _ptr(out), _dt(out), N, H, W, _stream(img)), "far3d_stem_im2col")
+        out = torch.empty((N, Ho, Wo, 64 if pair else 32), dtype=torch.bfloat16 if pair else out_dtype, device=img.device)
+    _lib.check(lib.far3d_stem_im2col(_ptr(img), _ptr(out), DT_BF16_PAIR if pair else _dt(out), N, H, W, _stream(img)), "far3d_stem_im2col")
     return out
 
 
@@ -601,8 +670,17 @@ def topk(vals, K, with_values=False):
     return (idx, out) if with_values else idx
 
 
-def decode_topk(cls_last, box_last, K, post_center_range):
-    """NMS-free decode of the last layer: returns dict(boxes_3d (K,code-1), scores_3d (K), labels_3d (K) i64, keep (K) bool)."""
+DECODE_CHUNK = 40960     # logits one workgroup ranks (csrc/post.hip)
+
+
+def decode_ws_bytes(n, K):
+    """FAR3D_DECODE_WS_BYTES: workspace far3d_decode_topk needs for n = A * num_classes logits (0: single-launch path)."""
+    return 0 if n <= DECODE_CHUNK else -(-n // DECODE_CHUNK) * K * 8
+
+
+def decode_topk(cls_last, box_last, K, post_center_range, workspace=None):
+    """NMS-free decode of the last layer: returns dict(boxes_3d (K,code-1), scores_3d (K), labels_3d (K) i64, keep (K) bool).
+    workspace: optional uint8 device buffer of decode_ws_bytes(A * ncls, K) bytes (allocated here when needed and not given)."""
     lib = _lib.require_device()
     _chk(cls_last, "cls_last", torch.float32, 2)
     _chk(box_last, "box_last", torch.float32, 2)
@@ -614,8 +692,11 @@ def decode_topk(cls_last, box_last, K, post_center_range):
     labels = torch.empty((K,), dtype=torch.int64, device=dev)
     keep = torch.empty((K,), dtype=torch.bool, device=dev)
     rk, rp = _host_f32(list(post_center_range))
+    need = decode_ws_bytes(A * ncls, int(K))
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
     _lib.check(lib.far3d_decode_topk(_ptr(cls_last), _ptr(box_last), A, ncls, code, int(K), rp, _ptr(boxes), _ptr(scores), _ptr(labels),
-                                     _ptr(keep), _stream(cls_last)), "far3d_decode_topk")
+                                     _ptr(keep), _ptr(workspace) if need else None, need, _stream(cls_last)), "far3d_decode_topk")
     return dict(boxes_3d=boxes, scores_3d=scores, labels_3d=labels, keep=keep)
 
 

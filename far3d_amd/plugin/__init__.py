@@ -103,10 +103,6 @@ class _SchemaModule(nn.Module):
         return self._eng
 
 
-def _to_nhwc(x, dtype):
-    return x.permute(0, 2, 3, 1).contiguous().to(dtype)
-
-
 def _to_nchw(x):
     return x.float().permute(0, 3, 1, 2).contiguous()
 
@@ -344,7 +340,7 @@ class VoVNet(_SchemaModule):
                                             precision=self.precision, parts=("backbone",))
         outs = self._eng.backbone(x.float().contiguous())
         names = ["stage2", "stage3", "stage4", "stage5"]
-        return [o.float().permute(0, 3, 1, 2).contiguous() for n, o in zip(names, outs) if n in self._out_features]
+        return [self._eng.act_to_nchw(o) for n, o in zip(names, outs) if n in self._out_features]
 
 
 @NECKS.register_module()
@@ -376,12 +372,11 @@ class FPN(_SchemaModule):
         dev = inputs[0].device
         name = next(k for k, v in weights.VOV_SPECS.items() if tuple(v["stage_out_ch"]) == tuple(self.in_channels))
         eng = self._part_engine(dev, ("neck",), _engine.default_cfg(backbone=name))
-        act = eng.prec["act"]
-        feats = [_to_nhwc(x, act) for x in inputs]
+        feats = [eng.act_from_nchw(x) for x in inputs]
         n = feats[0].shape[0]
         one, zero = torch.ones(n, self.out_channels, device=dev), torch.zeros(n, self.out_channels, device=dev)
         raw, _, _, _ = eng.fpn(feats, one, zero)
-        return tuple(_to_nchw(r) for r in raw)
+        return tuple(eng.act_to_nchw(r) for r in raw)
 
 
 @HEADS.register_module()
@@ -419,7 +414,7 @@ class YOLOXHeadCustom(_SchemaModule):
         feats = data["img_feats"]
         dev = feats[0].device
         eng = self._engine_for(dev)
-        raw = [_to_nhwc(f.flatten(0, 1), eng.prec["act"]) for f in feats]
+        raw = [eng.act_from_nchw(f.flatten(0, 1)) for f in feats]
         ctr = []
         cls, reg, depth_logit = eng.roi_head(raw, centers2d=ctr)
         out = dict(enc_cls_scores=[_to_nchw(c) for c in cls], enc_bbox_preds=[_to_nchw(r[..., :4]) for r in reg],

@@ -25,6 +25,14 @@ extern "C" {
  * and row stride of the fp32 layout, but holds the split: every 32-channel block of a row (128 B) is 32 hi bf16 followed by
  * 32 lo bf16 (hi = bf16(w), lo = bf16(w - hi)). */
 #define FAR3D_DT_F32_BF16X3 2
+/* activation storage code ("pair"): a map of C logical channels (C % 32 == 0) holds fp32 values as 2C bf16 per pixel; every
+ * 32-channel block is 32 hi = bf16(x) followed by 32 lo = bf16(x - hi) (hi + lo is exact in fp32 and carries 16 significant bits
+ * at fp32's byte size).  Pointers, pixel strides and image strides of pair tensors count bf16 elements of the 2C-wide rows; channel
+ * slices start at multiples of 32 logical channels.  Accepted by far3d_conv2d_nhwc (x / y / res, with w_dt = FAR3D_DT_F32_BF16X3:
+ * the 64-byte hi / lo runs are what the LDS-DMA kernels stream, each product = 3 bf16 MFMAs), far3d_ese_nhwc,
+ * far3d_groupnorm_nhwc, far3d_maxpool3x3s2_nhwc (dt) and far3d_stem_im2col (out_dt).  The "bf16x3" engine mode stores every
+ * conv-stage activation this way. */
+#define FAR3D_DT_BF16_PAIR 3
 /* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */
 #define FAR3D_SUMS_MAX_PARTS 32
 /* partial sums [N][PARTS][C][2] + gates / group statistics [N][C] */
@@ -100,7 +108,11 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  * tile: 0 auto (host callers pass the measured choice of far3d_amd/data/tuning_mi355x.json).  Any dtype: 1 128x128, 2 64x128,
  *    3 64x64, 4 128x64, 5 64x256 (channels x pixels).  bf16 with Cin % 32 == 0 only: 18, 43, 46, 48 (LDS-DMA ring variants, any
  *    kernel size / stride); 50-67, 90-97, 100-103 pipelined 3x3/s1/p1 kernel (channels x rows of 32 pixels, 4/8/16 waves, 2- or 3-deep
- *    weight ring, one kernel row or -- 100-103 -- all 9 taps per barrier step); 70-81 pipelined 1x1/s1 GEMM kernel.  An id the layer cannot use is an error, not a silent fallback. */
+ *    weight ring, one kernel row or -- 100-103 -- all 9 taps per barrier step); 70-81 pipelined 1x1/s1 GEMM kernel.
+ *    x_dt = FAR3D_DT_BF16_PAIR (w_dt must be FAR3D_DT_F32_BF16X3; y_dt pair or f32; res_dt any): 1-5 register-staged kernel (any
+ *    kernel size / stride); 150-168, 191-197 the pipelined 3x3 shapes 50-68 / 91-97 with split products; 170-181 the pipelined 1x1
+ *    shapes; 252, 260, 265, 279, 280: the hi halves only (ONE bf16 product per term: a single-bf16 layer inside a pair-stored
+ *    network).  An id the layer cannot use is an error, not a silent fallback. */
 int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y, int y_dt,
                       int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
                       long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,
@@ -231,10 +243,14 @@ int far3d_topk(const float* vals, int n, int K, int64_t* idx_out, float* val_out
  * = (cx,cy,cz,log w,log l,log h,sin,cos[,vx,vy]); post_center_range 6 floats HOST.  Outputs, sorted by descending score:
  * boxes (K,code_size-1) = (cx,cy,cz-h/2,w,l,h,atan2(sin,cos)[,vx,vy]), scores (K) = sigmoid, labels (K) int64,
  * keep (K) uint8 = centre (before the z shift) inside post_center_range (the reference drops the others).
- * A*num_classes <= 40960, K <= 1024. */
+ * K <= 1024.  A*num_classes <= 40960: one launch, workspace may be NULL.  Larger inputs (the reference's threshold proposal mode
+ * on a busy frame): every 40960-logit chunk is ranked by its own workgroup and a second launch ranks the chunks' K best; that needs
+ * `workspace` = FAR3D_DECODE_WS_BYTES(A*num_classes, K) bytes of 8-byte aligned DEVICE memory (contents irrelevant) and
+ * ceil(A*num_classes / 40960) * K <= 40960.  Ties: the lower flat index (query-major, then class) first, in both paths. */
+#define FAR3D_DECODE_WS_BYTES(n, K) ((((long)(n) + 40959) / 40960) * (long)(K) * 8)
 int far3d_decode_topk(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
                       const float* post_center_range, float* boxes, float* scores, int64_t* labels, unsigned char* keep,
-                      void* stream);
+                      void* workspace, long workspace_bytes, void* stream);
 
 /* Per-frame camera calibration in one launch: img2lidar (N,4,4) = inverse(lidar2img) (ref models/dense_heads/farhead.py:798;
  * Gauss-Jordan with partial pivoting in f64) and c14 (N,14) = [fx/1e3, fy/1e3, extrinsics[:3,:4]] (ref farhead.py:553-556).

@@ -103,7 +103,7 @@ def _run_engine(sd, precision):
                         memory_topk=o["memory_topk"].cpu().clone(),
                         all_cls_scores=o["all_cls_scores"].cpu().clone(), all_bbox_preds=o["all_bbox_preds"].cpu().clone(),
                         outs_dec=o["outs_dec"].cpu().clone(), feat_flatten=o["feat_flatten"].float().cpu().clone(),
-                        fpn=[f.float().cpu().clone() for f in o["fpn"]],
+                        fpn=[eng.act_to_nchw(f).permute(0, 2, 3, 1).cpu().clone() for f in o["fpn"]],   # NHWC f32 (pair storage decoded)
                         result={k: v.cpu().clone() for k, v in o["result"].items()}))
     del eng
     torch.cuda.empty_cache()

@@ -113,10 +113,12 @@ def test_engine_graph_mode_with_scene_change_is_bitwise_eager(hip_lib, precision
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_pipelined_frames_in_flight_end_in_the_same_state(hip_lib, precision):
+@pytest.mark.parametrize("seq", [[0, 1, 1, 1, 2, 3, 3, 3, 3], [0, 1, 2, 3, 3]])
+def test_pipelined_frames_in_flight_end_in_the_same_state(hip_lib, precision, seq):
     """Pipeline mode with frames submitted back to back and NO wait in between (camera stages of frame i+1 really overlap the
-    head of frame i; a scene change in the middle): the last frame's outputs and the streaming memory equal the eager engine's."""
-    seq = [0, 1, 1, 1, 2, 3, 3, 3, 3]
+    head of frame i; a scene change in the middle): the last frame's outputs and the streaming memory equal the eager engine's.
+    The short sequence is ADVICE r2's case: scene A, A, B -- the scene start arrives while the FIRST steady frame (whose buffer set
+    was allocated inside the pipelined call) still has its head in flight; the eager scene start must wait for it."""
     fin = {}
     for mode in ("eager", "pipeline"):
         eng, z, rc = _golden_engine(precision, proposal_topk=12)

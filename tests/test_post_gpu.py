@@ -49,6 +49,33 @@ def test_decode_topk_matches_oracle_decode(hip_lib):
     assert (s[:-1] >= s[1:]).all()
 
 
+@pytest.mark.parametrize("A", [1576, 4484, 9000])
+def test_decode_topk_large_query_counts_take_the_chunked_path(hip_lib, A):
+    """the reference's threshold proposal mode can exceed A * 26 = 40960 logits (M > 675 adaptive queries); the decode
+    then ranks 40960-logit chunks in parallel and the chunks' winners in a second launch -- same result as the single launch,
+    ties (planted across chunk borders) to the lower flat index, NaN logits first like torch.topk."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(A)
+    ncls, K = 26, 300
+    cls = torch.randn(A, ncls, generator=g) * 2
+    flat = cls.view(-1)
+    flat[::4099] = 3.25                                # ties, some in every chunk
+    flat[-1] = 3.25
+    flat[40961 % flat.numel()] = float("nan")
+    box = torch.randn(A, 8, generator=g)
+    got = ops.decode_topk(cls.to(DEV), box.to(DEV), K, [-1e3] * 3 + [1e3] * 3)
+    key = torch.where(torch.isnan(flat), torch.full_like(flat, float("inf")), flat)
+    order = np.lexsort((np.arange(flat.numel()), -key.numpy()))[:K]
+    assert np.array_equal(got["labels_3d"].cpu().numpy(), order % ncls)
+    want_s = torch.sigmoid(flat[torch.as_tensor(order)])
+    gs = got["scores_3d"].cpu()
+    assert torch.isnan(gs[0]) and torch.isnan(want_s[0])
+    assert (gs[1:] - want_s[1:]).abs().max().item() < 1e-6
+    q = torch.as_tensor(order // ncls)
+    assert torch.allclose(got["boxes_3d"].cpu()[:, :2], box[q][:, :2])
+    assert ops.decode_ws_bytes(A * ncls, K) == (0 if A * ncls <= 40960 else -(-A * ncls // 40960) * K * 8)
+
+
 def test_decode_topk_keeps_velocity_channels(hip_lib):
     """code_size 10 (the reference nuScenes layout): vx, vy are appended like denormalize_bbox does (core/bbox/util.py:45-50)."""
     from far3d_amd import ops

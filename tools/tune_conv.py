@@ -60,6 +60,7 @@ def main():
     table, seen = {}, set()
     only = os.environ.get("ONLY_K")
     x3 = os.environ.get("MODE") == "bf16x3"
+    pair = os.environ.get("MODE") == "pair"      # pair-stored activations (the bf16x3 engine mode): tiles 150+ -> tuning_mi355x_pair.json
     tdt = torch.float32 if x3 else torch.bfloat16
     for name, N, H, W, Cin, Cout, k, stride in shapes():
         if only and int(only) != k:
@@ -70,16 +71,23 @@ def main():
         if key in seen:
             continue
         seen.add(key)
+        if pair and (name.startswith("dec.") or Cin % 32):
+            continue
         x = torch.randn(N, H, W, Cin, device=dev).to(tdt)
-        pc = ops.PackedConv(torch.randn(Cout, Cin, k, k) * 0.05, torch.randn(Cout), stride=stride, pad=k // 2, dtype=tdt, device=dev,
-                            compute="bf16x3" if x3 else None)
+        if pair:
+            x = ops.pair_from_float(x.float())
+        pc = ops.PackedConv(torch.randn(Cout, Cin, k, k) * 0.05, torch.randn(Cout), stride=stride, pad=k // 2, dtype=torch.float32 if pair else tdt,
+                            device=dev, compute="bf16x3" if (x3 or pair) else None)
         Ho, Wo = pc.out_hw(H, W)
-        y = torch.empty(N, Ho, Wo, Cout, device=dev, dtype=tdt)
+        y = torch.empty(N, Ho, Wo, Cout * 2 if (pair and Cout % 32 == 0) else Cout, device=dev, dtype=tdt if not (pair and Cout % 32) else torch.float32)
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         res = {}
         tiles = ((0, 1, 2, 3, 4, 18, 43, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81) if (k == 1 and stride == 1) else ()) + ((50, 52, 60, 61, 63, 64, 65, 90, 92, 93, 96, 100, 101, 102, 103) if (k == 3 and stride == 1) else ())
         if x3:
             tiles = (0, 1, 2, 3, 4, 5)
+        if pair:
+            tiles = (0, 150, 152, 154, 155, 157, 160, 161, 162, 163, 164, 165, 166, 167, 168, 191, 192, 193, 197) if (k == 3 and stride == 1) else \
+                    ((0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181) if (k == 1 and stride == 1) else (0, 1, 2, 3, 4, 5))
         if k == 3 and stride == 1 and os.environ.get("EXTRA_TILES"):
             tiles = tiles + tuple(int(v) for v in os.environ["EXTRA_TILES"].split(","))
         for tile in tiles:
@@ -89,7 +97,7 @@ def main():
         table[key] = best[1]
         print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %4.0f" % (tl, res[tl] * 1e6) for tl in tiles if tl) +
               " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
-    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x_bf16x3.json" if x3 else "tuning_mi355x.json"), "w"), indent=0, sort_keys=True)
+    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x_pair.json" if pair else ("tuning_mi355x_bf16x3.json" if x3 else "tuning_mi355x.json")), "w"), indent=0, sort_keys=True)
 
 if __name__ == "__main__":
     main()
