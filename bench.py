@@ -40,11 +40,10 @@ def agg_algorithmic_bytes(N, S, C, A, P, G, L, ev):
     return N * S * C * ev + A * P * N * 2 * 4 + N * A * G * L * P * 4 + A * C * 4
 
 
-def cpu_baseline_and_parity(precision, eng_frames):
+def oracle_frames(nframes):
     """The oracle (CPU port of the reference path, proven equal to the reference's own files by tools/gen_golden.py) on this
-    box's host cores: frame 0 of the benchmark sequence, ALL 7 cameras, timed once (the bounded sample), then frame 1 (streaming
-    memory in use).  Its logits are the checker for the engine's first two frames (frame 0 eager, frame 1 = the captured
-    hipGraph's first replay): the `parity` block of the bench line."""
+    box's host cores: frames 0.. of the benchmark sequence, ALL 7 cameras, each timed (frame 0 is the bounded CPU-baseline sample;
+    frame 1 has the streaming memory in use).  Returns (cpu_baseline block, per-frame oracle outputs)."""
     from far3d_amd import synth, weights
     from oracle import far3d_oracle
     ncpu = os.cpu_count() or 1
@@ -62,42 +61,49 @@ def cpu_baseline_and_parity(precision, eng_frames):
     torch.set_num_threads(cores)
     sd = weights.init_state_dict(weights.detector_spec("V-99-eSE"), seed=0)
     orc = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K_PROP))
-    times, par = [], []
+    times, outs = [], []
     with torch.no_grad():
-        for fi, got in enumerate(eng_frames):
+        for fi in range(nframes):
             data, metas = synth.make_frame(7, (640, 960), seed=0, frame_index=fi, ego_motion=True)
             t0 = time.perf_counter()
             o = orc.simple_test(data, metas)
             times.append(time.perf_counter() - t0)
-            # adaptive queries are comparable row by row only where both picked the same 2D peak: map them through (camera, cell)
-            want_sel = [(int(n), int(i)) for n, i, _ in o["roi"]["valid_indices"].nonzero().numpy()]
-            pos = {k: j for j, k in enumerate(want_sel)}
-            nq = 644
-            rows_g, rows_w = list(range(nq)), list(range(nq))
-            common = 0
-            for j, k in enumerate(got["sel"]):
-                if k in pos:
-                    rows_g.append(nq + j); rows_w.append(nq + pos[k]); common += 1
-            A = got["logits"].shape[2]
-            M = len(want_sel)
-            rows_g += list(range(nq + len(got["sel"]), A)); rows_w += list(range(nq + M, A))
-            d = (got["logits"][:, 0, rows_g] - o["all_cls_scores"][:, 0, rows_w]).abs()
-            qs = torch.quantile(d.flatten()[::2].double(), torch.tensor([0.5, 0.99], dtype=torch.float64))
-            par.append(dict(frame=fi, logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(), logit_p50_abs=qs[0].item(), logit_p99_abs=qs[1].item(),
-                            last_layer_logit_max_abs=d[-1].max().item(), proposals_in_common=common, proposals=M,
-                            rows_compared=len(rows_g), engine_path=got["path"]))
+            outs.append(dict(logits=o["all_cls_scores"], sel=[(int(n), int(i)) for n, i, _ in o["roi"]["valid_indices"].nonzero().numpy()]))
     baseline = dict(value=1.0 / times[0], unit="samples/s", cores=cores, kind="port",
                     sample="1 frame of the benchmark workload, all 7 cameras, whole path (VoV-99+FPN+2D head+FarHead+decoder+decode) "
                            "timed once: %.2f s (second, streaming frame: %.2f s); torch %s fp32, %d threads (fastest of a probe; host has "
                            "%d logical CPUs)" % (times[0], times[1] if len(times) > 1 else float("nan"), torch.__version__, cores, ncpu))
+    return baseline, outs
+
+
+def parity_block(precision, eng_frames, orc_frames):
+    """The engine's first frames (frame 0 eager, frame 1 = the captured hipGraph's first replay) against the oracle's logits."""
+    par = []
+    for fi, (got, o) in enumerate(zip(eng_frames, orc_frames)):
+        # adaptive queries are comparable row by row only where both picked the same 2D peak: map them through (camera, cell)
+        want_sel = o["sel"]
+        pos = {k: j for j, k in enumerate(want_sel)}
+        nq = 644
+        rows_g, rows_w = list(range(nq)), list(range(nq))
+        common = 0
+        for j, k in enumerate(got["sel"]):
+            if k in pos:
+                rows_g.append(nq + j); rows_w.append(nq + pos[k]); common += 1
+        A = got["logits"].shape[2]
+        M = len(want_sel)
+        rows_g += list(range(nq + len(got["sel"]), A)); rows_w += list(range(nq + M, A))
+        d = (got["logits"][:, 0, rows_g] - o["logits"][:, 0, rows_w]).abs()
+        qs = torch.quantile(d.flatten()[::2].double(), torch.tensor([0.5, 0.99], dtype=torch.float64))
+        par.append(dict(frame=fi, logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(), logit_p50_abs=qs[0].item(), logit_p99_abs=qs[1].item(),
+                        last_layer_logit_max_abs=d[-1].max().item(), proposals_in_common=common, proposals=M,
+                        rows_compared=len(rows_g), engine_path=got["path"]))
     # Frame 0 is the clean comparison.  From frame 1 on the two sides also differ through the streaming memory: which 256 queries
     # are kept is a discrete top-k on scores ~1e-4 apart, so any rounding difference (let alone bf16) changes the memory contents
     # and the frames stop being the same computation (tests/test_engine_full_gpu.py quantifies this with an fp64 oracle).
-    parity = dict(precision=precision, tolerance_north_star=1e-3, checker="oracle (fp32 CPU port of the reference path), same seeded weights/inputs",
-                  logit_max_abs=par[0]["logit_max_abs"], logit_mean_abs=par[0]["logit_mean_abs"],
-                  meets_tolerance=bool(par[0]["logit_max_abs"] < 1e-3), headline_frame=0, frames=par,
-                  see="tests/test_engine_full_gpu.py (per-stage budget, fp64 yardstick), DESIGN.md section 4")
-    return baseline, parity
+    return dict(precision=precision, tolerance_north_star=1e-3, checker="oracle (fp32 CPU port of the reference path), same seeded weights/inputs",
+                logit_max_abs=par[0]["logit_max_abs"], logit_mean_abs=par[0]["logit_mean_abs"],
+                meets_tolerance=bool(par[0]["logit_max_abs"] < 1e-3), headline_frame=0, frames=par,
+                see="tests/test_engine_full_gpu.py (per-stage budget, fp64 yardstick), DESIGN.md section 4")
 
 
 def agg_traffic():
@@ -116,39 +122,15 @@ def agg_traffic():
         return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16_fp32dec", "bf16_fp32val"])
-    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
-    ap.add_argument("--no-pipeline", action="store_true", help="single GPU: do not overlap the camera stages of frame i+1 with the head of frame i")
-    ap.add_argument("--agg-variant", type=int, default=0, help="far3d_aggregate_forward kernel variant (A/B timing)")
-    args = ap.parse_args()
-
-    import torch.distributed as dist
-    from far3d_amd import engine, synth, weights
+def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True):
+    """Build an engine of `precision`, run the parity frames, the warm-up, the timed region (K frames between two syncs), the
+    reference's sync-per-frame protocol and (optionally) the per-kernel roofline timings.  Returns a dict of raw figures."""
+    from far3d_amd import engine, ops, synth, weights
     from far3d_amd import dist as fdist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    sharded = world > 1 and args.mode == "sharded"
-
     cfg = engine.default_cfg(proposal_topk=K_PROP)
     spec = weights.detector_spec(cfg["backbone"])
     sd = weights.init_state_dict(spec, seed=0)
-    eng = engine.Far3DEngine(sd, cfg, device=dev, precision=args.precision)
+    eng = engine.Far3DEngine(sd, cfg, device=dev, precision=precision)
     eng.agg_variant = args.agg_variant
     del sd
     frames = []
@@ -176,20 +158,20 @@ def main():
         eng_frames.append(dict(logits=o["all_cls_scores"].float().cpu().clone(), sel=sel,
                                path="eager (first frame of the scene)" if fi == 0 or args.eager else "hipGraph replay"))
     step_i = 2
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         runner.forward_frame(*frames[step_i % len(frames)])
         step_i += 1
     sync()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     evs[0].record(eng.output_stream())
-    for k in range(args.steps):
+    for k in range(steps):
         out = runner.forward_frame(*frames[step_i % len(frames)])
         evs[k + 1].record(eng.output_stream())      # completion of frame k (the head's stream in pipeline mode)
         step_i += 1
     sync()
     dt = time.perf_counter() - t0
-    dev_ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
+    dev_ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(steps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,7 +182,7 @@ def main():
 
     # ---- the reference's own protocol: sync before and after every frame (tools/analysis_tools/benchmark.py:84-111)
     per_frame = []
-    for _ in range(min(args.steps, 50)):
+    for _ in range(min(steps, 50)):
         sync()
         t1 = time.perf_counter()
         runner.forward_frame(*frames[step_i % len(frames)])
@@ -212,8 +194,6 @@ def main():
     # Kernel durations for the rooflines: HIP events (on the launch stream) around hipGraph replays that contain ONLY
     # that kernel, fed with this run's live tensors (last decoder layer's operands / the staged images) -- a launch-gap-free
     # device time that agrees with rocprofv3's per-kernel average (profiles/).
-    from far3d_amd import ops
-
     def device_time(fn, iters, reps=3):
         fn()
         torch.cuda.synchronize(dev)
@@ -233,64 +213,137 @@ def main():
 
     agg_ms, bb_ms, timing_error = [], [], None
     try:        # the per-kernel figures must never cost the headline line (e.g. a capture problem on one rank of N)
-        tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_ = eng.last_agg
-        agg_out = torch.empty(ref_.shape[0], 256, device=dev, dtype=eng.prec["dec"])
-        agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
-                                                            num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
-                                                            variant=args.agg_variant), 24)]
         img_in = eng._ins[0]["img"]
         img_local = img_in if not sharded else img_in[runner.cams[0]:runner.cams[-1] + 1] if runner.cams else img_in[:0]
+        if kernel_timings:
+            tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_ = eng.last_agg
+            agg_out = torch.empty(ref_.shape[0], 256, device=dev, dtype=eng.prec["dec"])
+            agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
+                                                                num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
+                                                                variant=args.agg_variant), 24)]
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+    res = dict(steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
+               timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(eng.pipeline), cfg=cfg,
+               ncam_local=len(runner.cams) if sharded else 7)
+    del eng, runner, frames, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def backbone_roofline(res):
+    """roofline_backbone block: 2 * 201.87 GMAC per camera over the measured backbone time, against the dense
+    MFMA peak of the mode's arithmetic."""
+    prec = res["prec"]
+    mode = prec.get("mma") or ("bf16" if prec["act"] == torch.bfloat16 else "fp32")
+    peak = MFMA_PEAK[mode]
+    bb_t = (sum(res["bb_ms"]) / len(res["bb_ms"])) * 1e-3 if res["bb_ms"] else float("nan")
+    n = res["ncam_local"]
+    kernels = {"bf16": "conv3x3_pipe_kernel + gemm1x1_pipe_kernel <NT=1> (bf16 MFMA)",
+               "bf16x3": ("conv3x3_pipe_kernel + gemm1x1_pipe_kernel <NT=3, PAIR> (pair-stored activations, 3 bf16 MFMAs per product)"
+                          if prec.get("pair") else "igemm_kernel<float, split_t> (register-staged, 3 bf16 MFMAs per product)"),
+               "fp32": "igemm_kernel<float, float> (exact fp32 MFMA)"}[mode]
+    return {"kernel": kernels + " -- VoV-99 backbone: all launches incl. eSE / pooling", "bound": "mfma",
+            "achieved": n * BACKBONE_FLOP_PER_CAM / bb_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": n * BACKBONE_FLOP_PER_CAM / bb_t / peak, "backbone_ms": bb_t * 1e3, "cameras_on_this_rank": n,
+            "peak_what": "dense bf16 MFMA 2.5 PF" + (" / 3 (three MFMAs per useful product)" if mode == "bf16x3" else "") if mode != "fp32" else "fp32 MFMA"}
+
+
+def build_commit():
+    """Commit the library was built from: git when available, else far3d_amd/_build_commit.txt (written by far3d_amd/build.py
+    here, travels with the snapshot to boxes without .git), else FAR3D_COMMIT."""
+    try:
+        c = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if c:
+            return c
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        with open(os.path.join(ROOT, "far3d_amd", "_build_commit.txt")) as f:
+            return f.read().strip() or None
+    except OSError:
+        return os.environ.get("FAR3D_COMMIT")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act", "bf16_fp32dec", "bf16_fp32val"])
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-in-tolerance", action="store_true", help="skip the second, in-tolerance (bf16x3) engine of the default run")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true", help="single GPU: do not overlap the camera stages of frame i+1 with the head of frame i")
+    ap.add_argument("--agg-variant", type=int, default=0, help="far3d_aggregate_forward kernel variant (A/B timing)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sharded = world > 1 and args.mode == "sharded"
+
+    res = measure(args, args.precision, args.steps, args.warmup, world, rank, dev, sharded, dist)
+    # The headline precision is what BASELINE configs[1] names (bf16) and misses the north-star logit tolerance; the same run
+    # therefore also times the fastest assignment that MEETS it (bf16x3: pair-stored activations, 3 bf16 MFMAs per conv product,
+    # exact-fp32 decoder) -- same workload, same protocol, fewer timed frames -- and reports it as the `in_tolerance` block.
+    res_tol = None
+    if world == 1 and args.precision == "bf16" and not args.no_in_tolerance and not args.eager:
+        res_tol = measure(args, "bf16x3", max(10, args.steps // 2), args.warmup, world, rank, dev, sharded, dist, kernel_timings=False)
 
     if rank == 0:
-        evb = 2 if eng.prec["value"] == torch.bfloat16 else 4
-        agg_t = (sum(agg_ms) / len(agg_ms)) * 1e-3 if agg_ms else float("nan")
+        dt, dev_ms, per_frame, A, N, S, C, cfg = (res[k] for k in ("dt", "dev_ms", "per_frame", "A", "N", "S", "C", "cfg"))
+        evb = 2 if res["prec"]["value"] == torch.bfloat16 else 4
+        agg_t = (sum(res["agg_ms"]) / len(res["agg_ms"])) * 1e-3 if res["agg_ms"] else float("nan")
         by = agg_algorithmic_bytes(N, S, C, A, cfg["num_pts"], cfg["num_groups"], cfg["num_levels"], evb)
-        bb_t = (sum(bb_ms) / len(bb_ms)) * 1e-3 if bb_ms else float("nan")
-        ncam_local = len(runner.cams) if sharded else 7
-        mfma_peak = MFMA_PEAK["bf16" if eng.prec["act"] == torch.bfloat16 else (eng.prec.get("mma") or "fp32")]
         samples = args.steps * (world if (world > 1 and not sharded) else 1)
         # the committed PMC passes measured the bf16-row kernel: no traffic figure for the fp32-row modes
-        traffic, traffic_src = agg_traffic() if eng.prec["value"] == torch.bfloat16 else (None, None)
-        try:
-            commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
-        except Exception:   # noqa: BLE001
-            commit = None
-        commit = commit or os.environ.get("FAR3D_COMMIT")     # the GPU box gets a snapshot without .git
+        traffic, traffic_src = agg_traffic() if res["prec"]["value"] == torch.bfloat16 else (None, None)
+        sync_rate = 1e3 * len(per_frame) / sum(per_frame)
         line = {
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak",
             "vs_baseline": (samples / dt) / 6.4 if world == 1 else None,   # BASELINE.md: 6.4 samples/s (hardware not stated)
-            "dtype": args.precision if args.precision in ("fp32", "bf16x3", "bf16x3_all") else "bf16", "data": "synthetic",
+            # the reference's figure was taken with a device sync around every frame (benchmark.py:84-111): the like-for-like ratio
+            "vs_baseline_sync_per_frame": sync_rate / 6.4 if world == 1 else None,
+            "dtype": args.precision if args.precision in ("fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act") else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 7 cameras 3x640x960, VoV-99, A=%d queries (644 learned + 644 adaptive + 256 "
                                    "propagated), 2312 self-attn keys, 6 decoder layers, streaming memory on, ego motion on" % A,
                        "parallelism": "single GPU" if world == 1 else ("camera-sharded x%d + 1 all-gather" % world if sharded else
                                                                        "%d independent scene streams (replicas, no collective)" % world),
-                       "precision_assignment": {k: str(v).replace("torch.", "") for k, v in eng.prec.items()},
-                       "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)", "commit": commit},
+                       "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res["prec"].items()},
+                       "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)", "commit": build_commit()},
             "protocol": {"pipelined": {"frames": args.steps, "mean_ms": dt / args.steps * 1e3, "p50_ms_device_events": dev_ms[len(dev_ms) // 2],
                                        "what": "frames issued back to back, one sync at each end (this file's contract -> `value`)",
-                                       "frame_overlap": bool(eng.pipeline),
+                                       "frame_overlap": res["pipeline"],
                                        "frame_overlap_what": "per-camera stages of frame i+1 run on their own stream while the head of frame i is in flight "
                                                              "(two buffer sets, head graphs ordered on one stream: results identical to the unpipelined engine)"},
                          "sync_per_frame": {"frames": len(per_frame), "mean_ms": sum(per_frame) / len(per_frame), "p50_ms": per_frame[len(per_frame) // 2],
-                                            "samples_per_s_mean": 1e3 * len(per_frame) / sum(per_frame),
+                                            "samples_per_s_mean": sync_rate,
                                             "what": "reference protocol (tools/analysis_tools/benchmark.py:84-111): device sync before and after every frame"}},
             "roofline": {"kernel": AGG_KERNEL + " (fused perspective-aware aggregation, one launch per decoder layer)" if args.agg_variant in (0, 7)
                          else "aggregate_v3_kernel (A/B variant %d)" % args.agg_variant,
                          "bound": "hbm", "achieved": by / agg_t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": by / agg_t / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by,
+                         "frac": by / agg_t / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_in_this_run": False if traffic is not None else None,
+                         "algorithmic_bytes_per_launch": by,
                          "avg_launch_us": agg_t * 1e6, "timing": "HIP events around a hipGraph of 24 launches x 3 replays, live frame operands"},
-            "roofline_backbone": {"kernel": "conv3x3_pipe_kernel + gemm1x1_pipe_kernel (VoV-99 backbone: all launches incl. eSE / pooling)", "bound": "mfma",
-                                  "achieved": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / 1e12, "peak": mfma_peak / 1e12,
-                                  "unit": "TFLOP/s", "frac": ncam_local * BACKBONE_FLOP_PER_CAM / bb_t / mfma_peak,
-                                  "backbone_ms": bb_t * 1e3, "cameras_on_this_rank": ncam_local},
+            "roofline_backbone": backbone_roofline(res),
         }
-        if timing_error:
-            line["kernel_timing_error"] = timing_error
+        if res["timing_error"]:
+            line["kernel_timing_error"] = res["timing_error"]
 
         def finite(o):           # strict JSON: no NaN / Infinity (a missing kernel timing becomes null)
             if isinstance(o, dict):
@@ -300,8 +353,25 @@ def main():
             if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
                 return None
             return o
+        orc = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(args.precision, eng_frames)
+            line["cpu_baseline"], orc = oracle_frames(2)
+            line["parity"] = parity_block(args.precision, res["eng_frames"], orc)
+        if res_tol is not None:
+            pf = res_tol["per_frame"]
+            blk = {"dtype": "bf16x3", "what": "the fastest precision assignment that meets the north-star logit tolerance (1e-3): conv-stage "
+                                              "activations pair-stored ([hi|lo] bf16, 16 significant bits), every conv product = 3 bf16 MFMAs "
+                                              "with fp32 accumulation, fp32 value maps, exact-fp32 decoder / FarHead GEMMs; same workload, "
+                                              "same timing protocol as `value`",
+                   "value": res_tol["steps"] / res_tol["dt"], "unit": "samples/s", "steps": res_tol["steps"],
+                   "ms_per_step": res_tol["dt"] / res_tol["steps"] * 1e3, "vs_baseline": res_tol["steps"] / res_tol["dt"] / 6.4,
+                   "sync_per_frame": {"mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2], "samples_per_s_mean": 1e3 * len(pf) / sum(pf)},
+                   "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res_tol["prec"].items()},
+                   "roofline_backbone": backbone_roofline(res_tol)}
+            if orc is not None:
+                blk["parity"] = parity_block("bf16x3", res_tol["eng_frames"], orc)
+                blk["meets_tolerance"] = blk["parity"]["meets_tolerance"]
+            line["in_tolerance"] = blk
         print(json.dumps(finite(line)))
     if world > 1:
         dist.destroy_process_group()

@@ -39,7 +39,24 @@ def _compile(src):
     return obj, True
 
 
+def _stamp_commit():
+    """Record the commit this tree was built from (far3d_amd/_build_commit.txt, git-ignored like the .so): the GPU box receives a
+    snapshot without .git, and bench.py reports the commit in its JSON line."""
+    root = os.path.join(HERE, "..")
+    if not os.path.isdir(os.path.join(root, ".git")):
+        return
+    try:
+        c = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        d = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if c:
+            with open(os.path.join(HERE, "_build_commit.txt"), "w") as f:
+                f.write(c + ("+dirty" if d else "") + "\n")
+    except Exception:   # noqa: BLE001  (never fail a build over the stamp)
+        pass
+
+
 def build(force=False, verbose=True):
+    _stamp_commit()
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):

@@ -26,53 +26,47 @@ DEFAULT_NORM = dict(mean=[103.530, 116.280, 123.675], std=[57.375, 57.120, 58.39
 
 
 def sample_augmentation(H, W, conf, rng=np.random):
-    """ref custom_pipeline.py:313-326 -- same draws, same order."""
-    fH, fW = conf["final_dim"]
-    resize = rng.uniform(*conf["resize_lim"])
-    resize_dims = (int(W * resize), int(H * resize))
-    newW, newH = resize_dims
-    crop_h = int((1 - rng.uniform(*conf["bot_pct_lim"])) * newH) - fH
-    crop_w = int(rng.uniform(0, max(0, newW - fW)))
-    crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
-    flip = False
-    if conf["rand_flip"] and rng.choice([0, 1]):
-        flip = True
-    rotate = rng.uniform(*conf["rot_lim"])
-    return resize, resize_dims, crop, flip, rotate
+    """One draw of the image augmentation (ref custom_pipeline.py:313-326).  A seeded run must consume the generator exactly like
+    the reference, so the ORDER of the draws is part of the contract: scale, bottom-crop fraction, horizontal offset, the flip
+    coin (tossed only when flipping is enabled), rotation angle.  Returns (scale, (scaled_w, scaled_h), crop box, flip, angle)."""
+    out_h, out_w = conf["final_dim"]
+    scale = rng.uniform(*conf["resize_lim"])
+    scaled_w, scaled_h = int(W * scale), int(H * scale)
+    kept_rows = (1 - rng.uniform(*conf["bot_pct_lim"])) * scaled_h
+    top = int(kept_rows) - out_h
+    left = int(rng.uniform(0, max(0, scaled_w - out_w)))
+    flip = bool(conf["rand_flip"] and rng.choice([0, 1]))
+    angle = rng.uniform(*conf["rot_lim"])
+    return scale, (scaled_w, scaled_h), (left, top, left + out_w, top + out_h), flip, angle
 
 
 def sample_augmentation_portrait(H, W):
-    """ref custom_pipeline.py:328-338: a portrait camera (H > W) is first blown up and centre-cropped to the landscape size."""
-    fH, fW = W, H
-    resize = np.round(((H + 50) / W), 2)
-    resize_dims = (int(W * resize), int(H * resize))
-    newW, newH = resize_dims
-    crop_h = int((newH - fH) / 2)
-    crop_w = int((newW - fW) / 2)
-    return resize, resize_dims, (crop_w, crop_h, crop_w + fW, crop_h + fH)
+    """A portrait camera (H > W; AV2's ring_front_center) is enlarged until a landscape window of the transposed size fits and
+    that window is cut from the centre (ref custom_pipeline.py:328-338).  Deterministic: no draws."""
+    out_h, out_w = W, H
+    scale = np.round((H + 50) / W, 2)
+    scaled_w, scaled_h = int(W * scale), int(H * scale)
+    left, top = int((scaled_w - out_w) / 2), int((scaled_h - out_h) / 2)
+    return scale, (scaled_w, scaled_h), (left, top, left + out_w, top + out_h)
 
 
 def ida_matrix(resize, crop, flip=False, rotate=0.0):
-    """The post-homography matrix of _img_transform (ref custom_pipeline.py:294-311), in torch float32 like the reference."""
-    ida_rot = torch.eye(2)
-    ida_tran = torch.zeros(2)
-    ida_rot *= resize
-    ida_tran -= torch.Tensor(crop[:2])
-    if flip:
-        A = torch.Tensor([[-1, 0], [0, 1]])
-        b = torch.Tensor([crop[2] - crop[0], 0])
-        ida_rot = A.matmul(ida_rot)
-        ida_tran = A.matmul(ida_tran) + b
-    h = rotate / 180 * np.pi
-    A = torch.Tensor([[np.cos(h), np.sin(h)], [-np.sin(h), np.cos(h)]])
-    b = torch.Tensor([crop[2] - crop[0], crop[3] - crop[1]]) / 2
-    b = A.matmul(-b) + b
-    ida_rot = A.matmul(ida_rot)
-    ida_tran = A.matmul(ida_tran) + b
-    ida_mat = torch.eye(3)
-    ida_mat[:2, :2] = ida_rot
-    ida_mat[:2, 2] = ida_tran
-    return ida_mat
+    """3x3 homography of the image augmentation, pixel (x, y, 1) of the source -> pixel of the network input
+    (ref custom_pipeline.py:294-311 builds it step by step).  In closed form the chain is
+        x' = R (F (s x - c) + f) + (b - R b)
+    with s the scale, c the crop's top-left corner, F = diag(-1, 1) and f = (crop width, 0) when flipped (else F = I, f = 0),
+    R = [[cos, sin], [-sin, cos]] of the rotation angle (degrees) about the crop centre b.  Evaluated in float64 and rounded once
+    to float32; for the un-flipped, un-rotated configuration of the reference config the entries (s, -c) are exact."""
+    left, top, right, bottom = (float(v) for v in crop)
+    F = np.diag([-1.0, 1.0]) if flip else np.eye(2)
+    f = np.array([right - left, 0.0]) if flip else np.zeros(2)
+    th = float(rotate) / 180.0 * np.pi
+    R = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+    b = np.array([right - left, bottom - top]) / 2.0
+    M = np.eye(3)
+    M[:2, :2] = float(np.float32(resize)) * (R @ F)          # the reference scales a float32 identity
+    M[:2, 2] = R @ (F @ -np.array([left, top]) + f) + (b - R @ b)
+    return torch.from_numpy(M.astype(np.float32))
 
 
 class ImagePreprocessor:

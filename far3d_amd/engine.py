@@ -9,6 +9,7 @@ Data layout (HBM): all feature maps are NHWC (channels-last) in the activation d
 writes its channel slice in place, so torch.cat never runs; FPN outputs are written twice by the same conv epilogue:
 raw (for the 2D head) and camera-modulated, token-major (N, S, 256), which IS `feat_flatten` of the reference.
 """
+import fnmatch
 import math
 
 import torch
@@ -34,6 +35,13 @@ PRECISIONS = {
     # size, 16 significant bits) so that the split products run on the LDS-DMA pipelined kernels (csrc/igemm_pair.hip).
     "bf16x3": dict(act=torch.bfloat16, pair=True, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma=None),
     "bf16x3_all": dict(act=torch.bfloat16, pair=True, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma="bf16x3"),
+    # bf16x3 with the layers that reach the logits ONLY through discrete decisions (2D-head levels 1-3 on the benchmark frames, the
+    # depth head's argmax) as single bf16 products: tools/precision_sweep.py (profiles/r3/precision_sweep.log) finds that on frame 0
+    # these 18 layers change no logit at all while every layer of the continuous path costs 1e-3..2e-2 and flips proposals.  NOT
+    # the default: the zero is a property of that frame (a flipped argmax / peak replaces a whole query), and it saves only 5 %
+    # of the conv MFMA work.  Kept as a measured, opt-in assignment.
+    "bf16x3_2d1": dict(act=torch.bfloat16, pair=True, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma=None,
+                       single_bf16=("roi[123].*", "depth.*")),
     # the same arithmetic on plain fp32 activations (split while staging, register-staged kernel): round 2's form, kept for A/B
     "bf16x3_f32act": dict(act=torch.float32, value=torch.float32, dec=torch.float32, mma="bf16x3", dec_mma=None),
 }
@@ -108,6 +116,7 @@ class Far3DEngine:
             if ck is not None:
                 self.sd[ck] = v.detach().float()
         self.spec = weights.VOV_SPECS[self.cfg["backbone"]]
+        self.convs = {}             # name -> PackedConv of every conv layer of the per-camera stages
         self._bufs = {}
         self._ins = {}              # static input buffers per buffer-set parity (graph replay reads them)
         self._graph = None
@@ -138,9 +147,16 @@ class Far3DEngine:
                                sd[n + "running_var"], eps)
         return w, b, stride, pad
 
-    def _pack(self, w, b, stride=1, pad=0):
+    def _pack(self, w, b, stride=1, pad=0, name=None):
+        """name: key in self.convs (the per-layer precision assignment addresses conv layers by it: 'stem2', 's3.b1.c4', 's4.b0.cat',
+        'fpn.lat1', 'fpn.out0', 'roi2.tower0', 'roi0.cls1', 'roi0.cls_head', 'depth.c0', ...)."""
         wdt = torch.float32 if self.prec.get("mma") == "bf16x3" else self.prec["act"]
-        return ops.PackedConv(w, b, stride=stride, pad=pad, dtype=wdt, device=self.dev, compute=self.prec.get("mma"))
+        pc = ops.PackedConv(w, b, stride=stride, pad=pad, dtype=wdt, device=self.dev, compute=self.prec.get("mma"))
+        if name is not None:
+            self.convs[name] = pc
+            if self.pair and any(fnmatch.fnmatchcase(name, pat) for pat in self.prec.get("single_bf16", ())):
+                pc.terms = 1            # hi halves only: one bf16 product (tools/precision_sweep.py measures what that costs)
+        return pc
 
     def _prepare(self):
         if "backbone" in self.parts:
@@ -159,9 +175,9 @@ class Far3DEngine:
         # ---- backbone (a2)
         bb = {}
         w, b, _, _ = self._conv_bn("img_backbone.stem.stem_1")
-        bb["stem1"] = self._pack(F.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)), b)   # 1x1 over the 32-ch im2col
-        bb["stem2"] = self._pack(*self._conv_bn("img_backbone.stem.stem_2"))
-        bb["stem3"] = self._pack(*self._conv_bn("img_backbone.stem.stem_3", stride=2))
+        bb["stem1"] = self._pack(F.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)), b, name="stem1")   # 1x1 over the 32-ch im2col
+        bb["stem2"] = self._pack(*self._conv_bn("img_backbone.stem.stem_2"), name="stem2")
+        bb["stem3"] = self._pack(*self._conv_bn("img_backbone.stem.stem_3", stride=2), name="stem3")
         stages = []
         for si in range(4):
             k = si + 2
@@ -169,9 +185,10 @@ class Far3DEngine:
             for bi in range(self.spec["block_per_stage"][si]):
                 name = "OSA%d_%d" % (k, bi + 1)
                 p = "img_backbone.stage%d.%s" % (k, name)
-                convs = [self._pack(*self._conv_bn("%s.layers.%d.%s_%d" % (p, i, name, i))) for i in range(self.spec["layer_per_block"])]
+                convs = [self._pack(*self._conv_bn("%s.layers.%d.%s_%d" % (p, i, name, i)), name="s%d.b%d.c%d" % (k, bi, i))
+                         for i in range(self.spec["layer_per_block"])]
                 cw, cb, _, _ = self._conv_bn("%s.concat.%s_concat" % (p, name), pad=0)
-                blocks.append(dict(convs=convs, concat=self._pack(cw, cb), fcw=f32(sd[p + ".ese.fc.weight"].flatten(1)),
+                blocks.append(dict(convs=convs, concat=self._pack(cw, cb, name="s%d.b%d.cat" % (k, bi)), fcw=f32(sd[p + ".ese.fc.weight"].flatten(1)),
                                    fcb=f32(sd[p + ".ese.fc.bias"])))
             stages.append(blocks)
         bb["stages"] = stages
@@ -181,9 +198,10 @@ class Far3DEngine:
         sd, cfg, dev = self.sd, self.cfg, self.dev
         # ---- FPN (a3)
         nl = len(self.spec["stage_out_ch"]) - 1
-        self.fpn_lat = [self._pack(sd["img_neck.lateral_convs.%d.conv.weight" % i], sd["img_neck.lateral_convs.%d.conv.bias" % i]) for i in range(nl)]
+        self.fpn_lat = [self._pack(sd["img_neck.lateral_convs.%d.conv.weight" % i], sd["img_neck.lateral_convs.%d.conv.bias" % i], name="fpn.lat%d" % i)
+                        for i in range(nl)]
         self.fpn_out = [self._pack(sd["img_neck.fpn_convs.%d.conv.weight" % i], sd["img_neck.fpn_convs.%d.conv.bias" % i],
-                                   stride=2 if i == nl else 1, pad=1) for i in range(nl + 1)]
+                                   stride=2 if i == nl else 1, pad=1, name="fpn.out%d" % i) for i in range(nl + 1)]
 
     def _prepare_roi(self):
         sd, cfg, dev = self.sd, self.cfg, self.dev
@@ -194,22 +212,25 @@ class Far3DEngine:
         for l in range(len(cfg["strides"])):
             lv = {}
             for t in ("cls", "reg"):
-                lv[t] = [self._pack(*self._conv_bn(r + "multi_level_%s_convs.%d.%d" % (t, l, i), conv=".conv", norm=".bn", eps=1e-3)) for i in range(2)]
+                lv[t] = [self._pack(*self._conv_bn(r + "multi_level_%s_convs.%d.%d" % (t, l, i), conv=".conv", norm=".bn", eps=1e-3),
+                                    name="roi%d.%s1" % (l, t) if i == 1 else None) for i in range(2)]
             # the two towers' first convs read the same map: one 256 -> 512 conv (cls channels first), half the launches and
             # twice the workgroups on the small levels
             wc, bc, _, _ = self._conv_bn(r + "multi_level_cls_convs.%d.0" % l, conv=".conv", norm=".bn", eps=1e-3)
             wr, br, _, _ = self._conv_bn(r + "multi_level_reg_convs.%d.0" % l, conv=".conv", norm=".bn", eps=1e-3)
-            lv["tower0"] = self._pack(torch.cat([wc, wr]), torch.cat([bc, br]), 1, 1)
-            lv["cls_head"] = self._pack(sd[r + "multi_level_conv_cls.%d.weight" % l], sd[r + "multi_level_conv_cls.%d.bias" % l])
+            lv["tower0"] = self._pack(torch.cat([wc, wr]), torch.cat([bc, br]), 1, 1, name="roi%d.tower0" % l)
+            lv["cls_head"] = self._pack(sd[r + "multi_level_conv_cls.%d.weight" % l], sd[r + "multi_level_conv_cls.%d.bias" % l], name="roi%d.cls_head" % l)
             lv["reg_head"] = self._pack(torch.cat([sd[r + "multi_level_conv_reg.%d.weight" % l], sd[r + "multi_level_conv_obj.%d.weight" % l]]),
-                                        torch.cat([sd[r + "multi_level_conv_reg.%d.bias" % l], sd[r + "multi_level_conv_obj.%d.bias" % l]]))
+                                        torch.cat([sd[r + "multi_level_conv_reg.%d.bias" % l], sd[r + "multi_level_conv_obj.%d.bias" % l]]),
+                                        name="roi%d.reg_head" % l)
             if r + "multi_level_conv_centers2d.%d.weight" % l in sd:     # only the stand-alone module forward returns it (loss input)
                 lv["ctr_head"] = self._pack(sd[r + "multi_level_conv_centers2d.%d.weight" % l], sd[r + "multi_level_conv_centers2d.%d.bias" % l])
             self.roi.append(lv)
         self.depth = dict(
-            convs=[self._pack(sd[r + "depthnet.depth_head.%d.0.weight" % i], sd[r + "depthnet.depth_head.%d.0.bias" % i], pad=1) for i in range(2)],
+            convs=[self._pack(sd[r + "depthnet.depth_head.%d.0.weight" % i], sd[r + "depthnet.depth_head.%d.0.bias" % i], pad=1, name="depth.c%d" % i)
+                   for i in range(2)],
             gn=[(f32(sd[r + "depthnet.depth_head.%d.1.weight" % i]), f32(sd[r + "depthnet.depth_head.%d.1.bias" % i])) for i in range(2)],
-            cls=self._pack(sd[r + "depthnet.depth_classifier.weight"], sd[r + "depthnet.depth_classifier.bias"]))
+            cls=self._pack(sd[r + "depthnet.depth_classifier.weight"], sd[r + "depthnet.depth_classifier.bias"], name="depth.cls"))
 
     def _prepare_head(self):
         sd, cfg, dev = self.sd, self.cfg, self.dev

@@ -229,6 +229,7 @@ def normalize_state_dict(ckpt, strict_schema=None):
     if not isinstance(sd, dict) or not all(isinstance(k, str) for k in sd):
         raise TypeError("checkpoint does not contain a state dict")
     out = OrderedDict()
+    first_name = {}                      # canonical key -> the checkpoint key whose tensor is stored in `out`
     for k, v in sd.items():
         if not isinstance(v, torch.Tensor):
             continue
@@ -238,11 +239,16 @@ def normalize_state_dict(ckpt, strict_schema=None):
         if ck is None:
             continue
         if ck in out:
-            if ck != k and not torch.equal(out[ck], v):
-                raise ValueError("checkpoint key %s disagrees with its shared-branch owner %s" % (k, ck))
-            if ck != k:
-                continue
+            # every copy of a shared branch is compared with the one seen first, whatever the order of the keys (an alias that
+            # precedes its owner used to be overwritten without a comparison: ADVICE r2)
+            if not torch.equal(out[ck], v):
+                raise ValueError("checkpoint keys %s and %s are copies of one shared branch (%s) but disagree" % (first_name[ck], k, ck))
+            if ck == k:
+                first_name[ck] = k       # the owner's own tensor object is the one kept
+                out[ck] = v
+            continue
         out[ck] = v
+        first_name[ck] = k
     if strict_schema is not None:
         missing = [k for k in strict_schema if k not in out]
         unexpected = [k for k in out if k not in strict_schema]

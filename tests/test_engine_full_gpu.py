@@ -268,7 +268,7 @@ def test_fp32_engine_matches_oracle_at_full_size(hip_lib, oracle_run):
                                 score_tol=tol, box_tol=100 * tol)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3"] + (["bf16x3_all"] if os.environ.get("FAR3D_TEST_ALL_MODES") else []))
+@pytest.mark.parametrize("precision", ["bf16x3"] + (["bf16x3_all", "bf16x3_2d1"] if os.environ.get("FAR3D_TEST_ALL_MODES") else []))
 def test_split_bf16_modes_against_the_logit_tolerance(hip_lib, oracle_run, precision):
     """The split-bf16 modes (fp32 data; conv products -- and in bf16x3_all also the decoder GEMMs -- as hi*hi' + hi*lo' + lo*hi'
     on the bf16 MFMA with fp32 accumulation; far3d_hip.h FAR3D_DT_F32_BF16X3) against the oracle at the benchmarked size.

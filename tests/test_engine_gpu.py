@@ -28,15 +28,19 @@ def _golden_engine(precision, name="far3d_small_seq", **over):
     return engine.Far3DEngine(sd, cfg, device=DEV, precision=precision), z, rc
 
 
+# Every frame of both golden sequences is held to the north-star bar itself (1e-3 on logits).  Round 2 allowed 10x on the streaming
+# frame of the single-camera case, citing a 1.2e-2 oracle-vs-reference deviation measured with the ROUND-1 weight initialisation;
+# with the reference-like key-point initialisation the goldens were regenerated with tools/gen_golden.py
+# measures 5.2e-4 * scale there, and the allowance is gone.  The observed errors are printed and recorded in
+# gpurun_out/golden_errors.json.
+LOOSE = {}
+
+
 @pytest.mark.parametrize("name", ["far3d_small_seq", "far3d_c1_seq"])
 def test_engine_fp32_matches_reference_golden_sequence(hip_lib, name):
     eng, z, rc = _golden_engine("fp32", name)
     for fi in range(rc["frames"]):
-        # The streaming frame of the single-camera case is ill-conditioned (one camera, 256x256: many key points project next to
-        # the camera plane, and the propagated queries feed that back): tools/gen_golden.py measured 1.2e-2 between the oracle and
-        # the REFERENCE itself on it, both fp32 on the CPU.  Its tolerance is therefore 10x; see tests/test_engine_full_gpu.py for
-        # the fp64 yardstick behind this.
-        loose = 10.0 if (name == "far3d_c1_seq" and fi >= 1) else 1.0
+        loose = LOOSE.get((name, fi), 1.0)
         data, metas = synth.recipe_frame(rc, fi)
         o = eng.forward_frame(data, metas)
         # 2D proposals: same peaks, same order
@@ -54,6 +58,8 @@ def test_engine_fp32_matches_reference_golden_sequence(hip_lib, name):
             # logits: the north_star's absolute 1e-3.  Box codes: the centre is sigmoid(reg logit) * 304.8 m, so 1e-3 on the
             # reg logit is 1e-3 * 304.8 / 4 = 0.076 m; the other channels (log sizes, sin, cos) are raw outputs: 1e-3.
             err = np.abs(g - want)
+            print("%s frame %d %s: max abs err %.3e (centre %.3e)" % (name, fi, key, err.max() if key == "all_cls_scores" else err[..., 3:].max(),
+                                                                     err[..., :3].max()))
             if key == "all_cls_scores":
                 assert err.max() < 1e-3 * loose, "frame %d logits: max abs err %.3e" % (fi, err.max())
             else:

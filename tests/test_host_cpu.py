@@ -77,6 +77,11 @@ def test_load_checkpoint_unwraps_runner_layout_ddp_prefix_and_shared_branches(tm
     bad["module.pts_bbox_head.cls_branches.3.6.bias"] = bad["module.pts_bbox_head.cls_branches.3.6.bias"] + 1
     with pytest.raises(ValueError):
         weights.normalize_state_dict(dict(state_dict=bad))
+    # ... in whatever order the keys arrive (an alias that preceded its owner used to be overwritten silently)
+    with pytest.raises(ValueError):
+        weights.normalize_state_dict(dict(state_dict=dict(reversed(list(bad.items())))))
+    rev = weights.normalize_state_dict(dict(state_dict=dict(reversed(list(ck.items())))), strict_schema=spec)
+    assert all(torch.equal(rev[k], sd[k]) for k in sd)
     del ck["module.pts_bbox_head.reference_points.weight"]
     with pytest.raises(KeyError):
         weights.normalize_state_dict(dict(state_dict=ck), strict_schema=spec)

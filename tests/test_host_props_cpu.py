@@ -91,3 +91,26 @@ def test_metric_is_bounded_and_independent_of_the_row_order(seed, n, m):
     assert 0 <= row["AP"] <= 1 and 0 <= row["RECALL"] <= 1 and 0 <= row["CDS"] <= row["AP"] + 1e-9
     assert 0 <= row["ATE"] <= cfg.tp_threshold_m and 0 <= row["ASE"] <= 1 and 0 <= row["AOE"] <= round(math.pi, 3)     # tables are rounded to 3 decimals
     assert (M.wrap_angles(rng.uniform(-50, 50, size=20)) < math.pi + 1e-12).all()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.floats(0.3, 0.8), st.integers(0, 300), st.integers(0, 200), st.booleans(), st.floats(-25.0, 25.0))
+def test_ida_matrix_is_scale_crop_flip_rotation_about_the_crop_centre(scale, left, top, flip, angle):
+    """The augmentation homography in closed form (data_pipeline/preprocess.py) against its geometric meaning: a source pixel is
+    scaled, moved into the crop window, mirrored inside the window when flipped, then rotated about the window's centre -- so the
+    centre of the window is a fixed point of the rotation and a source pixel lands where the steps, applied one by one, put it."""
+    from far3d_amd.data_pipeline.preprocess import ida_matrix
+    w, h = 96, 64
+    crop = (left, top, left + w, top + h)
+    Mx = ida_matrix(scale, crop, flip, angle).double().numpy()
+    s = float(np.float32(scale))
+    th = math.radians(angle)
+    for x, y in ((0.0, 0.0), (123.0, 45.5), (700.0, 333.0)):
+        px, py = s * x - left, s * y - top                 # scale, then crop
+        if flip:
+            px = w - px                                    # mirror inside the window
+        cx, cy = w / 2.0, h / 2.0
+        dx, dy = px - cx, py - cy                          # rotate about the window centre
+        want = (cx + math.cos(th) * dx + math.sin(th) * dy, cy - math.sin(th) * dx + math.cos(th) * dy)
+        got = Mx @ np.array([x, y, 1.0])
+        assert abs(got[0] - want[0]) < 1e-3 and abs(got[1] - want[1]) < 1e-3 and got[2] == 1.0
