@@ -46,7 +46,8 @@ __device__ __forceinline__ int vt_pos(int key) {
 template <typename T, int NS>     // NS: key-range parts per workgroup (2 waves each)
 __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                             const T* __restrict__ V, void* __restrict__ O, int out_dt, int Aq,
-                                                            int Nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+                                                            int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
+                                                            const int* __restrict__ hole_count, int hole_start, int hole_end) {
   // Workgroup = 64 queries of one head, 2*NS waves.  Waves 2p, 2p+1 walk part p of the keys for queries [0,32) / [32,64)
   // (flash-decoding style split); the NS partial (max, sum, O) states are merged through LDS at the end.  The loop is a chain
   // of latencies (global load -> LDS -> MFMA -> exp -> MFMA, ~1.7 us per 64-key tile), and 200 workgroups of 4 waves leave most
@@ -67,6 +68,9 @@ __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict_
   const bool q_ok = q < Aq;
   const int ntiles = (Nk + ATT_KT - 1) / ATT_KT;
   const int htiles = (ntiles + NS - 1) / NS;    // tiles per part; the last parts may have fewer (or none)
+  // keys [hole_lo, hole_end) hold no query (fixed-capacity proposal mode): masked like keys past Nk; their K / V rows must be
+  // finite (the producer zero-fills them) because a masked probability is an exact 0 that still multiplies V
+  const int hole_lo = hole_count ? hole_start + min(max(*hole_count, 0), hole_end - hole_start) : hole_end;
   unsigned char* Ks = KsAll + half * KBYTES;
   unsigned char* Vs = VsAll + half * VBYTES;
 
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict_
     const bool more = it + 1 < htiles;
     if (more) gload(it + 1);
     const int tile = it + half * htiles;
-    if (tile < ntiles) {   // wave-uniform
+    if (tile < ntiles && !(tile * ATT_KT >= hole_lo && (tile + 1) * ATT_KT <= hole_end)) {   // wave-uniform; tiles inside the hole are skipped
       // ---- S^T = K Q^T for the two 32-key sub-tiles
       f32x16_t s[2];
 #pragma unroll
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict_
           float v = s[u][r];
           if constexpr (sizeof(T) == 2) v *= scale;
           const int key = kbase + u * 32 + (r & 3) + 8 * (r >> 2);
-          v = key < Nk ? v : -INFINITY;
+          v = (key < Nk && !(key >= hole_lo && key < hole_end)) ? v : -INFINITY;
           s[u][r] = v;
           mloc = fmaxf(mloc, v);
         }
@@ -259,11 +263,14 @@ __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict_
 
 extern "C" int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq,
                                        int Nk, int heads, int head_dim, int ldq, int ldk, int ldv, int ldo,
-                                       float scale, void* stream) {
+                                       float scale, const int32_t* hole_count, int hole_start, int hole_end, void* stream) {
   FAR3D_CHECK_ARG(q && k && v && out, "far3d_attention_forward: null pointer argument");
   FAR3D_CHECK_ARG(head_dim == ATT_D, "far3d_attention_forward: head_dim must be %d (got %d)", ATT_D, head_dim);
   FAR3D_CHECK_ARG(Aq > 0 && Nk > 0 && heads > 0, "far3d_attention_forward: bad sizes Aq=%d Nk=%d heads=%d", Aq, Nk, heads);
   FAR3D_CHECK_ARG(dtype == FAR3D_DT_F32 || dtype == FAR3D_DT_BF16, "far3d_attention_forward: unsupported dtype %d", dtype);
+  FAR3D_CHECK_ARG(!hole_count || (0 <= hole_start && hole_start <= hole_end && hole_end <= Nk), "far3d_attention_forward: bad key hole [%d, %d) for Nk=%d",
+                  hole_start, hole_end, Nk);
+  if (!hole_count) hole_start = hole_end = 0;
   const int es = dtype == FAR3D_DT_F32 ? 4 : 2;
   FAR3D_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                   (ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && ldo % 4 == 0 &&
@@ -273,10 +280,10 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FAR3D_DT_F32)
     hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
-                       Aq, Nk, ldq, ldk, ldv, ldo, scale);
+                       Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale);
+                       out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
   FAR3D_CHECK_LAUNCH("far3d_attention_forward");
   return FAR3D_OK;
 }

@@ -222,14 +222,35 @@ struct GatherParams {
   float* score;                               // (Mcap)
   int cap, C, hd, wd, nd, ds;
   float depth_min, bin_size, pc_lo[3], pc_span[3], thr_logodds;
+  int N, rows_total;                          // rows_total > 0: fixed-capacity mode (rows past it are dropped, unused ones zero-filled)
+  int* m_out; int* overflow_out;              // optional: number of valid rows; 1 if a proposal was (or may have been) dropped
 };
 
 __global__ __launch_bounds__(64) void prop_gather_kernel(GatherParams g) {
   const int n = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
+  if (n == g.N) {
+    // fixed-capacity bookkeeping (one extra row of workgroups): total count, overflow flag, zero-fill of the unused rows so that
+    // everything computed from them downstream stays finite (they are masked as attention keys, not removed)
+    int M = 0, full = 0;
+    for (int k = 0; k < g.N; ++k) { M += g.sel_cnt[k]; full |= g.sel_cnt[k] >= g.cap; }
+    const int Mv = min(M, g.rows_total);
+    if (j == 0 && lane == 0) {
+      if (g.m_out) *g.m_out = Mv;
+      if (g.overflow_out) *g.overflow_out = (M > g.rows_total || full) ? 1 : 0;
+    }
+    for (int row = Mv + j; row < g.rows_total; row += gridDim.x) {
+      if (lane < 3) g.ref2d[row * 3 + lane] = 0.f;
+      if (lane < 4) g.box2d[row * 4 + lane] = 0.f;
+      if (lane == 0) g.score[row] = 0.f;
+      for (int c = lane; c <= g.C; c += 64) g.ctx[(long)row * (g.C + 1) + c] = 0.f;
+    }
+    return;
+  }
   if (j >= g.sel_cnt[n]) return;
   const int s = g.sel_idx[(long)n * g.cap + j];
   int row = j;                                 // output row = exclusive prefix of sel_cnt over the cameras before n, + j
   for (int k = 0; k < n; ++k) row += g.sel_cnt[k];
+  if (g.rows_total > 0 && row >= g.rows_total) return;      // over capacity: dropped, flagged through overflow_out
   const PropLevels& lv = g.lv;
   int l = 0;
 #pragma unroll
@@ -315,10 +336,12 @@ extern "C" int far3d_proposal_gather(const float* const* reg, int nreg, int N, i
                                      int cap, const float* weights, const float* depth_logit, int hd, int wd, int nd,
                                      int depth_stride, float depth_min, float depth_max, int depth_bins,
                                      const float* img2lidar, const void* feat, int feat_dt, int C, const float* pc_range,
-                                     float score_thr, float* ref2d, float* ctx, float* box2d, float* score, void* stream) {
+                                     float score_thr, float* ref2d, float* ctx, float* box2d, float* score, int rows_total,
+                                     int32_t* m_out, int32_t* overflow_out, void* stream) {
   FAR3D_CHECK_ARG(reg && level_hw && strides && sel_idx && sel_cnt && weights && depth_logit && img2lidar && feat &&
                   pc_range && ref2d && ctx && box2d && score, "far3d_proposal_gather: null argument");
-  FAR3D_CHECK_ARG(L >= 1 && L <= PROP_MAX_L && N > 0 && cap > 0, "far3d_proposal_gather: bad sizes");
+  FAR3D_CHECK_ARG(L >= 1 && L <= PROP_MAX_L && N > 0 && cap > 0 && rows_total >= 0, "far3d_proposal_gather: bad sizes");
+  FAR3D_CHECK_ARG(rows_total > 0 || (!m_out && !overflow_out), "far3d_proposal_gather: m_out / overflow_out need rows_total > 0");
   GatherParams g;
   memset(&g, 0, sizeof(g));
   const float* none[PROP_MAX_L] = {nullptr, nullptr, nullptr, nullptr};
@@ -330,8 +353,45 @@ extern "C" int far3d_proposal_gather(const float* const* reg, int nreg, int N, i
   g.bin_size = 2.f * (depth_max - depth_min) / ((float)depth_bins * (1.f + depth_bins));
   for (int k = 0; k < 3; ++k) { g.pc_lo[k] = pc_range[k]; g.pc_span[k] = pc_range[3 + k] - pc_range[k]; }
   g.thr_logodds = logf(score_thr / (1.f - score_thr));
-  hipLaunchKernelGGL(prop_gather_kernel, dim3(cap, N), dim3(64), 0, (hipStream_t)stream, g);
+  g.N = N; g.rows_total = rows_total; g.m_out = m_out; g.overflow_out = overflow_out;
+  hipLaunchKernelGGL(prop_gather_kernel, dim3(cap, rows_total > 0 ? N + 1 : N), dim3(64), 0, (hipStream_t)stream, g);
   FAR3D_CHECK_LAUNCH("far3d_proposal_gather");
+  return FAR3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------ block -> compact rows
+// Camera-sharded fixed-capacity mode: every rank contributes a block of `rows_per_block` record rows of which the first
+// counts[b] are valid (its own cameras' proposals, compacted by far3d_proposal_gather).  After the all-gather the blocks are
+// packed into ONE compact run in block (= camera) order: dst rows [0, M) valid, [M, dst_rows) zero, M = min(sum counts, dst_rows).
+__global__ __launch_bounds__(64) void compact_rows_kernel(const float* __restrict__ src, const int* __restrict__ counts, int nblocks,
+                                                          int rows_per_block, int D, float* __restrict__ dst, int dst_rows,
+                                                          int* __restrict__ m_out, int* __restrict__ overflow_out) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  int M = 0, b = -1, local = 0;
+  for (int k = 0; k < nblocks; ++k) {
+    const int c = min(max(counts[k], 0), rows_per_block);
+    if (b < 0 && r < M + c) { b = k; local = r - M; }
+    M += c;
+  }
+  if (r == 0 && lane == 0) {
+    if (m_out) *m_out = min(M, dst_rows);
+    if (overflow_out) *overflow_out = (*overflow_out != 0 || M > dst_rows) ? 1 : 0;
+  }
+  float* d = dst + (long)r * D;
+  if (b >= 0) {
+    const float* s = src + ((long)b * rows_per_block + local) * D;
+    for (int c = lane; c < D; c += 64) d[c] = s[c];
+  } else {
+    for (int c = lane; c < D; c += 64) d[c] = 0.f;
+  }
+}
+
+extern "C" int far3d_compact_rows(const float* src, const int32_t* counts, int nblocks, int rows_per_block, int D, float* dst,
+                                  int dst_rows, int32_t* m_out, int32_t* overflow_out, void* stream) {
+  FAR3D_CHECK_ARG(src && counts && dst && nblocks > 0 && rows_per_block > 0 && D > 0 && dst_rows > 0, "far3d_compact_rows: bad arguments");
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(dst_rows), dim3(64), 0, (hipStream_t)stream, src, (const int*)counts, nblocks, rows_per_block,
+                     D, dst, dst_rows, (int*)m_out, (int*)overflow_out);
+  FAR3D_CHECK_LAUNCH("far3d_compact_rows");
   return FAR3D_OK;
 }
 

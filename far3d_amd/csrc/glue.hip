@@ -127,11 +127,15 @@ extern "C" int far3d_memory_prepare(const float* emb, const float* ref, const do
 // ------------------------------------------------------------------------------------------ heads: box finalisation + scores
 // ref models/dense_heads/farhead.py:649-664: xyz = sigmoid(reg[:3] + inverse_sigmoid(ref)) * range + min (mmdet
 // inverse_sigmoid: clamp to [0,1], eps 1e-5); also score[a] = max_c sigmoid(cls_last[a,c]) (farhead.py:490).
+// Fixed-capacity proposal mode (far3d_proposal_gather rows_total): the query rows [hole_start + *hole_count, hole_end) hold no
+// query.  They get score = -inf (never picked by the memory top-k) and -inf logits in every layer (never picked by the decode).
 __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ reg, const float* __restrict__ ref,
-                                                            const float* __restrict__ cls_last, float* __restrict__ box,
+                                                            float* __restrict__ cls_all, float* __restrict__ box,
                                                             float* __restrict__ score, int layers, int A, int code, int ncls,
-                                                            float lo0, float lo1, float lo2, float sp0, float sp1, float sp2) {
+                                                            float lo0, float lo1, float lo2, float sp0, float sp1, float sp2,
+                                                            const int* __restrict__ hole_count, int hole_start, int hole_end) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hole_lo = hole_count ? hole_start + min(max(*hole_count, 0), hole_end - hole_start) : hole_end;
   if (i < layers * A) {
     const int a = i % A;
     const float lo[3] = {lo0, lo1, lo2}, sp[3] = {sp0, sp1, sp2};
@@ -145,24 +149,35 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
       b[k] = (1.f / (1.f + expf(-z))) * sp[k] + lo[k];
     }
     for (int k = 3; k < code; ++k) b[k] = r[k];
+    if (cls_all && a >= hole_lo && a < hole_end) {
+      float* c = cls_all + (long)i * ncls;
+      for (int k = 0; k < ncls; ++k) c[k] = -INFINITY;
+    }
   }
   if (i < A && score) {
-    const float* c = cls_last + (long)i * ncls;
-    float m = c[0];
-    for (int k = 1; k < ncls; ++k) m = fmaxf(m, c[k]);
-    score[i] = 1.f / (1.f + expf(-m));
+    if (i >= hole_lo && i < hole_end) {
+      score[i] = -INFINITY;
+    } else {
+      const float* c = cls_all + ((long)(layers - 1) * A + i) * ncls;
+      float m = c[0];
+      for (int k = 1; k < ncls; ++k) m = fmaxf(m, c[k]);
+      score[i] = 1.f / (1.f + expf(-m));
+    }
   }
 }
 
-extern "C" int far3d_head_finalize(const float* reg, const float* ref, const float* cls_last, float* box, float* score,
-                                   int layers, int A, int code_size, int num_classes, const float* pc_range, void* stream) {
+extern "C" int far3d_head_finalize(const float* reg, const float* ref, float* cls_all, float* box, float* score,
+                                   int layers, int A, int code_size, int num_classes, const float* pc_range,
+                                   const int32_t* hole_count, int hole_start, int hole_end, void* stream) {
   FAR3D_CHECK_ARG(reg && ref && box && pc_range && layers > 0 && A >= 0 && code_size >= 3, "far3d_head_finalize: bad arguments");
-  FAR3D_CHECK_ARG(!score || cls_last, "far3d_head_finalize: score needs cls_last");
+  FAR3D_CHECK_ARG(!score || cls_all, "far3d_head_finalize: score needs the logits");
+  FAR3D_CHECK_ARG(!hole_count || (cls_all && 0 <= hole_start && hole_start <= hole_end && hole_end <= A),
+                  "far3d_head_finalize: bad hole [%d, %d) for A=%d", hole_start, hole_end, A);
   if (A == 0) return FAR3D_OK;
   const int n = layers * A;
-  hipLaunchKernelGGL(head_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, reg, ref, cls_last, box, score,
+  hipLaunchKernelGGL(head_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, reg, ref, cls_all, box, score,
                      layers, A, code_size, num_classes, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0],
-                     pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]);
+                     pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], (const int*)hole_count, hole_start, hole_count ? hole_end : 0);
   FAR3D_CHECK_LAUNCH("far3d_head_finalize");
   return FAR3D_OK;
 }

@@ -296,10 +296,14 @@ extern "C" int far3d_camera_prep(const float* lidar2img, const float* intrinsics
 #define AGGO_MAX_BINS 1024
 __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict__ ref, const float* __restrict__ l2i,
                                                          int* __restrict__ perm, int A, int N, float lo0, float lo1, float lo2,
-                                                         float sp0, float sp1, float sp2, float pad_h, float pad_w) {
+                                                         float sp0, float sp1, float sp2, float pad_h, float pad_w,
+                                                         const int* __restrict__ hole_count, int hole_start, int hole_end, int row_base) {
   __shared__ int hist[AGGO_MAX_BINS];
   __shared__ int wsum[16];
   const int t = threadIdx.x, nb = N * 64;
+  // query rows [hole_lo, hole_end) hold no query (fixed-capacity proposal mode): they still get a slot (every row of `out` is
+  // written) but their entry is ~a (negative), which far3d_aggregate_forward answers with a zero row and no work
+  const int hole_lo = hole_count ? hole_start + min(max(*hole_count, 0), hole_end - hole_start) : hole_end;
   for (int i = t; i < AGGO_MAX_BINS; i += 1024) hist[i] = 0;
   __syncthreads();
   constexpr int MAXQ = 8;   // A <= 8192
@@ -309,7 +313,8 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
     const int a = t + k * 1024;
     key[k] = -1;
     if (a < A) {
-      const float X = ref[a * 3] * sp0 + lo0, Y = ref[a * 3 + 1] * sp1 + lo1, Z = ref[a * 3 + 2] * sp2 + lo2;
+      const float* rp = ref + (long)(row_base + a) * 3;      // rows [row_base, row_base + A) of the caller's reference points
+      const float X = rp[0] * sp0 + lo0, Y = rp[1] * sp1 + lo1, Z = rp[2] * sp2 + lo2;
       float best = 3.0e9f, bu = 0.f, bv = 0.f;
       int cam = 0;
       for (int n = 0; n < N; ++n) {
@@ -343,17 +348,24 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k)
-    if (key[k] >= 0) perm[hist[key[k]] + rank[k]] = t + k * 1024;
+    if (key[k] >= 0) {
+      const int a = row_base + t + k * 1024;                 // absolute row
+      perm[hist[key[k]] + rank[k]] = (a >= hole_lo && a < hole_end) ? ~a : a;
+    }
 }
 
 extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range,
-                               float pad_h, float pad_w, void* stream) {
+                               float pad_h, float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
+                               void* stream) {
   FAR3D_CHECK_ARG(ref && lidar2img && perm && pc_range && A >= 0 && N > 0, "far3d_agg_order: bad arguments");
   FAR3D_CHECK_ARG(A <= 8192 && N * 64 <= AGGO_MAX_BINS, "far3d_agg_order: A=%d (<= 8192) or N=%d (<= 16) too large", A, N);
+  FAR3D_CHECK_ARG(row_base >= 0 && (!hole_count || (0 <= hole_start && hole_start <= hole_end)), "far3d_agg_order: bad hole [%d, %d) / row_base %d",
+                  hole_start, hole_end, row_base);
+  if (!hole_count) hole_start = hole_end = 0;
   if (A == 0) return FAR3D_OK;
   hipLaunchKernelGGL(agg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ref, lidar2img, perm, A, N, pc_range[0],
                      pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], pad_h,
-                     pad_w);
+                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base);
   FAR3D_CHECK_LAUNCH("far3d_agg_order");
   return FAR3D_OK;
 }

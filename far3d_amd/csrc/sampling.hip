@@ -139,6 +139,12 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
   int a = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
   if (a >= prm.A) return;
   if (perm) a = perm[a];
+  if (a < 0) {      // ~a: a row without a query (see far3d_agg_order): zero row
+    a = ~a;
+    if (prm.out_dt == FAR3D_DT_F32) reinterpret_cast<float*>(out)[(long)a * 256 + threadIdx.x] = 0.f;
+    else reinterpret_cast<bf16_t*>(out)[(long)a * 256 + threadIdx.x] = 0;
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NP = prm.N * prm.P, NLP = NP * prm.L, J = prm.L * prm.P;
   float* w_s = reinterpret_cast<float*>(smem);                 // [NLP][8] softmax weights; reused as [4][256] reduction buffer
@@ -375,7 +381,9 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
 // ------------------------------------------------------------------------------------------
 #define AGG4_MAX_N 16
 
-template <typename TV, int UNR>
+typedef float agg_f2 __attribute__((ext_vector_type(2)));
+
+template <typename TV, int UNR, int OPT = 0>
 __device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const int* off_s, const float* wt_s, int cnt, int lane,
                                             float (&acc)[8]) {
   if (cnt <= 0) return;
@@ -399,8 +407,15 @@ __device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const i
       for (int i = 0; i < UNR; ++i) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          acc[2 * k] += w[i] * __uint_as_float(v[i][k] << 16);
-          acc[2 * k + 1] += w[i] * __uint_as_float(v[i][k] & 0xffff0000u);
+          if constexpr (OPT) {          // one v_pk_fma_f32 per bf16 pair
+            const agg_f2 x = {__uint_as_float(v[i][k] << 16), __uint_as_float(v[i][k] & 0xffff0000u)};
+            agg_f2 a = {acc[2 * k], acc[2 * k + 1]};
+            a = x * w[i] + a;
+            acc[2 * k] = a.x; acc[2 * k + 1] = a.y;
+          } else {
+            acc[2 * k] += w[i] * __uint_as_float(v[i][k] << 16);
+            acc[2 * k + 1] += w[i] * __uint_as_float(v[i][k] & 0xffff0000u);
+          }
         }
       }
     };
@@ -445,6 +460,46 @@ __device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const i
   }
 }
 
+// ---- cross-lane reductions on the VALU (variant 11): DPP quad_perm / row_ror inside a 16-lane row, v_permlane16_swap /
+// v_permlane32_swap across rows -- instead of __shfl_xor, which compiles to a dependent ds_bpermute round trip through the LDS pipe
+template <int CTRL> __device__ __forceinline__ float agg_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// lane i <- v[i ^ 16] (within each 32-lane half) / v[i ^ 32]: returns the two sides for a commutative combine
+__device__ __forceinline__ void agg_swap16(float v, float& a, float& b) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const u2_t r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  a = __builtin_bit_cast(float, r.x); b = __builtin_bit_cast(float, r.y);
+}
+__device__ __forceinline__ void agg_swap32(float v, float& a, float& b) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const u2_t r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  a = __builtin_bit_cast(float, r.x); b = __builtin_bit_cast(float, r.y);
+}
+// reductions over the lanes of a wave that share (lane & 1): quad xor 2, row rotations by 4 and 8 (parity preserving), then rows
+struct AggMax { static __device__ __forceinline__ float op(float a, float b) { return fmaxf(a, b); } };
+struct AggMin { static __device__ __forceinline__ float op(float a, float b) { return fminf(a, b); } };
+struct AggSum { static __device__ __forceinline__ float op(float a, float b) { return a + b; } };
+template <typename OP> __device__ __forceinline__ float agg_row_reduce_parity(float v) {     // over the 8 same-parity lanes of a 16-lane row
+  v = OP::op(v, agg_dpp<0x4E>(v));       // quad_perm [2,3,0,1]
+  v = OP::op(v, agg_dpp<0x124>(v));      // row_ror:4
+  v = OP::op(v, agg_dpp<0x128>(v));      // row_ror:8
+  return v;
+}
+template <typename OP> __device__ __forceinline__ float agg_wave_reduce_parity(float v) {
+  v = agg_row_reduce_parity<OP>(v);
+  float a, b;
+  agg_swap16(v, a, b); v = OP::op(a, b);
+  agg_swap32(v, a, b); v = OP::op(a, b);
+  return v;
+}
+template <typename OP> __device__ __forceinline__ float agg_row_reduce(float v) {            // over all 16 lanes of a row
+  v = OP::op(v, agg_dpp<0xB1>(v));       // quad_perm [1,0,3,2]
+  return agg_row_reduce_parity<OP>(v);
+}
+
 __device__ __forceinline__ int agg4_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 #ifdef FAR3D_PROFILING
@@ -468,7 +523,7 @@ extern "C" int far3d_prof_set_agg_timestamps(long long* buf) {
 // ------------------------------------------------------------------------------------------
 #define AGG7_CAPW 128     // list entries per wave between flushes (2 x 128 x 36 B; 7 workgroups of 22.1 KB fit a CU's 160 KB)
 
-template <typename TV, int PT>
+template <typename TV, int PT, int OPT = 0>      // OPT 1 (variant 11): VALU reductions, early matrix loads, packed FMAs
 __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ Vc,
@@ -504,7 +559,22 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
       lg[i] = i4 < n4 ? V4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
   }
+  // OPT: the projection matrix of this lane's camera does not depend on the query either: loaded before the perm lookup returns
+  float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0, pm2 = pm0;
+  if constexpr (OPT != 0 && PT >= 1 && PT <= 16) {
+    if ((t >> 4) < N) {
+      const float4* m = reinterpret_cast<const float4*>(l2i + (t >> 4) * 16);
+      pm0 = m[0]; pm1 = m[1]; pm2 = m[2];
+    }
+  }
   if (perm) a = perm[a0];
+  if (a < 0) {      // ~a: row a holds no query (far3d_agg_order marks the hole of the fixed-capacity proposal mode): zero row, no work
+    a = ~a;
+    const int c = t * 2;
+    if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(0.f, 0.f);
+    else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = 0u;
+    return;
+  }
   // query-dependent loads, all issued together: reference point, this lane's key-point offset, the query part of the logits
   const float rf0 = ref[a * 3], rf1 = ref[a * 3 + 1], rf2 = ref[a * 3 + 2];
   float of0 = 0.f, of1 = 0.f, of2 = 0.f;
@@ -554,12 +624,29 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
         const int n = c0 + (t >> 4), p = t & 15;
         const bool act = n < N && p < P;
         float u = 0.f, v = 0.f;
-        if (act) { project3(n, r0 + of0, r1 + of1, r2 + of2, u, v); uv_s[n * P + p] = make_float2(u, v); }
+        if (act) {
+          if (OPT != 0 && c0 == 0) {           // matrices already in registers
+            const float k0 = r0 + of0, k1 = r1 + of1, k2 = r2 + of2;
+            const float x = pm0.x * k0 + pm0.y * k1 + pm0.z * k2 + pm0.w;
+            const float y = pm1.x * k0 + pm1.y * k1 + pm1.z * k2 + pm1.w;
+            const float z = pm2.x * k0 + pm2.y * k1 + pm2.z * k2 + pm2.w;
+            const float zc = fmaxf(z, 1e-5f);
+            u = (x / zc) / prm.pad_w; v = (y / zc) / prm.pad_h;
+          } else {
+            project3(n, r0 + of0, r1 + of1, r2 + of2, u, v);
+          }
+          uv_s[n * P + p] = make_float2(u, v);
+        }
         float umin = act ? u : INFINITY, umax = act ? u : -INFINITY, vmin = act ? v : INFINITY, vmax = act ? v : -INFINITY;
+        if constexpr (OPT) {
+          umin = agg_row_reduce<AggMin>(umin); umax = agg_row_reduce<AggMax>(umax);
+          vmin = agg_row_reduce<AggMin>(vmin); vmax = agg_row_reduce<AggMax>(vmax);
+        } else {
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
-          vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+          for (int o = 1; o < 16; o <<= 1) {
+            umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
+            vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+          }
         }
         if (p == 0 && n < N) {
           bb_s[n] = make_float4(umin, umax, vmin, vmax);
@@ -597,10 +684,15 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
     for (int i = 1; i < NV; ++i) {
       mx.x = fmaxf(mx.x, lg[i].x); mx.y = fmaxf(mx.y, lg[i].y); mx.z = fmaxf(mx.z, lg[i].z); mx.w = fmaxf(mx.w, lg[i].w);
     }
+    if constexpr (OPT) {
+      mx.x = agg_wave_reduce_parity<AggMax>(mx.x); mx.y = agg_wave_reduce_parity<AggMax>(mx.y);
+      mx.z = agg_wave_reduce_parity<AggMax>(mx.z); mx.w = agg_wave_reduce_parity<AggMax>(mx.w);
+    } else {
 #pragma unroll
-    for (int o = 2; o < 64; o <<= 1) {      // lanes with equal (lane & 1) hold the same 4 groups
-      mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o));
-      mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o));
+      for (int o = 2; o < 64; o <<= 1) {      // lanes with equal (lane & 1) hold the same 4 groups
+        mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o));
+        mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o));
+      }
     }
     if (lane < 2) *reinterpret_cast<float4*>(stat_s + wv * 8 + gh) = mx;
   }
@@ -621,9 +713,14 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
         w4[i4] = e;
       }
     }
+    if constexpr (OPT) {
+      sm.x = agg_wave_reduce_parity<AggSum>(sm.x); sm.y = agg_wave_reduce_parity<AggSum>(sm.y);
+      sm.z = agg_wave_reduce_parity<AggSum>(sm.z); sm.w = agg_wave_reduce_parity<AggSum>(sm.w);
+    } else {
 #pragma unroll
-    for (int o = 2; o < 64; o <<= 1) {
-      sm.x += __shfl_xor(sm.x, o); sm.y += __shfl_xor(sm.y, o); sm.z += __shfl_xor(sm.z, o); sm.w += __shfl_xor(sm.w, o);
+      for (int o = 2; o < 64; o <<= 1) {
+        sm.x += __shfl_xor(sm.x, o); sm.y += __shfl_xor(sm.y, o); sm.z += __shfl_xor(sm.z, o); sm.w += __shfl_xor(sm.w, o);
+      }
     }
     if (lane < 2) *reinterpret_cast<float4*>(stat_s + 16 + wv * 8 + gh) = sm;
   }
@@ -639,7 +736,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
     const unsigned long long m = __ballot(hit);
     const int c = __popcll(m);
     if (cnt + c > AGG7_CAPW) {            // wave-uniform; the list is private to the wave (LDS is in order per wave)
-      agg7_gather<TV, 4>(feat, off_s, wt_s, cnt, lane, acc);
+      agg7_gather<TV, 4, OPT>(feat, off_s, wt_s, cnt, lane, acc);
       cnt = 0;
     }
     if (hit) {
@@ -682,8 +779,15 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
           const float w = fmaxf(1.f - fabsf(px - ftx), 0.f) * fmaxf(1.f - fabsf(py - fty), 0.f);
           const float4 a0 = *reinterpret_cast<const float4*>(wrow + p * 8), a1 = *reinterpret_cast<const float4*>(wrow + p * 8 + 4);
           any = fmaxf(any, w);
-          wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
-          wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
+          if constexpr (OPT) {            // four v_pk_fma_f32 instead of eight v_fma_f32
+            const agg_f2 b0 = {a0.x, a0.y}, b1 = {a0.z, a0.w}, b2 = {a1.x, a1.y}, b3 = {a1.z, a1.w};
+            agg_f2 c0 = {wa[0], wa[1]}, c1 = {wa[2], wa[3]}, c2 = {wa[4], wa[5]}, c3 = {wa[6], wa[7]};
+            c0 = b0 * w + c0; c1 = b1 * w + c1; c2 = b2 * w + c2; c3 = b3 * w + c3;
+            wa[0] = c0.x; wa[1] = c0.y; wa[2] = c1.x; wa[3] = c1.y; wa[4] = c2.x; wa[5] = c2.y; wa[6] = c3.x; wa[7] = c3.y;
+          } else {
+            wa[0] += w * a0.x; wa[1] += w * a0.y; wa[2] += w * a0.z; wa[3] += w * a0.w;
+            wa[4] += w * a1.x; wa[5] += w * a1.y; wa[6] += w * a1.z; wa[7] += w * a1.w;
+          }
         }
         append(active && any > 0.f, (rowbase + ty * Wl + tx) * 256, wa);
       } else {
@@ -717,7 +821,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
     }
   }
   AGG_TS(4);
-  agg7_gather<TV, 4>(feat, off_s, wt_s, cnt, lane, acc);
+  agg7_gather<TV, 4, OPT>(feat, off_s, wt_s, cnt, lane, acc);
   AGG_TS(5);
 #ifdef FAR3D_PROFILING
   if (g_agg_ts && lane == 0) g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 7] = cnt;
@@ -762,7 +866,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7, "far3d_aggregate_forward: unknown kernel variant %d (0 = 7 = default, 3 = round-1 kernel)", variant);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 11,
+                  "far3d_aggregate_forward: unknown kernel variant %d (0 = 7 = default, 3 = round-1 kernel, 11 = default with VALU reductions / packed FMAs)", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -792,6 +897,16 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, dim3(256), lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 1>), grid, dim3(256), lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+  } else if (variant == 11) {     // v7 with DPP / permlane reductions, early matrix loads, packed FMAs (A/B against the default)
+    const int NP = N * P;
+    const size_t lds7 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + 32 * 4 + AGG4_MAX_N * 4 + (size_t)2 * AGG7_CAPW * 36;
+    if (feat_dtype == FAR3D_DT_F32) {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<float, 13, 1>), grid, dim3(128), lds7, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+      else hipLaunchKernelGGL((aggregate_v7_kernel<float, 0, 1>), grid, dim3(128), lds7, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    } else {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+      else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
+    }
   } else if (variant == 0 || variant == 7) {     // 2 waves per query
     const int NP = N * P;
     const size_t lds7 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + 32 * 4 + AGG4_MAX_N * 4 + (size_t)2 * AGG7_CAPW * 36;

@@ -54,8 +54,13 @@ def default_cfg(**over):
         num_layers=6, num_heads=8, num_groups=8, num_levels=4, num_pts=13, ffn_dim=1024,
         pc_range=[-152.4, -152.4, -5.0, 152.4, 152.4, 5.0], code_size=8, max_num=300,
         depthnet=dict(num_depth_bins=50, depth_min=0.1, depth_max=110.0, stride=8), score_thr=0.1,
-        proposal_topk=None,      # None = reference (score > thr, dynamic M, one host sync); K = static K best per camera
-        proposal_cap=512,        # per-camera capacity in threshold mode
+        proposal_topk=None,      # None = reference rule (score > thr, data-dependent M); K = static K best per camera
+        proposal_cap=512,        # per-camera capacity of the selection in threshold mode
+        # Threshold mode with STATIC shapes ("cap + count"): the adaptive queries occupy `proposal_capacity`
+        # rows of which the first M (counted on the device) are real; the rest is a masked hole (attention keys, memory top-k,
+        # decode, aggregation).  Graph-capturable, pipelinable, shardable -- no host sync; `check_proposal_overflow()` reports, after
+        # the fact, a frame whose proposals did not fit.  None = legacy threshold mode (host sync on M, buffers grow).
+        proposal_capacity=None,
     )
     cfg.update(over)
     return cfg
@@ -121,7 +126,8 @@ class Far3DEngine:
         self._ins = {}              # static input buffers per buffer-set parity (graph replay reads them)
         self._graph = None
         self._graph_outs = None
-        self.use_graph = False      # set True to capture the steady-state frame into one hipGraph (static proposal mode only)
+        self.use_graph = False      # set True to capture the steady-state frame into one hipGraph (needs static shapes: top-K or
+                                    # fixed-capacity threshold proposals, static_adaptive_rows() is not None)
         # pipeline (with use_graph): consecutive frames of a stream are software-pipelined -- the per-camera stages of frame
         # i+1 (which do not depend on the streaming memory) run on their own HIP stream while the head of frame i is still in
         # flight.  Two complete buffer sets (parity = frame index & 1) and two graphs per parity (camera stages, head); the
@@ -130,6 +136,7 @@ class Far3DEngine:
         # forward_frame are ready on `output_stream()`; a caller that reads them on its own stream calls `wait_outputs()` first
         # (ordering the caller's stream after every head automatically would serialise the next frame's camera stages again).
         self.pipeline = False
+        self._overflow = None       # fixed-capacity threshold mode: device flag of the latest frame (check_proposal_overflow)
         self._ready = None          # event of the latest pipelined head (None: outputs are on the caller's stream)
         self._par = 0               # buffer-set parity currently in use (always 0 without pipelining)
         self._fidx = 0
@@ -315,6 +322,23 @@ class Far3DEngine:
     def _query_pos(self, ref):
         return self.qe[1](self.qe[0](ops.posemb3d(ref, self.dim_t128), act="relu"))
 
+    def static_adaptive_rows(self, ncam=None):
+        """Rows the adaptive queries occupy when that number is static (top-K mode: ncam * K; fixed-capacity threshold mode:
+        proposal_capacity), else None (legacy threshold mode: data-dependent, needs a host sync)."""
+        K = self.cfg["proposal_topk"]
+        if K is not None:
+            return (self.cfg["num_cams"] if ncam is None else ncam) * K
+        return self.cfg.get("proposal_capacity")
+
+    def check_proposal_overflow(self):
+        """Fixed-capacity threshold mode: raise if the latest frame had more proposals than rows (or a camera filled its selection
+        capacity).  Synchronises; call it when the outputs are read, not between pipelined frames."""
+        f = getattr(self, "_overflow", None)
+        if f is not None and int(f.item()) != 0:
+            raise _lib.Far3dHipError("proposal capacity exceeded: more than proposal_capacity=%s proposals in the frame, or a camera reached "
+                                     "proposal_cap=%s; raise them (the reference keeps every peak above the threshold)" %
+                                     (self.cfg.get("proposal_capacity"), self.cfg["proposal_cap"]))
+
     def act_from_nchw(self, x):
         """(N,C,H,W) float map -> the engine's NHWC activation storage (bf16 / f32 / pair-stored bf16)."""
         y = x.permute(0, 2, 3, 1).contiguous()
@@ -449,9 +473,12 @@ class Far3DEngine:
         self.prev_scene = None
 
     # ------------------------------------------------------------------------------------------ a7/a8: decoder
-    def decoder(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A):
+    def decoder(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole=None, qshard=None):
         """X2 (A+Km, 2E) `dec` dtype: rows [:A] = [tgt+pos | tgt] of the queries, rows [A:] = [mem+mempos | mem] of the memory
-        keys; x0 (A,E) f32 = tgt; qpos (A,E) f32.  Returns the stacked post-LN outputs (layers, A, E) f32."""
+        keys; x0 (A,E) f32 = tgt; qpos (A,E) f32.  Returns the stacked post-LN outputs (layers, A, E) f32.
+        qshard: query-sharded execution over several ranks (far3d_amd.dist.QueryShard), see decoder_query_sharded."""
+        if qshard is not None:
+            return self.decoder_query_sharded(X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, qshard)
         cfg = self.cfg
         E = cfg["embed_dims"]
         nL = len(self.layers)
@@ -462,7 +489,7 @@ class Far3DEngine:
         nO = cfg["num_pts"] * 3
         outs = self._buf(("outs_dec",), (nL, A, E), torch.float32)
         # reference points are fixed across the layers: one camera-sorted workgroup order per frame (scheduling only)
-        perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32))
+        perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32), hole=hole)
         QKV = self._buf(("qkv",), (Kt, nL * 3 * E), at)          # per layer a [q | k | v] column block
         XW = self._buf(("xw",), (A, 2 * E), at)                   # [x+pos | x] operand of the cross-attention GEMM
         UL = self._buf(("ul",), (A, -(-(nJ + nO) // 64) * 64), torch.float32)    # [U (nJ) | key-point offsets (nO)] per query
@@ -480,7 +507,7 @@ class Far3DEngine:
             # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
             ops.linear(X2[:A], ly["qkv"], out=QKV[:A, c0:c0 + 3 * E], out_dtype=at)
             att = ops.attention_forward(QKV[:A, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
-                                        num_heads=cfg["num_heads"], out_dtype=at)
+                                        num_heads=cfg["num_heads"], out_dtype=at, hole=hole)
             y = ops.linear(att, ly["out"], res=x)
             ops.layernorm(y, *ly["norms"][0], out=x1, add=qpos, y2=XW[:, :E], yb=XW[:, E:])
             # cross-attention: fused perspective-aware aggregation (detr3d_transformer.py:522-569)
@@ -501,8 +528,74 @@ class Far3DEngine:
             x = outs[li]
         return outs
 
+    def decoder_query_sharded(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, qs):
+        """The decoder with its QUERIES sharded over the ranks of a camera-sharded frame (SURVEY.md 8(e) "alternatives"): every rank
+        holds all value maps (they were gathered for the replicated head anyway) and runs rows [a0, a1) of the A queries through
+        each layer -- attention queries, out-projection, aggregation, FFN, the three LayerNorms -- against the K / V of ALL rows; one
+        small all-gather per layer (A x E fp32 = 1.5 MB at the benchmark size) hands every rank the full layer output, from which
+        the next layer's keys / values are recomputed locally (one GEMM over all rows: cheaper than gathering K and V).
+        Row-wise kernels give every row the same bits whatever subset of rows a launch covers, so the result is BIT-IDENTICAL to
+        the replicated decoder (tests/test_dist_gpu.py).  Per layer the sharded part is ~11 of 12 launches; what stays replicated is
+        the qkv GEMM, the memory K/V GEMM, the camera term and the cls / reg heads."""
+        cfg = self.cfg
+        E = cfg["embed_dims"]
+        nL = len(self.layers)
+        Kt = X2.shape[0]
+        at = self.prec["dec"]
+        fast = at == torch.bfloat16
+        nJ = cfg["num_groups"] * cfg["num_levels"] * cfg["num_pts"]
+        nO = cfg["num_pts"] * 3
+        per = qs.rows_per_rank(A)
+        a0, a1 = min(qs.rank * per, A), min((qs.rank + 1) * per, A)
+        nr = a1 - a0
+        outs = self._buf(("outs_dec",), (nL, A, E), torch.float32)
+        QKV = self._buf(("qkv",), (Kt, nL * 3 * E), at)
+        XW = self._buf(("xw",), (A, 2 * E), at)
+        UL = self._buf(("ul",), (A, -(-(nJ + nO) // 64) * 64), torch.float32)
+        x1 = self._buf(("x1",), (A, E), torch.float32)
+        x2 = self._buf(("x2",), (A, E), torch.float32)
+        x2b = self._buf(("x2b",), (A, E), at) if fast else None
+        agg = self._buf(("agg_out",), (A, E), at)
+        gsrc = self._buf(("qs_src",), (per, E), torch.float32)           # this rank's rows of a layer output (zero padded)
+        gdst = self._buf(("qs_dst",), (qs.world * per, E), torch.float32)
+        if nr < per:
+            gsrc[nr:].zero_()
+        perm = None
+        if nr > 0:
+            perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm_qs",), (nr,), torch.int32), hole=hole,
+                                         rows=(a0, a1))
+        if Kt > A:
+            ops.linear(X2[A:], self.memkv, out=QKV[A:], out_dtype=at)
+        vc_all = ops.cam_embed_chain(lidar2img, self.cam_chain)
+        x = x0
+        for li, ly in enumerate(self.layers):
+            c0 = li * 3 * E
+            ops.linear(X2[:A], ly["qkv"], out=QKV[:A, c0:c0 + 3 * E], out_dtype=at)          # all rows: every rank needs every K / V
+            if nr > 0:
+                att = ops.attention_forward(QKV[a0:a1, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
+                                            num_heads=cfg["num_heads"], out_dtype=at, hole=hole)
+                y = ops.linear(att, ly["out"], res=x[a0:a1])
+                ops.layernorm(y, *ly["norms"][0], out=x1[a0:a1], add=qpos[a0:a1], y2=XW[a0:a1, :E], yb=XW[a0:a1, E:])
+                ops.linear(XW[a0:a1], ly["wl"], out=UL[a0:a1, :nJ + nO])
+                ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
+                                      cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg, variant=self.agg_variant)
+                y = ops.linear(agg[a0:a1], ly["oproj"], res=x1[a0:a1])
+                if fast:
+                    ops.layernorm(y, *ly["norms"][1], out=x2[a0:a1], yb=x2b[a0:a1])
+                else:
+                    ops.layernorm(y, *ly["norms"][1], out=x2[a0:a1])
+                hdn = ops.linear((x2b if fast else x2)[a0:a1], ly["ffn1"], act="relu", out_dtype=at)
+                y = ops.linear(hdn, ly["ffn2"], res=x2[a0:a1])
+                ops.layernorm(y, *ly["norms"][2], out=gsrc[:nr])
+            qs.gather(gsrc, gdst)                                       # the layer's ONE exchange (never captured into a graph)
+            outs[li].copy_(gdst[:A])       # rank r owns rows [r * per, (r + 1) * per): the blocks are already in row order, padding last
+            # next layer's operand [x + pos | x] for ALL rows (what the fused LayerNorm epilogue writes in the replicated decoder)
+            ops.add_cast(outs[li], qpos, at, out_sum=X2[:A, :E], out_a=X2[:A, E:])
+            x = outs[li]
+        return outs
+
     # ------------------------------------------------------------------------------------------ one frame
-    def camera_stage(self, img, dd, cam_ids, pad_hw):
+    def camera_stage(self, img, dd, cam_ids, pad_hw, block_rows=None):
         """Everything that is independent per camera: backbone, FPN (+MLN), 2D head, depth, proposal
         selection and adaptive-query construction.  img (n,3,H,W) on device for the contiguous camera block `cam_ids`."""
         cfg = self.cfg
@@ -520,43 +613,54 @@ class Far3DEngine:
         raw, tokens, hw, starts = self.fpn(feats, mln_scale, mln_shift)
         st = dict(tokens=tokens, hw=hw, starts=starts, raw=raw, lidar2img=lidar2img)
         cls, reg, depth_logit = self.roi_head(raw)
-        st.update(self.proposals(cls, reg, depth_logit, img2lidar, tokens))
+        st.update(self.proposals(cls, reg, depth_logit, img2lidar, tokens, block_rows))
         return st
 
-    def proposals(self, cls, reg, depth_logit, img2lidar, tokens):
-        """a5 + the adaptive-query part of a6: peak selection and 3D proposal construction for n cameras."""
+    def proposals(self, cls, reg, depth_logit, img2lidar, tokens, block_rows=None):
+        """a5 + the adaptive-query part of a6: peak selection and 3D proposal construction for n cameras.
+        block_rows: fixed-capacity threshold mode on a camera shard -- rows of this rank's (compacted, zero-padded) record block."""
         cfg = self.cfg
         n = tokens.shape[0]
         E = cfg["embed_dims"]
         K = cfg["proposal_topk"]
+        capT = cfg.get("proposal_capacity") if K is None else None
         cap = K if K is not None else min(cfg["proposal_cap"], tokens.shape[1])
         while True:
             wgt, sel_idx, sel_cnt = ops.proposal_select(cls, reg, cfg["strides"], cap, thr=cfg["score_thr"], topk=K is not None)
-            if K is not None or cap >= tokens.shape[1]:
+            if K is not None or capT is not None or cap >= tokens.shape[1]:
                 break
-            # threshold (reference) mode keeps EVERY peak above score_thr (yolox_head.py:429-438): a camera that fills the
+            # legacy threshold mode keeps EVERY peak above score_thr (yolox_head.py:429-438): a camera that fills the
             # capacity may have lost peaks, so grow and redo (this mode syncs on M anyway)
             if int(sel_cnt.max().item()) < cap:
                 break
             cap = min(2 * cap, tokens.shape[1])
-        M = n * cap
-        if K is not None and n == cfg["num_cams"] and "head" in self.parts:
-            # every camera is local and M is static: the reference points land directly in the adaptive-query rows of the
-            # head's query-major buffer (head_stage then has nothing to copy)
+        whole = n == cfg["num_cams"] and "head" in self.parts and block_rows is None
+        rows = n * cap if capT is None else (capT if block_rows is None else block_rows)
+        if (K is not None or capT is not None) and whole:
+            # every camera is local and the row count is static: the reference points land directly in the adaptive-query rows
+            # of the head's query-major buffer (head_stage then has nothing to copy)
             nq = cfg["num_query"]
-            ref_out = self._buf(("rf",), (nq + M + cfg["memory_len"], 3), torch.float32)[nq:nq + M]
+            ref_out = self._buf(("rf",), (nq + rows + cfg["memory_len"], 3), torch.float32)[nq:nq + rows]
         else:
-            ref_out = self._buf(("ref2d",), (M, 3), torch.float32)
-        out = (ref_out, self._buf(("ctx",), (M, E + 1), torch.float32),
-               self._buf(("box2d",), (M, 4), torch.float32), self._buf(("score2d",), (M,), torch.float32))
+            ref_out = self._buf(("ref2d",), (rows, 3), torch.float32)
+        out = (ref_out, self._buf(("ctx",), (rows, E + 1), torch.float32),
+               self._buf(("box2d",), (rows, 4), torch.float32), self._buf(("score2d",), (rows,), torch.float32))
+        m_dev = ovf = None
+        if capT is not None:
+            m_dev, ovf = self._buf(("m_dev",), (1,), torch.int32), self._buf(("ovf",), (1,), torch.int32)
+            self._overflow = ovf
         # the log-odds threshold is the reference's hard-coded 0.1 (farhead.py:577), not cfg score_thr
         ref2d, ctx, box2d, score2d = ops.proposal_gather(reg, cfg["strides"], sel_idx, sel_cnt, wgt, depth_logit,
                                                          cfg["depthnet"]["stride"], cfg["depthnet"], img2lidar, tokens,
-                                                         cfg["pc_range"], score_thr=0.1, out=out)
-        return dict(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit, peak_weight=wgt)
+                                                         cfg["pc_range"], score_thr=0.1, out=out, rows_total=rows if capT is not None else 0,
+                                                         m_out=m_dev, overflow_out=ovf)
+        return dict(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit, peak_weight=wgt,
+                    m_dev=m_dev, overflow=ovf)
 
-    def head_stage(self, tokens, ref2d, ctx, M, dd, img_metas, hw, starts, pad_hw):
-        """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12)."""
+    def head_stage(self, tokens, ref2d, ctx, M, dd, img_metas, hw, starts, pad_hw, m_dev=None, qshard=None):
+        """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12).
+        M: adaptive-query ROWS.  m_dev (int32 device scalar; fixed-capacity threshold mode): only the first m_dev of them are
+        queries, rows [nq + m_dev, nq + M) are the masked hole (their inputs are zero-filled by proposal_gather)."""
         cfg = self.cfg
         E = cfg["embed_dims"]
         lidar2img = dd["lidar2img"][0]
@@ -603,7 +707,8 @@ class Far3DEngine:
         X2 = self._buf(("x2op",), (Kt, 2 * E), at)
         ops.add_cast(TQ, QP, at, out_sum=X2[:, :E], out_a=X2[:, E:])
         ref = RF[:A]
-        outs_dec = self.decoder(X2, TQ[:A], QP[:A], tokens, ref, hw, starts, lidar2img, pad_hw, A)
+        hole = (m_dev, nq, nq + M) if m_dev is not None else None
+        outs_dec = self.decoder(X2, TQ[:A], QP[:A], tokens, ref, hw, starts, lidar2img, pad_hw, A, hole=hole, qshard=qshard)
         # ---- a10: shared heads over all layers at once (farhead.py:646-664)
         flat = outs_dec.view(-1, E)
         flatb = ops.nan_to_num_(flat, bf16_copy=fast)
@@ -613,13 +718,13 @@ class Far3DEngine:
         r2 = ops.layernorm(self.cls_b[1](r1[1] if fast else r1), *self.cls_ln[1], act="relu", bf16_copy=fast)
         all_cls = self.cls_b[2](r2[1] if fast else r2).view(nl, 1, A, cfg["num_classes"])
         rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](hin, act="relu", out_dtype=at), act="relu", out_dtype=at))
-        box_flat, sc = ops.head_finalize(rr, ref, all_cls[-1][0], cfg["pc_range"], nl, cfg["num_classes"])
+        box_flat, sc = ops.head_finalize(rr, ref, all_cls, cfg["pc_range"], nl, cfg["num_classes"], hole=hole)
         all_box = box_flat.view(nl, 1, A, cfg["code_size"])
         # ---- a11: memory post-update (farhead.py:479-508): top-k by max-class score, push, truncate, ego warp -- in place
         idx = ops.topk(sc, cfg["topk_proposals"])
         ops.memory_post_update(m, idx, outs_dec[-1], all_box[-1][0], dd["ego_pose"], dd["timestamp"], self.mem)
-        outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, feat_flatten=tokens,
-                    reference_points=ref, memory_topk=idx)
+        outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, num_adaptive_dev=m_dev,
+                    feat_flatten=tokens, reference_points=ref, memory_topk=idx)
         outs["result"] = self.decode(all_cls, all_box)
         return outs
 
@@ -656,11 +761,12 @@ class Far3DEngine:
     def _head_part(self, st, dd, img_metas, pad_hw):
         cfg = self.cfg
         N = dd["img"].shape[0]
-        K = cfg["proposal_topk"]
-        M = N * K if K is not None else int(st["sel_cnt"].sum().item())   # the reference's data-dependent M: one host sync
-        outs = self.head_stage(st["tokens"], st["ref2d"], st["ctx"], M, dd, img_metas, st["hw"], st["starts"], pad_hw)
+        M = self.static_adaptive_rows(N)
+        if M is None:
+            M = int(st["sel_cnt"].sum().item())      # legacy threshold mode: the reference's data-dependent M, one host sync
+        outs = self.head_stage(st["tokens"], st["ref2d"], st["ctx"], M, dd, img_metas, st["hw"], st["starts"], pad_hw, m_dev=st["m_dev"])
         outs.update(fpn=st["raw"], depth_logit=st["depth_logit"], bbox2d=st["box2d"][:M], bbox2d_scores=st["score2d"][:M],
-                    sel_idx=st["sel_idx"], sel_cnt=st["sel_cnt"])
+                    sel_idx=st["sel_idx"], sel_cnt=st["sel_cnt"], proposal_overflow=st["overflow"])
         return outs
 
     def _pipelined_frame(self, data, img_metas, pad_hw):
@@ -727,7 +833,7 @@ class Far3DEngine:
     def _alloc_query_buffers(self, ncam):
         cfg = self.cfg
         E, nq = cfg["embed_dims"], cfg["num_query"]
-        Kt = nq + ncam * cfg["proposal_topk"] + cfg["memory_len"]
+        Kt = nq + self.static_adaptive_rows(ncam) + cfg["memory_len"]
         TQ = self._buf(("tq",), (Kt, E), torch.float32)
         QP = self._buf(("qp",), (Kt, E), torch.float32)
         RF = self._buf(("rf",), (Kt, 3), torch.float32)
@@ -742,7 +848,7 @@ class Far3DEngine:
         Outputs live in engine-owned buffers that the next frame overwrites: clone what must outlive it."""
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
-        if self.pipeline and self.use_graph and self.cfg["proposal_topk"] is not None:
+        if self.pipeline and self.use_graph and self.static_adaptive_rows() is not None:
             self._par = self._fidx & 1
             self._fidx += 1
             if steady:
@@ -753,7 +859,7 @@ class Far3DEngine:
             self._ready = None
             return self._frame_body(self._stage_inputs(data), img_metas, pad_hw)
         dd = self._stage_inputs(data)
-        if self.use_graph and steady and self.cfg["proposal_topk"] is not None:
+        if self.use_graph and steady and self.static_adaptive_rows() is not None:
             if self._graph is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -767,4 +873,7 @@ class Far3DEngine:
     def decode(self, all_cls, all_box):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245
         cfg = self.cfg
         cls, box = all_cls[-1][0], all_box[-1][0]
-        return ops.decode_topk(cls, box, min(cfg["max_num"], cls.numel()), cfg.get("post_center_range", cfg["pc_range"]))
+        K = min(cfg["max_num"], cls.numel())
+        need = ops.decode_ws_bytes(cls.numel(), K)      # > 0 beyond 40960 logits (many adaptive queries): chunked two-launch decode
+        ws = self._buf(("decode_ws",), (need,), torch.uint8) if need else None
+        return ops.decode_topk(cls, box, K, cfg.get("post_center_range", cfg["pc_range"]), workspace=ws)

@@ -30,7 +30,7 @@ SIGNATURES = {
     "far3d_conv2d_nhwc": (c_int, [_p, c_int, _p, c_int, _p, _p, c_int] + [c_int] * 5 + [c_long] + [c_int] * 4 +
                           [c_long] + [c_int] * 5 + [_p, c_int, c_int, c_long, c_int, c_int] +
                           [_p, c_int, c_int, c_long, _p, _p, c_int, _p]),
-    "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p, c_int] + [c_int] * 8 + [c_float, _p]),
+    "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p, c_int] + [c_int] * 8 + [c_float, _p, c_int, c_int, _p]),
     "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, c_int, _p]),
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
                                c_int, c_long, _p]),
@@ -40,14 +40,15 @@ SIGNATURES = {
     "far3d_stem_im2col": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p]),
     "far3d_proposal_select": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_float, c_int, _p]),
     "far3d_proposal_gather": (c_int, [_p, c_int, c_int, c_int, _p, _p, _p, _p, c_int, _p, _p, c_int, c_int, c_int, c_int,
-                                      c_float, c_float, c_int, _p, _p, c_int, c_int, _p, c_float, _p, _p, _p, _p, _p]),
+                                      c_float, c_float, c_int, _p, _p, c_int, c_int, _p, c_float, _p, _p, _p, _p, c_int, _p, _p, _p]),
+    "far3d_compact_rows": (c_int, [_p, _p, c_int, c_int, c_int, _p, c_int, _p, _p, _p]),
     "far3d_row_affine_ln": (c_int, [_p, _p, _p, _p, _p] + [c_int] * 6 + [c_float, c_int, _p]),
     "far3d_posemb3d": (c_int, [_p, _p, _p, c_int, _p]),
     "far3d_memory_prepare": (c_int, [_p] * 9 + [c_float, c_int, _p, c_int, c_int, c_int] + [_p] * 9),
-    "far3d_head_finalize": (c_int, [_p] * 5 + [c_int] * 4 + [_p, _p]),
+    "far3d_head_finalize": (c_int, [_p] * 5 + [c_int] * 4 + [_p, _p, c_int, c_int, _p]),
     "far3d_memory_post_update": (c_int, [_p] * 10 + [c_int] * 4 + [_p] * 6),
     "far3d_add_cast": (c_int, [_p, _p, _p, c_int, _p, c_int, c_int, c_int, c_long, c_long, _p]),
-    "far3d_agg_order": (c_int, [_p, _p, _p, c_int, c_int, _p, c_float, c_float, _p]),
+    "far3d_agg_order": (c_int, [_p, _p, _p, c_int, c_int, _p, c_float, c_float, _p, c_int, c_int, c_int, _p]),
     "far3d_topk": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "far3d_decode_topk": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_long, _p]),
     "far3d_camera_prep": (c_int, [_p, _p, _p, _p, _p, c_int, _p]),

@@ -75,6 +75,16 @@ def _host_f32(vals):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _hole(hole):
+    """hole: None or (count int32 device tensor (1,), start, end): the query rows [start + count, end) hold no query (fixed-capacity
+    proposal mode, far3d_hip.h far3d_proposal_gather).  -> (pointer | None, start, end) C arguments."""
+    if hole is None:
+        return None, 0, 0
+    cnt, start, end = hole
+    _chk(cnt, "hole count", torch.int32)
+    return _ptr(cnt), int(start), int(end)
+
+
 def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step=64):
     """mmcv `ms_deform_attn_forward` contract (reference call site detr3d_transformer.py:561-563).
 
@@ -140,14 +150,14 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         out = torch.empty((A, C), dtype=out_dtype, device=feat.device)
     if perm is not None:
         _chk(perm, "perm", torch.int32, 1)
-        if perm.numel() != A:
-            raise ValueError("aggregate_forward: perm must have A entries")
+        if perm.numel() > A:
+            raise ValueError("aggregate_forward: perm has more entries than there are rows")
     hw_keep, hw_p = _host_i32([list(x) for x in level_hw])
     st_keep, st_p = _host_i32(list(level_start))
     pc_keep, pc_p = _host_f32(list(pc_range))
     _lib.check(lib.far3d_aggregate_forward(_ptr(feat), _dt(feat), _ptr(ref), _ptr(offsets), _ptr(lidar2img),
                                            _ptr(U), _ptr(Vc), _ptr(perm) if perm is not None else None, _ptr(out), _dt(out),
-                                           A, N, S, C, G, P, L, hw_p, st_p, pc_p,
+                                           A if perm is None else perm.numel(), N, S, C, G, P, L, hw_p, st_p, pc_p,
                                            float(pad_hw[0]), float(pad_hw[1]), U.stride(0) if A > 0 else 0,
                                            offsets.stride(0) if A > 0 else 0, int(variant), _stream(feat)),
                "far3d_aggregate_forward")
@@ -339,8 +349,9 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
 # --------------------------------------------------------------------------------------------------
 # attention / normalisation / pooling
 # --------------------------------------------------------------------------------------------------
-def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32):
-    """softmax(q k^T / sqrt(d)) v per head.  q (Aq,E), k/v (Nk,E) f32|bf16 with unit inner stride; out (Aq,E) f32."""
+def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32, hole=None):
+    """softmax(q k^T / sqrt(d)) v per head.  q (Aq,E), k/v (Nk,E) f32|bf16 with unit inner stride; out (Aq,E) f32.
+    hole: keys [start + count, end) are masked (see _hole)."""
     lib = _lib.require_device()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
@@ -354,7 +365,7 @@ def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32):
         out = torch.empty((Aq, E), dtype=out_dtype, device=q.device)
     _lib.check(lib.far3d_attention_forward(_ptr(q), _ptr(k), _ptr(v), _dt(q), _ptr(out), _dt(out), Aq, Nk, num_heads, hd,
                                            q.stride(0), k.stride(0), v.stride(0), out.stride(0),
-                                           float(hd) ** -0.5, _stream(q)), "far3d_attention_forward")
+                                           float(hd) ** -0.5, *_hole(hole), _stream(q)), "far3d_attention_forward")
     return out
 
 
@@ -501,9 +512,11 @@ def proposal_select(cls_maps, reg_maps, strides, cap, thr=0.1, topk=False):
 
 
 def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, weights, depth_logit, depth_stride, depth_cfg, img2lidar,
-                    feat, pc_range, score_thr=0.1, out=None):
+                    feat, pc_range, score_thr=0.1, out=None, rows_total=0, m_out=None, overflow_out=None):
     """Returns ref2d (N*cap,3), ctx (N*cap,C+1), box2d (N*cap,4), score (N*cap); rows >= sum(sel_cnt) are NOT written
-    (callers slice [:M]).  out: optional (ref2d, ctx, box2d, score) buffers to write into."""
+    (callers slice [:M]).  out: optional (ref2d, ctx, box2d, score) buffers to write into.
+    rows_total > 0: fixed-capacity mode -- the buffers have rows_total rows, rows past M = sum(sel_cnt) are zero-filled, m_out /
+    overflow_out (int32 device tensors of one element) receive min(M, rows_total) and the dropped-proposal flag."""
     lib = _lib.require_device()
     L = len(reg_maps)
     N, cap = sel_idx.shape
@@ -513,7 +526,7 @@ def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, weights, depth_logit, d
     _chk(feat, "feat", ndim=3)
     C = feat.shape[2]
     dev = feat.device
-    M = N * cap
+    M = N * cap if not rows_total else int(rows_total)
     if out is not None:
         ref2d, ctx, box2d, score = out
     else:
@@ -523,6 +536,11 @@ def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, weights, depth_logit, d
         score = torch.empty((M,), dtype=torch.float32, device=dev)
     if ref2d.stride(0) != 3 or ctx.stride(0) != C + 1:
         raise ValueError("proposal_gather: ref2d / ctx must be dense rows")
+    if rows_total and min(ref2d.shape[0], ctx.shape[0], box2d.shape[0], score.shape[0]) < rows_total:
+        raise ValueError("proposal_gather: the output buffers need rows_total=%d rows" % rows_total)
+    for t in (m_out, overflow_out):
+        if t is not None:
+            _chk(t, "m_out / overflow_out", torch.int32)
     hk, hp = _host_i32([list(x) for x in hw])
     sk, sp = _host_i32(list(strides))
     pk, pp = _host_f32(list(pc_range))
@@ -532,9 +550,28 @@ def proposal_gather(reg_maps, strides, sel_idx, sel_cnt, weights, depth_logit, d
                                          _ptr(weights), _ptr(depth_logit), hd, wd, nd, int(depth_stride),
                                          float(depth_cfg["depth_min"]), float(depth_cfg["depth_max"]),
                                          int(depth_cfg["num_depth_bins"]), _ptr(img2lidar), _ptr(feat), _dt(feat), C, pp,
-                                         float(score_thr), _ptr(ref2d), _ptr(ctx), _ptr(box2d), _ptr(score), _stream(feat)),
+                                         float(score_thr), _ptr(ref2d), _ptr(ctx), _ptr(box2d), _ptr(score), int(rows_total),
+                                         _ptr(m_out) if m_out is not None else None,
+                                         _ptr(overflow_out) if overflow_out is not None else None, _stream(feat)),
                "far3d_proposal_gather")
     return ref2d, ctx, box2d, score
+
+
+def compact_rows(src, counts, dst, m_out, overflow_out):
+    """src (nblocks, rows_per_block, D) f32 with counts[b] valid rows in block b -> dst (dst_rows, D): the valid rows in block order,
+    the rest zero; m_out = min(sum counts, dst_rows); overflow_out |= (sum counts > dst_rows).  One launch, no sync."""
+    lib = _lib.require_device()
+    _chk(src, "src", torch.float32, 3)
+    _chk(counts, "counts", torch.int32, 1)
+    _chk(dst, "dst", torch.float32, 2)
+    _chk(m_out, "m_out", torch.int32)
+    _chk(overflow_out, "overflow_out", torch.int32)
+    nb, rpb, D = src.shape
+    if counts.numel() != nb or dst.shape[1] != D:
+        raise ValueError("compact_rows: inconsistent shapes")
+    _lib.check(lib.far3d_compact_rows(_ptr(src), _ptr(counts), nb, rpb, D, _ptr(dst), dst.shape[0], _ptr(m_out), _ptr(overflow_out),
+                                      _stream(src)), "far3d_compact_rows")
+    return dst
 
 
 def row_affine_ln(x, gamma, beta, add=None, do_ln=True, eps=1e-5, out=None):
@@ -607,15 +644,20 @@ def memory_prepare(state, ego_pose_inv, timestamp, pseudo_ref, dim_t256, prev_ex
     return m, temp_ref, nerf, tpos
 
 
-def head_finalize(reg, ref, cls_last, pc_range, layers, num_classes):
-    """reg (layers*A, code) -> box (layers*A, code) with metres in [:3]; score (A,) = max-class sigmoid of the last layer."""
+def head_finalize(reg, ref, cls_all, pc_range, layers, num_classes, hole=None):
+    """reg (layers*A, code) -> box (layers*A, code) with metres in [:3]; score (A,) = max-class sigmoid of the last layer.
+    cls_all: the contiguous (layers, ..., A, num_classes) logits.  hole: rows without a query get score -inf and -inf logits in
+    every layer, written into cls_all in place (see _hole)."""
     lib = _lib.require_device()
     A, code = ref.shape[0], reg.shape[1]
+    _chk(cls_all, "cls_all", torch.float32)
+    if cls_all.numel() != layers * A * num_classes:
+        raise ValueError("head_finalize: cls_all must hold layers * A * num_classes logits")
     box = torch.empty_like(reg)
     score = torch.empty((A,), dtype=torch.float32, device=reg.device)
     pk, pp = _host_f32(list(pc_range))
-    _lib.check(lib.far3d_head_finalize(_ptr(reg), _ptr(ref), _ptr(cls_last), _ptr(box), _ptr(score), layers, A, code, num_classes, pp,
-                                       _stream(reg)), "far3d_head_finalize")
+    _lib.check(lib.far3d_head_finalize(_ptr(reg), _ptr(ref), _ptr(cls_all), _ptr(box), _ptr(score), layers, A, code, num_classes, pp,
+                                       *_hole(hole), _stream(reg)), "far3d_head_finalize")
     return box, score
 
 
@@ -647,15 +689,19 @@ def add_cast(a, b, sum_dtype, a_dtype=None, out_sum=None, out_a=None):
     return osum, oa
 
 
-def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None):
+def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None):
     """Query order for aggregate_forward's `perm` (camera, then 8x8 image cell), one single-workgroup launch.  Groups the
-    same way as camera_sorted_order(spatial=True); the order inside a cell is arbitrary (scheduling only)."""
+    same way as camera_sorted_order(spatial=True); the order inside a cell is arbitrary (scheduling only).  hole: rows without a
+    query are entered as ~a so that aggregate_forward writes zero rows for them (see _hole).  rows=(a0, a1): order only the rows
+    [a0, a1) of ref; the entries are absolute row indices (pass the full-size buffers and this perm to aggregate_forward)."""
     lib = _lib.require_device()
-    A = ref.shape[0]
+    _chk(ref, "ref", torch.float32, 2)
+    a0, a1 = (0, ref.shape[0]) if rows is None else rows
+    A = a1 - a0
     perm = out if out is not None else torch.empty((A,), dtype=torch.int32, device=ref.device)
     pk, pp = _host_f32(list(pc_range))
     _lib.check(lib.far3d_agg_order(_ptr(ref), _ptr(lidar2img), _ptr(perm), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
-                                   _stream(ref)), "far3d_agg_order")
+                                   *_hole(hole), int(a0), _stream(ref)), "far3d_agg_order")
     return perm
 
 

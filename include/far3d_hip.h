@@ -77,11 +77,14 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * blocks of one merged-GEMM output.
  * pad_h/pad_w = img_metas['pad_shape'] (ref :551-552).  out (A,C) of dtype out_dt (f32 | bf16).  perm: optional (A) int32 DEVICE permutation giving
  * the order in which queries are assigned to workgroups (camera-sorted order keeps one XCD's L2 on 1-2 cameras); it never
- * changes results (row a of `out` is always query a).  Requires C=256, G=8, L<=4, N<=16,
+ * changes results (row a of `out` is always query a); an entry ~a (negative) means "row a holds no query": a zero row is
+ * written and nothing else is done (far3d_agg_order produces such entries).  With perm, A counts the ENTRIES of perm (workgroups);
+ * the rows they name may lie anywhere in ref / offsets / U / out (a subset of a larger query set).  Requires C=256, G=8, L<=4, N<=16,
  * N*P<=256, N*P*L<=384.  variant: 0 (= 7) default kernel: two waves per query, bilinear taps merged per token row through
  * the tent form of the interpolation weights (no atomics), LDS row lists, 16-byte row gathers; 3 = round-1 kernel (workgroup
- * per query, one gather per sample corner pair) kept for A/B measurements.  Both give the same result up to fp32
- * re-association. */
+ * per query, one gather per sample corner pair) kept for A/B measurements; 11 = the default kernel with its cross-lane
+ * reductions on the VALU (DPP / v_permlane swaps instead of ds_bpermute), the projection matrices loaded ahead of the query and
+ * packed FMAs (A/B).  All give the same result up to fp32 re-association. */
 int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
                             const float* lidar2img, const float* U, const float* Vc, const int32_t* perm, void* out, int out_dt, int A,
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
@@ -125,9 +128,13 @@ int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const fl
  *   statement of the wrapper models/utils/petr_transformer.py:286-326).  The in/out projections are
  *   far3d_conv2d_nhwc calls.
  * q (Aq, heads*32), k/v (Nk, heads*32) of `dtype` (F32 -> exact fp32 MFMA, BF16 -> bf16 MFMA), row strides
- * ldq/ldk/ldv elements; out (Aq, heads*32) of dtype out_dt (f32 | bf16), row stride ldo.  head_dim must be 32.  No masks (inference). */
+ * ldq/ldk/ldv elements; out (Aq, heads*32) of dtype out_dt (f32 | bf16), row stride ldo.  head_dim must be 32.
+ * The one mask of the inference path -- the "query hole" of the fixed-capacity proposal mode (see FAR3D "hole" below): with
+ * hole_count != NULL (DEVICE int32) the keys [hole_start + *hole_count, hole_end) are excluded from every softmax; their K / V
+ * rows must hold finite numbers.  hole_count NULL: no mask. */
 int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq, int Nk,
-                            int heads, int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+                            int heads, int head_dim, int ldq, int ldk, int ldv, int ldo, float scale,
+                            const int32_t* hole_count, int hole_start, int hole_end, void* stream);
 
 /* y = act(LayerNorm_C(x) * gamma + beta); optional y2 = y + add (next GEMM's "query + query_pos").
  * Replaces nn.LayerNorm at ref models/utils/detr3d_transformer.py:304-307,398-400,506-512 and
@@ -182,13 +189,26 @@ int far3d_proposal_select(const float* const* cls, const float* const* reg, int 
  * un-projection with img2lidar = inverse(lidar2img) and pc_range normalisation (:792-811), context = value-map token ||
  * log-odds(score) - log-odds(thr) (:576-581,773-784; the score is clamped to >= 1e-6 first so that zero-weight padding rows
  * of the static top-K mode stay finite).  Camera n's rows start at sum(sel_cnt[:n]) (camera-major, like the reference).
- * Outputs: ref2d (M,3), ctx (M,C+1), box2d (M,4 cxcywh), score (M). */
+ * Outputs: ref2d (M,3), ctx (M,C+1), box2d (M,4 cxcywh), score (M).
+ * FIXED-CAPACITY MODE (rows_total > 0; the reference's data-dependent M = sum(sel_cnt), ref yolox_head.py:429-458, farhead.py:
+ * 576-581, without a host sync and with static shapes -- "cap + count"): the outputs have rows_total rows; rows [0, M) are
+ * the proposals in the reference's order, rows [M, rows_total) are zero-filled and form the HOLE that the consumers
+ * mask: *m_out = min(M, rows_total) (DEVICE int32; the `hole_count` of far3d_attention_forward / far3d_head_finalize /
+ * far3d_agg_order), *overflow_out = 1 when proposals were dropped (M > rows_total) or a camera filled its `cap` (peaks may have
+ * been lost in far3d_proposal_select), else 0 -- the host checks it after the fact instead of syncing on M.
+ * rows_total = 0: legacy behaviour (rows past M untouched; m_out / overflow_out must be NULL). */
 int far3d_proposal_gather(const float* const* reg, int nreg, int N, int L, const int32_t* level_hw, const int32_t* strides,
                           const int* sel_idx, const int* sel_cnt, int cap, const float* weights,
                           const float* depth_logit, int hd, int wd, int nd, int depth_stride, float depth_min,
                           float depth_max, int depth_bins, const float* img2lidar, const void* feat, int feat_dt, int C,
                           const float* pc_range, float score_thr, float* ref2d, float* ctx, float* box2d, float* score,
-                          void* stream);
+                          int rows_total, int32_t* m_out, int32_t* overflow_out, void* stream);
+
+/* Blocks of rows -> one compact run (camera-sharded fixed-capacity mode): src (nblocks, rows_per_block, D) f32 of which the first
+ * counts[b] rows of block b are valid; dst (dst_rows, D): rows [0, M) the valid rows in block order, the rest zero,
+ * *m_out = M = min(sum counts, dst_rows); *overflow_out is OR-ed with (sum counts > dst_rows) (initialise it). */
+int far3d_compact_rows(const float* src, const int32_t* counts, int nblocks, int rows_per_block, int D, float* dst, int dst_rows,
+                       int32_t* m_out, int32_t* overflow_out, void* stream);
 
 /* y[r] = gamma[r] * LN_noaffine(x[r]) + beta[r] (+ add[r]);  C = 256.  ldg / lda = 0 broadcast one row.  do_ln = 0 skips
  * the normalisation (MLN with use_ln=False).  Replaces MLN.forward, ref models/utils/misc.py:182-190, at
@@ -212,9 +232,13 @@ int far3d_memory_prepare(const float* emb, const float* ref, const double* ts, c
                          double* m_ts, float* m_pose, float* m_velo, float* temp_ref, float* nerf, float* tpos, void* stream);
 
 /* Box-code finalisation of the shared reg branch + memory scores, ref models/dense_heads/farhead.py:649-664,490.
- * reg (layers*A, code) f32, ref (A,3), cls_last (A,ncls) logits of the last layer (may be NULL with score NULL). */
-int far3d_head_finalize(const float* reg, const float* ref, const float* cls_last, float* box, float* score, int layers, int A,
-                        int code_size, int num_classes, const float* pc_range, void* stream);
+ * reg (layers*A, code) f32, ref (A,3), cls_all (layers,A,ncls) logits (may be NULL with score NULL); score (A) from the last
+ * layer.  hole_count != NULL (DEVICE int32): the query rows [hole_start + *hole_count, hole_end) hold no query (fixed-capacity
+ * proposal mode): their score and their logits in EVERY layer are set to -inf, so neither the memory top-k nor the decode can pick
+ * them.  hole_count NULL: cls_all is only read. */
+int far3d_head_finalize(const float* reg, const float* ref, float* cls_all, float* box, float* score, int layers, int A,
+                        int code_size, int num_classes, const float* pc_range, const int32_t* hole_count, int hole_start, int hole_end,
+                        void* stream);
 
 /* Streaming-memory post-update, ref models/dense_heads/farhead.py:479-508: the K top-scoring queries (topk_idx, int64
  * DEVICE) are pushed in front, the queue is truncated to L and warped by ego_pose; writes the persistent state in place. */
@@ -229,9 +253,14 @@ int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, vo
                    long ld_a, void* stream);
 
 /* Query order for far3d_aggregate_forward's `perm`: queries sorted by (nearest camera, 8x8 image cell) of their reference
- * point, one single-workgroup launch (keys + LDS counting sort).  A <= 8192, N <= 16.  Scheduling only. */
+ * point, one single-workgroup launch (keys + LDS counting sort).  A <= 8192, N <= 16.  Scheduling only -- except that with
+ * hole_count != NULL the rows [hole_start + *hole_count, hole_end) (no query there: fixed-capacity proposal mode) are entered as
+ * ~a (negative): far3d_aggregate_forward writes a zero row for such an entry and does no work.
+ * row_base: order the A rows [row_base, row_base + A) of `ref` (a rank's share of the queries in the query-sharded decoder); the
+ * entries of perm are ABSOLUTE row indices (the hole is given in absolute rows too), so far3d_aggregate_forward is then called
+ * with the full-size ref / offsets / U / out buffers, A = the share's row count and this perm. */
 int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range, float pad_h,
-                    float pad_w, void* stream);
+                    float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base, void* stream);
 
 /* Descending top-K of n <= 40960 floats (ties -> lower index), one workgroup: idx_out (K) int64, val_out (K) f32 or NULL.
  * Replaces torch.topk in post_update_memory, ref models/dense_heads/farhead.py:488-491 (K <= 1024). */

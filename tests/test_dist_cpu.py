@@ -40,6 +40,15 @@ def _worker(rank, world, port, q):
     for _ in range(2):
         _, fn = fdist.gather_camera_major(tok, num_cams, out=dst)
         ok = ok and fn().data_ptr() == dst.data_ptr() and torch.equal(dst[:num_cams], full_tok)
+    # the frame's ONE exchange: value maps, records and per-rank counts in one call (coalesced on RCCL, sequential on gloo);
+    # fixed-capacity blocks: rank r contributes a block of 4 rows with r + 2 valid ones -> (world, 4, 6) + counts
+    blk = torch.full((4, 6), float(rank + 1))
+    cnt = torch.tensor([[rank + 2, 0]], dtype=torch.int32)
+    d_tok, d_blk, d_cnt = torch.empty((world * per, S, C)), torch.empty((world * 4, 6)), torch.empty((world, 2), dtype=torch.int32)
+    for w in fdist.gather_many([(tok, d_tok), (blk, d_blk), (cnt, d_cnt)]):
+        w.wait()
+    ok = ok and torch.equal(d_tok[:num_cams], full_tok) and d_cnt[:, 0].tolist() == [r + 2 for r in range(world)]
+    ok = ok and all(bool((d_blk[4 * r:4 * r + 4] == r + 1).all()) for r in range(world))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

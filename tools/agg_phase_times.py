@@ -25,7 +25,7 @@ def build_prof():
 
 def main():
     A = int(sys.argv[1]) if len(sys.argv) > 1 else 1544
-    variant, nw = 7, 2
+    variant, nw = (int(sys.argv[2]) if len(sys.argv) > 2 else 7), 2
     if not os.path.exists(PROF) or os.path.getmtime(PROF) < os.path.getmtime(os.path.join(fbuild.CSRC, "sampling.hip")):
         build_prof()
     flib.LIB_PATH = PROF
@@ -52,7 +52,7 @@ def main():
     t = ts.cpu().numpy().reshape(nblk, 4, 16)[:, :nw]
     live = t[:, :, 0] != 0
     t = t[live[:, 0]]
-    if variant == 7:
+    if variant in (7, 11):
         for nm, i, j in (("  issue logit loads", 0, 8), ("  projection+bbox", 8, 9), ("  local max", 9, 1)):
             dlt = (t[:, :, j] - t[:, :, i]).astype(np.float64)
             print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
