@@ -470,13 +470,15 @@ __device__ __forceinline__ void agg_swap16(float v, float& a, float& b) {
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
   const unsigned x = __builtin_bit_cast(unsigned, v);
   const u2_t r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-  a = __builtin_bit_cast(float, r.x); b = __builtin_bit_cast(float, r.y);
+  const unsigned rx = r.x, ry = r.y;      // (bit-casting a vector ELEMENT reads element 0 both times: go through scalars)
+  a = __uint_as_float(rx); b = __uint_as_float(ry);
 }
 __device__ __forceinline__ void agg_swap32(float v, float& a, float& b) {
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
   const unsigned x = __builtin_bit_cast(unsigned, v);
   const u2_t r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-  a = __builtin_bit_cast(float, r.x); b = __builtin_bit_cast(float, r.y);
+  const unsigned rx = r.x, ry = r.y;
+  a = __uint_as_float(rx); b = __uint_as_float(ry);
 }
 // reductions over the lanes of a wave that share (lane & 1): quad xor 2, row rotations by 4 and 8 (parity preserving), then rows
 struct AggMax { static __device__ __forceinline__ float op(float a, float b) { return fmaxf(a, b); } };
@@ -523,7 +525,12 @@ extern "C" int far3d_prof_set_agg_timestamps(long long* buf) {
 // ------------------------------------------------------------------------------------------
 #define AGG7_CAPW 128     // list entries per wave between flushes (2 x 128 x 36 B; 7 workgroups of 22.1 KB fit a CU's 160 KB)
 
-template <typename TV, int PT, int OPT = 0>      // OPT 1 (variant 11): VALU reductions, early matrix loads, packed FMAs
+// OPT 1 (variant 11): VALU reductions, early matrix loads, packed FMAs.
+// Measured and removed this round (profiles/r3): a scatter-add tap merge through LDS float atomics (52 lanes add their
+// 8 group weights into per-token accumulators, ~100 instead of ~340 VALU instructions per patch: build phase 2.2x SLOWER, 35 us per
+// launch); patches of 65..128 tokens merged in two passes instead of the per-corner fallback (78 instead of 92 rows per query, but
+// 23.2 vs 21.2 us); three / four waves per query with one shared, evenly split work list (24.1 .. 28.3 us).
+template <typename TV, int PT, int OPT = 0, int CAPW = AGG7_CAPW>
 __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ Vc,
@@ -541,9 +548,9 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
   float* stat_s = reinterpret_cast<float*>(bb_s + AGG4_MAX_N);            // [2][2][8]: per-wave max, per-wave sum, by group
   int* vis_s = reinterpret_cast<int*>(stat_s + 32);                       // [AGG4_MAX_N] bit l: level l of the camera is touched
   int* off_all = vis_s + AGG4_MAX_N;                                      // [2][CAPW] row offsets, then [2][CAPW][8] weights
-  float* wt_all = reinterpret_cast<float*>(off_all + 2 * AGG7_CAPW);
-  int* off_s = off_all + wv * AGG7_CAPW;
-  float* wt_s = wt_all + wv * AGG7_CAPW * 8;
+  float* wt_all = reinterpret_cast<float*>(off_all + 2 * CAPW);
+  int* off_s = off_all + wv * CAPW;
+  float* wt_s = wt_all + wv * CAPW * 8;
 
   AGG_TS(0);
   // ---- logits (float4 index i4 covers groups (i4&1)*4..+3 of one (camera, level*P+point) row); loads issued first
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
   }
   // OPT: the projection matrix of this lane's camera does not depend on the query either: loaded before the perm lookup returns
   float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0, pm2 = pm0;
-  if constexpr (OPT != 0 && PT >= 1 && PT <= 16) {
+  if constexpr ((OPT & 1) != 0 && PT >= 1 && PT <= 16) {
     if ((t >> 4) < N) {
       const float4* m = reinterpret_cast<const float4*>(l2i + (t >> 4) * 16);
       pm0 = m[0]; pm1 = m[1]; pm2 = m[2];
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
         const bool act = n < N && p < P;
         float u = 0.f, v = 0.f;
         if (act) {
-          if (OPT != 0 && c0 == 0) {           // matrices already in registers
+          if ((OPT & 1) != 0 && c0 == 0) {     // matrices already in registers
             const float k0 = r0 + of0, k1 = r1 + of1, k2 = r2 + of2;
             const float x = pm0.x * k0 + pm0.y * k1 + pm0.z * k2 + pm0.w;
             const float y = pm1.x * k0 + pm1.y * k1 + pm1.z * k2 + pm1.w;
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
   auto append = [&](bool hit, int off, const float (&wa)[8]) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(hit);
     const int c = __popcll(m);
-    if (cnt + c > AGG7_CAPW) {            // wave-uniform; the list is private to the wave (LDS is in order per wave)
+    if (cnt + c > CAPW) {                 // wave-uniform; the list is private to the wave (LDS is in order per wave)
       agg7_gather<TV, 4, OPT>(feat, off_s, wt_s, cnt, lane, acc);
       cnt = 0;
     }
@@ -844,7 +851,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
   {
     const int c = t * 2, g = c >> 5;       // channels 2t, 2t+1 belong to group 2t / 32
     const float inv = 1.f / (stat_s[16 + g] + stat_s[24 + g]);
-    const float2 p0 = *reinterpret_cast<const float2*>(wt_all + c), p1 = *reinterpret_cast<const float2*>(wt_all + AGG7_CAPW * 8 + c);
+    const float2 p0 = *reinterpret_cast<const float2*>(wt_all + c), p1 = *reinterpret_cast<const float2*>(wt_all + CAPW * 8 + c);
     const float r0 = (p0.x + p1.x) * inv, r1 = (p0.y + p1.y) * inv;
     if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(r0, r1);
     else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = pack_bf16x2(r0, r1);
@@ -867,7 +874,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
   FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 11,
-                  "far3d_aggregate_forward: unknown kernel variant %d (0 = 7 = default, 3 = round-1 kernel, 11 = default with VALU reductions / packed FMAs)", variant);
+                  "far3d_aggregate_forward: unknown kernel variant %d (0 = 7 = default, 3 = round-1 kernel, 11 = VALU reductions / packed FMAs)", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -897,7 +904,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, dim3(256), lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 1>), grid, dim3(256), lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-  } else if (variant == 11) {     // v7 with DPP / permlane reductions, early matrix loads, packed FMAs (A/B against the default)
+  } else if (variant == 11) {     // v7 with DPP / permlane reductions, early matrix loads, packed FMAs; A/B against the default
     const int NP = N * P;
     const size_t lds7 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + 32 * 4 + AGG4_MAX_N * 4 + (size_t)2 * AGG7_CAPW * 36;
     if (feat_dtype == FAR3D_DT_F32) {

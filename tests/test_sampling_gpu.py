@@ -93,6 +93,11 @@ def test_aggregate_strided_operands_and_perm(hip_lib):
         got32 = ops.aggregate_forward(feat, ref, buf[:, J:J + 39], l2i, buf[:, :J], Vc, c["level_hw"], c["level_start"], c["pc_range"],
                                       c["pad_hw"], perm=perm, variant=variant)
         assert (got32 - dense).abs().max().item() < 5e-5
+        # reproducible bit for bit, launch after launch and whatever the workgroup order (no float atomics anywhere)
+        for pm in (perm, None):
+            again = ops.aggregate_forward(feat, ref, buf[:, J:J + 39], l2i, buf[:, :J], Vc, c["level_hw"], c["level_start"], c["pc_range"],
+                                          c["pad_hw"], perm=pm, variant=variant)
+            assert torch.equal(again, got32), "variant %d is not reproducible" % variant
 
 
 def test_aggregate_equals_unfused_msda_sum(hip_lib):

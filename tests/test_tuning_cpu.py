@@ -39,10 +39,29 @@ def test_tuning_table_names_only_implemented_tiles():
 
 
 def test_tuned_tile_lookup_borrows_nearest_pixel_count():
+    """The table holds the same layer at several pixel counts (7 cameras on one GPU; 4 / 2 / 1 cameras per rank of a camera-sharded
+    run): an exact pixel count gets its own entry, anything else the entry with the nearest pixel count."""
     from far3d_amd import ops
     table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x.json")))
-    key = next(k for k in table if k.startswith("192,192,3,1,"))
-    npix = int(key.split(",")[-1])
-    assert ops._tuned_tile(192, 192, 3, 1, npix) == table[key]
-    assert ops._tuned_tile(192, 192, 3, 1, npix // 7) == table[key]          # one camera of seven: same layer geometry
-    assert ops._tuned_tile(191, 192, 3, 1, npix) == 0                         # unknown layer -> kernel heuristic
+    entries = sorted((int(k.split(",")[-1]), v) for k, v in table.items() if k.startswith("192,192,3,1,"))
+    assert len(entries) >= 2, "the stage-4 3x3 layer should be tuned for the sharded pixel counts too"
+    for npix, tile in entries:
+        assert ops._tuned_tile(192, 192, 3, 1, npix) == tile
+    lo, hi = entries[0], entries[-1]
+    assert ops._tuned_tile(192, 192, 3, 1, lo[0] // 3) == lo[1] and ops._tuned_tile(192, 192, 3, 1, hi[0] * 3) == hi[1]
+    assert ops._tuned_tile(191, 192, 3, 1, hi[0]) == 0                        # unknown layer -> kernel heuristic
+
+
+def test_pair_tuning_table_names_only_implemented_tiles():
+    """Same for the pair-storage (bf16x3) table: ids 150+ of igemm_pair.hip, 1..5 for the register-staged kernel."""
+    src = open(os.path.join(ROOT, "far3d_amd", "csrc", "igemm_pair.hip")).read()
+    ids = {"igemm": set(), "pipe3": set(), "gemm": set()}
+    for m in re.finditer(r"case (\d+): (launch_[a-z0-9_]+)<", src):
+        ids[{"launch_igemm": "igemm", "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm"}[m.group(2)]].add(int(m.group(1)))
+    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json")))
+    assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5}
+    for key, tile in table.items():
+        cout, cin, k, stride, npix = (int(v) for v in key.split(","))
+        assert cin % 32 == 0, key
+        allowed = ids["igemm"] | (ids["pipe3"] if (k == 3 and stride == 1) else ids["gemm"] if (k == 1 and stride == 1) else set())
+        assert tile in allowed and not 200 <= tile < 300, "tile %d is not a split-product tile for layer %s" % (tile, key)

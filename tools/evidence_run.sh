@@ -1,6 +1,8 @@
-# One GPU call that regenerates everything profiles/<round>/ cites: full GPU test suite, smoke, bench (+CPU baseline + parity),
-# the fp32 and bf16x3 bench lines, the aggregation kernel's per-phase s_memtime stamps, rocprofv3 kernel stats of the bench, per-layer / per-frame reports, per-kernel micro-benchmarks and the
-# IN-FRAME PMC traffic passes for the aggregation kernel.   usage: [PMC=1] [TESTS=0] bash tools/evidence_run.sh <tag>
+# One GPU call that regenerates everything profiles/<round>/ cites: full GPU test suite, smoke, the default bench (bf16 headline + the
+# in_tolerance bf16x3 block + CPU baseline + parity), the fp32 and threshold-proposal bench lines, stage times for the multi-GPU model,
+# the aggregation kernel's per-phase s_memtime stamps, rocprofv3 kernel stats of the bench (bf16 and bf16x3) with per-layer /
+# per-frame reports, per-kernel micro-benchmarks and the IN-FRAME PMC traffic passes for the aggregation kernel.
+#   usage: [PMC=1] [TESTS=0] bash tools/evidence_run.sh <tag>
 R=$GRAFT_REPO_ROOT; TAG=${1:-final}; O=$R/gpurun_out/ev_$TAG; mkdir -p $O
 cd $R
 if [ "${TESTS:-1}" = "1" ]; then
@@ -10,12 +12,20 @@ fi
 timeout 900 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-300 $O/bench.json
 timeout 600 python bench.py --precision fp32 --steps 20 --no-cpu-baseline 2>$O/bench_fp32.err | tail -1 > $O/bench_fp32.json; cut -c1-200 $O/bench_fp32.json
 timeout 600 python bench.py --precision bf16x3 --steps 50 2>$O/bench_bf16x3.err | tail -1 > $O/bench_bf16x3.json; cut -c1-200 $O/bench_bf16x3.json
+timeout 600 python bench.py --proposals threshold --capacity 4096 --steps 30 --no-cpu-baseline 2>$O/bench_thr.err | tail -1 > $O/bench_threshold.json; cut -c1-200 $O/bench_threshold.json
+timeout 300 python tools/stage_times.py bf16 > $O/stage_times_bf16.txt 2>&1; tail -16 $O/stage_times_bf16.txt
+timeout 300 python tools/stage_times.py bf16x3 > $O/stage_times_bf16x3.txt 2>&1
 timeout 300 python tools/agg_phase_times.py > $O/agg_phase_times.txt 2>&1; tail -14 $O/agg_phase_times.txt
 python tools/bench_kernels.py --iters 50 --out $O/kernels.jsonl > /dev/null 2>&1; cut -c1-160 $O/kernels.jsonl
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/prof_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-in-tolerance > $O/prof_bench.log 2>&1
 python $R/tools/layer_report.py $O/prof_bench/run_kernel_trace.csv v > $O/conv_layers.txt 2>&1; tail -9 $O/conv_layers.txt
 python $R/tools/frame_report.py $O/prof_bench/run_kernel_trace.csv 40 > $O/frame_report.txt 2>&1; head -12 $O/frame_report.txt
+cp $O/prof_bench/run_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null; rm -f $O/prof_bench/run_kernel_trace.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_x3 -o run -- python $R/bench.py --precision bf16x3 --no-pipeline --steps 10 --warmup 3 --no-cpu-baseline > $O/prof_x3.log 2>&1
+python $R/tools/layer_report.py $O/prof_x3/run_kernel_trace.csv v > $O/conv_layers_bf16x3.txt 2>&1; tail -9 $O/conv_layers_bf16x3.txt
+python $R/tools/frame_report.py $O/prof_x3/run_kernel_trace.csv 45 > $O/frame_report_bf16x3.txt 2>&1
+cp $O/prof_x3/run_kernel_stats.csv $O/bench_kernel_stats_bf16x3.csv 2>/dev/null; rm -rf $O/prof_x3
 # PMC: one derived counter per pass (FETCH_SIZE + WRITE_SIZE together exceed the hardware), every pass under `timeout` (a failed
 # rocprofv3 does not exit on its own); the eager bench so that every kernel is its own dispatch
 if [ -n "$PMC" ]; then
@@ -24,10 +34,14 @@ if [ -n "$PMC" ]; then
   done
   timeout 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_tcc -o run -- python $R/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_tcc.log 2>&1 || echo "pmc pass tcc failed"
   python $R/tools/pmc_to_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc aggregate_v7_kernel $O/aggregate_pmc.json
+  # SQ counters of the aggregation kernel: where the wave cycles go (VALU issue vs waiting)
+  timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python $R/tools/run_agg_once.py > $O/pmc_sq.log 2>&1 || echo "pmc pass sq failed"
+  for f in $(find $O/pmc_sq -name '*counter_collection.csv'); do (head -1 $f; grep aggregate $f) > $O/aggregate_sq_counters.csv; done
   # keep only the aggregation rows of the (large) counter files
   for d in $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc; do
     for f in $(find $d -name '*counter_collection.csv'); do (head -1 $f; grep aggregate $f) > $f.agg; rm -f $f; done
     find $d -name '*kernel_trace.csv' -delete
   done
+  rm -rf $O/pmc_sq
 fi
-grep -i aggregate $O/prof_bench/run_kernel_stats.csv | cut -c1-200
+grep -i aggregate $O/bench_kernel_stats.csv | cut -c1-200

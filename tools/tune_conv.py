@@ -8,7 +8,7 @@ from far3d_amd import ops, weights
 
 def shapes():
     spec = weights.VOV_SPECS["V-99-eSE"]
-    N, H, W = 7, 640, 960
+    N, H, W = int(os.environ.get("NCAM", "7")), 640, 960      # NCAM=1/2/4: the per-rank shapes of camera-sharded runs
     out = []   # (name, N, H, W, Cin, Cout, k, stride)
     h, w = H // 2, W // 2
     out.append(("stem1", N, h, w, 32, 64, 1, 1)); out.append(("stem2", N, h, w, 64, 64, 3, 1)); out.append(("stem3", N, h, w, 64, 128, 3, 2))
@@ -33,7 +33,7 @@ def shapes():
         out.append(("head5.l%d" % l, N, hw[l][0], hw[l][1], 256, 5, 1, 1))
     out.append(("fpn.out3", N, 20, 30, 256, 256, 3, 2)); out.append(("depth.cls", N, 80, 120, 256, 51, 1, 1))
     # decoder linears (A = 1544 queries, 768 memory rows, 644 adaptive proposals)
-    for nm, M, ci, co in (("dec.qk", 1544, 256, 512), ("dec.v", 1544, 256, 256), ("dec.memk", 768, 256, 256), ("dec.wfc", 1544, 256, 416),
+    for nm, M, ci, co in () if N != 7 else (("dec.qk", 1544, 256, 512), ("dec.v", 1544, 256, 256), ("dec.memk", 768, 256, 256), ("dec.wfc", 1544, 256, 416),
                           ("dec.lfc", 1544, 256, 39), ("dec.ffn1", 1544, 256, 1024), ("dec.ffn2", 1544, 1024, 256), ("dec.m644", 644, 256, 256),
                           ("dec.m300", 300, 256, 256), ("dec.ce", 7, 256, 256)):
         out.append((nm, 1, 1, M, ci, co, 1, 1))
@@ -97,7 +97,10 @@ def main():
         table[key] = best[1]
         print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %4.0f" % (tl, res[tl] * 1e6) for tl in tiles if tl) +
               " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
-    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuning_mi355x_pair.json" if pair else ("tuning_mi355x_bf16x3.json" if x3 else "tuning_mi355x.json")), "w"), indent=0, sort_keys=True)
+    name = "tuning_mi355x_pair" if pair else ("tuning_mi355x_bf16x3" if x3 else "tuning_mi355x")
+    if os.environ.get("NCAM", "7") != "7":
+        name += "_n" + os.environ["NCAM"]
+    json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", name + ".json"), "w"), indent=0, sort_keys=True)
 
 if __name__ == "__main__":
     main()
