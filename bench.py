@@ -134,6 +134,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     sd = weights.init_state_dict(spec, seed=0)
     eng = engine.Far3DEngine(sd, cfg, device=dev, precision=precision)
     eng.agg_variant = args.agg_variant
+    eng.cam_priority = args.cam_priority
     del sd
     frames = []
     for fi in range(4):   # a few distinct frames (ego motion on), resident in HBM before the timed region
@@ -286,6 +287,7 @@ def main():
     ap.add_argument("--proposals", default="topk", choices=["topk", "threshold"],
                     help="adaptive queries: 92 best 2D peaks per camera (static 644), or the reference's score > 0.1 rule with a fixed capacity")
     ap.add_argument("--capacity", type=int, default=1024, help="--proposals threshold: rows reserved for the adaptive queries")
+    ap.add_argument("--cam-priority", type=int, default=0, help="HIP stream priority of the camera-stage stream in pipeline mode (-1 = high; A/B)")
     args = ap.parse_args()
 
     import torch.distributed as dist

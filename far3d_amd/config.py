@@ -41,7 +41,7 @@ def load_config(path):
 
 
 def default_model_cfg(num_cams=7, num_query=644, num_propagated=256, memory_len=1024, topk_proposals=256, backbone="V-99-eSE",
-                      proposal_topk=None):
+                      proposal_topk=None, proposal_capacity=None):
     """The Far3D VoV-99 Argoverse-2 model (values of the reference's only config), assembled programmatically."""
     depthnet = dict(type=0, hidden_dim=256, num_depth_bins=50, depth_min=0.1, depth_max=110, stride=8)
     strides = [8, 16, 32, 64]
@@ -67,4 +67,4 @@ def default_model_cfg(num_cams=7, num_query=644, num_propagated=256, memory_len=
                                   out_features=("stage2", "stage3", "stage4", "stage5")),
                 img_neck=dict(type="FPN", start_level=1, add_extra_convs="on_output", relu_before_extra_convs=True,
                               in_channels=[256, 512, 768, 1024], out_channels=256, num_outs=4),
-                img_roi_head=roi, pts_bbox_head=head, proposal_topk=proposal_topk)
+                img_roi_head=roi, pts_bbox_head=head, proposal_topk=proposal_topk, proposal_capacity=proposal_capacity)

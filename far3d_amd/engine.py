@@ -136,6 +136,7 @@ class Far3DEngine:
         # forward_frame are ready on `output_stream()`; a caller that reads them on its own stream calls `wait_outputs()` first
         # (ordering the caller's stream after every head automatically would serialise the next frame's camera stages again).
         self.pipeline = False
+        self.cam_priority = 0       # HIP stream priority of the camera-stage stream in pipeline mode (-1 = high)
         self._overflow = None       # fixed-capacity threshold mode: device flag of the latest frame (check_proposal_overflow)
         self._ready = None          # event of the latest pipelined head (None: outputs are on the caller's stream)
         self._par = 0               # buffer-set parity currently in use (always 0 without pipelining)
@@ -773,7 +774,9 @@ class Far3DEngine:
         """One steady-state frame in pipeline mode (see __init__).  Stream s_cam: [wait until the head that last used this
         buffer set is done] -> input staging -> camera-stage graph.  Stream s_head: [wait for the camera stages] -> head graph."""
         if self._pipe is None:
-            self._pipe = dict(s_cam=torch.cuda.Stream(self.dev), s_head=torch.cuda.Stream(self.dev), g_cam={}, g_head={}, outs={},
+            # the camera stages are the throughput-critical half: their stream gets the higher priority so that the head of the
+            # previous frame (latency-bound, few CUs) does not delay their workgroups (self.cam_priority, A/B in bench.py)
+            self._pipe = dict(s_cam=torch.cuda.Stream(self.dev, priority=self.cam_priority), s_head=torch.cuda.Stream(self.dev), g_cam={}, g_head={}, outs={},
                               cam_done={}, head_done={})
         P = self._pipe
         p = self._par

@@ -569,7 +569,7 @@ class Far3D(nn.Module):
 
     def __init__(self, use_grid_mask=False, img_backbone=None, img_neck=None, pts_bbox_head=None, img_roi_head=None,
                  train_cfg=None, test_cfg=None, stride=(16,), position_level=(0,), aux_2d_only=True, single_test=False,
-                 pretrained=None, proposal_topk=None, **kwargs):
+                 pretrained=None, proposal_topk=None, proposal_capacity=None, **kwargs):
         super().__init__()
         self.img_backbone = BACKBONES.build(img_backbone)
         self.img_neck = NECKS.build(img_neck)
@@ -578,6 +578,9 @@ class Far3D(nn.Module):
         self.stride, self.position_level = list(stride), list(position_level)
         self.use_grid_mask = use_grid_mask     # GridMask is the identity in eval mode (models/utils/grid_mask.py:85)
         self.proposal_topk = proposal_topk     # build-side extension: static K proposals per camera (None = reference)
+        # build-side extension: the reference's threshold rule with static shapes -- rows reserved for the adaptive queries, count on
+        # the device (None = the legacy form with a host sync on M); see INTEGRATION.md "Proposal modes"
+        self.proposal_capacity = proposal_capacity
         self.engine = None
         self.eval()
 
@@ -607,7 +610,7 @@ class Far3D(nn.Module):
             code_size=h.code_size, max_num=h.bbox_coder.max_num,
             depthnet=dict(num_depth_bins=r.depthnet_config.get("num_depth_bins", 50), depth_min=r.depthnet_config.get("depth_min", 0.1),
                           depth_max=r.depthnet_config.get("depth_max", 110.0), stride=r.depthnet_config.get("stride", 8)),
-            score_thr=r.threshold_score, proposal_topk=self.proposal_topk)
+            score_thr=r.threshold_score, proposal_topk=self.proposal_topk, proposal_capacity=self.proposal_capacity)
 
     def prepare(self, device="cuda:0", precision="bf16"):
         """Fold BN, pack weights for the kernels, upload.  Must be called again after loading new weights."""
@@ -635,6 +638,8 @@ class Far3D(nn.Module):
             raise _lib.Far3dHipError("call Far3D.prepare(device, precision) before inference")
         outs = self.engine.forward_frame(data, img_metas)
         self.engine.wait_outputs()       # pipeline mode produces the outputs on the head stream (no-op otherwise)
+        if self.proposal_capacity is not None:
+            self.engine.check_proposal_overflow()      # a frame that did not fit the reserved rows is an error, never a silent truncation
         r = outs["result"]
         keep = r["keep"]
         res = dict(boxes_3d=r["boxes_3d"][keep], scores_3d=r["scores_3d"][keep], labels_3d=r["labels_3d"][keep])

@@ -204,3 +204,28 @@ def test_capacity_overflow_is_reported(hip_lib):
     assert int(o["num_adaptive_dev"].item()) == 2 and torch.isfinite(o["all_cls_scores"][:, 0, :rc["num_query"] + 2]).all()
     with pytest.raises(lib.Far3dHipError):
         eng.check_proposal_overflow()
+
+
+def test_detector_from_registry_config_in_capacity_mode(hip_lib):
+    """The registry-level detector with `proposal_capacity` (INTEGRATION.md "Proposal modes"): graphs + pipeline on, the reference's
+    boxes of the golden sequence come out, and a capacity that is too small raises instead of truncating."""
+    from far3d_amd import config, lib, plugin
+    z = np.load(os.path.join(GOLD, "far3d_small_seq.npz"))
+    rc = json.loads(bytes(z["recipe"]).decode())
+    spec = weights.detector_spec(rc["backbone"], num_query=rc["num_query"], num_propagated=rc["num_propagated"])
+    for cap in (48, 4):
+        det = plugin.build_detector(config.default_model_cfg(num_cams=rc["num_cams"], num_query=rc["num_query"], num_propagated=rc["num_propagated"],
+                                                             memory_len=rc["memory_len"], topk_proposals=rc["topk_proposals"], proposal_capacity=cap))
+        det.load_state_dict(weights.init_state_dict(spec, seed=rc["weight_seed"]))
+        det.prepare(DEV, precision="fp32")
+        det.engine.use_graph = det.engine.pipeline = True
+        if cap == 4:
+            data, metas = synth.recipe_frame(rc, 0)
+            with pytest.raises(lib.Far3dHipError):
+                det(return_loss=False, rescale=True, img_metas=metas, **data)
+            continue
+        for fi in range(rc["frames"]):
+            data, metas = synth.recipe_frame(rc, fi)
+            res = det(return_loss=False, rescale=True, img_metas=metas, **data)[0]["pts_bbox"]
+            assert_detections_match(tuple(res[k].cpu().numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")),
+                                    tuple(z["f%d_%s" % (fi, k)] for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi)
