@@ -107,17 +107,18 @@ def parity_block(precision, eng_frames, orc_frames):
 
 
 def agg_traffic():
-    """HBM bytes per launch of the aggregation kernel from the committed in-frame PMC pass (profiles/r2/aggregate_pmc.json:
+    """HBM bytes per launch of the aggregation kernel from the committed in-frame PMC pass (profiles/r3/aggregate_pmc.json:
     FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes over `bench.py --eager`, tools/evidence_run.sh with
     PMC=1).  Counters cannot be read from inside this process; the file carries the kernel name and the commit it was taken
     at, and a figure for another kernel is not reported."""
-    p = os.path.join(ROOT, "profiles", "r2", "aggregate_pmc.json")
+    p = os.path.join(ROOT, "profiles", "r3", "aggregate_pmc.json")
     try:
         with open(p) as f:
             j = json.load(f)
         if j.get("kernel") != AGG_KERNEL:
             return None, None
-        return j["hbm_bytes_per_launch"], "profiles/r2/aggregate_pmc.json @ %s (in-frame, eager bench)" % j.get("commit", "?")
+        return j["hbm_bytes_per_launch"], ("profiles/r3/aggregate_pmc.json @ %s (in-frame rocprofv3 --pmc passes over `bench.py --eager`; a committed "
+                                           "figure, NOT measured by the run that prints this line)" % j.get("commit", "?"))
     except Exception:   # noqa: BLE001
         return None, None
 

@@ -15,8 +15,6 @@ overlap the head of frame i, so the frame time tends to max(camera stages + exch
 Host logic here is device-agnostic so the shard / gather / un-pad arithmetic is covered by 2-process gloo tests on CPU;
 the compute itself has no CPU path.
 """
-import contextlib
-
 import torch
 import torch.distributed as dist
 
@@ -53,16 +51,11 @@ def gather_many(pairs, group=None):
     single group (one launch moves the value maps, the records and the counts); elsewhere (gloo: CPU tests, the one-GPU test rig)
     they run one after the other.  Returns a list of work handles to wait() on (stream-ordered on the device backends)."""
     backend = dist.get_backend(group)
-    if backend == "nccl" and len(pairs) > 1:
-        cm = getattr(dist, "_coalescing_manager", None)
-        if cm is not None:
-            try:
-                with cm(group=group, device=pairs[0][0].device, async_ops=True) as c:
-                    for local, out in pairs:
-                        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-                return [c]
-            except (TypeError, RuntimeError):     # coalescing not available for this op in this torch build: plain calls below
-                pass
+    if backend == "nccl" and len(pairs) > 1 and _COALESCE is not None:
+        with _COALESCE(group=group, device=pairs[0][0].device, async_ops=True) as c:
+            for local, out in pairs:
+                dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return [c]
     works = []
     for local, out in pairs:
         if local.is_cuda and backend == "gloo":
@@ -72,6 +65,23 @@ def gather_many(pairs, group=None):
         else:
             works.append(dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=True))
     return works
+
+
+def _coalescing_manager():
+    """torch.distributed's group-call manager if this build has it with the (group, device, async_ops) signature, else None.
+    Decided once, by inspection: an exchange must never be retried in another form after part of it was issued."""
+    import inspect
+    cm = getattr(dist, "_coalescing_manager", None)
+    if cm is None:
+        return None
+    try:
+        params = inspect.signature(cm).parameters
+    except (TypeError, ValueError):
+        return None
+    return cm if all(k in params for k in ("group", "device", "async_ops")) else None
+
+
+_COALESCE = _coalescing_manager()
 
 
 class _Done:
@@ -286,7 +296,11 @@ class ShardedFrame:
         qs.gather = cut
         try:
             begin()
-            out = fn()
+            try:
+                out = fn()
+            except BaseException as e:        # leave the stream-capture state clean before the error travels on
+                state["ctx"].__exit__(type(e), e, e.__traceback__)
+                raise
             end()
         finally:
             qs.gather = qs.exchange

@@ -1,4 +1,4 @@
-"""CPU: the committed evidence under profiles/r2/ is internally consistent with the bench contract -- the JSON lines carry every
+"""CPU: the committed evidence under profiles/r3/ is internally consistent with the bench contract -- the JSON lines carry every
 field the contract names, the roofline block is arithmetic on its own fields, the kernel it names is the one in the committed
 rocprofv3 stats and in the PMC file, and the live HIP-event timing agrees with the profiler's average for that kernel."""
 import csv
@@ -9,7 +9,7 @@ import pytest
 
 from tests.conftest import ROOT
 
-P = os.path.join(ROOT, "profiles", "r2")
+P = os.path.join(ROOT, "profiles", "r3")
 LINES = ["bench.json", "bench_fp32.json", "bench_bf16x3.json"]
 
 
@@ -46,6 +46,15 @@ def test_headline_line_has_cpu_baseline_and_parity():
     assert p["tolerance_north_star"] == 1e-3 and p["meets_tolerance"] is False and p["logit_max_abs"] > 1e-3   # bf16: measured, not met
     x3 = _load("bench_bf16x3.json")["parity"]
     assert x3["meets_tolerance"] is True and x3["logit_max_abs"] < 1e-3
+    # the SAME driver-style run also times an engine that is inside the tolerance: a first-class block
+    t = d["in_tolerance"]
+    assert t["dtype"] == "bf16x3" and t["meets_tolerance"] is True and t["parity"]["logit_max_abs"] < 1e-3
+    assert t["unit"] == "samples/s" and abs(t["value"] * t["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    assert t["value"] >= 70.0, "the in-tolerance engine fell below the round's 70 samples/s bar: %.1f" % t["value"]
+    rb = t["roofline_backbone"]
+    assert rb["bound"] == "mfma" and abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9 and abs(rb["peak"] - 2500.0 / 3) < 1e-6
+    # the like-for-like ratio against the reference's sync-per-frame protocol is printed next to vs_baseline
+    assert abs(d["vs_baseline_sync_per_frame"] - d["protocol"]["sync_per_frame"]["samples_per_s_mean"] / 6.4) < 1e-9
 
 
 def test_roofline_kernel_matches_the_committed_profiles():
@@ -53,6 +62,7 @@ def test_roofline_kernel_matches_the_committed_profiles():
     kernel = d["roofline"]["kernel"].split(" ")[0]
     pmc = _load("aggregate_pmc.json")
     assert pmc["kernel"] == kernel and pmc["commit"] == d["config"]["commit"]
+    assert d["roofline"]["traffic_measured_in_this_run"] is False
     assert d["roofline"]["traffic"] is None or abs(d["roofline"]["traffic"] - pmc["hbm_bytes_per_launch"]) / pmc["hbm_bytes_per_launch"] < 0.02
     rows = [r for r in csv.DictReader(open(os.path.join(P, "bench_kernel_stats.csv"))) if kernel in r["Name"]]
     assert len(rows) == 1, [r["Name"][:40] for r in rows]
@@ -63,6 +73,16 @@ def test_roofline_kernel_matches_the_committed_profiles():
     # the fp32-row modes time the same kernel on 1-KiB rows and do not borrow the bf16 traffic figure
     for name in ("bench_fp32.json", "bench_bf16x3.json"):
         assert _load(name)["roofline"]["traffic"] is None
+
+
+def test_threshold_mode_and_stage_time_evidence():
+    thr = _load("bench_threshold.json")
+    assert thr["config"]["proposals"] == "threshold" and thr["value"] > 30.0 and "count on the device" in thr["config"]["workload"]
+    txt = open(os.path.join(P, "stage_times_bf16.txt")).read()
+    st = json.loads(txt[txt.index("{"):])
+    # the query-sharded decoder's measured non-result: an eighth of the queries costs as much as all of them (latency floors)
+    assert st["decoder_query_share_1_of_8_ms"] > 0.85 * st["decoder_all_queries_ms"]
+    assert st["camera_stages_1cam_ms"] < st["camera_stages_2cam_ms"] < st["camera_stages_4cam_ms"] < st["camera_stages_7cam_ms"]
 
 
 def test_gpu_suite_and_smoke_logs_are_green():

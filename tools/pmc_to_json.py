@@ -32,6 +32,11 @@ def main():
     tcc = mean_counter(args[2], kernel, ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum")) if len(args) > 4 else {}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    if not commit:      # the GPU box has no .git: the stamp far3d_amd/build.py wrote (the same source bench.py reports)
+        try:
+            commit = open(os.path.join(root, "far3d_amd", "_build_commit.txt")).read().strip()
+        except OSError:
+            commit = ""
     j = dict(kernel=kernel, commit=commit or os.environ.get("FAR3D_COMMIT", "?"),
              source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --eager`: every aggregation launch of "
                     "every benchmark frame in the trace (in-frame traffic, not an isolated micro-benchmark)",
