@@ -114,3 +114,34 @@ def test_ida_matrix_is_scale_crop_flip_rotation_about_the_crop_centre(scale, lef
         want = (cx + math.cos(th) * dx + math.sin(th) * dy, cy - math.sin(th) * dx + math.cos(th) * dy)
         got = Mx @ np.array([x, y, 1.0])
         assert abs(got[0] - want[0]) < 1e-3 and abs(got[1] - want[1]) < 1e-3 and got[2] == 1.0
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 9000), st.integers(1, 8))
+def test_query_shard_rows_partition_the_queries(A, world):
+    """Query-sharded decoder: rank r owns rows [r * per, min((r + 1) * per, A)) -- disjoint, in order, covering every query once; the
+    gathered (world * per, E) buffer therefore holds the A rows in order followed only by padding."""
+    class _QS(fdist.QueryShard):
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+    per = _QS(0, world).rows_per_rank(A)
+    assert per % 4 == 0 and per * world >= A and (per - 4) * world < A + 4 * world
+    seen = []
+    for r in range(world):
+        a0, a1 = min(r * per, A), min((r + 1) * per, A)
+        assert 0 <= a1 - a0 <= per
+        seen += list(range(a0, a1))
+    assert seen == list(range(A))
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.integers(1, 7), st.integers(1, 8), st.integers(1, 600), st.integers(1, 4096))
+def test_capacity_block_rows_bound_the_exchange(num_cams, world, cam_cap, capacity):
+    """Camera-sharded fixed-capacity mode: a rank's record block has min(capacity, per * cam_cap) rows -- never more than the
+    global capacity (what the head can hold) nor more than its cameras can select."""
+    per, shards = fdist.camera_shards(num_cams, world)
+    block = min(capacity, per * cam_cap)
+    assert 1 <= block <= capacity and block <= per * cam_cap
+    # every camera-major prefix of valid rows across the blocks fits the compaction's destination or raises the overflow flag
+    total_possible = sum(min(block, sum(1 for c in s if c >= 0) * cam_cap) for s in shards)
+    assert total_possible <= world * block
