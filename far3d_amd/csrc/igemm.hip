@@ -109,6 +109,35 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 79: launch_gemm1x1_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves (1x2 tiles per wave)
         case 80: launch_gemm1x1_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
         case 81: launch_gemm1x1_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
+        // deeper LDS rings (NS - 1 steps of 64 channels in flight, counted vmcnt)
+        case 82: launch_gemm1x1_pipe<4, 2, 1, 2, 1, false, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
+        case 83: launch_gemm1x1_pipe<2, 2, 1, 2, 1, false, 3>(P, st); break;   // 64 x 128, 4 waves, 3 stages
+        case 84: launch_gemm1x1_pipe<2, 2, 2, 2, 1, false, 3>(P, st); break;   // 128 x 128, 4 waves, 3 stages
+        case 85: launch_gemm1x1_pipe<4, 2, 2, 2, 1, false, 3>(P, st); break;   // 256 x 128, 8 waves, 3 stages
+        case 86: launch_gemm1x1_pipe<2, 2, 1, 2, 1, false, 4>(P, st); break;   // 64 x 128, 4 waves, 4 stages
+        case 87: launch_gemm1x1_pipe<2, 2, 1, 1, 1, false, 4>(P, st); break;   // 64 x 64, 4 waves, 4 stages
+        case 88: launch_gemm1x1_pipe<2, 2, 1, 1, 1, false, 3>(P, st); break;   // 64 x 64, 4 waves, 3 stages
+        case 89: launch_gemm1x1_pipe<2, 2, 2, 1, 1, false, 3>(P, st); break;   // 128 x 64, 4 waves, 3 stages
+        // 256 x 256 tiles: half the L2 -> LDS bytes per MFMA of the 128 x 128 tiles (the GEMMs are fill-bound)
+        case 110: launch_gemm1x1_pipe<4, 2, 2, 4>(P, st); break;   // 8 waves of 64 ch x 128 px
+        case 111: launch_gemm1x1_pipe<2, 4, 4, 2>(P, st); break;   // 8 waves of 128 ch x 64 px
+        case 112: launch_gemm1x1_pipe<4, 4, 2, 2>(P, st); break;   // 16 waves of 64 x 64
+        case 113: launch_gemm1x1_pipe<2, 2, 4, 4>(P, st); break;   // 4 waves of 128 x 128
+        case 114: launch_gemm1x1_pipe<2, 4, 2, 4>(P, st); break;   // 128 ch x 512 px, 8 waves of 64 x 128
+        case 115: launch_gemm1x1_pipe<4, 2, 4, 2>(P, st); break;   // 512 ch x 128 px
+        case 116: launch_gemm1x1_pipe<2, 4, 4, 1>(P, st); break;   // 256 ch x 128 px, 8 waves of 128 x 32
+        case 117: launch_gemm1x1_pipe<4, 2, 1, 4>(P, st); break;   // 128 ch x 256 px, 8 waves of 32 x 128
+        // full-line DMA pieces (8 rows x 128 B per instruction, 128-byte LDS rows)
+        case 120: launch_gemm1x1_wide<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves
+        case 121: launch_gemm1x1_wide<2, 2, 2, 2>(P, st); break;   // 128 x 128, 4 waves
+        case 122: launch_gemm1x1_wide<4, 2, 2, 2>(P, st); break;   // 256 x 128, 8 waves
+        case 123: launch_gemm1x1_wide<4, 2, 2, 4>(P, st); break;   // 256 x 256, 8 waves
+        case 124: launch_gemm1x1_wide<2, 2, 1, 2>(P, st); break;   // 64 x 128, 4 waves
+        case 125: launch_gemm1x1_wide<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
+        case 126: launch_gemm1x1_wide<2, 4, 2, 2>(P, st); break;   // 128 x 256, 8 waves
+        case 127: launch_gemm1x1_wide<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
+        case 128: launch_gemm1x1_wide<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
+        case 129: launch_gemm1x1_wide<4, 2, 1, 2, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
         default: done = false;
       }
     }

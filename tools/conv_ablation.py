@@ -1,0 +1,85 @@
+"""Where does the time of the pipelined convolution / GEMM kernels go?  Timing-only ablations (far3d_amd/csrc/igemm_kernels.hpp,
+FAR3D_ABLATE): the same launch with one ingredient removed -- 1 the epilogue, 2 the LDS-DMA inside the K loop, 3 the MFMAs (and
+the fragment reads that feed them), 4 the fragment reads only, 5 the barrier + vmcnt wait at the top of every step.  The outputs
+of an ablated launch are wrong by construction; only its duration is used.
+
+  python tools/conv_ablation.py build        # here (no GPU needed): far3d_amd/libfar3d_hip_abl<k>.so, k = 1..5
+  python tools/conv_ablation.py run <k>      # on the GPU box: one line per layer for variant k (0 = the shipped library)
+  python tools/conv_ablation.py all          # on the GPU box: every variant in its own process, one table
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARIANTS = {0: "shipped", 1: "no epilogue", 2: "no in-loop DMA", 3: "no MFMA / fragment reads", 4: "no fragment reads", 5: "no barrier / vmcnt wait"}
+# (name, N, H, W, Cin, Cout, k, tile): the shipped tile of each layer at the benchmarked size (far3d_amd/data/tuning_mi355x.json)
+LAYERS = [("s2.c1", 7, 160, 240, 128, 128, 3, 60), ("s3.c1", 7, 80, 120, 160, 160, 3, 92), ("s3.c0", 7, 80, 120, 512, 160, 3, 101),
+          ("s4.c1", 7, 40, 60, 192, 192, 3, 100), ("s4.c0", 7, 40, 60, 768, 192, 3, 100), ("s5.c1", 7, 20, 30, 224, 224, 3, 102),
+          ("s2.cat", 7, 160, 240, 768, 256, 1, 70), ("s3.cat", 7, 80, 120, 1312, 512, 1, 79), ("s4.cat", 7, 40, 60, 1728, 768, 1, 79),
+          ("s5.cat", 7, 20, 30, 2144, 1024, 1, 79)]
+
+
+def lib_path(k):
+    return os.path.join(ROOT, "far3d_amd", "libfar3d_hip.so" if k == 0 else "libfar3d_hip_abl%d.so" % k)
+
+
+def build():
+    from far3d_amd import build as fbuild
+    fbuild.build(verbose=False)
+    objs = [os.path.join(fbuild.OBJ, f) for f in os.listdir(fbuild.OBJ) if f.endswith(".o") and f != "igemm.o"]
+    procs = []
+    for k in range(1, 6):
+        o = os.path.join("/tmp", "igemm_abl%d.o" % k)
+        procs.append((k, o, subprocess.Popen([fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_ABLATE=%d" % k, "-c", os.path.join(fbuild.CSRC, "igemm.hip"), "-o", o])))
+    for k, o, p in procs:
+        assert p.wait() == 0
+        subprocess.run([fbuild.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(k), o] + objs, check=True)
+        print("built", lib_path(k))
+
+
+def run(k):
+    import torch
+    from far3d_amd import lib as flib
+    flib.LIB_PATH = lib_path(k)
+    from far3d_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from tune_conv import timeit
+    dev = "cuda:0"
+    out = {}
+    for name, N, H, W, Cin, Cout, ks, tile in LAYERS:
+        x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
+        pc = ops.PackedConv(torch.randn(Cout, Cin, ks, ks) * 0.05, torch.randn(Cout), stride=1, pad=ks // 2, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(N, H, W, Cout, device=dev, dtype=torch.bfloat16)
+        out[name] = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile)) * 1e6
+    print(json.dumps({"variant": k, "us": out}))
+
+
+def all_variants():
+    rows = {}
+    for k in VARIANTS:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "run", str(k)], capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print("variant %d failed: %s" % (k, r.stderr[-300:]))
+            continue
+        rows[k] = json.loads(line[-1])["us"]
+    names = [l[0] for l in LAYERS]
+    fl = {l[0]: 2.0 * l[1] * l[2] * l[3] * l[4] * l[5] * l[6] * l[6] for l in LAYERS}
+    print("%-28s" % "launch time, us" + "".join("%9s" % n for n in names))
+    for k, us in rows.items():
+        print("%-28s" % ("%d %s" % (k, VARIANTS[k])) + "".join("%9.1f" % us[n] for n in names))
+    if 0 in rows:
+        print("%-28s" % "shipped, TF/s" + "".join("%9.0f" % (fl[n] / rows[0][n] / 1e6) for n in names))
+        print("%-28s" % "MFMA time at 2.5 PF, us" + "".join("%9.1f" % (fl[n] / 2.5e15 * 1e6) for n in names))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    elif sys.argv[1] == "run":
+        run(int(sys.argv[2]))
+    else:
+        all_variants()
