@@ -15,6 +15,7 @@
 #define FAR3D_DT_F32_BF16X3 2   // far3d_conv2d_nhwc weight code: fp32 data, two-term bf16 split products (include/far3d_hip.h)
 #define FAR3D_DT_BF16_PAIR 3    // activation storage: fp32 values kept as [32 hi | 32 lo] bf16 per 32-channel block (include/far3d_hip.h)
 #define FAR3D_SUMS_MAX_PARTS 32
+#define FAR3D_SUMS_FRAC_BITS 18      // fixed-point channel sums of far3d_conv2d_nhwc (include/far3d_hip.h)
 
 void far3d_set_error(const char* fmt, ...);
 

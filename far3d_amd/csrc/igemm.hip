@@ -10,7 +10,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
                                  int Wo, int Cout, int ldy, long y_img_stride, int KH, int KW, int stride,
                                  int pad, int act, const void* res, int res_dt, int ldr, long res_img_stride,
                                  int Hr, int Wr, void* y2, int y2_dt, int ldy2, long y2_img_stride,
-                                 const float* y2_scale, const float* y2_shift, int tile, void* stream) {
+                                 const float* y2_scale, const float* y2_shift, long long* chan_sums, int tile, void* stream) {
   FAR3D_CHECK_ARG(x && w && y, "far3d_conv2d_nhwc: null x/w/y");
   FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Ho > 0 && Wo > 0 && Cout > 0,
                   "far3d_conv2d_nhwc: bad sizes N=%d H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d", N, H, W, Cin, Ho, Wo, Cout);
@@ -49,8 +49,15 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.x_vec = aligned(x, 16) && (ldx % ve == 0) && (x_img_stride % ve == 0) && (long)ve * xe % 16 == 0;
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
+  P.chan_sums = chan_sums; P.sums_hw = Ho * Wo;
   P.y_rows16 = (y_dt == FAR3D_DT_BF16 || pair_out) && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
+  if (chan_sums) {       // only the pipelined GEMM kernels accumulate them; anything else is an error, not a silent fallback
+    const bool gemm_tile = pair_in ? (tile == 0 || (tile >= 170 && tile <= 181) || tile == 279 || tile == 280)
+                                   : ((tile >= 70 && tile <= 89) || (tile >= 110 && tile <= 129));
+    FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && gemm_tile && (pair_in || (x_dt == FAR3D_DT_BF16 && Cin % 32 == 0 && P.x_vec)),
+                    "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-129; pair: 170-181, 279, 280); got k=%d tile=%d", KH, tile);
+  }
   if (pair_in) {
     FAR3D_CHECK_ARG(aligned(x, 16) && ldx % 8 == 0 && x_img_stride % 8 == 0 && (!pair_out || (aligned(y, 8) && ldy % 4 == 0 && y_img_stride % 4 == 0)),
                     "far3d_conv2d_nhwc: pair-stored tensors must be 16-byte aligned with pixel strides that are multiples of 8 elements");
@@ -81,6 +88,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     // global_load_lds ring kernel (any kernel size / stride): (channels x pixels, ring depth) 1 128x128/3  2 64x128/4  3 64x64/4
     // 4 128x64/4; 5 falls back to the register-staged 64x256
     bool done = true;
+    int rc = 0;
     switch (tile) {
       case 1: launch_igemm_dma<2, 2, 2, 2, 3>(P, st); break;
       case 2: launch_igemm_dma<2, 2, 1, 2, 4>(P, st); break;
@@ -97,47 +105,47 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     if (!done && KH == 1 && KW == 1 && stride == 1 && pad == 0) {   // pipelined GEMM kernel (channels x pixels, waves)
       done = true;
       switch (tile) {
-        case 70: launch_gemm1x1_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 128, 4 waves
-        case 71: launch_gemm1x1_pipe<2, 4, 2, 1>(P, st); break;   // 128 x 128, 8 waves
-        case 72: launch_gemm1x1_pipe<2, 4, 2, 2>(P, st); break;   // 128 x 256, 8 waves
-        case 73: launch_gemm1x1_pipe<4, 2, 2, 2>(P, st); break;   // 256 x 128, 8 waves
-        case 74: launch_gemm1x1_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 128, 4 waves
-        case 75: launch_gemm1x1_pipe<2, 4, 1, 1>(P, st); break;   // 64 x 128, 8 waves
-        case 76: launch_gemm1x1_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 64, 4 waves
-        case 77: launch_gemm1x1_pipe<4, 4, 2, 1>(P, st); break;   // 256 x 128, 16 waves
-        case 78: launch_gemm1x1_pipe<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
-        case 79: launch_gemm1x1_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves (1x2 tiles per wave)
-        case 80: launch_gemm1x1_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
-        case 81: launch_gemm1x1_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
+        case 70: rc = launch_gemm1x1_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 128, 4 waves
+        case 71: rc = launch_gemm1x1_pipe<2, 4, 2, 1>(P, st); break;   // 128 x 128, 8 waves
+        case 72: rc = launch_gemm1x1_pipe<2, 4, 2, 2>(P, st); break;   // 128 x 256, 8 waves
+        case 73: rc = launch_gemm1x1_pipe<4, 2, 2, 2>(P, st); break;   // 256 x 128, 8 waves
+        case 74: rc = launch_gemm1x1_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 128, 4 waves
+        case 75: rc = launch_gemm1x1_pipe<2, 4, 1, 1>(P, st); break;   // 64 x 128, 8 waves
+        case 76: rc = launch_gemm1x1_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 64, 4 waves
+        case 77: rc = launch_gemm1x1_pipe<4, 4, 2, 1>(P, st); break;   // 256 x 128, 16 waves
+        case 78: rc = launch_gemm1x1_pipe<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
+        case 79: rc = launch_gemm1x1_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves (1x2 tiles per wave)
+        case 80: rc = launch_gemm1x1_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
+        case 81: rc = launch_gemm1x1_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
         // deeper LDS rings (NS - 1 steps of 64 channels in flight, counted vmcnt)
-        case 82: launch_gemm1x1_pipe<4, 2, 1, 2, 1, false, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
-        case 83: launch_gemm1x1_pipe<2, 2, 1, 2, 1, false, 3>(P, st); break;   // 64 x 128, 4 waves, 3 stages
-        case 84: launch_gemm1x1_pipe<2, 2, 2, 2, 1, false, 3>(P, st); break;   // 128 x 128, 4 waves, 3 stages
-        case 85: launch_gemm1x1_pipe<4, 2, 2, 2, 1, false, 3>(P, st); break;   // 256 x 128, 8 waves, 3 stages
-        case 86: launch_gemm1x1_pipe<2, 2, 1, 2, 1, false, 4>(P, st); break;   // 64 x 128, 4 waves, 4 stages
-        case 87: launch_gemm1x1_pipe<2, 2, 1, 1, 1, false, 4>(P, st); break;   // 64 x 64, 4 waves, 4 stages
-        case 88: launch_gemm1x1_pipe<2, 2, 1, 1, 1, false, 3>(P, st); break;   // 64 x 64, 4 waves, 3 stages
-        case 89: launch_gemm1x1_pipe<2, 2, 2, 1, 1, false, 3>(P, st); break;   // 128 x 64, 4 waves, 3 stages
+        case 82: rc = launch_gemm1x1_pipe<4, 2, 1, 2, 1, false, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
+        case 83: rc = launch_gemm1x1_pipe<2, 2, 1, 2, 1, false, 3>(P, st); break;   // 64 x 128, 4 waves, 3 stages
+        case 84: rc = launch_gemm1x1_pipe<2, 2, 2, 2, 1, false, 3>(P, st); break;   // 128 x 128, 4 waves, 3 stages
+        case 85: rc = launch_gemm1x1_pipe<4, 2, 2, 2, 1, false, 3>(P, st); break;   // 256 x 128, 8 waves, 3 stages
+        case 86: rc = launch_gemm1x1_pipe<2, 2, 1, 2, 1, false, 4>(P, st); break;   // 64 x 128, 4 waves, 4 stages
+        case 87: rc = launch_gemm1x1_pipe<2, 2, 1, 1, 1, false, 4>(P, st); break;   // 64 x 64, 4 waves, 4 stages
+        case 88: rc = launch_gemm1x1_pipe<2, 2, 1, 1, 1, false, 3>(P, st); break;   // 64 x 64, 4 waves, 3 stages
+        case 89: rc = launch_gemm1x1_pipe<2, 2, 2, 1, 1, false, 3>(P, st); break;   // 128 x 64, 4 waves, 3 stages
         // 256 x 256 tiles: half the L2 -> LDS bytes per MFMA of the 128 x 128 tiles (the GEMMs are fill-bound)
-        case 110: launch_gemm1x1_pipe<4, 2, 2, 4>(P, st); break;   // 8 waves of 64 ch x 128 px
-        case 111: launch_gemm1x1_pipe<2, 4, 4, 2>(P, st); break;   // 8 waves of 128 ch x 64 px
-        case 112: launch_gemm1x1_pipe<4, 4, 2, 2>(P, st); break;   // 16 waves of 64 x 64
-        case 113: launch_gemm1x1_pipe<2, 2, 4, 4>(P, st); break;   // 4 waves of 128 x 128
-        case 114: launch_gemm1x1_pipe<2, 4, 2, 4>(P, st); break;   // 128 ch x 512 px, 8 waves of 64 x 128
-        case 115: launch_gemm1x1_pipe<4, 2, 4, 2>(P, st); break;   // 512 ch x 128 px
-        case 116: launch_gemm1x1_pipe<2, 4, 4, 1>(P, st); break;   // 256 ch x 128 px, 8 waves of 128 x 32
-        case 117: launch_gemm1x1_pipe<4, 2, 1, 4>(P, st); break;   // 128 ch x 256 px, 8 waves of 32 x 128
+        case 110: rc = launch_gemm1x1_pipe<4, 2, 2, 4>(P, st); break;   // 8 waves of 64 ch x 128 px
+        case 111: rc = launch_gemm1x1_pipe<2, 4, 4, 2>(P, st); break;   // 8 waves of 128 ch x 64 px
+        case 112: rc = launch_gemm1x1_pipe<4, 4, 2, 2>(P, st); break;   // 16 waves of 64 x 64
+        case 113: rc = launch_gemm1x1_pipe<2, 2, 4, 4>(P, st); break;   // 4 waves of 128 x 128
+        case 114: rc = launch_gemm1x1_pipe<2, 4, 2, 4>(P, st); break;   // 128 ch x 512 px, 8 waves of 64 x 128
+        case 115: rc = launch_gemm1x1_pipe<4, 2, 4, 2>(P, st); break;   // 512 ch x 128 px
+        case 116: rc = launch_gemm1x1_pipe<2, 4, 4, 1>(P, st); break;   // 256 ch x 128 px, 8 waves of 128 x 32
+        case 117: rc = launch_gemm1x1_pipe<4, 2, 1, 4>(P, st); break;   // 128 ch x 256 px, 8 waves of 32 x 128
         // full-line DMA pieces (8 rows x 128 B per instruction, 128-byte LDS rows)
-        case 120: launch_gemm1x1_wide<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves
-        case 121: launch_gemm1x1_wide<2, 2, 2, 2>(P, st); break;   // 128 x 128, 4 waves
-        case 122: launch_gemm1x1_wide<4, 2, 2, 2>(P, st); break;   // 256 x 128, 8 waves
-        case 123: launch_gemm1x1_wide<4, 2, 2, 4>(P, st); break;   // 256 x 256, 8 waves
-        case 124: launch_gemm1x1_wide<2, 2, 1, 2>(P, st); break;   // 64 x 128, 4 waves
-        case 125: launch_gemm1x1_wide<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
-        case 126: launch_gemm1x1_wide<2, 4, 2, 2>(P, st); break;   // 128 x 256, 8 waves
-        case 127: launch_gemm1x1_wide<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
-        case 128: launch_gemm1x1_wide<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
-        case 129: launch_gemm1x1_wide<4, 2, 1, 2, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
+        case 120: rc = launch_gemm1x1_wide<4, 2, 1, 2>(P, st); break;   // 128 x 128, 8 waves
+        case 121: rc = launch_gemm1x1_wide<2, 2, 2, 2>(P, st); break;   // 128 x 128, 4 waves
+        case 122: rc = launch_gemm1x1_wide<4, 2, 2, 2>(P, st); break;   // 256 x 128, 8 waves
+        case 123: rc = launch_gemm1x1_wide<4, 2, 2, 4>(P, st); break;   // 256 x 256, 8 waves
+        case 124: rc = launch_gemm1x1_wide<2, 2, 1, 2>(P, st); break;   // 64 x 128, 4 waves
+        case 125: rc = launch_gemm1x1_wide<2, 2, 1, 1>(P, st); break;   // 64 x 64, 4 waves
+        case 126: rc = launch_gemm1x1_wide<2, 4, 2, 2>(P, st); break;   // 128 x 256, 8 waves
+        case 127: rc = launch_gemm1x1_wide<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
+        case 128: rc = launch_gemm1x1_wide<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
+        case 129: rc = launch_gemm1x1_wide<4, 2, 1, 2, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
         default: done = false;
       }
     }
@@ -182,6 +190,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
       }
     }
     if (done) {
+      if (rc) return FAR3D_ERR_ARG;
       FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
       return FAR3D_OK;
     }

@@ -28,8 +28,8 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // Timing-only ablations of the pipelined kernels (tools/conv_ablation.py builds libfar3d_hip_abl<k>.so with -DFAR3D_ABLATE=k;
 // the results are WRONG by construction, only the launch time means something).  The shipped library is built with 0.
-//   1 no epilogue   2 no LDS-DMA inside the K loop   3 no MFMA (and no fragment reads)   4 no fragment reads (MFMA on the first
-//   fragments)   5 no barrier / vmcnt wait at the top of a step
+// A bit mask:  1 no epilogue   2 no LDS-DMA inside the K loop   4 no MFMA (and no fragment reads)   8 no fragment reads (MFMA on the
+//   step's first fragments)   16 no barrier / vmcnt wait at the top of a step;  e.g. 27 = the bare MFMA loop
 #ifndef FAR3D_ABLATE
 #define FAR3D_ABLATE 0
 #endif
@@ -64,6 +64,8 @@ struct IgemmParams {
   int res_dt, ldr, Hr, Wr;
   int x_vec, y_vec, y2_vec, res_vec;
   int y_rows16;         // plain bf16 output whose pixel rows take 16-byte stores (LDS-transposed coalesced epilogue)
+  long long* chan_sums; // optional [N][Cout] fixed-point sums over the pixels of the STORED output (GEMM kernels, rows16 epilogue)
+  int sums_hw;          // Ho * Wo (>= the pixel tile: a tile then spans at most two images)
 };
 
 template <typename TC> struct Cfg;
@@ -242,11 +244,41 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&
 // that cover whole pixel rows (the MFMA layout alone gives 8-byte pieces 2*ldy bytes apart).  pix_off(pl) -> element
 // offset of local pixel pl in y, or -1.  smem must hold BPX * (2*BM + 16) bytes and is free once every wave has passed
 // the first barrier.
+// Channel sums (P.chan_sums, GEMM kernels): every STORED element v (bf16, or the hi and the lo half of a pair) adds
+// rint(v * 2^FAR3D_SUMS_FRAC_BITS) to a 64-bit integer sum of its (image, channel).  Integer addition is associative, so the result
+// does not depend on tile shapes, on which workgroup finishes first or on how many images a launch holds: run-to-run and
+// sharded-vs-single-rank results are bit-identical although the sums are accumulated with atomics (fp32 partial sums would depend
+// on the grouping).  The quantisation is per element (|error| <= 2^-19; a bf16 value >= 2^-10 is represented exactly).
+// sums_p0: flattened index of the tile's first pixel; lsum_off: byte offset of a [2][BM] int64 scratch behind the staged tile.
+__device__ __forceinline__ void sums_add8(int (&s)[8], float& mx, const u32x4_t& ch) {
+  const unsigned w[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = __uint_as_float(w[k] << 16), b = __uint_as_float(w[k] & 0xffff0000u);
+    mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
+    s[2 * k] += __float2int_rn(a * (float)(1 << FAR3D_SUMS_FRAC_BITS));
+    s[2 * k + 1] += __float2int_rn(b * (float)(1 << FAR3D_SUMS_FRAC_BITS));
+  }
+}
+__device__ __forceinline__ void sums_add8_wide(long long (&s)[8], const u32x4_t& ch) {     // any finite magnitude (rare path)
+  const unsigned w[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s[2 * k] += __double2ll_rn((double)__uint_as_float(w[k] << 16) * (double)(1 << FAR3D_SUMS_FRAC_BITS));
+    s[2 * k + 1] += __double2ll_rn((double)__uint_as_float(w[k] & 0xffff0000u) * (double)(1 << FAR3D_SUMS_FRAC_BITS));
+  }
+}
+
 template <int NW, int WM, int WN, int BM, int BPX, bool PO = false, typename PixFn>   // PO: pair-storage output ([32 hi | 32 lo] blocks)
 __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned char* smem, f32x16_t (&acc)[WM][WN], int m0,
-                                                int wm, int wn, int l31, int hi, PixFn pix_off) {
+                                                int wm, int wn, int l31, int hi, PixFn pix_off, long sums_p0 = -1, int lsum_off = 0) {
   constexpr int EB = PO ? 4 : 2;                       // bytes per logical channel of a staged row
   constexpr int RS = BM * EB + 16, CPP = BM * EB / 16, NT = 64 * NW;
+  constexpr bool SUMS_OK = NT % CPP == 0;              // a thread keeps one 16-byte chunk column over its pixels (every GEMM tile)
+  const bool do_sums = SUMS_OK && P.chan_sums != nullptr && sums_p0 >= 0;     // workgroup-uniform
+  long long* lsum = reinterpret_cast<long long*>(smem + lsum_off);
+  if (do_sums)
+    for (int i = threadIdx.x; i < 2 * BM; i += NT) lsum[i] = 0;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
@@ -289,13 +321,75 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
   __syncthreads();
   bf16_t* y = reinterpret_cast<bf16_t*>(P.y);
   constexpr int ES = EB / 2;                            // stored bf16 elements per logical channel
+  if (!do_sums) {
 #pragma unroll 2
-  for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
-    const int pl = idx / CPP, c = idx - pl * CPP;
-    if (m0 * ES + c * 8 >= P.Cout * ES) continue;
-    const long off = pix_off(pl);
-    if (off < 0) continue;
-    *reinterpret_cast<u32x4_t*>(y + off + m0 * ES + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+    for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
+      const int pl = idx / CPP, c = idx - pl * CPP;
+      if (m0 * ES + c * 8 >= P.Cout * ES) continue;
+      const long off = pix_off(pl);
+      if (off < 0) continue;
+      *reinterpret_cast<u32x4_t*>(y + off + m0 * ES + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+    }
+    return;
+  }
+  // ---- stores + channel sums.  NT % CPP == 0: a thread keeps ONE 16-byte chunk column c (8 stored channels) over all its pixels
+  if constexpr (SUMS_OK) {
+  const int cam0 = (int)(sums_p0 / P.sums_hw);
+  const long bnd = (long)(cam0 + 1) * P.sums_hw;       // first pixel of the next image; a tile holds at most two (sums_hw >= BPX)
+  const int nslots = sums_p0 + BPX > bnd ? 2 : 1;       // workgroup-uniform
+  for (int slot = 0; slot < nslots; ++slot) {
+    int s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mx = 0.f;
+    int cc = -1;
+#pragma unroll 2
+    for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
+      const int pl = idx / CPP, c = idx - pl * CPP;
+      if (m0 * ES + c * 8 >= P.Cout * ES) continue;
+      const long off = pix_off(pl);
+      if (off < 0) continue;
+      const u32x4_t ch = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+      if (slot == 0) *reinterpret_cast<u32x4_t*>(y + off + m0 * ES + c * 8) = ch;
+      if ((sums_p0 + pl >= bnd) == (slot == 1)) { sums_add8(s, mx, ch); cc = c; }
+    }
+    // a magnitude the 32-bit per-wave sums cannot hold (|v| >= 2^(24 - FRAC_BITS) = 64 over up to 64 pixels): redo this slot in 64 bits
+    const bool wide = __any(mx >= (float)(1 << (24 - FAR3D_SUMS_FRAC_BITS)));
+    if (wide) {                                                                   // wave-uniform, practically never taken
+      long long sw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
+        const int pl = idx / CPP, c = idx - pl * CPP;
+        if (m0 * ES + c * 8 >= P.Cout * ES || pix_off(pl) < 0) continue;
+        if ((sums_p0 + pl >= bnd) == (slot == 1)) sums_add8_wide(sw, *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16));
+      }
+      if (cc >= 0) {
+        const int chn = PO ? (cc >> 3) * 32 + (cc & 3) * 8 : cc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (sw[e]) atomicAdd(reinterpret_cast<unsigned long long*>(lsum + slot * BM + chn + e), (unsigned long long)sw[e]);
+      }
+    } else {
+      // lanes with the same chunk column (lane % CPP) add up first: one LDS atomic per (wave, channel)
+#pragma unroll
+      for (int o = 32; o >= CPP && o >= 1; o >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += __shfl_xor(s[e], o);
+      }
+      const int lane = threadIdx.x & 63;
+      const int c = threadIdx.x % CPP;               // == cc wherever this thread saw a pixel
+      if (lane < CPP && m0 * ES + c * 8 < P.Cout * ES) {
+        const int chn = PO ? (c >> 3) * 32 + (c & 3) * 8 : c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (s[e]) atomicAdd(reinterpret_cast<unsigned long long*>(lsum + slot * BM + chn + e), (unsigned long long)(long long)s[e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nslots * BM; i += NT) {
+    const int slot = i / BM, chn = i - slot * BM, cam = cam0 + slot;
+    const long long v = lsum[i];
+    if (v != 0 && cam < P.N && m0 + chn < P.Cout)
+      atomicAdd(reinterpret_cast<unsigned long long*>(P.chan_sums + (long)cam * P.Cout + m0 + chn), (unsigned long long)v);
+  }
   }
 }
 
@@ -641,7 +735,7 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
 #pragma unroll
   for (int it = 0; it < 2 * NTAPS; ++it) {
     const int cur = it & 1, nxt = cur ^ 1;
-    if (it + 1 < 2 * NTAPS && FAR3D_ABLATE != 4) {
+    if (it + 1 < 2 * NTAPS && !(FAR3D_ABLATE & 8)) {
       const int tp = (it + 1) >> 1, kk = (it + 1) & 1;     // tap tp of this step = kernel row KY + tp / 3, column tp % 3
 #pragma unroll
       for (int pl = 0; pl < PL; ++pl) {
@@ -652,9 +746,9 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
       }
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the next fragments' reads ahead of this iteration's MFMAs
-    constexpr int fb = FAR3D_ABLATE == 4 ? 0 : -1;      // ablation 4: every MFMA reads the step's first fragments
+    constexpr int fb = (FAR3D_ABLATE & 8) ? 0 : -1;      // ablation 4: every MFMA reads the step's first fragments
     const int rb = fb < 0 ? cur : fb;
-    if constexpr (FAR3D_ABLATE != 3) {
+    if constexpr (!(FAR3D_ABLATE & 4)) {
     if constexpr (NT == 3) {               // small terms first; term-major so that consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -671,7 +765,7 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
       for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[rb][0][i], bf[rb][0][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FAR3D_ABLATE != 2) dma(it);        // this iteration's share of the next step's LDS-DMA pieces: their issue cost hides under the MFMAs above
+    if constexpr (!(FAR3D_ABLATE & 2)) dma(it);        // this iteration's share of the next step's LDS-DMA pieces: their issue cost hides under the MFMAs above
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -814,7 +908,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   {                                                                                                                    \
     const bool more = (CH) + 1 < nchunks;                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if constexpr (FAR3D_ABLATE != 5) {                                                                                 \
+    if constexpr (!(FAR3D_ABLATE & 16)) {                                                                                 \
     wait_vmcnt<0>();                                                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                      \
     }                                                                                                                  \
@@ -848,7 +942,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     constexpr int STG = NSW == 2 ? ((PAR * 3 + KY) & 1) : KY;                                                          \
     const bool more = (CH) + 1 < nchunks;                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if constexpr (FAR3D_ABLATE != 5) {                                                                                 \
+    if constexpr (!(FAR3D_ABLATE & 16)) {                                                                                 \
     if (NSW == 2) {                                                                                                    \
       if (KY == 1 && more) wait_vmcnt<PLD * GPL>(); else wait_vmcnt<0>();                                              \
     } else {                                                                                                           \
@@ -883,7 +977,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   }   // RPS == 1
 #undef FAR3D_WAITC
 #undef FAR3D_DMA_PIECES
-  if constexpr (FAR3D_ABLATE == 1) { ablate_epilogue<WM, WN>(P, acc); return; }
+  if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
     epilogue_rows16<NW, WM, WN, BM, TH * 32, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
@@ -942,7 +1036,7 @@ __device__ __forceinline__ void gemm_step_pipelined(const unsigned char* smem, c
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int cur = it & 1, nxt = cur ^ 1;
-    if (it + 1 < NIT && FAR3D_ABLATE != 4) {
+    if (it + 1 < NIT && !(FAR3D_ABLATE & 8)) {
       const int sb = ((it + 1) >> 1) * SUBB, kk = (it + 1) & 1;
 #pragma unroll
       for (int i = 0; i < WM; ++i) af[nxt][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + sb + aaddr[kk][i]);
@@ -950,8 +1044,8 @@ __device__ __forceinline__ void gemm_step_pipelined(const unsigned char* smem, c
       for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + sb + baddr[kk][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int rb = FAR3D_ABLATE == 4 ? 0 : cur;
-    if constexpr (FAR3D_ABLATE != 3) {
+    const int rb = (FAR3D_ABLATE & 8) ? 0 : cur;
+    if constexpr (!(FAR3D_ABLATE & 4)) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1121,7 +1215,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   // wait until step S has landed: the steps S+1 .. S+D-1 that were already issued may stay in flight
 #define FAR3D_GEMM_SYNC(S)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if constexpr (FAR3D_ABLATE == 5) {                                                                       \
+    if constexpr (FAR3D_ABLATE & 16) {                                                                       \
     } else if constexpr (D == 1) {                                                                           \
       wait_vmcnt<0>();                                                                                       \
     } else {                                                                                                 \
@@ -1131,14 +1225,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
         if ((S) + q_ < nsteps) units_ += ((S) + q_ < nfull) ? 2 : 1;                                         \
       wait_vmcnt_units<UNIT, 2 * (D - 1)>(units_);                                                           \
     }                                                                                                        \
-    if constexpr (FAR3D_ABLATE != 5) __builtin_amdgcn_s_barrier();                                           \
+    if constexpr (!(FAR3D_ABLATE & 16)) __builtin_amdgcn_s_barrier();                                           \
     asm volatile("" ::: "memory");                                                                           \
     __builtin_amdgcn_sched_barrier(0);
   // the barrier also says that every wave is done with step S-1, whose stage is the one step S+D goes into
 #define FAR3D_GEMM_STEP(STG, S)                                                                              \
   {                                                                                                          \
     FAR3D_GEMM_SYNC(S)                                                                                       \
-    if constexpr (FAR3D_ABLATE != 2) {                                                                       \
+    if constexpr (!(FAR3D_ABLATE & 2)) {                                                                     \
     if ((S) + D < nfull) issue((S) + D, (((STG) + D) % NS) * STAGE, 2);                                      \
     else if ((S) + D < nsteps) issue((S) + D, (((STG) + D) % NS) * STAGE, 1);                                \
     }                                                                                                        \
@@ -1163,18 +1257,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   }
 #undef FAR3D_GEMM_STEP
 #undef FAR3D_GEMM_SYNC
-  if constexpr (FAR3D_ABLATE == 1) { ablate_epilogue<WM, WN>(P, acc); return; }
+  if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
+    constexpr int RING = NS * 2 * (BM + BP) * 64, OUTB = BP * (BM * (PAIR ? 4 : 2) + 16);
     epilogue_rows16<NW, WM, WN, BM, BP, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const long p = (long)p0 + pl;
       if (p >= Npix) return -1L;
       const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
-    });
+    }, (long)p0, RING > OUTB ? RING : OUTB);
     return;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
 #endif
+}
+
+// far3d_conv2d_nhwc with channel sums: what a GEMM tile needs (a refusal is an error of the call, never a silent fallback)
+template <int BM, int BP, int NTHREADS>
+static bool gemm_sums_ok(const IgemmParams& P, size_t lds_sums) {
+  static_assert(BP / (NTHREADS / 64) <= 64, "32-bit per-wave sums hold 64 pixels of |v| < 2^(24 - FRAC_BITS)");
+  if (!P.y_rows16) { far3d_set_error("far3d_conv2d_nhwc: channel sums need the coalesced bf16 / pair output path (16-byte aligned rows, no residual / second output)"); return false; }
+  if (P.sums_hw < BP) { far3d_set_error("far3d_conv2d_nhwc: channel sums need Ho*Wo (%d) >= the tile's %d pixels", P.sums_hw, BP); return false; }
+  if (lds_sums > 163840) { far3d_set_error("far3d_conv2d_nhwc: this tile has no LDS left for the channel-sum scratch"); return false; }
+  return true;
 }
 
 template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2>
@@ -1184,10 +1289,13 @@ static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
   constexpr size_t lds_ring = (size_t)NS * 2 * (BM + BP) * 64, lds_out = (size_t)BP * (BM * (PAIR ? 4 : 2) + 16);
   static_assert(lds_ring <= 163840, "LDS budget");
-  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
+  constexpr size_t lds0 = lds_ring > lds_out ? lds_ring : lds_out, lds_sums = lds0 + 2 * BM * sizeof(long long);
+  const size_t lds = P.chan_sums ? lds_sums : lds0;
+  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return 1;
   static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!attr_set && lds_sums > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(lds_sums <= 163840 ? lds_sums : lds0));
     attr_set = true;
   }
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
@@ -1352,12 +1460,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
 #undef FAR3D_WIDE_STEP
 #undef FAR3D_WIDE_SYNC
   if (P.y_rows16) {
+    constexpr int RING = NS * (BM + BP) * 128, OUTB = BP * (BM * 2 + 16);
     epilogue_rows16<NW, WM, WN, BM, BP, false>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const long p = (long)p0 + pl;
       if (p >= Npix) return -1L;
       const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
-    });
+    }, (long)p0, RING > OUTB ? RING : OUTB);
     return;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
@@ -1371,10 +1480,13 @@ static int launch_gemm1x1_wide(const IgemmParams& P, hipStream_t st) {
   const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
   constexpr size_t lds_ring = (size_t)NS * (BM + BP) * 128, lds_out = (size_t)BP * (BM * 2 + 16);
   static_assert(lds_ring <= 163840, "LDS budget");
-  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
+  constexpr size_t lds0 = lds_ring > lds_out ? lds_ring : lds_out, lds_sums = lds0 + 2 * BM * sizeof(long long);
+  const size_t lds = P.chan_sums ? lds_sums : lds0;
+  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return 1;
   static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_wide_kernel<WGM, WGN, WM, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!attr_set && lds_sums > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_wide_kernel<WGM, WGN, WM, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(lds_sums <= 163840 ? lds_sums : lds0));
     attr_set = true;
   }
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;

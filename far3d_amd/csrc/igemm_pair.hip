@@ -31,20 +31,20 @@ int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
   }
   if (k1) {
     switch (tile) {
-      case 170: launch_gemm1x1_pipe<2, 2, 2, 2, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 4 waves
-      case 171: launch_gemm1x1_pipe<2, 4, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 8 waves
-      case 172: launch_gemm1x1_pipe<2, 4, 2, 2, 3, true>(P, st); return FAR3D_OK;   // 128 x 256, 8 waves
-      case 173: launch_gemm1x1_pipe<4, 2, 2, 2, 3, true>(P, st); return FAR3D_OK;   // 256 x 128, 8 waves
-      case 174: launch_gemm1x1_pipe<2, 2, 1, 2, 3, true>(P, st); return FAR3D_OK;   // 64 x 128, 4 waves
-      case 175: launch_gemm1x1_pipe<2, 4, 1, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 128, 8 waves
-      case 176: launch_gemm1x1_pipe<2, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 64, 4 waves
-      case 177: launch_gemm1x1_pipe<4, 4, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 256 x 128, 16 waves
-      case 178: launch_gemm1x1_pipe<2, 4, 1, 2, 3, true>(P, st); return FAR3D_OK;   // 64 x 256, 8 waves
-      case 179: launch_gemm1x1_pipe<4, 2, 1, 2, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 8 waves (1x2 tiles per wave)
-      case 180: launch_gemm1x1_pipe<2, 2, 1, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 64, 4 waves
-      case 181: launch_gemm1x1_pipe<4, 4, 1, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 128, 16 waves
-      case 279: launch_gemm1x1_pipe<4, 2, 1, 2, 1, true>(P, st); return FAR3D_OK;   // hi only: 128 x 128, 8 waves
-      case 280: launch_gemm1x1_pipe<2, 2, 1, 1, 1, true>(P, st); return FAR3D_OK;   // hi only: 64 x 64, 4 waves
+      case 170: return launch_gemm1x1_pipe<2, 2, 2, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 4 waves
+      case 171: return launch_gemm1x1_pipe<2, 4, 2, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 8 waves
+      case 172: return launch_gemm1x1_pipe<2, 4, 2, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 256, 8 waves
+      case 173: return launch_gemm1x1_pipe<4, 2, 2, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 256 x 128, 8 waves
+      case 174: return launch_gemm1x1_pipe<2, 2, 1, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 128, 4 waves
+      case 175: return launch_gemm1x1_pipe<2, 4, 1, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 128, 8 waves
+      case 176: return launch_gemm1x1_pipe<2, 2, 2, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 64, 4 waves
+      case 177: return launch_gemm1x1_pipe<4, 4, 2, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 256 x 128, 16 waves
+      case 178: return launch_gemm1x1_pipe<2, 4, 1, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 256, 8 waves
+      case 179: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 8 waves (1x2 tiles per wave)
+      case 180: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 64, 4 waves
+      case 181: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 16 waves
+      case 279: return launch_gemm1x1_pipe<4, 2, 1, 2, 1, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // hi only: 128 x 128, 8 waves
+      case 280: return launch_gemm1x1_pipe<2, 2, 1, 1, 1, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // hi only: 64 x 64, 4 waves
       default: break;
     }
   }

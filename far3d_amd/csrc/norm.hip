@@ -199,9 +199,10 @@ __device__ __forceinline__ void sum_parts(const float2* __restrict__ src, int np
 // gate[n][c] = hsigmoid( sum_k fcw[c][k] * mean[n][k] + fcb[c] ).  A workgroup owns 16 output channels of one image: it first
 // adds the per-workgroup partial channel sums of the pooling kernel (every workgroup of the image does; they are L2 hits), then
 // each wave does 4 rows of the mat-vec.
+// fixed != null: the channel sums arrive as 64-bit fixed-point integers [N][C] (far3d_conv2d_nhwc's chan_sums) instead of partials.
 __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ part, const float* __restrict__ fcw,
                                                        const float* __restrict__ fcb, float* __restrict__ gate, int C,
-                                                       float inv_hw, int nparts) {
+                                                       float inv_hw, int nparts, const long long* __restrict__ fixed) {
   __shared__ float mean[1024];
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float2* src = reinterpret_cast<const float2*>(part) + (long)n * nparts * C;
@@ -219,7 +220,12 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
     for (int j = 0; j < 4; ++j)
       w[i][j] = (k < C && c0 + j < C) ? *reinterpret_cast<const float4*>(fcw + (long)(c0 + j) * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  {
+  if (fixed) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (threadIdx.x + j * 256 < C)
+        mean[threadIdx.x + j * 256] = (float)((double)fixed[(long)n * C + threadIdx.x + j * 256] * (1.0 / (1 << FAR3D_SUMS_FRAC_BITS)) * (double)inv_hw);
+  } else {
     float2 sm[4];                                  // C <= 1024: channels t, t + 256, t + 512, t + 768
     sum_parts<4>(src, nparts, C, threadIdx.x, 256, sm);
 #pragma unroll
@@ -250,7 +256,11 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x, const float* __restrict__ gate,
                                                         const T* __restrict__ idn, T* __restrict__ y, long total4, int C,
-                                                        int HW, int ldx, long xs, int ldi, long is, int ldy, long ys) {
+                                                        int HW, int ldx, long xs, int ldi, long is, int ldy, long ys,
+                                                        long long* __restrict__ consumed, int nconsumed) {
+  // the fixed-point channel sums the gate kernel (an earlier launch) read are returned to zero for their next producer
+  if (consumed)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nconsumed; i += (long)gridDim.x * blockDim.x) consumed[i] = 0;
   const int cq = C / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cq) * 4;
@@ -273,8 +283,9 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
 // needs zeroing, and one workspace (sized for the widest layer) serves a whole stream of calls.
 extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                               float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi,
-                              long i_img_stride, int ldy, long y_img_stride, void* stream) {
+                              long i_img_stride, int ldy, long y_img_stride, long long* chan_sums, void* stream) {
   FAR3D_CHECK_ARG(x && fcw && fcb && y && scratch, "far3d_ese_nhwc: null pointer argument");
+  FAR3D_CHECK_ARG(!chan_sums || dt != FAR3D_DT_F32, "far3d_ese_nhwc: fixed-point channel sums describe a bf16 / pair map");
   FAR3D_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && (!identity || ldi % 4 == 0),
                   "far3d_ese_nhwc: bad sizes (C=%d must be a multiple of 4, <= 1024)", C);
   FAR3D_CHECK_ARG(dt == FAR3D_DT_F32 || dt == FAR3D_DT_BF16 || dt == FAR3D_DT_BF16_PAIR, "far3d_ese_nhwc: unsupported dtype");
@@ -282,20 +293,20 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   hipStream_t st = (hipStream_t)stream;
   float* sums = scratch;
   float* gate = scratch + (long)N * FAR3D_SUMS_MAX_PARTS * C * 2;
-  const int nparts = launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
-  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, nparts);
+  const int nparts = chan_sums ? 0 : launch_chan_sums(x, dt, sums, N, HW, C, ldx, x_img_stride, st);
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, sums, fcw, fcb, gate, C, 1.f / HW, nparts, (const long long*)chan_sums);
   const long total4 = (long)N * HW * (C / 4);
   long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (dt == FAR3D_DT_F32)
     hipLaunchKernelGGL(ese_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, gate,
-                       (const float*)identity, (float*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
+                       (const float*)identity, (float*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride, chan_sums, N * C);
   else if (dt == FAR3D_DT_BF16_PAIR)
     hipLaunchKernelGGL(ese_apply_kernel<pair_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const pair_t*)x, gate,
-                       (const pair_t*)identity, (pair_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
+                       (const pair_t*)identity, (pair_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride, chan_sums, N * C);
   else
     hipLaunchKernelGGL(ese_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, gate,
-                       (const bf16_t*)identity, (bf16_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride);
+                       (const bf16_t*)identity, (bf16_t*)y, total4, C, HW, ldx, x_img_stride, ldi, i_img_stride, ldy, y_img_stride, chan_sums, N * C);
   FAR3D_CHECK_LAUNCH("far3d_ese_nhwc");
   return FAR3D_OK;
 }

@@ -201,6 +201,7 @@ class Far3DEngine:
             stages.append(blocks)
         bb["stages"] = stages
         self.bb = bb
+        self._esums = torch.zeros((self.cfg["num_cams"], max(self.spec["stage_out_ch"])), dtype=torch.int64, device=dev)
 
     def _prepare_neck(self):
         sd, cfg, dev = self.sd, self.cfg, self.dev
@@ -366,6 +367,11 @@ class Far3DEngine:
         Lb = spec["layer_per_block"]
         # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
         scratch = self._buf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
+        # fixed-point channel sums the concat convolutions accumulate in their epilogue (the eSE pooling without a second pass over the
+        # map); zero at rest: every eSE call consumes and re-zeroes them, and a scene start re-zeroes them in case a frame was aborted
+        esums = self._esums if act == torch.bfloat16 else None
+        if esums is not None and not torch.cuda.is_current_stream_capturing():
+            esums.zero_()
         x = ops.stem_im2col(img, act, pair=pair)
         x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
@@ -395,7 +401,9 @@ class Far3DEngine:
                     dst = cat[..., (cur_in + i * sc) * cs: (cur_in + (i + 1) * sc) * cs]
                     ops.conv2d_nhwc(src, pc, out=dst, act="relu")
                     src = dst
-                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc * cs), act), act="relu")
+                fuse = esums is not None and ops.conv_can_fuse_sums(cat, blk["concat"])
+                xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc * cs), act), act="relu",
+                                     sums=esums if fuse else None)
                 if last:
                     out = self._buf(("stage", si), (N, H, W, oc * cs), act)
                     nxt = None
@@ -403,7 +411,7 @@ class Far3DEngine:
                     nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, (oc + Lb * sc) * cs), act)
                     out = nxt[..., :oc * cs]
                 ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in * cs] if bi > 0 else None, out=out, scratch=scratch,
-                             pair=pair)
+                             pair=pair, sums=esums if fuse else None)
                 if not last:
                     cat, cur_in = nxt, oc
             stage_in = self._bufs[(self._par, "stage", si)]

@@ -29,11 +29,11 @@ SIGNATURES = {
                                 [_p, _p, _p, c_float, c_float, c_int, c_int, c_int, _p]),
     "far3d_conv2d_nhwc": (c_int, [_p, c_int, _p, c_int, _p, _p, c_int] + [c_int] * 5 + [c_long] + [c_int] * 4 +
                           [c_long] + [c_int] * 5 + [_p, c_int, c_int, c_long, c_int, c_int] +
-                          [_p, c_int, c_int, c_long, _p, _p, c_int, _p]),
+                          [_p, c_int, c_int, c_long, _p, _p, _p, c_int, _p]),
     "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p, c_int] + [c_int] * 8 + [c_float, _p, c_int, c_int, _p]),
     "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, c_int, _p]),
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
-                               c_int, c_long, _p]),
+                               c_int, c_long, _p, _p]),
     "far3d_cam_embed_chain": (c_int, [_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_int, _p]),
     "far3d_groupnorm_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p]),
     "far3d_maxpool3x3s2_nhwc": (c_int, [_p, c_int, _p] + [c_int] * 7 + [c_long, _p]),

@@ -276,11 +276,13 @@ def conv_tile(x, pc):
     return _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W) if x.dtype == torch.bfloat16 else 0
 
 
-def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0):
+def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2_scale=None, y2_shift=None, tile=0, sums=None):
     """x: (N,H,W,Cin) NHWC view (f32|bf16).  pc: PackedConv.  out: optional (N,Ho,Wo,Cout) NHWC view to write
     into (e.g. a channel slice of an OSA concat buffer).  Returns out.
     Pair storage: with split weights (compute="bf16x3") a bf16 `x` is a pair-stored map (N,H,W,2*Cin) (pair_from_float); a bf16
-    `out` / `res` is then pair-stored too ((..., 2*Cout)), an f32 `out` / `y2` is plain."""
+    `out` / `res` is then pair-stored too ((..., 2*Cout)), an f32 `out` / `y2` is plain.
+    sums: optional zeroed int64 (N, Cout) device tensor -- the layer's epilogue adds the fixed-point channel sums of its stored output
+    (far3d_hip.h, chan_sums; see conv_can_fuse_sums); ese_nhwc(sums=...) consumes them."""
     lib = _lib.require_device()
     N, H, W, Cx = x.shape
     pair_in = _is_pair_input(x, pc)
@@ -322,9 +324,38 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
         _ptr(x), DT_BF16_PAIR if pair_in else _dt(x), _ptr(pc.w), pc.w_code, _ptr(pc.bias) if pc.bias is not None else None, _ptr(out),
         DT_BF16_PAIR if pair_out else _dt(out),
         N, H, W, Cin, ldx, xs, Ho, Wo, pc.Cout, ldy, ys, pc.KH, pc.KW, pc.stride, pc.pad, ACT[act],
-        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, tile,
+        rp, rdt, ldr, rs, Hr, Wr, y2p, y2dt, ldy2, y2s, sp, hp, _sums_ptr(sums, N, pc.Cout), tile,
         _stream(x)), "far3d_conv2d_nhwc")
     return out
+
+
+SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
+_GEMM_TILES = set(range(70, 90)) | set(range(110, 130)) | set(range(170, 182)) | {279, 280}
+_GEMM_TILE_PIXELS = 512  # no GEMM tile holds more pixels
+
+
+def _sums_ptr(sums, N, C):
+    if sums is None:
+        return None
+    if sums.dtype != torch.int64 or sums.numel() < N * C or not sums.is_contiguous():
+        raise ValueError("channel sums: contiguous int64 tensor of at least N*C = %d elements" % (N * C))
+    return _ptr(sums)
+
+
+def conv_can_fuse_sums(x, pc, out_dtype=torch.bfloat16):
+    """True if conv2d_nhwc(x, pc, sums=...) is possible: a 1x1 / stride-1 layer whose measured tile is one of the pipelined GEMM
+    kernels, bf16 or pair output, and a map of at least one pixel tile (otherwise the eSE op pools the map itself)."""
+    N, H, W, Cx = x.shape
+    if pc.KH != 1 or pc.KW != 1 or pc.stride != 1 or pc.pad != 0 or out_dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        return False
+    if H * W < _GEMM_TILE_PIXELS or pc.Cout % 8:
+        return False
+    pair_in = _is_pair_input(x, pc)
+    Cin = Cx // 2 if pair_in else Cx
+    if Cin % 32:
+        return False
+    tile = _pair_tile(pc, Cin, N * H * W, 0) if pair_in else _tuned_tile(pc.Cout, Cin, 1, 1, N * H * W)
+    return tile in _GEMM_TILES or (pair_in and tile == 0)
 
 
 def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0):
@@ -399,10 +430,11 @@ def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=
     return res if len(res) > 1 else y
 
 
-def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, pair=False):
+def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, pair=False, sums=None):
     """x * hsigmoid(fc(mean_hw x)) (+ identity) on NHWC views (any channel slice / pixel stride).  scratch: optional
     ese_scratch_floats(N, C) f32 workspace (never needs zeroing; the pooling is deterministic).  pair: x / identity / out are
-    pair-stored bf16 maps (2C stored channels)."""
+    pair-stored bf16 maps (2C stored channels).  sums: the int64 channel sums conv2d_nhwc(..., sums=) accumulated while it produced
+    x -- the pooling pass is skipped and the sums come back zeroed."""
     lib = _lib.require_device()
     N, H, W, C = x.shape
     if pair:
@@ -422,7 +454,7 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, pair=False):
     if scratch.numel() < ese_scratch_floats(N, C):
         raise ValueError("ese_nhwc: scratch needs %d floats" % ese_scratch_floats(N, C))
     _lib.check(lib.far3d_ese_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(fcw), _ptr(fcb), ip, _ptr(out), _ptr(scratch), N, H * W, C,
-                                  ldx, xs, ldi, isd, ldy, ys, _stream(x)), "far3d_ese_nhwc")
+                                  ldx, xs, ldi, isd, ldy, ys, _sums_ptr(sums, N, C), _stream(x)), "far3d_ese_nhwc")
     return out
 
 

@@ -35,6 +35,8 @@ extern "C" {
 #define FAR3D_DT_BF16_PAIR 3
 /* upper bound on the per-image partial-sum workgroups of far3d_ese_nhwc / far3d_groupnorm_nhwc (sizes their scratch) */
 #define FAR3D_SUMS_MAX_PARTS 32
+/* fraction bits of the fixed-point channel sums of far3d_conv2d_nhwc (chan_sums) */
+#define FAR3D_SUMS_FRAC_BITS 18
 /* partial sums [N][PARTS][C][2] + gates / group statistics [N][C] */
 #define FAR3D_SUMS_SCRATCH_FLOATS(N, C) ((long)(N) * (C) * (2 * FAR3D_SUMS_MAX_PARTS + 1))
 
@@ -115,12 +117,22 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  *    x_dt = FAR3D_DT_BF16_PAIR (w_dt must be FAR3D_DT_F32_BF16X3; y_dt pair or f32; res_dt any): 1-5 register-staged kernel (any
  *    kernel size / stride); 150-168, 191-197 the pipelined 3x3 shapes 50-68 / 91-97 with split products; 170-181 the pipelined 1x1
  *    shapes; 252, 260, 265, 279, 280: the hi halves only (ONE bf16 product per term: a single-bf16 layer inside a pair-stored
- *    network).  An id the layer cannot use is an error, not a silent fallback. */
+ *    network).  An id the layer cannot use is an error, not a silent fallback.
+ *    bf16, 1x1/s1 only: 82-89 the GEMM tiles with 3- / 4-deep LDS rings, 110-117 256 x 256 (and other large) tiles, 120-129 the
+ *    GEMM with full-line LDS-DMA pieces (8 rows x 128 bytes per piece instead of 16 x 64).
+ * chan_sums (optional, DEVICE int64 [N][Cout]; 1x1/s1 layers on a pipelined GEMM tile with a bf16 or pair output, Ho*Wo >= the
+ *    tile's pixel count): every STORED output element v (for a pair output: its hi and its lo half) ADDS
+ *    rint(v * 2^FAR3D_SUMS_FRAC_BITS) to chan_sums[n][channel] -- the global average pool of VoVNet's eSE block (ref
+ *    models/backbones/vovnet.py:173-185) comes out of the concat convolution's epilogue instead of a second pass over its output.
+ *    Integer sums are associative: the result does not depend on tile shapes, workgroup order or the number of images in the launch
+ *    (bit-identical run to run, hipGraph vs eager, camera-sharded vs single rank) although they are accumulated with atomics.
+ *    The caller provides zeros; far3d_ese_nhwc(chan_sums) consumes them and returns them to zero. */
 int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y, int y_dt,
                       int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho, int Wo, int Cout, int ldy,
                       long y_img_stride, int KH, int KW, int stride, int pad, int act, const void* res, int res_dt,
                       int ldr, long res_img_stride, int Hr, int Wr, void* y2, int y2_dt, int ldy2,
-                      long y2_img_stride, const float* y2_scale, const float* y2_shift, int tile, void* stream);
+                      long y2_img_stride, const float* y2_scale, const float* y2_shift, long long* chan_sums, int tile,
+                      void* stream);
 
 /* Multi-head self-attention core: out = softmax(q k^T * scale) v per head (flash-style, no score tensor in HBM).
  * Replaces the bmm/softmax/bmm inside torch.nn.MultiheadAttention as wrapped by mmcv's MultiheadAttention
@@ -151,10 +163,12 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
  * scratch: device workspace of FAR3D_SUMS_SCRATCH_FLOATS(N, C) floats; never needs zeroing.  The average pool writes
  * per-workgroup partial channel sums with plain stores and the gate kernel adds them in index order, so the sums are
- * deterministic: no atomics, bit-identical run to run and hipGraph vs eager.  C a multiple of 4, <= 1024. */
+ * deterministic: no atomics, bit-identical run to run and hipGraph vs eager.  C a multiple of 4, <= 1024.
+ * chan_sums (optional, bf16 / pair maps): the fixed-point channel sums [N][C] that far3d_conv2d_nhwc accumulated while it wrote x;
+ * the pooling pass is skipped, the gate is computed from them and the apply kernel returns them to zero for the next producer. */
 int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y,
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
-                   int ldy, long y_img_stride, void* stream);
+                   int ldy, long y_img_stride, long long* chan_sums, void* stream);
 
 /* GroupNorm(groups, C) (+ReLU) on dense NHWC maps.  Replaces nn.GroupNorm(32, 256)+ReLU of the depth head,
  * ref models/depth_predictor/depth_predictor.py:43-45.  scratch: FAR3D_SUMS_SCRATCH_FLOATS(N, C) floats (no zeroing needed);

@@ -1,9 +1,10 @@
 """Where does the time of the pipelined convolution / GEMM kernels go?  Timing-only ablations (far3d_amd/csrc/igemm_kernels.hpp,
-FAR3D_ABLATE): the same launch with one ingredient removed -- 1 the epilogue, 2 the LDS-DMA inside the K loop, 3 the MFMAs (and
-the fragment reads that feed them), 4 the fragment reads only, 5 the barrier + vmcnt wait at the top of every step.  The outputs
-of an ablated launch are wrong by construction; only its duration is used.
+FAR3D_ABLATE, a bit mask): the same launch with ingredients removed -- 1 the epilogue, 2 the LDS-DMA inside the K loop, 4 the MFMAs
+(and the fragment reads that feed them), 8 the fragment reads only, 16 the barrier + vmcnt wait at the top of every step; 26 = MFMA
+loop + epilogue only, 27 = the bare MFMA loop, 21 = the bare DMA stream.  The outputs of an ablated launch are wrong by construction;
+only its duration is used.
 
-  python tools/conv_ablation.py build        # here (no GPU needed): far3d_amd/libfar3d_hip_abl<k>.so, k = 1..5
+  python tools/conv_ablation.py build        # here (no GPU needed): far3d_amd/libfar3d_hip_abl<k>.so for every variant
   python tools/conv_ablation.py run <k>      # on the GPU box: one line per layer for variant k (0 = the shipped library)
   python tools/conv_ablation.py all          # on the GPU box: every variant in its own process, one table
 """
@@ -14,7 +15,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = {0: "shipped", 1: "no epilogue", 2: "no in-loop DMA", 3: "no MFMA / fragment reads", 4: "no fragment reads", 5: "no barrier / vmcnt wait"}
+VARIANTS = {0: "shipped", 1: "no epilogue", 2: "no in-loop DMA", 4: "no MFMA / fragment reads", 8: "no fragment reads", 16: "no barrier / vmcnt wait",
+            26: "MFMA loop + epilogue", 27: "bare MFMA loop", 21: "bare DMA stream", 5: "DMA + barriers, no epilogue", 11: "MFMA + barriers"}
 # (name, N, H, W, Cin, Cout, k, tile): the shipped tile of each layer at the benchmarked size (far3d_amd/data/tuning_mi355x.json)
 LAYERS = [("s2.c1", 7, 160, 240, 128, 128, 3, 60), ("s3.c1", 7, 80, 120, 160, 160, 3, 92), ("s3.c0", 7, 80, 120, 512, 160, 3, 101),
           ("s4.c1", 7, 40, 60, 192, 192, 3, 100), ("s4.c0", 7, 40, 60, 768, 192, 3, 100), ("s5.c1", 7, 20, 30, 224, 224, 3, 102),
@@ -31,7 +33,7 @@ def build():
     fbuild.build(verbose=False)
     objs = [os.path.join(fbuild.OBJ, f) for f in os.listdir(fbuild.OBJ) if f.endswith(".o") and f != "igemm.o"]
     procs = []
-    for k in range(1, 6):
+    for k in [v for v in VARIANTS if v]:
         o = os.path.join("/tmp", "igemm_abl%d.o" % k)
         procs.append((k, o, subprocess.Popen([fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_ABLATE=%d" % k, "-c", os.path.join(fbuild.CSRC, "igemm.hip"), "-o", o])))
     for k, o, p in procs:
