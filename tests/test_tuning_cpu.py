@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _dispatch_ids():
     src = open(os.path.join(ROOT, "far3d_amd", "csrc", "igemm.hip")).read()
     ids = {"igemm": set(), "dma": set(), "patch": set(), "pipe3": set(), "gemm": set()}
-    for m in re.finditer(r"case (\d+): (launch_[a-z0-9_]+)<", src):
+    for m in re.finditer(r"case (\d+): (?:rc = |return )?(launch_[a-z0-9_]+)<", src):
         tile, fn = int(m.group(1)), m.group(2)
         key = {"launch_igemm": "igemm", "launch_igemm_dma": "dma", "launch_conv3x3_patch": "patch",
                "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm", "launch_gemm1x1_wide": "gemm"}[fn]
@@ -56,7 +56,7 @@ def test_pair_tuning_table_names_only_implemented_tiles():
     """Same for the pair-storage (bf16x3) table: ids 150+ of igemm_pair.hip, 1..5 for the register-staged kernel."""
     src = open(os.path.join(ROOT, "far3d_amd", "csrc", "igemm_pair.hip")).read()
     ids = {"igemm": set(), "pipe3": set(), "gemm": set()}
-    for m in re.finditer(r"case (\d+): (launch_[a-z0-9_]+)<", src):
+    for m in re.finditer(r"case (\d+): (?:rc = |return )?(launch_[a-z0-9_]+)<", src):
         ids[{"launch_igemm": "igemm", "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm"}[m.group(2)]].add(int(m.group(1)))
     table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json")))
     assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5}
