@@ -1,0 +1,2 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/call21; mkdir -p $O; cd $R
+timeout 600 python tools/conv_ablation.py all 2>&1 | tee $O/conv_ablation.txt
