@@ -85,3 +85,30 @@ def test_load_checkpoint_unwraps_runner_layout_ddp_prefix_and_shared_branches(tm
     del ck["module.pts_bbox_head.reference_points.weight"]
     with pytest.raises(KeyError):
         weights.normalize_state_dict(dict(state_dict=ck), strict_schema=spec)
+
+
+def test_channel_sum_fusion_is_offered_exactly_where_the_gemm_epilogue_can_produce_it():
+    """Host rule of the eSE pooling fusion (ops.conv_can_fuse_sums): the OSA concat layers of the benchmarked frame -- 1x1, bf16 or
+    pair-stored, a measured pipelined-GEMM tile, maps of at least one pixel tile -- qualify in every stage and at the per-rank camera
+    counts of a sharded run; small maps, fp32 maps, 3x3 layers and untuned shapes do not (the eSE op then pools the map itself)."""
+    from far3d_amd import ops
+    spec = weights.VOV_SPECS["V-99-eSE"]
+    hw = [(160, 240), (80, 120), (40, 60), (20, 30)]
+    in_ch = spec["stem"][2]
+    for si in range(4):
+        sc, oc = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
+        for first in (True, False):
+            cin = (in_ch if first else oc) + 5 * sc
+            pc = ops.PackedConv(torch.zeros(oc, cin, 1, 1), torch.zeros(oc), dtype=torch.bfloat16, device="cpu")
+            for ncam in (7, 4, 2, 1):
+                x = torch.empty(ncam, hw[si][0], hw[si][1], cin, dtype=torch.bfloat16)
+                assert ops.conv_can_fuse_sums(x, pc), (si, first, ncam)
+            assert not ops.conv_can_fuse_sums(torch.empty(7, 8, 8, cin, dtype=torch.bfloat16), pc)            # 64-pixel maps (configs[0])
+            assert not ops.conv_can_fuse_sums(torch.empty(7, hw[si][0], hw[si][1], cin, dtype=torch.float32), pc)
+            if spec["block_per_stage"][si] == 1:
+                break
+        in_ch = oc
+    pc3 = ops.PackedConv(torch.zeros(128, 128, 3, 3), torch.zeros(128), pad=1, dtype=torch.bfloat16, device="cpu")
+    assert not ops.conv_can_fuse_sums(torch.empty(7, 160, 240, 128, dtype=torch.bfloat16), pc3)
+    odd = ops.PackedConv(torch.zeros(96, 352, 1, 1), torch.zeros(96), dtype=torch.bfloat16, device="cpu")       # no entry in the table
+    assert not ops.conv_can_fuse_sums(torch.empty(7, 40, 60, 352, dtype=torch.bfloat16), odd)
