@@ -232,11 +232,13 @@ class Far3DOracle:
         r = torch.cat([ref, torch.ones_like(ref[..., :1])], dim=-1)
         return (pose.unsqueeze(1) @ r.unsqueeze(-1)).squeeze(-1)[..., :3]
 
-    def _proposals(self, outs_roi, feat_flatten, data, pad_hw):   # farhead.py:571-610,710-827 (topk=1 path)
+    def _proposals(self, outs_roi, feat_flatten, data, pad_hw, forced_depth=None):   # farhead.py:571-610,710-827 (topk=1 path)
         h = "pts_bbox_head."
         pc = self.P(h + "pc_range")
         pred_depth = outs_roi["pred_depth"]
         depth_idx = torch.argmax(pred_depth.permute(0, 2, 3, 1), dim=-1, keepdim=True)   # (BN,H,W,1)
+        if forced_depth is not None:    # test rigs: resolve near-ties of the depth-bin argmax the way the device did
+            depth_idx = forced_depth(pred_depth, depth_idx)
         valid = outs_roi["valid_indices"]
         C = feat_flatten.shape[-1]
         ctx = feat_flatten[valid.repeat(1, 1, C)].reshape(-1, C)
@@ -345,7 +347,7 @@ class Far3DOracle:
         return torch.stack(outs)
 
     # ------------------------------------------------------------------ a6 + a10 + a11: FarHead.forward (farhead.py:533-693)
-    def head_forward(self, mlvl_feats, outs_roi, data, prev_exists, pad_hw, forced_topk=None):
+    def head_forward(self, mlvl_feats, outs_roi, data, prev_exists, pad_hw, forced_topk=None, forced_depth=None):
         h = "pts_bbox_head."
         cfg = self.cfg
         self._pre_update_memory(data, prev_exists)
@@ -365,7 +367,7 @@ class Far3DOracle:
             level_start.append(level_start[-1] + hh * ww)
         ref = self.P(h + "reference_points.weight")[None]
         query_pos = self._mlp2(pos2posemb3d(ref), h + "query_embedding")
-        ref2d, ctx = self._proposals(outs_roi, feat_flatten, data, pad_hw)
+        ref2d, ctx = self._proposals(outs_roi, feat_flatten, data, pad_hw, forced_depth)
         M = 0
         if ref2d is not None:
             M = ref2d.shape[1]
@@ -421,7 +423,10 @@ class Far3DOracle:
         return dict(boxes_3d=b, scores_3d=scores, labels_3d=labels)
 
     # ------------------------------------------------------------------ a1: one frame (detectors/far3d.py:64-99,244-277)
-    def simple_test(self, data, img_metas, forced_valid=None, forced_topk=None):
+    def simple_test(self, data, img_metas, forced_valid=None, forced_topk=None, forced_depth=None):
+        """forced_*: hooks of the test rigs (tests/test_engine_full_gpu.py) that make the oracle adopt the device's choice where a
+        discrete decision sits on a near-tie: forced_valid (2D peak selection), forced_topk (memory top-k), forced_depth
+        (callable(pred_depth (BN,D,H,W), depth_idx (BN,H,W,1)) -> depth_idx: the per-cell depth-bin argmax)."""
         img = data["img"]
         B, N = img.shape[:2]
         assert B == 1
@@ -437,7 +442,7 @@ class Far3DOracle:
             self.reset_memory()
         else:
             prev = img.new_ones(1)
-        outs = self.head_forward(feats, outs_roi, data, prev, pad_hw, forced_topk)
+        outs = self.head_forward(feats, outs_roi, data, prev, pad_hw, forced_topk, forced_depth)
         outs["roi"] = outs_roi
         outs["feat_levels"] = feats
         outs["result"] = self.decode(outs)

@@ -71,3 +71,31 @@ def test_closed_form_known_answers():
     assert e.shape == (1, 384) and torch.equal(e[0, 0::2], torch.zeros(192)) and torch.equal(e[0, 1::2], torch.ones(192))
     x = torch.tensor([0.0, 0.25, 1.0])
     assert torch.allclose(far3d_oracle.inverse_sigmoid(x).sigmoid(), torch.tensor([1e-5, 0.25, 1 - 1e-5]), atol=1e-6)
+
+
+def test_forced_depth_hook_replaces_exactly_the_argmax_it_is_given():
+    """The test-rig hook for near-tie depth bins (Far3DOracle.simple_test(forced_depth=...)): handing the oracle its own argmax changes
+    nothing; moving the bin of every cell moves the adaptive queries' reference points and with them the logits -- the hook reaches
+    the proposal construction, it is not a no-op."""
+    z, rc = load_small("far3d_small_seq")
+    seen = {}
+
+    def same(pred, idx):
+        seen["shape"] = (tuple(pred.shape), tuple(idx.shape))
+        return idx
+
+    def shifted(pred, idx):
+        return (idx + 7) % pred.shape[1]
+
+    outs = []
+    for hook in (None, same, shifted):
+        orc, _ = small_oracle(rc)
+        with torch.no_grad():
+            data, metas = synth.recipe_frame(rc, 0)
+            outs.append(orc.simple_test(data, metas, forced_depth=hook))
+    base, ident, moved = outs
+    assert seen["shape"][0][0] == seen["shape"][1][0] and seen["shape"][1][-1] == 1 and seen["shape"][0][2:] == seen["shape"][1][1:3]
+    assert torch.equal(ident["all_cls_scores"], base["all_cls_scores"]) and torch.equal(ident["reference_points"], base["reference_points"])
+    assert base["roi"]["valid_indices"].any(), "the recipe frame has proposals"
+    assert not torch.equal(moved["reference_points"], base["reference_points"])
+    assert (moved["all_cls_scores"] - base["all_cls_scores"]).abs().max().item() > 1e-4
