@@ -90,9 +90,21 @@ def main():
                     ((0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181) if (k == 1 and stride == 1) else (0, 1, 2, 3, 4, 5))
         if k == 3 and stride == 1 and os.environ.get("EXTRA_TILES"):
             tiles = tiles + tuple(int(v) for v in os.environ["EXTRA_TILES"].split(","))
+        # SUMS=1: time the 1x1 layers WITH the channel sums of the eSE fusion in their epilogue (GEMM tiles only, Ho*Wo >= 512)
+        sums = torch.zeros(N, Cout, dtype=torch.int64, device=dev) if (os.environ.get("SUMS") and k == 1 and Ho * Wo >= 512 and Cout % 8 == 0) else None
+        if sums is not None:
+            tiles = tuple(tl for tl in tiles if tl in ops._GEMM_TILES)
         for tile in tiles:
-            t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile))
+            try:
+                t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums))
+            except Exception:      # a tile that refuses the channel sums (no LDS left, map smaller than the tile)
+                if sums is None:
+                    raise
+                continue
             res[tile] = t
+        tiles = tuple(tl for tl in tiles if tl in res)
+        if 0 not in res:
+            res[0] = float("nan")
         best = min((t, tl) for tl, t in res.items() if tl != 0)
         table[key] = best[1]
         print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %4.0f" % (tl, res[tl] * 1e6) for tl in tiles if tl) +
