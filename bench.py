@@ -31,7 +31,7 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROAR
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12,     # dense FLOP/s (same guide)
              "bf16x3": 2.5e15 / 3}                 # split mode: three bf16 MFMAs per useful product
 BACKBONE_FLOP_PER_CAM = 2 * 201.87e9   # VoV-99 @ 640x960
-AGG_KERNEL = "aggregate_v7_kernel"
+AGG_KERNEL = "aggregate_v8_kernel"
 K_PROP = 92                # adaptive-query count fixed at 644 = 7 x 92 (static shapes)
 
 
@@ -221,11 +221,11 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         img_in = eng._ins[0]["img"]
         img_local = img_in if not sharded else img_in[runner.cams[0]:runner.cams[-1] + 1] if runner.cams else img_in[:0]
         if kernel_timings:
-            tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_ = eng.last_agg
+            tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_, tab_ = eng.last_agg
             agg_out = torch.empty(ref_.shape[0], 256, device=dev, dtype=eng.prec["dec"])
             agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
                                                                 num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
-                                                                variant=args.agg_variant), 24)]
+                                                                variant=args.agg_variant, tables=tab_), 24)]
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
@@ -273,6 +273,25 @@ def build_commit():
         return os.environ.get("FAR3D_COMMIT")
 
 
+def launch_plan(gpus, env, argv):
+    """The command that starts the N ranks of `bench.py --gpus N`, or None when this process already is one of them (or N == 1).
+    One process per GPU under torch.distributed.run on a free local port, rendezvous on 127.0.0.1 (the container hostname may
+    not resolve).  A WORLD_SIZE that disagrees with --gpus is a caller error."""
+    if "WORLD_SIZE" in env:
+        if int(env["WORLD_SIZE"]) != gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s (the launcher and the flag must agree)" % (gpus, env["WORLD_SIZE"]))
+        return None
+    if gpus <= 1:
+        return None
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,20 +308,45 @@ def main():
                     help="adaptive queries: 92 best 2D peaks per camera (static 644), or the reference's score > 0.1 rule with a fixed capacity")
     ap.add_argument("--capacity", type=int, default=1024, help="--proposals threshold: rows reserved for the adaptive queries")
     ap.add_argument("--cam-priority", type=int, default=0, help="HIP stream priority of the camera-stage stream in pipeline mode (-1 = high; A/B)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="N ranks on fewer than N GPUs (test rig only): ranks share devices and exchange over gloo; the line says so and "
+                         "is not a scaling measurement")
     args = ap.parse_args()
 
     import torch.distributed as dist
 
+    # `python bench.py --gpus N` without a launcher starts its own N ranks (the reference's tools/dist_test.sh:11-23 wraps
+    # torch.distributed.launch around tools/test.py the same way); under torch.distributed.run the environment already says N
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if plan is not None:
+        raise SystemExit(subprocess.call(plan))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    shared_gpu = False
+    if world > 1 and ndev < world:
+        if not (args.allow_shared_gpu and ndev > 0):
+            # not a crash: say what is missing in the one JSON line the caller parses, and on stderr
+            msg = ("bench.py --gpus %d needs %d visible GPUs, this box has %d: no multi-GPU figure was measured "
+                   "(--allow-shared-gpu runs the ranks on shared devices over gloo, for testing the launcher only)" % (world, world, ndev))
+            if rank == 0:
+                print(msg, file=sys.stderr)
+                print(json.dumps({"metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960", "value": None, "unit": "samples/s",
+                                  "n_gpus": world, "visible_gpus": ndev, "error": msg}))
+            return
+        shared_gpu = True
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if shared_gpu else "nccl"      # "nccl" IS RCCL on ROCm; RCCL refuses two ranks on one device
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     sharded = world > 1 and args.mode == "sharded"
 
     res = measure(args, args.precision, args.steps, args.warmup, world, rank, dev, sharded, dist, proposals=args.proposals)
@@ -326,6 +370,10 @@ def main():
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak",
+            # read back from the process group, not from the flag: how many ranks actually took part, and over which backend
+            "rccl_ranks": dist.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0),
+            "ranks": dist.get_world_size() if world > 1 else 1, "backend": backend or "none (single process)",
+            "visible_gpus": ndev, "shared_gpu": shared_gpu,
             "vs_baseline": (samples / dt) / 6.4 if world == 1 else None,   # 6.4 samples/s (hardware not stated)
             # the reference's figure was taken with a device sync around every frame (benchmark.py:84-111): the like-for-like ratio
             "vs_baseline_sync_per_frame": sync_rate / 6.4 if world == 1 else None,
@@ -348,8 +396,8 @@ def main():
                          "sync_per_frame": {"frames": len(per_frame), "mean_ms": sum(per_frame) / len(per_frame), "p50_ms": per_frame[len(per_frame) // 2],
                                             "samples_per_s_mean": sync_rate,
                                             "what": "reference protocol (tools/analysis_tools/benchmark.py:84-111): device sync before and after every frame"}},
-            "roofline": {"kernel": AGG_KERNEL + " (fused perspective-aware aggregation, one launch per decoder layer)" if args.agg_variant in (0, 7)
-                         else "aggregate_v3_kernel (A/B variant %d)" % args.agg_variant,
+            "roofline": {"kernel": AGG_KERNEL + " (fused perspective-aware aggregation, one launch per decoder layer)" if args.agg_variant in (0, 8)
+                         else "aggregate_v%d_kernel (A/B variant %d)" % (3 if args.agg_variant == 3 else 7, args.agg_variant),
                          "bound": "hbm", "achieved": by / agg_t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": by / agg_t / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured_in_this_run": False if traffic is not None else None,

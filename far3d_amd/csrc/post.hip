@@ -13,6 +13,7 @@
 //   far3d_agg_order       camera / image-cell sorted query order for far3d_aggregate_forward (scheduling only).
 //   far3d_nan_to_num      torch.nan_to_num on the stacked decoder outputs (ref farhead.py:646) (+ optional bf16 copy).
 #include "common.hpp"
+#include "agg_tables.hpp"
 
 // ------------------------------------------------------------------------------------------ block-wide top-K
 // order-preserving map float -> uint (larger float <-> larger uint; -0 == +0; every NaN, whatever its sign bit, maps to the
@@ -297,9 +298,14 @@ extern "C" int far3d_camera_prep(const float* lidar2img, const float* intrinsics
 __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict__ ref, const float* __restrict__ l2i,
                                                          int* __restrict__ perm, int A, int N, float lo0, float lo1, float lo2,
                                                          float sp0, float sp1, float sp2, float pad_h, float pad_w,
-                                                         const int* __restrict__ hole_count, int hole_start, int hole_end, int row_base) {
+                                                         const int* __restrict__ hole_count, int hole_start, int hole_end, int row_base,
+                                                         const float* __restrict__ Vc, float* __restrict__ tables, int J) {
   __shared__ int hist[AGGO_MAX_BINS];
   __shared__ int wsum[16];
+  if (blockIdx.x > 0) {      // blocks 1.. : the aggregation softmax factors of decoder layer blockIdx.x - 1 (csrc/agg_tables.hpp)
+    agg_tables_body(Vc + (long)(blockIdx.x - 1) * N * J, tables + (long)(blockIdx.x - 1) * (2 + N) * J, N, J, threadIdx.x, 1024);
+    return;
+  }
   const int t = threadIdx.x, nb = N * 64;
   // query rows [hole_lo, hole_end) hold no query (fixed-capacity proposal mode): they still get a slot (every row of `out` is
   // written) but their entry is ~a (negative), which far3d_aggregate_forward answers with a zero row and no work
@@ -356,16 +362,18 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
 
 extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range,
                                float pad_h, float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
-                               void* stream) {
+                               const float* Vc, float* tables, int layers, int J, void* stream) {
   FAR3D_CHECK_ARG(ref && lidar2img && perm && pc_range && A >= 0 && N > 0, "far3d_agg_order: bad arguments");
+  FAR3D_CHECK_ARG(!tables || (Vc && layers > 0 && J > 0), "far3d_agg_order: tables need Vc, layers > 0 and J > 0");
+  if (!tables) layers = 0;
   FAR3D_CHECK_ARG(A <= 8192 && N * 64 <= AGGO_MAX_BINS, "far3d_agg_order: A=%d (<= 8192) or N=%d (<= 16) too large", A, N);
   FAR3D_CHECK_ARG(row_base >= 0 && (!hole_count || (0 <= hole_start && hole_start <= hole_end)), "far3d_agg_order: bad hole [%d, %d) / row_base %d",
                   hole_start, hole_end, row_base);
   if (!hole_count) hole_start = hole_end = 0;
-  if (A == 0) return FAR3D_OK;
-  hipLaunchKernelGGL(agg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ref, lidar2img, perm, A, N, pc_range[0],
+  if (A == 0 && layers == 0) return FAR3D_OK;
+  hipLaunchKernelGGL(agg_order_kernel, dim3(1 + layers), dim3(1024), 0, (hipStream_t)stream, ref, lidar2img, perm, A, N, pc_range[0],
                      pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], pad_h,
-                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base);
+                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base, Vc, tables, J);
   FAR3D_CHECK_LAUNCH("far3d_agg_order");
   return FAR3D_OK;
 }

@@ -17,6 +17,7 @@
 //   lane = group*8 + chunk, 4 channels per lane.  All 8 groups sample the same pixel (the reference
 //   replicates locations over groups, :555), so a bilinear sample is 4 fully-coalesced row loads.
 #include "common.hpp"
+#include "agg_tables.hpp"
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
@@ -121,6 +122,8 @@ struct AggParams {
   int q_per_xcd;
   int out_dt;
   int ldU, ldO;   // row strides (floats) of U and of the key-point offsets
+  float ipw, iph;                       // 1 / pad_w, 1 / pad_h
+  float Wf[AGG_MAX_L], Hf[AGG_MAX_L];   // level sizes as floats
 };
 
 // ------------------------------------------------------------------------------------------
@@ -484,6 +487,41 @@ __device__ __forceinline__ void agg_swap32(float v, float& a, float& b) {
 struct AggMax { static __device__ __forceinline__ float op(float a, float b) { return fmaxf(a, b); } };
 struct AggMin { static __device__ __forceinline__ float op(float a, float b) { return fminf(a, b); } };
 struct AggSum { static __device__ __forceinline__ float op(float a, float b) { return a + b; } };
+// One-instruction DPP steps (v8): v_min/max/add_f32_dpp read the permuted operand directly.  Through __builtin_amdgcn_update_dpp
+// the compiler emits v_mov_dpp + a canonicalising v_max + the operation.  The two wait states a DPP read needs after a VALU
+// write of its source are inside the string (hipcc pads nothing inside an asm statement).
+#define AGG_DPP1(NAME, INSTR, CTRL)                                                                   \
+  __device__ __forceinline__ float NAME(float v) {                                                    \
+    float r;                                                                                          \
+    asm("s_nop 1\n\t" INSTR " %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));  \
+    return r;                                                                                         \
+  }
+AGG_DPP1(agg_min_q1, "v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+AGG_DPP1(agg_min_q2, "v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+AGG_DPP1(agg_min_r4, "v_min_f32_dpp", "row_ror:4")
+AGG_DPP1(agg_min_r8, "v_min_f32_dpp", "row_ror:8")
+AGG_DPP1(agg_max_q1, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+AGG_DPP1(agg_max_q2, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+AGG_DPP1(agg_max_r4, "v_max_f32_dpp", "row_ror:4")
+AGG_DPP1(agg_max_r8, "v_max_f32_dpp", "row_ror:8")
+AGG_DPP1(agg_add_q2, "v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+AGG_DPP1(agg_add_r4, "v_add_f32_dpp", "row_ror:4")
+AGG_DPP1(agg_add_r8, "v_add_f32_dpp", "row_ror:8")
+__device__ __forceinline__ float agg8_row_min(float v) { return agg_min_r8(agg_min_r4(agg_min_q2(agg_min_q1(v)))); }     // all 16 lanes of a row
+__device__ __forceinline__ float agg8_row_max(float v) { return agg_max_r8(agg_max_r4(agg_max_q2(agg_max_q1(v)))); }
+__device__ __forceinline__ float agg8_wave_max_parity(float v) {      // over the 32 lanes of a wave with equal (lane & 1)
+  v = agg_max_r8(agg_max_r4(agg_max_q2(v)));
+  float a, b;
+  agg_swap16(v, a, b); v = fmaxf(a, b);
+  agg_swap32(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float agg8_wave_sum_parity(float v) {
+  v = agg_add_r8(agg_add_r4(agg_add_q2(v)));
+  float a, b;
+  agg_swap16(v, a, b); v = a + b;
+  agg_swap32(v, a, b); return a + b;
+}
+
 template <typename OP> __device__ __forceinline__ float agg_row_reduce_parity(float v) {     // over the 8 same-parity lanes of a 16-lane row
   v = OP::op(v, agg_dpp<0x4E>(v));       // quad_perm [2,3,0,1]
   v = OP::op(v, agg_dpp<0x124>(v));      // row_ror:4
@@ -858,13 +896,438 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// v8 (default since round 4): the tap-merging algorithm of v7 with a FACTORED softmax and DECOUPLED waves.
+//
+// What the round-3 stamps said about v7 (profiles/r3/agg_phase_times.txt, profiles/r4): 40 % of a wave's life is its front end
+// (2 x 6 float4 logit loads, 24 exp, two block barriers for the softmax statistics), the launch lasts as long as its slowest wave,
+// and with the benchmark's metre-scale key-point offsets 65 % of the level-0 (camera, level) items spread over more than 64
+// tokens.  v8 therefore
+//  * factors the 364-way softmax.  logit[n][j][g] = U[a][j][g] + V[n][j][g] (j = level * P + point), so
+//      exp(logit - m) = exp(U + mV - m') * exp(V[n] - mV),   mV[j][g] = max_n V[n][j][g].
+//    The camera factor eV[n] = exp(V[n] - mV) in (0, 1], its camera sum EV = sum_n eV[n] and mV depend on the layer and the frame
+//    only: far3d_agg_tables computes them once per frame for all layers.  Per query that leaves 2 float4 loads of U, 8 exp per lane
+//    and S[g] = sum_j eU[j][g] * EV[j][g]; the largest term is exactly 1 (same overflow / underflow behaviour as the plain
+//    max-subtracted softmax).  Weights are formed only for the (camera, level) items that are visible: w = eU * eV[n].
+//  * lets each of the two waves compute the (cheap) statistics and the 91 projections itself: no barrier before the final
+//    cross-wave sum, nothing shared but identical LDS writes;
+//  * deals the visible (camera, level) items to the two waves by estimated work (greedy, computed identically by both) instead
+//    of by level parity, and raises the issue priority of waves that got a lot of it (the launch ends with its slowest wave);
+//  * projects with one v_rcp instead of four IEEE divisions, stores PIXEL coordinates per (camera, level, point) for the build
+//    loops, evaluates the tent weights with clamp modifiers, pads the row list so that the gather needs no bounds checks, and
+//    addresses rows as 32-bit byte offsets from a scalar base.
+// Limits: N <= 8, P <= 16, L <= 4, value maps < 4 GiB; other shapes take v7.
+// ------------------------------------------------------------------------------------------
+#define AGG8_CAPW 128
+#define AGG8_PAD 8
+#define AGG8_WSLOTS 4
+#define AGG8_LDS (8 * 4 * 16 * 8 + 64 + 2 * AGG8_WSLOTS * 32 * 16 + 2 * (AGG8_CAPW + AGG8_PAD) * 36)
+
+template <typename TV>
+__device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const unsigned* off_s, const float* wt_s, int cnt, int lane,
+                                            float (&acc)[8]) {
+  // cnt is a multiple of 8 (bf16 rows: 2 per load x 4 loads) / 4 (fp32 rows); padding entries carry weight 0 and offset 0
+  if (cnt <= 0) return;
+  typedef unsigned g8_u32x4 __attribute__((ext_vector_type(4)));
+  const char* base = reinterpret_cast<const char*>(feat);
+  if constexpr (sizeof(TV) == 2) {
+    const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
+    const unsigned lo = (unsigned)l31 * 16u;
+    const unsigned* op = off_s + hi;
+    const float* wp = wt_s + hi * 8 + g;
+    g8_u32x4 va[4], vb[4];
+    float wa[4], wb[4];
+    auto issue = [&](int k0, g8_u32x4 (&v)[4], float (&w)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = *reinterpret_cast<const g8_u32x4*>(base + (size_t)(op[k0 + 2 * i] + lo));
+        w[i] = wp[(k0 + 2 * i) * 8];
+      }
+    };
+    auto consume = [&](const g8_u32x4 (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const agg_f2 x = {__uint_as_float(v[i][k] << 16), __uint_as_float(v[i][k] & 0xffff0000u)};
+          agg_f2 a = {acc[2 * k], acc[2 * k + 1]};
+          a = x * w[i] + a;
+          acc[2 * k] = a.x; acc[2 * k + 1] = a.y;
+        }
+      }
+    };
+    issue(0, va, wa);
+    for (int k0 = 8; ; k0 += 16) {
+      if (k0 < cnt) issue(k0, vb, wb);
+      consume(va, wa);
+      if (k0 >= cnt) break;
+      if (k0 + 8 < cnt) issue(k0 + 8, va, wa);
+      consume(vb, wb);
+      if (k0 + 8 >= cnt) break;
+    }
+  } else {
+    const int g = lane >> 3;
+    const unsigned lo = (unsigned)lane * 16u;
+    const float* wp = wt_s + g;
+    float4 va[4], vb[4];
+    float wa[4], wb[4];
+    auto issue = [&](int k0, float4 (&v)[4], float (&w)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(base + (size_t)(off_s[k0 + i] + lo));
+        w[i] = wp[(k0 + i) * 8];
+      }
+    };
+    auto consume = [&](const float4 (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0] += w[i] * v[i].x; acc[1] += w[i] * v[i].y; acc[2] += w[i] * v[i].z; acc[3] += w[i] * v[i].w;
+      }
+    };
+    issue(0, va, wa);
+    for (int k0 = 4; ; k0 += 8) {
+      if (k0 < cnt) issue(k0, vb, wb);
+      consume(va, wa);
+      if (k0 >= cnt) break;
+      if (k0 + 4 < cnt) issue(k0 + 4, va, wa);
+      consume(vb, wb);
+      if (k0 + 4 >= cnt) break;
+    }
+  }
+}
+
+template <typename TV, int PT, int PRIO = 1>
+__global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
+                                                           const float* __restrict__ offs, const float* __restrict__ l2i,
+                                                           const float* __restrict__ U, const float* __restrict__ tab,
+                                                           const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
+  const int a0 = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  if (a0 >= prm.A) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int P = PT ? PT : prm.P, L = prm.L, N = prm.N;
+  const int n4 = L * P * 2;                                               // float4 per camera row of the tables (<= 128)
+  constexpr int CAPT = AGG8_CAPW + AGG8_PAD;
+  float2* pxy_s = reinterpret_cast<float2*>(smem);                        // [8][4][16] pixel coordinates per (camera, level, point)
+  float* stat_s = reinterpret_cast<float*>(pxy_s + 8 * 4 * 16);           // [8] softmax denominators (+ 8 pad)
+  float4* w_all = reinterpret_cast<float4*>(stat_s + 16);                 // [2 waves][WSLOTS][16 points x 2] item weights
+  unsigned* off_all = reinterpret_cast<unsigned*>(w_all + 2 * AGG8_WSLOTS * 32);     // [2][CAPT] row byte offsets
+  float* wt_all = reinterpret_cast<float*>(off_all + 2 * CAPT);           // [2][CAPT][8] merged weights
+  float4* w_s = w_all + wv * AGG8_WSLOTS * 32;
+  unsigned* off_s = off_all + wv * CAPT;
+  float* wt_s = wt_all + wv * CAPT * 8;
+
+  AGG_TS(0);
+  // ---- loads that do not depend on the query: table rows (mV, EV) and the projection matrices of this lane's two cameras
+  const float4 NEG4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), Z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* T4 = reinterpret_cast<const float4*>(tab);
+  // (every load is unconditional with a clamped index and the selection happens on registers: a load under a lane condition is
+  // split into dword loads behind exec-mask branches, and a load inside a branch is waited for inside it)
+  const bool v0 = lane < n4, v1 = lane + 64 < n4;
+  const int i0 = min(lane, n4 - 1), i1 = min(lane + 64, n4 - 1);
+  float4 mv0 = T4[i0], mv1 = T4[i1];
+  const float4 es0 = T4[n4 + i0], es1 = T4[n4 + i1];
+  const int r = lane >> 4, p = lane & 15;
+  const float4* mA = reinterpret_cast<const float4*>(l2i + min(r, N - 1) * 16);
+  const float4* mB = reinterpret_cast<const float4*>(l2i + min(r + 4, N - 1) * 16);
+  const float4 mA0 = mA[0], mA1 = mA[1], mA2 = mA[2], mB0 = mB[0], mB1 = mB[1], mB2 = mB[2];
+  int a = perm ? perm[a0] : a0;
+  if (a < 0) {      // ~a: row a holds no query (far3d_agg_order): zero row, no work
+    a = ~a;
+    const int c = t * 2;
+    if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(0.f, 0.f);
+    else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = 0u;
+    return;
+  }
+  // ---- query-dependent loads, issued together: reference point, this lane's key-point offset, the query part of the logits
+  const float rf0 = ref[a * 3], rf1 = ref[a * 3 + 1], rf2 = ref[a * 3 + 2];
+  const float* op_ = offs + (long)a * prm.ldO + min(p, P - 1) * 3;
+  const float of0 = op_[0], of1 = op_[1], of2 = op_[2];
+  const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
+  float4 eu0 = U4[i0], eu1 = U4[i1];
+  if (!v0) mv0 = NEG4;         // lanes past the row: logit -inf -> weight 0 (register selects)
+  if (!v1) mv1 = NEG4;
+  AGG_TS(8);
+
+  // ---- projection (detr3d_transformer.py:524-525,547-552) of the P key points into cameras r and r + 4, per-camera bounding box,
+  // per (camera, level) item descriptor in lane (r, level)
+  const float k0 = (rf0 * prm.pc_span[0] + prm.pc_lo[0]) + of0, k1 = (rf1 * prm.pc_span[1] + prm.pc_lo[1]) + of1,
+              k2 = (rf2 * prm.pc_span[2] + prm.pc_lo[2]) + of2;
+  // level sizes of level (lane & 15), as floats, without indexing the kernel arguments by a VGPR
+  float Wf0 = prm.Wf[0], Wf1 = prm.Wf[1], Wf2 = prm.Wf[2], Wf3 = prm.Wf[3], Hf0 = prm.Hf[0], Hf1 = prm.Hf[1], Hf2 = prm.Hf[2], Hf3 = prm.Hf[3];
+  asm volatile("" : "+s"(Wf0), "+s"(Wf1), "+s"(Wf2), "+s"(Wf3), "+s"(Hf0), "+s"(Hf1), "+s"(Hf2), "+s"(Hf3));   // in SGPRs here: selects, not branches around loads
+  const float Wme = p == 0 ? Wf0 : p == 1 ? Wf1 : p == 2 ? Wf2 : Wf3;
+  const float Hme = p == 0 ? Hf0 : p == 1 ? Hf1 : p == 2 ? Hf2 : Hf3;
+  const float WfL[AGG_MAX_L] = {Wf0, Wf1, Wf2, Wf3}, HfL[AGG_MAX_L] = {Hf0, Hf1, Hf2, Hf3};
+  auto project = [&](const float4& m0, const float4& m1, const float4& m2, int n, int& d0, int& d1, int& est, bool& is_patch) __attribute__((always_inline)) {
+    const bool act = n < N && p < P;
+    const float x = m0.x * k0 + m0.y * k1 + m0.z * k2 + m0.w;
+    const float y = m1.x * k0 + m1.y * k1 + m1.z * k2 + m1.w;
+    const float z = m2.x * k0 + m2.y * k1 + m2.z * k2 + m2.w;
+    const float rz = __builtin_amdgcn_rcpf(fmaxf(z, 1e-5f));
+    const float u = (x * rz) * prm.ipw, v = (y * rz) * prm.iph;
+    float umin = act ? u : INFINITY, umax = act ? u : -INFINITY, vmin = act ? v : INFINITY, vmax = act ? v : -INFINITY;
+    umin = agg8_row_min(umin); umax = agg8_row_max(umax);
+    vmin = agg8_row_min(vmin); vmax = agg8_row_max(vmax);
+    // item (camera n, level = lane & 15): token rectangle touched by the P bilinear footprints
+    const float fx0 = fmaxf(floorf(fmaf(umin, Wme, -0.5f)), 0.f), fx1 = fminf(floorf(fmaf(umax, Wme, -0.5f)) + 1.f, Wme - 1.f);
+    const float fy0 = fmaxf(floorf(fmaf(vmin, Hme, -0.5f)), 0.f), fy1 = fminf(floorf(fmaf(vmax, Hme, -0.5f)) + 1.f, Hme - 1.f);
+    const bool vis = n < N && p < L && fx1 >= fx0 && fy1 >= fy0;           // false for NaN / empty
+    const int x0 = vis ? (int)fx0 : 0, y0 = vis ? (int)fy0 : 0;
+    const int spanx = vis ? (int)(fx1 - fx0) + 1 : 1, spany = vis ? (int)(fy1 - fy0) + 1 : 1;
+    const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8) + (spanx > 16) + (spanx > 32);
+    is_patch = vis && spanx <= 64 && spany <= (64 >> lw);
+    d0 = x0 | (y0 << 16);
+    d1 = spanx | (spany << 16);
+    // work estimate in list entries: rows to gather + the build's own cost (a patch build is ~25 rows' worth, the per-corner one ~10)
+    est = is_patch ? min(spanx * spany, 4 * P) + 25 : 4 * P + 10;
+    // pixel coordinates of this lane's point on every level of camera n (read back by the build loops)
+    if (act) {
+#pragma unroll
+      for (int l = 0; l < AGG_MAX_L; ++l)
+        if (l < L) pxy_s[(n * 4 + l) * 16 + p] = make_float2(fmaf(u, WfL[l], -0.5f), fmaf(v, HfL[l], -0.5f));
+    }
+    return vis;
+  };
+  int dA0, dA1, estA, dB0, dB1, estB;
+  bool patA, patB;
+  const bool visA_ = project(mA0, mA1, mA2, r, dA0, dA1, estA, patA);
+  const bool visB_ = project(mB0, mB1, mB2, r + 4, dB0, dB1, estB, patB);
+  const unsigned long long visA = __ballot(visA_), visB = __ballot(visB_);
+  const unsigned long long patchA = __ballot(patA), patchB = __ballot(patB);
+  // ---- deal the items to the two waves: greedy on the running work estimates (both waves compute the same partition)
+  unsigned long long mineA = 0ull, mineB = 0ull;
+  int myload;
+  {
+    int ld0 = 0, ld1 = 0;
+    for (unsigned long long m = visA; m; m &= m - 1ull) {
+      const int b = __builtin_ctzll(m);
+      const int e = __builtin_amdgcn_readlane(estA, b);
+      const bool to1 = ld1 < ld0;
+      if (to1) ld1 += e; else ld0 += e;
+      if ((int)to1 == wv) mineA |= 1ull << b;
+    }
+    for (unsigned long long m = visB; m; m &= m - 1ull) {
+      const int b = __builtin_ctzll(m);
+      const int e = __builtin_amdgcn_readlane(estB, b);
+      const bool to1 = ld1 < ld0;
+      if (to1) ld1 += e; else ld0 += e;
+      if ((int)to1 == wv) mineB |= 1ull << b;
+    }
+    myload = wv ? ld1 : ld0;
+  }
+  // the launch ends with its slowest wave: waves that drew a lot of work get the issue slots first
+  if constexpr (PRIO) {
+    if (myload > 200) __builtin_amdgcn_s_setprio(3);
+    else if (myload > 120) __builtin_amdgcn_s_setprio(2);
+    else if (myload > 70) __builtin_amdgcn_s_setprio(1);
+  }
+  AGG_TS(9);
+
+  // ---- items are processed in batches of AGG8_WSLOTS: camera factors eV[n] of the batch (global, L2-resident) -> w = eU * eV -> LDS
+  unsigned long long qa = mineA, qb = mineB;
+  int items[AGG8_WSLOTS], ni = 0;
+  auto take_batch = [&]() __attribute__((always_inline)) {
+    ni = 0;
+#pragma unroll
+    for (int k = 0; k < AGG8_WSLOTS; ++k) {
+      items[k] = 0;
+      if (qa) { items[k] = __builtin_ctzll(qa); qa &= qa - 1ull; ni = k + 1; }
+      else if (qb) { items[k] = 64 + __builtin_ctzll(qb); qb &= qb - 1ull; ni = k + 1; }
+    }
+  };
+  float4 ev[AGG8_WSLOTS];
+  auto issue_ev = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < AGG8_WSLOTS; ++k) {
+      ev[k] = Z4;
+      if (k < ni) {
+        const int n = ((items[k] >> 4) & 3) + ((items[k] >> 6) << 2), l = items[k] & 15, base = l * 2 * P;
+        const bool in0 = (unsigned)(lane - base) < (unsigned)(2 * P);
+        ev[k] = T4[(2 + n) * n4 + (in0 ? lane : min(lane + 64, n4 - 1))];      // unconditional; lanes outside the slice are not used
+      }
+    }
+  };
+  take_batch();
+  issue_ev();
+
+  // ---- softmax statistics of the query factor (detr3d_transformer.py:539-540): eU = exp(U + mV - max), S[g] = sum_j eU[j][g] EV[j][g]
+  float4 S4;
+  {
+    constexpr float LOG2E = 1.4426950408889634f;
+    eu0 = make_float4(eu0.x + mv0.x, eu0.y + mv0.y, eu0.z + mv0.z, eu0.w + mv0.w);
+    eu1 = make_float4(eu1.x + mv1.x, eu1.y + mv1.y, eu1.z + mv1.z, eu1.w + mv1.w);
+    float4 mx = make_float4(fmaxf(eu0.x, eu1.x), fmaxf(eu0.y, eu1.y), fmaxf(eu0.z, eu1.z), fmaxf(eu0.w, eu1.w));
+    mx.x = agg8_wave_max_parity(mx.x); mx.y = agg8_wave_max_parity(mx.y);
+    mx.z = agg8_wave_max_parity(mx.z); mx.w = agg8_wave_max_parity(mx.w);
+    eu0 = make_float4(__builtin_amdgcn_exp2f((eu0.x - mx.x) * LOG2E), __builtin_amdgcn_exp2f((eu0.y - mx.y) * LOG2E),
+                      __builtin_amdgcn_exp2f((eu0.z - mx.z) * LOG2E), __builtin_amdgcn_exp2f((eu0.w - mx.w) * LOG2E));
+    eu1 = make_float4(__builtin_amdgcn_exp2f((eu1.x - mx.x) * LOG2E), __builtin_amdgcn_exp2f((eu1.y - mx.y) * LOG2E),
+                      __builtin_amdgcn_exp2f((eu1.z - mx.z) * LOG2E), __builtin_amdgcn_exp2f((eu1.w - mx.w) * LOG2E));
+    S4 = make_float4(eu0.x * es0.x + eu1.x * es1.x, eu0.y * es0.y + eu1.y * es1.y, eu0.z * es0.z + eu1.z * es1.z, eu0.w * es0.w + eu1.w * es1.w);
+    S4.x = agg8_wave_sum_parity(S4.x); S4.y = agg8_wave_sum_parity(S4.y);
+    S4.z = agg8_wave_sum_parity(S4.z); S4.w = agg8_wave_sum_parity(S4.w);
+    if (wv == 0 && lane < 2) *reinterpret_cast<float4*>(stat_s + (lane & 1) * 4) = S4;     // lanes of equal parity hold the same 4 groups
+  }
+  AGG_TS(1);
+  AGG_TS(2);
+  AGG_TS(3);
+
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int cnt = 0;
+  constexpr int GRAN = sizeof(TV) == 2 ? 8 : 4;
+  auto flush = [&]() __attribute__((always_inline)) {
+    const int padn = (-cnt) & (GRAN - 1);
+    if (lane < padn) {
+      off_s[cnt + lane] = 0u;
+      *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8) = Z4;
+      *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8 + 4) = Z4;
+    }
+    agg8_gather<TV>(feat, off_s, wt_s, cnt + padn, lane, acc);
+    cnt = 0;
+  };
+  auto append = [&](bool hit, unsigned off, const float (&wa)[8]) __attribute__((always_inline)) {
+    const unsigned long long m = __ballot(hit);
+    const int c = __popcll(m);
+    if (cnt + c > AGG8_CAPW) flush();          // wave-uniform; the list is private to the wave (LDS is in order per wave)
+    if (hit) {
+      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+      off_s[pos] = off;
+      *reinterpret_cast<float4*>(wt_s + pos * 8) = make_float4(wa[0], wa[1], wa[2], wa[3]);
+      *reinterpret_cast<float4*>(wt_s + pos * 8 + 4) = make_float4(wa[4], wa[5], wa[6], wa[7]);
+    }
+    cnt += c;
+  };
+  constexpr unsigned ROWB = 256u * (unsigned)sizeof(TV);      // bytes per token row
+
+  while (ni > 0) {
+    // -- weights of the batch's items: lanes that hold the item's slice of eU multiply it with the camera factor
+#pragma unroll
+    for (int k = 0; k < AGG8_WSLOTS; ++k) {
+      if (k < ni) {
+        const int l = items[k] & 15, base = l * 2 * P;
+        const bool in0 = (unsigned)(lane - base) < (unsigned)(2 * P), in1 = (unsigned)(lane + 64 - base) < (unsigned)(2 * P);
+        const float4 e = in0 ? eu0 : eu1;
+        if (in0 || in1)
+          w_s[k * 32 + (in0 ? lane : lane + 64) - base] = make_float4(e.x * ev[k].x, e.y * ev[k].y, e.z * ev[k].z, e.w * ev[k].w);
+      }
+    }
+    // -- build: merged row list of each item
+    for (int k = 0; k < ni; ++k) {
+      const int it = items[k], b = it & 63, second = it >> 6;
+      const int n = (b >> 4) + (second << 2), l = b & 15;
+      const int Wl = prm.W[l], Hl = prm.H[l];
+      const unsigned rowbase = (unsigned)(n * prm.S + prm.start[l]);
+      const float2* pq = pxy_s + (n * 4 + l) * 16;
+      const float4* wrow = w_s + k * 32;
+      const bool is_patch = (((second ? patchB : patchA) >> b) & 1ull) != 0ull;
+      if (is_patch) {
+        // lane T owns token (x0 + T % pw, y0 + T / pw) and merges the P points' corner weights onto it (tent form)
+        const int d0 = __builtin_amdgcn_readlane(second ? dB0 : dA0, b), d1 = __builtin_amdgcn_readlane(second ? dB1 : dA1, b);
+        const int x0 = d0 & 0xffff, y0 = d0 >> 16, spanx = d1 & 0xffff, spany = d1 >> 16;
+        const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8) + (spanx > 16) + (spanx > 32);
+        const int tx = x0 + (lane & ((1 << lw) - 1)), ty = y0 + (lane >> lw);
+        const bool active = tx < x0 + spanx && ty < y0 + spany;
+        const float ftx = (float)tx, fty = (float)ty;
+        agg_f2 c0 = {0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+        float any = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < P; ++q) {
+          const float2 pp = pq[q];
+          const float tx_ = __builtin_amdgcn_fmed3f(1.f - fabsf(pp.x - ftx), 0.f, 1.f);
+          const float ty_ = __builtin_amdgcn_fmed3f(1.f - fabsf(pp.y - fty), 0.f, 1.f);
+          const float w = tx_ * ty_;
+          const float4 a0 = wrow[q * 2], a1 = wrow[q * 2 + 1];
+          any = fmaxf(any, w);
+          const agg_f2 b0 = {a0.x, a0.y}, b1 = {a0.z, a0.w}, b2 = {a1.x, a1.y}, b3 = {a1.z, a1.w};
+          c0 = b0 * w + c0; c1 = b1 * w + c1; c2 = b2 * w + c2; c3 = b3 * w + c3;
+        }
+        const float wa[8] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y};
+        append(active && any > 0.f, (rowbase + (unsigned)(ty * Wl + tx)) * ROWB, wa);
+      } else {
+        // spread wider than 64 tokens: one entry per (point, corner), mmcv's bilinear arithmetic as is (4 P <= 64 lanes)
+        bool hit = false;
+        unsigned off = 0u;
+        float wa[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wa[q] = 0.f;
+        {
+          const int pt = min(lane >> 2, P - 1), tap = lane & 3;
+          const float2 pp = pq[pt];
+          const float4 a0 = wrow[pt * 2], a1 = wrow[pt * 2 + 1];
+          const float h_im = pp.y, w_im = pp.x;
+          const bool inside = lane < P * 4 && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+          const float fh = floorf(h_im), fw = floorf(w_im);
+          const float lh = h_im - fh, lw_ = w_im - fw;
+          const int ty = (int)fh + (tap >> 1), tx = (int)fw + (tap & 1);
+          const float bw = ((tap >> 1) ? lh : 1.f - lh) * ((tap & 1) ? lw_ : 1.f - lw_);
+          hit = inside && ty >= 0 && ty <= Hl - 1 && tx >= 0 && tx <= Wl - 1 && bw != 0.f;
+          off = hit ? (rowbase + (unsigned)(ty * Wl + tx)) * ROWB : 0u;
+          wa[0] = bw * a0.x; wa[1] = bw * a0.y; wa[2] = bw * a0.z; wa[3] = bw * a0.w;
+          wa[4] = bw * a1.x; wa[5] = bw * a1.y; wa[6] = bw * a1.z; wa[7] = bw * a1.w;
+        }
+        append(hit, off, wa);
+      }
+    }
+    take_batch();
+    if (ni > 0) issue_ev();
+  }
+  AGG_TS(4);
+#ifdef FAR3D_PROFILING
+  const int cnt_last = cnt;
+#endif
+  flush();
+  AGG_TS(5);
+#ifdef FAR3D_PROFILING
+  if (g_agg_ts && lane == 0) { g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 7] = cnt_last; g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 10] = myload; }
+#endif
+
+  // ---- cross-wave sum: partial sums go into the wave's own (now dead) list region; 1/S[g] applied once here
+  float* red = wt_s;                       // 256 floats: CAPT * 8 >= 256
+  if constexpr (sizeof(TV) == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { float x, y; agg_swap32(acc[k], x, y); acc[k] = x + y; }      // two token rows per load: add the halves
+    if (lane < 32) {
+      *reinterpret_cast<float4*>(red + lane * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(red + lane * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  } else {
+    *reinterpret_cast<float4*>(red + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();                                                                        // the kernel's only barrier
+  AGG_TS(6);
+  {
+    const int c = t * 2, g = c >> 5;       // channels 2t, 2t+1 belong to group 2t / 32
+    const float inv = 1.f / stat_s[g];
+    const float2 p0 = *reinterpret_cast<const float2*>(wt_all + c), p1 = *reinterpret_cast<const float2*>(wt_all + CAPT * 8 + c);
+    const float r0 = (p0.x + p1.x) * inv, r1 = (p0.y + p1.y) * inv;
+    if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(r0, r1);
+    else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = pack_bf16x2(r0, r1);
+  }
+}
+
+// far3d_agg_tables: the softmax factors of csrc/agg_tables.hpp for `layers` decoder layers, block = layer.
+__global__ __launch_bounds__(256) void agg_tables_kernel(const float* __restrict__ Vc, float* __restrict__ tab, int N, int J) {
+  agg_tables_body(Vc + (long)blockIdx.x * N * J, tab + (long)blockIdx.x * (2 + N) * J, N, J, threadIdx.x, blockDim.x);
+}
+
+extern "C" int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, void* stream) {
+  FAR3D_CHECK_ARG(Vc && tables && layers > 0 && N > 0 && J > 0 && J % 4 == 0, "far3d_agg_tables: bad arguments (layers=%d N=%d J=%d)", layers, N, J);
+  hipLaunchKernelGGL(agg_tables_kernel, dim3(layers), dim3(256), 0, (hipStream_t)stream, Vc, tables, N, J);
+  FAR3D_CHECK_LAUNCH("far3d_agg_tables");
+  return FAR3D_OK;
+}
+
 extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref,
                                        const float* offsets, const float* lidar2img, const float* U,
-                                       const float* Vc, const int32_t* perm, void* out, int out_dt, int A, int N, int S, int C, int G,
-                                       int P, int L, const int32_t* level_hw, const int32_t* level_start,
+                                       const float* Vc, const float* cam_tables, const int32_t* perm, void* out, int out_dt, int A, int N,
+                                       int S, int C, int G, int P, int L, const int32_t* level_hw, const int32_t* level_start,
                                        const float* pc_range, float pad_h, float pad_w, int ldU, int ldOffs, int variant,
                                        void* stream) {
-  FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && Vc && out && level_hw && level_start && pc_range,
+  FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && (Vc || cam_tables) && out && level_hw && level_start && pc_range,
                   "far3d_aggregate_forward: null pointer argument");
   FAR3D_CHECK_ARG(C == 256 && G == 8, "far3d_aggregate_forward: fused kernel is built for C=256,G=8 (got C=%d G=%d)", C, G);
   FAR3D_CHECK_ARG(L >= 1 && L <= AGG_MAX_L, "far3d_aggregate_forward: L=%d out of range [1,%d]", L, AGG_MAX_L);
@@ -873,8 +1336,13 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 11,
-                  "far3d_aggregate_forward: unknown kernel variant %d (0 = 7 = default, 3 = round-1 kernel, 11 = VALU reductions / packed FMAs)", variant);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11,
+                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
+  const size_t esz = feat_dtype == FAR3D_DT_F32 ? 4 : 2;
+  const bool v8_ok = cam_tables && N <= 8 && P <= 16 && L <= AGG_MAX_L && (size_t)N * S * C * esz < (1ull << 32);
+  if (variant == 0) variant = v8_ok ? 8 : 7;
+  FAR3D_CHECK_ARG((variant != 8 && variant != 9) || (v8_ok && (variant == 8 || P == 13)), "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
+  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -888,6 +1356,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   }
   for (int d = 0; d < 3; ++d) { prm.pc_lo[d] = pc_range[d]; prm.pc_span[d] = pc_range[3 + d] - pc_range[d]; }
   prm.pad_w = pad_w; prm.pad_h = pad_h;
+  prm.ipw = 1.f / pad_w; prm.iph = 1.f / pad_h;
+  for (int l = 0; l < AGG_MAX_L; ++l) { prm.Wf[l] = (float)prm.W[l]; prm.Hf[l] = (float)prm.H[l]; }
   prm.q_per_xcd = cdiv(A, 8);
   prm.out_dt = out_dt;
   prm.ldU = ldU > 0 ? ldU : L * P * G;
@@ -914,7 +1384,18 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
-  } else if (variant == 0 || variant == 7) {     // 2 waves per query
+  } else if (variant == 9) {      // A/B: 8 without the work-dependent issue priority
+    if (feat_dtype == FAR3D_DT_F32) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+    else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+  } else if (variant == 8) {      // factored softmax, decoupled waves (default)
+    if (feat_dtype == FAR3D_DT_F32) {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+    } else {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+    }
+  } else if (variant == 7) {     // 2 waves per query, levels split by parity, softmax over all 7 cameras
     const int NP = N * P;
     const size_t lds7 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + 32 * 4 + AGG4_MAX_N * 4 + (size_t)2 * AGG7_CAPW * 36;
     if (feat_dtype == FAR3D_DT_F32) {

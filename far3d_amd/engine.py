@@ -500,8 +500,6 @@ class Far3DEngine:
         nJ = cfg["num_groups"] * cfg["num_levels"] * cfg["num_pts"]
         nO = cfg["num_pts"] * 3
         outs = self._buf(("outs_dec",), (nL, A, E), torch.float32)
-        # reference points are fixed across the layers: one camera-sorted workgroup order per frame (scheduling only)
-        perm = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32), hole=hole)
         QKV = self._buf(("qkv",), (Kt, nL * 3 * E), at)          # per layer a [q | k | v] column block
         XW = self._buf(("xw",), (A, 2 * E), at)                   # [x+pos | x] operand of the cross-attention GEMM
         UL = self._buf(("ul",), (A, -(-(nJ + nO) // 64) * 64), torch.float32)    # [U (nJ) | key-point offsets (nO)] per query
@@ -513,6 +511,10 @@ class Far3DEngine:
         if Kt > A:
             ops.linear(X2[A:], self.memkv, out=QKV[A:], out_dtype=at)
         vc_all = ops.cam_embed_chain(lidar2img, self.cam_chain)             # (layers, N, nJ), bias included
+        # per-frame preparations of the aggregation in ONE launch: reference points are fixed across the layers -> one camera-sorted
+        # workgroup order (scheduling only); the camera factors of the factored softmax for all layers (include/far3d_hip.h)
+        perm, tabs = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32), hole=hole,
+                                           Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32))
         x = x0
         for li, ly in enumerate(self.layers):
             c0 = li * 3 * E
@@ -526,8 +528,8 @@ class Far3DEngine:
             ops.linear(XW, ly["wl"], out=UL[:, :nJ + nO])
             agg = ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
                                         cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out_dtype=at,
-                                        variant=self.agg_variant)
-            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm)
+                                        variant=self.agg_variant, tables=tabs[li])
+            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li])
             y = ops.linear(agg, ly["oproj"], res=x1)
             if fast:
                 ops.layernorm(y, *ly["norms"][1], out=x2, yb=x2b)
@@ -579,6 +581,7 @@ class Far3DEngine:
         if Kt > A:
             ops.linear(X2[A:], self.memkv, out=QKV[A:], out_dtype=at)
         vc_all = ops.cam_embed_chain(lidar2img, self.cam_chain)
+        tabs = ops.agg_tables(vc_all, out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32))
         x = x0
         for li, ly in enumerate(self.layers):
             c0 = li * 3 * E
@@ -590,7 +593,8 @@ class Far3DEngine:
                 ops.layernorm(y, *ly["norms"][0], out=x1[a0:a1], add=qpos[a0:a1], y2=XW[a0:a1, :E], yb=XW[a0:a1, E:])
                 ops.linear(XW[a0:a1], ly["wl"], out=UL[a0:a1, :nJ + nO])
                 ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
-                                      cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg, variant=self.agg_variant)
+                                      cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg, variant=self.agg_variant,
+                                      tables=tabs[li])
                 y = ops.linear(agg[a0:a1], ly["oproj"], res=x1[a0:a1])
                 if fast:
                     ops.layernorm(y, *ly["norms"][1], out=x2[a0:a1], yb=x2b[a0:a1])

@@ -117,8 +117,20 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, a
     return out
 
 
+def agg_tables(Vc, out=None):
+    """Softmax factors of the camera part of the aggregation logits (far3d_agg_tables): Vc (layers, N, J) or (N, J) f32 ->
+    (layers, 2 + N, J) / (2 + N, J) f32 = [max over cameras | sum of exp | exp(Vc - max)].  Per frame, for all layers at once."""
+    lib = _lib.require_device()
+    _chk(Vc, "Vc", torch.float32)
+    v3 = Vc if Vc.dim() == 3 else Vc[None]
+    Ls, N, J = v3.shape
+    tab = out if out is not None else torch.empty((Ls, 2 + N, J), dtype=torch.float32, device=Vc.device)
+    _lib.check(lib.far3d_agg_tables(_ptr(v3), _ptr(tab), Ls, N, J, _stream(Vc)), "far3d_agg_tables")
+    return tab if Vc.dim() == 3 else tab[0]
+
+
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0):
+                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
@@ -127,6 +139,8 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     pc_range 6 floats; pad_hw (H,W) of the padded image.  Returns (A,256) f32 = sum over cameras of
     MSDA(feat_n, project_n(ref+offsets), softmax_{n,l,p}(U+Vc)).  U / offsets may be row-strided views (unit inner stride)
     only through .contiguous() -- the kernel reads dense rows.  variant: see include/far3d_hip.h (0 = default).
+    tables: agg_tables(Vc) (2+N, L*P*G) -- the per-frame softmax factors the default kernel reads instead of Vc; computed here
+    (one more launch) when the default kernel runs and the caller did not pass them.
     """
     lib = _lib.require_device()
     _chk(feat, "feat", ndim=3)
@@ -152,11 +166,18 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         _chk(perm, "perm", torch.int32, 1)
         if perm.numel() > A:
             raise ValueError("aggregate_forward: perm has more entries than there are rows")
+    if tables is None and variant in (0, 8, 9) and A > 0 and N <= 8 and P <= 16:
+        tables = agg_tables(Vc)
+    if tables is not None:
+        _chk(tables, "tables", torch.float32, 2)
+        if tuple(tables.shape) != (2 + N, L * P * G):
+            raise ValueError("aggregate_forward: tables must be (2+N, L*P*G) = %s, got %s" % ((2 + N, L * P * G), tuple(tables.shape)))
     hw_keep, hw_p = _host_i32([list(x) for x in level_hw])
     st_keep, st_p = _host_i32(list(level_start))
     pc_keep, pc_p = _host_f32(list(pc_range))
     _lib.check(lib.far3d_aggregate_forward(_ptr(feat), _dt(feat), _ptr(ref), _ptr(offsets), _ptr(lidar2img),
-                                           _ptr(U), _ptr(Vc), _ptr(perm) if perm is not None else None, _ptr(out), _dt(out),
+                                           _ptr(U), _ptr(Vc), _ptr(tables) if tables is not None else None,
+                                           _ptr(perm) if perm is not None else None, _ptr(out), _dt(out),
                                            A if perm is None else perm.numel(), N, S, C, G, P, L, hw_p, st_p, pc_p,
                                            float(pad_hw[0]), float(pad_hw[1]), U.stride(0) if A > 0 else 0,
                                            offsets.stride(0) if A > 0 else 0, int(variant), _stream(feat)),
@@ -721,20 +742,29 @@ def add_cast(a, b, sum_dtype, a_dtype=None, out_sum=None, out_a=None):
     return osum, oa
 
 
-def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None):
+def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None, Vc=None, tables_out=None):
     """Query order for aggregate_forward's `perm` (camera, then 8x8 image cell), one single-workgroup launch.  Groups the
     same way as camera_sorted_order(spatial=True); the order inside a cell is arbitrary (scheduling only).  hole: rows without a
     query are entered as ~a so that aggregate_forward writes zero rows for them (see _hole).  rows=(a0, a1): order only the rows
-    [a0, a1) of ref; the entries are absolute row indices (pass the full-size buffers and this perm to aggregate_forward)."""
+    [a0, a1) of ref; the entries are absolute row indices (pass the full-size buffers and this perm to aggregate_forward).
+    Vc (layers, N, J): the same launch also computes agg_tables(Vc) (into tables_out when given); returns (perm, tables) then."""
     lib = _lib.require_device()
     _chk(ref, "ref", torch.float32, 2)
     a0, a1 = (0, ref.shape[0]) if rows is None else rows
     A = a1 - a0
     perm = out if out is not None else torch.empty((A,), dtype=torch.int32, device=ref.device)
     pk, pp = _host_f32(list(pc_range))
+    tab, layers, J = None, 0, 0
+    if Vc is not None:
+        _chk(Vc, "Vc", torch.float32, 3)
+        layers, Nv, J = Vc.shape
+        if Nv != lidar2img.shape[0]:
+            raise ValueError("aggregation_order: Vc has %d cameras, lidar2img %d" % (Nv, lidar2img.shape[0]))
+        tab = tables_out if tables_out is not None else torch.empty((layers, 2 + Nv, J), dtype=torch.float32, device=ref.device)
     _lib.check(lib.far3d_agg_order(_ptr(ref), _ptr(lidar2img), _ptr(perm), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
-                                   *_hole(hole), int(a0), _stream(ref)), "far3d_agg_order")
-    return perm
+                                   *_hole(hole), int(a0), _ptr(Vc) if Vc is not None else None, _ptr(tab) if tab is not None else None,
+                                   layers, J, _stream(ref)), "far3d_agg_order")
+    return perm if Vc is None else (perm, tab)
 
 
 def topk(vals, K, with_values=False):

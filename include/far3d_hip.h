@@ -82,16 +82,28 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * changes results (row a of `out` is always query a); an entry ~a (negative) means "row a holds no query": a zero row is
  * written and nothing else is done (far3d_agg_order produces such entries).  With perm, A counts the ENTRIES of perm (workgroups);
  * the rows they name may lie anywhere in ref / offsets / U / out (a subset of a larger query set).  Requires C=256, G=8, L<=4, N<=16,
- * N*P<=256, N*P*L<=384.  variant: 0 (= 7) default kernel: two waves per query, bilinear taps merged per token row through
- * the tent form of the interpolation weights (no atomics), LDS row lists, 16-byte row gathers; 3 = round-1 kernel (workgroup
- * per query, one gather per sample corner pair) kept for A/B measurements; 11 = the default kernel with its cross-lane
- * reductions on the VALU (DPP / v_permlane swaps instead of ds_bpermute), the projection matrices loaded ahead of the query and
- * packed FMAs (A/B).  All give the same result up to fp32 re-association. */
+ * N*P<=256, N*P*L<=384.
+ * cam_tables: the per-layer softmax factors of Vc from far3d_agg_tables / far3d_agg_order ((2+N)*L*P*G floats), or NULL.
+ * variant: 0 = default: kernel 8 when cam_tables is given and N<=8, P<=16, value maps < 4 GiB, else kernel 7.
+ *   8: two DECOUPLED waves per query (one barrier), softmax factored into a query part (8 exp per lane) and the per-frame camera
+ *      tables, (camera, level) items dealt to the waves by estimated work, bilinear taps merged per token row through the tent
+ *      form of the interpolation weights (no atomics), padded LDS row lists, 16-byte row gathers from 32-bit byte offsets;
+ *   7: round 2/3's kernel (two waves, levels split by parity, full 7-camera softmax from Vc, three barriers); 11 = 7 with its
+ *      cross-lane reductions on the VALU and packed FMAs; 3 = round-1 kernel (workgroup per query, one gather per sample corner
+ *      pair) -- 3, 7, 11 need Vc and are kept for A/B measurements.  All give the same result up to fp32 rounding. */
 int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, const float* offsets,
-                            const float* lidar2img, const float* U, const float* Vc, const int32_t* perm, void* out, int out_dt, int A,
+                            const float* lidar2img, const float* U, const float* Vc, const float* cam_tables,
+                            const int32_t* perm, void* out, int out_dt, int A,
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
                             int ldU, int ldOffs, int variant, void* stream);
+
+/* Softmax factors of the aggregation logits' camera part, for `layers` decoder layers in one launch (block = layer):
+ * Vc (layers, N, J) f32 (far3d_cam_embed_chain's output, J = L*P*G, J % 4 == 0) -> tables (layers, 2+N, J) f32 =
+ * [ mV = max_n Vc | EV = sum_n eV[n] | eV[n] = exp(Vc[n] - mV) ].  softmax_{n,j}(U[a][j] + Vc[n][j]) (ref models/utils/
+ * detr3d_transformer.py:539-540) = exp(U[a][j] + mV[j] - m_a) * eV[n][j] / sum_j exp(U[a][j] + mV[j] - m_a) EV[j]: the camera
+ * factors depend on the layer and the frame only, the per-query part shrinks to 8 exp per lane. */
+int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, void* stream);
 
 /* Implicit-GEMM convolution / linear layer on the matrix cores (bf16 MFMA, or exact-fp32 MFMA when w_dt = F32).
  * Replaces the torch/cuDNN convolutions and nn.Linear GEMMs of the path:
@@ -272,9 +284,12 @@ int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, vo
  * ~a (negative): far3d_aggregate_forward writes a zero row for such an entry and does no work.
  * row_base: order the A rows [row_base, row_base + A) of `ref` (a rank's share of the queries in the query-sharded decoder); the
  * entries of perm are ABSOLUTE row indices (the hole is given in absolute rows too), so far3d_aggregate_forward is then called
- * with the full-size ref / offsets / U / out buffers, A = the share's row count and this perm. */
+ * with the full-size ref / offsets / U / out buffers, A = the share's row count and this perm.
+ * tables != NULL: the same launch also computes far3d_agg_tables(Vc, tables, layers, N, J) in `layers` extra workgroups (both are
+ * per-frame preparations of the aggregation; one launch instead of two). */
 int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range, float pad_h,
-                    float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base, void* stream);
+                    float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
+                    const float* Vc, float* tables, int layers, int J, void* stream);
 
 /* Descending top-K of n <= 40960 floats (ties -> lower index), one workgroup: idx_out (K) int64, val_out (K) f32 or NULL.
  * Replaces torch.topk in post_update_memory, ref models/dense_heads/farhead.py:488-491 (K <= 1024). */

@@ -44,7 +44,7 @@ def test_msda_empty_queries(hip_lib):
     assert out.shape == (1, 0, 8)
 
 
-VARIANTS = [0, 3, 11]   # far3d_aggregate_forward kernel variants (include/far3d_hip.h): 0 = default (two waves per query), 3 = round-1 kernel, 11 = default + VALU reductions / packed FMAs
+VARIANTS = [0, 3, 7, 11]   # far3d_aggregate_forward kernel variants (include/far3d_hip.h): 0 = default (v8: factored softmax, decoupled waves), 3 = round-1 kernel, 7 = round 2/3 kernel, 11 = 7 + VALU reductions / packed FMAs
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -24,8 +24,13 @@ def build_prof():
 
 
 def main():
+    """argv: [A] [variant] [operands.pt] [layer] [raw_out.npz] -- with an operands file (tools/dump_agg_operands.py) the kernel runs on
+    the live operands of that decoder layer of a benchmark frame instead of the seeded test case."""
     A = int(sys.argv[1]) if len(sys.argv) > 1 else 1544
     variant, nw = (int(sys.argv[2]) if len(sys.argv) > 2 else 7), 2
+    opfile = sys.argv[3] if len(sys.argv) > 3 else None
+    layer = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+    raw_out = sys.argv[5] if len(sys.argv) > 5 else None
     if not os.path.exists(PROF) or os.path.getmtime(PROF) < os.path.getmtime(os.path.join(fbuild.CSRC, "sampling.hip")):
         build_prof()
     flib.LIB_PATH = PROF
@@ -33,14 +38,21 @@ def main():
     from far3d_amd import ops
     from tests import cases
     dev = "cuda:0"
-    c = cases.aggregate_case(num_cams=7, pad_hw=(640, 960), A=A, seed=0)
     d = lambda t: t.to(dev).contiguous()
-    feat = d(c["feat"].to(torch.bfloat16))
+    if opfile:
+        c = torch.load(opfile)["layers"][layer]
+        A = c["ref"].shape[0]
+        feat = torch.randn(c["feat_shape"], device=dev).to(torch.bfloat16)
+        print("live operands: %s layer %d, A = %d" % (opfile, layer, A))
+    else:
+        c = cases.aggregate_case(num_cams=7, pad_hw=(640, 960), A=A, seed=0)
+        feat = d(c["feat"].to(torch.bfloat16))
     args = [d(c[k]) for k in ("ref", "offsets", "lidar2img", "U", "Vc")]
     perm = ops.aggregation_order(args[0], args[2], c["pc_range"], c["pad_hw"])
     nblk = 8 * ((A + 7) // 8)
     ts = torch.zeros(nblk * 4 * 16, dtype=torch.int64, device=dev)
-    run = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=variant)
+    tab = ops.agg_tables(args[4])
+    run = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=variant, tables=tab)
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -50,9 +62,11 @@ def main():
     run()
     torch.cuda.synchronize()
     t = ts.cpu().numpy().reshape(nblk, 4, 16)[:, :nw]
+    if raw_out:      # raw stamps + the workgroup -> query map, for offline analysis of the tail
+        np.savez_compressed(raw_out, stamps=t, perm=perm.cpu().numpy(), q_per_xcd=(A + 7) // 8)
     live = t[:, :, 0] != 0
     t = t[live[:, 0]]
-    if variant in (7, 11):
+    if variant in (7, 8, 11):
         for nm, i, j in (("  issue logit loads", 0, 8), ("  projection+bbox", 8, 9), ("  local max", 9, 1)):
             dlt = (t[:, :, j] - t[:, :, i]).astype(np.float64)
             print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
