@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "agg_tables.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Generic MSDA (mmcv contract).  value (bs,S,H,Dh) TV; shapes (L,2) i64 (h,w); lsi (L) i64;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
 #define AGG4_MAX_N 16
 
 typedef float agg_f2 __attribute__((ext_vector_type(2)));
+typedef float agg8_f4 __attribute__((ext_vector_type(4)));
 
 template <typename TV, int UNR, int OPT = 0>
 __device__ __forceinline__ void agg7_gather(const TV* __restrict__ feat, const int* off_s, const float* wt_s, int cnt, int lane,
@@ -919,14 +921,14 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
 // Limits: N <= 8, P <= 16, L <= 4, value maps < 4 GiB; other shapes take v7.
 // ------------------------------------------------------------------------------------------
 #define AGG8_CAPW 128
-#define AGG8_PAD 8
+#define AGG8_PAD 16
 #define AGG8_WSLOTS 4
 #define AGG8_LDS (8 * 4 * 16 * 8 + 64 + 2 * AGG8_WSLOTS * 32 * 16 + 2 * (AGG8_CAPW + AGG8_PAD) * 36)
 
-template <typename TV>
+template <typename TV, int NB>     // NB loads in flight per buffer, two buffers
 __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const unsigned* off_s, const float* wt_s, int cnt, int lane,
                                             float (&acc)[8]) {
-  // cnt is a multiple of 8 (bf16 rows: 2 per load x 4 loads) / 4 (fp32 rows); padding entries carry weight 0 and offset 0
+  // cnt is a multiple of 2 NB (bf16 rows: 2 per load) / NB (fp32 rows); padding entries carry weight 0 and offset 0
   if (cnt <= 0) return;
   typedef unsigned g8_u32x4 __attribute__((ext_vector_type(4)));
   const char* base = reinterpret_cast<const char*>(feat);
@@ -935,18 +937,18 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
     const unsigned lo = (unsigned)l31 * 16u;
     const unsigned* op = off_s + hi;
     const float* wp = wt_s + hi * 8 + g;
-    g8_u32x4 va[4], vb[4];
-    float wa[4], wb[4];
-    auto issue = [&](int k0, g8_u32x4 (&v)[4], float (&w)[4]) __attribute__((always_inline)) {
+    g8_u32x4 va[NB], vb[NB];
+    float wa[NB], wb[NB];
+    auto issue = [&](int k0, g8_u32x4 (&v)[NB], float (&w)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NB; ++i) {
         v[i] = *reinterpret_cast<const g8_u32x4*>(base + (size_t)(op[k0 + 2 * i] + lo));
         w[i] = wp[(k0 + 2 * i) * 8];
       }
     };
-    auto consume = [&](const g8_u32x4 (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+    auto consume = [&](const g8_u32x4 (&v)[NB], const float (&w)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NB; ++i) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const agg_f2 x = {__uint_as_float(v[i][k] << 16), __uint_as_float(v[i][k] & 0xffff0000u)};
@@ -956,42 +958,43 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
         }
       }
     };
+    constexpr int E = 2 * NB;      // entries per buffer
     issue(0, va, wa);
-    for (int k0 = 8; ; k0 += 16) {
+    for (int k0 = E; ; k0 += 2 * E) {
       if (k0 < cnt) issue(k0, vb, wb);
       consume(va, wa);
       if (k0 >= cnt) break;
-      if (k0 + 8 < cnt) issue(k0 + 8, va, wa);
+      if (k0 + E < cnt) issue(k0 + E, va, wa);
       consume(vb, wb);
-      if (k0 + 8 >= cnt) break;
+      if (k0 + E >= cnt) break;
     }
   } else {
     const int g = lane >> 3;
     const unsigned lo = (unsigned)lane * 16u;
     const float* wp = wt_s + g;
-    float4 va[4], vb[4];
-    float wa[4], wb[4];
-    auto issue = [&](int k0, float4 (&v)[4], float (&w)[4]) __attribute__((always_inline)) {
+    float4 va[NB], vb[NB];
+    float wa[NB], wb[NB];
+    auto issue = [&](int k0, float4 (&v)[NB], float (&w)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NB; ++i) {
         v[i] = *reinterpret_cast<const float4*>(base + (size_t)(off_s[k0 + i] + lo));
         w[i] = wp[(k0 + i) * 8];
       }
     };
-    auto consume = [&](const float4 (&v)[4], const float (&w)[4]) __attribute__((always_inline)) {
+    auto consume = [&](const float4 (&v)[NB], const float (&w)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NB; ++i) {
         acc[0] += w[i] * v[i].x; acc[1] += w[i] * v[i].y; acc[2] += w[i] * v[i].z; acc[3] += w[i] * v[i].w;
       }
     };
     issue(0, va, wa);
-    for (int k0 = 4; ; k0 += 8) {
+    for (int k0 = NB; ; k0 += 2 * NB) {
       if (k0 < cnt) issue(k0, vb, wb);
       consume(va, wa);
       if (k0 >= cnt) break;
-      if (k0 + 4 < cnt) issue(k0 + 4, va, wa);
+      if (k0 + NB < cnt) issue(k0 + NB, va, wa);
       consume(vb, wb);
-      if (k0 + 4 >= cnt) break;
+      if (k0 + NB >= cnt) break;
     }
   }
 }
@@ -1177,21 +1180,23 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
   int cnt = 0;
-  constexpr int GRAN = sizeof(TV) == 2 ? 8 : 4;
-  auto flush = [&]() __attribute__((always_inline)) {
+  // gather the listed rows: NB loads per buffer in flight (4 inside the item loop, 8 -- all of a typical list at once -- for the last one)
+  auto flush_nb = [&](auto nbtag) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nbtag)::value;
+    constexpr int GRAN = sizeof(TV) == 2 ? 2 * NB : NB;
     const int padn = (-cnt) & (GRAN - 1);
     if (lane < padn) {
       off_s[cnt + lane] = 0u;
       *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8) = Z4;
       *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8 + 4) = Z4;
     }
-    agg8_gather<TV>(feat, off_s, wt_s, cnt + padn, lane, acc);
+    agg8_gather<TV, NB>(feat, off_s, wt_s, cnt + padn, lane, acc);
     cnt = 0;
   };
+  auto flush = [&]() __attribute__((always_inline)) { flush_nb(std::integral_constant<int, 4>{}); };
   auto append = [&](bool hit, unsigned off, const float (&wa)[8]) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(hit);
     const int c = __popcll(m);
-    if (cnt + c > AGG8_CAPW) flush();          // wave-uniform; the list is private to the wave (LDS is in order per wave)
     if (hit) {
       const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
       off_s[pos] = off;
@@ -1214,8 +1219,15 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
           w_s[k * 32 + (in0 ? lane : lane + 64) - base] = make_float4(e.x * ev[k].x, e.y * ev[k].y, e.z * ev[k].z, e.w * ev[k].w);
       }
     }
+    AGG_TS(11);
     // -- build: merged row list of each item
     for (int k = 0; k < ni; ++k) {
+#ifdef FAR3D_PROFILING
+      const long long ts_item = (long long)__builtin_amdgcn_s_memtime();
+#endif
+      // one item adds at most 64 rows (a patch's tokens; 4 P <= 64 corners): gather what is listed once fewer might fit.  The only
+      // flush site inside the loops (the list is private to the wave: LDS is in order per wave, the test is wave-uniform)
+      if (cnt > AGG8_CAPW - 64) flush();
       const int it = items[k], b = it & 63, second = it >> 6;
       const int n = (b >> 4) + (second << 2), l = b & 15;
       const int Wl = prm.W[l], Hl = prm.H[l];
@@ -1224,28 +1236,54 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
       const float4* wrow = w_s + k * 32;
       const bool is_patch = (((second ? patchB : patchA) >> b) & 1ull) != 0ull;
       if (is_patch) {
-        // lane T owns token (x0 + T % pw, y0 + T / pw) and merges the P points' corner weights onto it (tent form)
+        // merged weights of the patch's tokens as a small matrix product on the (otherwise idle) matrix pipe:
+        //   Wt[g][T] = sum_p w[p][g] * tent(T, p),   tent(T, p) = max(0, 1 - |px_p - tx_T|) * max(0, 1 - |py_p - ty_T|)
+        // (the tent form of the four mmcv corner weights).  v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain: rows = groups (8 of
+        // 16 used), columns = 16 tokens, K = 4 points per step, 4 steps.  Lane (kk = lane >> 4, j = lane & 15) supplies
+        // A = w[4 s + kk][j] and B = tent(token j of the block, point 4 s + kk): ONE tent per lane and step instead of one per
+        // (lane, point), 8 LDS reads per item instead of 39, and a patch of <= 16 tokens costs a quarter of a 64-token one.
         const int d0 = __builtin_amdgcn_readlane(second ? dB0 : dA0, b), d1 = __builtin_amdgcn_readlane(second ? dB1 : dA1, b);
         const int x0 = d0 & 0xffff, y0 = d0 >> 16, spanx = d1 & 0xffff, spany = d1 >> 16;
         const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8) + (spanx > 16) + (spanx > 32);
-        const int tx = x0 + (lane & ((1 << lw) - 1)), ty = y0 + (lane >> lw);
-        const bool active = tx < x0 + spanx && ty < y0 + spany;
-        const float ftx = (float)tx, fty = (float)ty;
-        agg_f2 c0 = {0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-        float any = 0.f;
-#pragma unroll 4
-        for (int q = 0; q < P; ++q) {
-          const float2 pp = pq[q];
-          const float tx_ = __builtin_amdgcn_fmed3f(1.f - fabsf(pp.x - ftx), 0.f, 1.f);
-          const float ty_ = __builtin_amdgcn_fmed3f(1.f - fabsf(pp.y - fty), 0.f, 1.f);
-          const float w = tx_ * ty_;
-          const float4 a0 = wrow[q * 2], a1 = wrow[q * 2 + 1];
-          any = fmaxf(any, w);
-          const agg_f2 b0 = {a0.x, a0.y}, b1 = {a0.z, a0.w}, b2 = {a1.x, a1.y}, b3 = {a1.z, a1.w};
-          c0 = b0 * w + c0; c1 = b1 * w + c1; c2 = b2 * w + c2; c3 = b3 * w + c3;
+        const int nblk = ((spany << lw) + 15) >> 4;                       // 16-token blocks of the pw x spany token grid (<= 4)
+        const int kk = lane >> 4, jt = lane & 15;
+        const float* wf = reinterpret_cast<const float*>(wrow);
+        float aw[4];
+        float2 pp[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int pt = 4 * st + kk, ptc = min(pt, P - 1);
+          pp[st] = pq[ptc];                                               // a valid point for lanes past P (their A is 0; B must stay finite)
+          const float wv_ = wf[ptc * 8 + (jt & 7)];
+          aw[st] = (pt < P && jt < 8) ? wv_ : 0.f;
         }
-        const float wa[8] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y};
-        append(active && any > 0.f, (rowbase + (unsigned)(ty * Wl + tx)) * ROWB, wa);
+        for (int blk = 0; blk < nblk; ++blk) {
+          const int T = blk * 16 + jt;
+          const int tx = x0 + (T & ((1 << lw) - 1)), ty = y0 + (T >> lw);
+          const float ftx = (float)tx, fty = (float)ty;
+          agg8_f4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            if (4 * st < P) {
+              const float tent = __builtin_amdgcn_fmed3f(1.f - fabsf(pp[st].x - ftx), 0.f, 1.f) *
+                                 __builtin_amdgcn_fmed3f(1.f - fabsf(pp[st].y - fty), 0.f, 1.f);
+              acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[st], tent, acc4, 0, 0, 0);
+            }
+          }
+          // lane (kk, jt) now holds groups 4 kk .. 4 kk + 3 of token jt (kk < 2); a token is listed when any of its 8 weights is > 0
+          float hv = fmaxf(fmaxf(acc4[0], acc4[1]), fmaxf(acc4[2], acc4[3])), ha, hb;
+          agg_swap16(hv, ha, hb);
+          hv = fmaxf(ha, hb);
+          const bool hit = lane < 32 && tx < x0 + spanx && ty < y0 + spany && hv > 0.f;
+          const unsigned m16 = (unsigned)__ballot(hit) & 0xffffu;         // rows kk = 0 and kk = 1 carry the same 16-bit pattern
+          const int c = __popc(m16);
+          if (hit) {
+            const int pos = cnt + __popc(m16 & ((1u << jt) - 1u));
+            *reinterpret_cast<float4*>(wt_s + pos * 8 + kk * 4) = make_float4(acc4[0], acc4[1], acc4[2], acc4[3]);
+            if (kk == 0) off_s[pos] = (rowbase + (unsigned)(ty * Wl + tx)) * ROWB;
+          }
+          cnt += c;
+        }
       } else {
         // spread wider than 64 tokens: one entry per (point, corner), mmcv's bilinear arithmetic as is (4 P <= 64 lanes)
         bool hit = false;
@@ -1270,6 +1308,12 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
         }
         append(hit, off, wa);
       }
+#ifdef FAR3D_PROFILING
+      if (g_agg_ts && lane == 0) {
+        long long* q = g_agg_ts + ((long)blockIdx.x * 4 + wv) * 16 + (is_patch ? 12 : 14);
+        q[0] += (long long)__builtin_amdgcn_s_memtime() - ts_item; q[1] += 1;
+      }
+#endif
     }
     take_batch();
     if (ni > 0) issue_ev();
@@ -1278,7 +1322,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
 #ifdef FAR3D_PROFILING
   const int cnt_last = cnt;
 #endif
-  flush();
+  flush_nb(std::integral_constant<int, 8>{});
   AGG_TS(5);
 #ifdef FAR3D_PROFILING
   if (g_agg_ts && lane == 0) { g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 7] = cnt_last; g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 10] = myload; }

@@ -62,6 +62,18 @@ def main():
     run()
     torch.cuda.synchronize()
     t = ts.cpu().numpy().reshape(nblk, 4, 16)[:, :nw]
+    if variant in (8, 9):     # finer account of v8's build phase: weights of the first batch, then per-item times (they include list flushes = gathers)
+        w = (t[:, :, 11] - t[:, :, 3]).astype(np.float64)
+        w = w[t[:, :, 11] > 0]
+        print("  v8 build: first batch's weights (eV wait + products)  median %6.0f p90 %6.0f" % (np.median(w), np.percentile(w, 90)))
+        for nm, i in (("patch item", 12), ("per-corner item", 14)):
+            n = t[:, :, i + 1].sum()
+            print("  v8 build: %-16s count %6d  mean %7.0f ticks" % (nm, n, t[:, :, i].sum() / max(n, 1)))
+        ld = t[:, :, 10].astype(np.float64)
+        tot_ = (t[:, :, 5] - t[:, :, 3]).astype(np.float64)
+        print("  v8 work estimate per wave: median %.0f p90 %.0f max %.0f; corr(estimate, build+gather ticks) = %.3f" %
+              (np.median(ld), np.percentile(ld, 90), ld.max(), np.corrcoef(ld.flatten(), tot_.flatten())[0, 1]))
+        print("  v8 |wave0 - wave1| build+gather ticks: median %.0f p90 %.0f" % (np.median(np.abs(tot_[:, 0] - tot_[:, 1])), np.percentile(np.abs(tot_[:, 0] - tot_[:, 1]), 90)))
     if raw_out:      # raw stamps + the workgroup -> query map, for offline analysis of the tail
         np.savez_compressed(raw_out, stamps=t, perm=perm.cpu().numpy(), q_per_xcd=(A + 7) // 8)
     live = t[:, :, 0] != 0

@@ -40,6 +40,11 @@ def main():
                 outs[v] = out.clone()
                 print(json.dumps(dict(layer=li, variant=v, dtype=str(dt).split(".")[-1], us=round(t * 1e6, 2), frac_hbm_peak=round(by / t / 8e12, 4),
                                       max_abs_diff_vs_first=round((outs[v] - outs[variants[0]]).abs().max().item(), 8))))
+            if os.environ.get("NOPERM") and li == len(layers) - 1:     # the same launch in natural query order (no camera / cell sort)
+                v = variants[-1]
+                fn = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], out=out,
+                                                   perm=None, variant=v, tables=tab)
+                print(json.dumps(dict(layer=li, variant=v, dtype=str(dt).split(".")[-1], order="natural", us=round(timeit(fn, 24) * 1e6, 2))))
 
 
 if __name__ == "__main__":
