@@ -177,7 +177,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     dt = time.perf_counter() - t0
     dev_ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(steps))
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     A = out["all_cls_scores"].shape[2]

@@ -186,6 +186,12 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 101: launch_conv3x3_pipe<1, 8, 1, 1, 2, 3>(P, st); break;   // 32 x 8 rows, 8 waves
         case 102: launch_conv3x3_pipe<1, 4, 1, 1, 2, 3>(P, st); break;   // 32 x 4 rows, 4 waves
         case 103: launch_conv3x3_pipe<2, 4, 1, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 8 waves
+        // whole-chunk steps, deeper rings (NSW - 1 chunks in flight, counted vmcnt).  Measured in round 4 and NOT faster anywhere
+        // (profiles/r4/tune_bf16_3x3_deep_rings.log: stage-4 c1 21 -> 22 us, stage-5 c1 9.2 -> 10 us): the K-short layers are not
+        // waiting for their DMA round trips; kept as tested tiles
+        case 104: launch_conv3x3_pipe<2, 4, 1, 1, 3, 3>(P, st); break;   // 64 x 4 rows, 8 waves, 3 chunks (150 KB)
+        case 105: launch_conv3x3_pipe<1, 4, 1, 1, 3, 3>(P, st); break;   // 32 x 4 rows, 4 waves, 3 chunks (94 KB)
+        case 106: launch_conv3x3_pipe<1, 4, 1, 1, 4, 3>(P, st); break;   // 32 x 4 rows, 4 waves, 4 chunks (126 KB)
         default: done = false;
       }
     }

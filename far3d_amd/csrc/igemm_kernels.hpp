@@ -564,6 +564,14 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int U, int MAXK> __device__ __forceinline__ void wait_vmcnt_units(int k) {      // s_waitcnt vmcnt(U * k), k wave-uniform
+  if constexpr (MAXK <= 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (k >= MAXK) wait_vmcnt<U * MAXK>();
+    else wait_vmcnt_units<U, MAXK - 1>(k);
+  }
+}
 
 template <int WGM, int WGN, int WM, int WN, int NS, int KPS = 1>   // KPS: 32-channel K chunks per barrier step
 __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
@@ -785,10 +793,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   constexpr int PLD = NT == 3 ? 2 : 1;               // 64-byte planes of a chunk brought to LDS
   constexpr int PLS = PAIR ? 2 : 1;                  // planes a chunk occupies in memory
   constexpr int TAPB = PLD * WST;                    // one tap of a weight stage: [plane][BM rows x 64 B]
-  static_assert(NSW == 2 || NSW == 3, "weight ring of 2 or 3 steps");
-  static_assert(RPS == 1 || (RPS == 3 && NSW == 2), "whole-chunk steps use the 2-deep ring");
+  static_assert(RPS == 3 ? (NSW >= 2 && NSW <= 5) : (NSW == 2 || NSW == 3), "weight ring of 2 or 3 steps; whole-chunk rings of 2..5 chunks");
   static_assert(NT == 1 || (NT == 3 && PAIR && RPS == 1), "split products need pair-stored operands and one kernel row per step");
-  constexpr int WBASE = 2 * PLD * PATCH_B;           // patches: [2 buffers][PLD planes][PATCH_B]; then the weight ring [NSW][TPSN][TAPB]
+  constexpr int NPB = RPS == 3 ? NSW : 2;            // patch buffers: whole-chunk steps keep a patch per ring stage
+  constexpr int WBASE = NPB * PLD * PATCH_B;         // patches: [NPB buffers][PLD planes][PATCH_B]; then the weight ring [NSW][TPSN][TAPB]
   static_assert(WBASE + NSW * TPSN * TAPB <= 163840, "LDS budget");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -900,29 +908,42 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
           else if (DO_P) { const int sl = (k - GWL * PLD) / PLD, pl = (k - GWL * PLD) % PLD; PCALL; }                  \
         }
   if constexpr (RPS == 3) {
-    // whole-chunk steps: step c reads patch buffer / weight stage c & 1 (all 9 taps); both were issued during step c - 1
-    // (weights first, then the patch), so the top of every step waits for everything (vmcnt 0)
-    issue_patch(0, 0);
-    issue_w(0, 0, 0);
-#define FAR3D_PIPE_CHUNK(PAR, CH)                                                                                      \
+    // whole-chunk steps over an NSW-deep ring: chunk c lives in stage c % NSW = [patch | all 9 taps]; NSW - 1 chunks are in flight
+    // ahead of the one being computed and a step waits for the OLDEST only (counted vmcnt: a wave's LDS-DMAs retire in order).
+    // The K loop of the small maps is 5-7 chunks of ~0.3 us of MFMA work each against ~1.5 us of L2 / Infinity-Cache latency per
+    // DMA round trip: with the 2-deep ring every step waited for a round trip (stage 4/5 of VoV-99 ran at 640 / 310 TF/s); with
+    // most of the K loop issued up front the launch pays the latency once (profiles/r4).  The barrier at the top of step c also
+    // says that every wave is done with step c - 1, whose stage chunk c + NSW - 1 goes into.
+    constexpr int AHEAD = NSW - 1;
+#pragma unroll
+    for (int c = 0; c < AHEAD; ++c)
+      if (c < nchunks) { issue_w(c, 0, c); issue_patch(c, c); }
+#define FAR3D_PIPE_CHUNK(STG, CH)                                                                                      \
   {                                                                                                                    \
-    const bool more = (CH) + 1 < nchunks;                                                                              \
+    const bool more = (CH) + AHEAD < nchunks;                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if constexpr (!(FAR3D_ABLATE & 16)) {                                                                                 \
-    wait_vmcnt<0>();                                                                                                   \
+    if constexpr (!(FAR3D_ABLATE & 16)) {                                                                              \
+    int ahead_ = nchunks - 1 - (CH);                        /* chunks issued after CH: they may stay in flight */      \
+    if (ahead_ > AHEAD - 1) ahead_ = AHEAD - 1;                                                                        \
+    if (wfull) wait_vmcnt_units<PLD * (GWL + GPL), AHEAD - 1>(ahead_);                                                 \
+    else wait_vmcnt_units<PLD * (GWL - 1 + GPL), AHEAD - 1>(ahead_);                                                   \
     __builtin_amdgcn_s_barrier();                                                                                      \
     }                                                                                                                  \
     asm volatile("" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    constexpr int NXT = ((STG) + AHEAD) % NSW;                                                                         \
     constexpr int PIECES = (GWL + GPL) * PLD, PPI = (PIECES + 17) / 18;                                                \
-    patch_step_pipelined<WM, WN, 0, (PAR) * PLD * PATCH_B, WBASE + (PAR) * TPSN * TAPB, TAPB, 9, NT, PATCH_B, WST>(    \
+    patch_step_pipelined<WM, WN, 0, (STG) * PLD * PATCH_B, WBASE + (STG) * TPSN * TAPB, TAPB, 9, NT, PATCH_B, WST>(    \
       smem, aaddr, baddr, acc, [&](int it) __attribute__((always_inline)) {                                            \
-        FAR3D_DMA_PIECES(more, w_piece(sl, pl, (CH) + 1, 0, (PAR) ^ 1), more, patch_piece(sl, pl, (CH) + 1, (PAR) ^ 1)) \
+        FAR3D_DMA_PIECES(more, w_piece(sl, pl, (CH) + AHEAD, 0, NXT), more, patch_piece(sl, pl, (CH) + AHEAD, NXT))    \
       });                                                                                                              \
   }
-    for (int c = 0; c < nchunks; c += 2) {
+    for (int c = 0; c < nchunks; c += NSW) {
       FAR3D_PIPE_CHUNK(0, c)
       if (c + 1 < nchunks) FAR3D_PIPE_CHUNK(1, c + 1)
+      if constexpr (NSW > 2) { if (c + 2 < nchunks) FAR3D_PIPE_CHUNK(2, c + 2) }
+      if constexpr (NSW > 3) { if (c + 3 < nchunks) FAR3D_PIPE_CHUNK(3, c + 3) }
+      if constexpr (NSW > 4) { if (c + 4 < nchunks) FAR3D_PIPE_CHUNK(4, c + 4) }
     }
 #undef FAR3D_PIPE_CHUNK
   } else {
@@ -1000,7 +1021,7 @@ template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1
 static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PLD = NT == 3 ? 2 : 1;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds_ring = (size_t)2 * PLD * PG * 1024 + (size_t)NSW * 3 * RPS * PLD * BM * 64;
+  constexpr size_t lds_ring = (size_t)(RPS == 3 ? NSW : 2) * PLD * PG * 1024 + (size_t)NSW * 3 * RPS * PLD * BM * 64;
   constexpr size_t lds_out = (size_t)TH * 32 * (BM * (PAIR ? 4 : 2) + 16);
   constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   static_assert(lds <= 163840, "LDS budget");
@@ -1102,14 +1123,6 @@ __device__ __forceinline__ void gemm_step_split(const unsigned char* smem, const
 // for vmcnt(0)).  NS >= 3: NS - 1 steps are in flight and a barrier waits for the OLDEST one only (counted vmcnt: the LDS-DMAs of a
 // wave retire in order), so a step's HBM / L2 latency has NS - 1 steps of MFMA work to hide under -- for the K-short GEMMs of the
 // decoder (4..16 steps) that is most of the K loop issued up front.
-template <int U, int MAXK> __device__ __forceinline__ void wait_vmcnt_units(int k) {      // s_waitcnt vmcnt(U * k), k wave-uniform
-  if constexpr (MAXK <= 0) {
-    wait_vmcnt<0>();
-  } else {
-    if (k >= MAXK) wait_vmcnt<U * MAXK>();
-    else wait_vmcnt_units<U, MAXK - 1>(k);
-  }
-}
 
 template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {

@@ -56,7 +56,10 @@ def ida_matrix(resize, crop, flip=False, rotate=0.0):
         x' = R (F (s x - c) + f) + (b - R b)
     with s the scale, c the crop's top-left corner, F = diag(-1, 1) and f = (crop width, 0) when flipped (else F = I, f = 0),
     R = [[cos, sin], [-sin, cos]] of the rotation angle (degrees) about the crop centre b.  Evaluated in float64 and rounded once
-    to float32; for the un-flipped, un-rotated configuration of the reference config the entries (s, -c) are exact."""
+    to float32.  With rotate == 0 (the only value the reference pipeline accepts, custom_pipeline.py:69 -- flipped or not) every
+    entry is an integer or the float32 scale, so the result EQUALS the reference's float32 chain; with a rotation the reference
+    rounds cos / sin and every intermediate product to float32 and the two differ by float32 rounding (<= 4e-6 relative to the
+    largest entry; tests/test_host_cpu.py holds both statements)."""
     left, top, right, bottom = (float(v) for v in crop)
     F = np.diag([-1.0, 1.0]) if flip else np.eye(2)
     f = np.array([right - left, 0.0]) if flip else np.zeros(2)

@@ -51,7 +51,7 @@ def gather_many(pairs, group=None):
     single group (one launch moves the value maps, the records and the counts); elsewhere (gloo: CPU tests, the one-GPU test rig)
     they run one after the other.  Returns a list of work handles to wait() on (stream-ordered on the device backends)."""
     backend = dist.get_backend(group)
-    if backend == "nccl" and len(pairs) > 1 and _COALESCE is not None:
+    if backend == "nccl" and len(pairs) > 1 and _COALESCE is not None and _coalesce_ok(group, pairs[0][0].device):
         with _COALESCE(group=group, device=pairs[0][0].device, async_ops=True) as c:
             for local, out in pairs:
                 dist.all_gather_into_tensor(out, local.contiguous(), group=group)
@@ -82,6 +82,38 @@ def _coalescing_manager():
 
 
 _COALESCE = _coalescing_manager()
+_COALESCE_CHECKED = {}
+
+
+def _coalesce_ok(group, device):
+    """One-time self-check of the coalesced exchange on this process group (it rides on a private torch API whose
+    mixed-dtype fast path has only ever run here with a world of one).  Every rank gathers a small known pattern of the three
+    dtypes the frame exchange mixes (bf16, f32, int32) through the coalescing manager and compares; a mismatch or an exception
+    switches the group to sequential async gathers for good.  Collective: the first gather_many of a group runs it on every rank."""
+    key = id(group)
+    if key in _COALESCE_CHECKED:
+        return _COALESCE_CHECKED[key]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ok = True
+    try:
+        srcs = [torch.full((5,), rank + 1, dtype=torch.bfloat16, device=device), torch.full((3,), 0.5 * (rank + 1), dtype=torch.float32, device=device),
+                torch.full((1, 2), 7 * (rank + 1), dtype=torch.int32, device=device)]
+        dsts = [torch.zeros((world,) + tuple(t.shape), dtype=t.dtype, device=device) for t in srcs]
+        with _COALESCE(group=group, device=device, async_ops=True) as c:
+            for t, d in zip(srcs, dsts):
+                dist.all_gather_into_tensor(d.view(-1, *t.shape[1:]) if t.dim() > 1 else d.view(-1), t, group=group)
+        c.wait()
+        torch.cuda.synchronize(device)
+        for t, d in zip(srcs, dsts):
+            want = torch.stack([torch.full_like(t, float(v)) for v in ((r + 1) * (1 if t.dtype == torch.bfloat16 else 0.5 if t.dtype == torch.float32 else 7)
+                                                                         for r in range(world))])
+            ok = ok and bool(torch.equal(d, want))
+    except Exception:   # noqa: BLE001  (any failure of the private API: use the public one)
+        ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)     # all ranks take the same path
+    _COALESCE_CHECKED[key] = bool(flag.item())
+    return _COALESCE_CHECKED[key]
 
 
 class _Done:
@@ -348,6 +380,7 @@ class ShardedFrame:
         if p not in self._g_head:
             self._g_head[p], self._head_out[p] = self._capture_head(lambda: self._head(p, dd, img_metas, st["hw"], st["starts"], pad_hw))
         self._g_head[p].replay()
+        eng._overflow = self._head_out[p].get("proposal_overflow")
         return self._head_out[p]
 
     def _pipelined_frame(self, data, img_metas, pad_hw):
@@ -406,4 +439,5 @@ class ShardedFrame:
             self._g_head[p].replay()
             P["head_done"][p].record(P["s_head"])
         eng._ready = P["head_done"][p]
+        eng._overflow = self._head_out[p].get("proposal_overflow")      # this frame's flag (its buffer set), not the last captured one
         return self._head_out[p]

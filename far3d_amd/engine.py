@@ -373,6 +373,14 @@ class Far3DEngine:
         # -- tests/test_engine_full_gpu.py, three frames against the oracle -- sits on near-tie discrete decisions, and the 1e-7-level
         # change of the pooled means moved one of them on frame 1)
         esums = self._esums if (act == torch.bfloat16 and not pair) else None
+        if esums is not None and esums.shape[0] < N:
+            # more images than cfg["num_cams"] (a standalone / batched backbone call, plugin VoVNet.forward): grow the zero-initialised
+            # sums once -- the kernels leave them zero after every use
+            # (a second tensor: captured graphs keep the address of the first)
+            big = getattr(self, "_esums_big", None)
+            if big is None or big.shape[0] < N:
+                big = self._esums_big = torch.zeros((N, esums.shape[1]), dtype=torch.int64, device=self.dev)
+            esums = big
         if esums is not None and not torch.cuda.is_current_stream_capturing():
             esums.zero_()
         x = ops.stem_im2col(img, act, pair=pair)
@@ -837,6 +845,9 @@ class Far3DEngine:
             P["g_head"][p].replay()
             P["head_done"][p].record(P["s_head"])
         self._ready = P["head_done"][p]
+        # the overflow flag this frame writes lives in ITS buffer set: bind it per frame (the replayed graph never runs the Python
+        # line that recorded it at capture time)
+        self._overflow = P["outs"][p].get("proposal_overflow")
         return P["outs"][p]
 
     def output_stream(self):
@@ -875,7 +886,9 @@ class Far3DEngine:
                 cur = torch.cuda.current_stream(self.dev)
                 cur.wait_stream(self._pipe["s_cam"]); cur.wait_stream(self._pipe["s_head"])
             self._ready = None
-            return self._frame_body(self._stage_inputs(data), img_metas, pad_hw)
+            outs = self._frame_body(self._stage_inputs(data), img_metas, pad_hw)
+            self._overflow = outs.get("proposal_overflow")
+            return outs
         dd = self._stage_inputs(data)
         if self.use_graph and steady and self.static_adaptive_rows() is not None:
             if self._graph is None:
@@ -884,8 +897,11 @@ class Far3DEngine:
                     self._graph_outs = self._frame_body(dd, img_metas, pad_hw)
                 self._graph = g
             self._graph.replay()
+            self._overflow = self._graph_outs.get("proposal_overflow")
             return self._graph_outs
-        return self._frame_body(dd, img_metas, pad_hw)
+        outs = self._frame_body(dd, img_metas, pad_hw)
+        self._overflow = outs.get("proposal_overflow")
+        return outs
 
     # ------------------------------------------------------------------------------------------ a12: NMS-free decode
     def decode(self, all_cls, all_box):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245

@@ -229,3 +229,27 @@ def test_detector_from_registry_config_in_capacity_mode(hip_lib):
             res = det(return_loss=False, rescale=True, img_metas=metas, **data)[0]["pts_bbox"]
             assert_detections_match(tuple(res[k].cpu().numpy() for k in ("labels_3d", "boxes_3d", "scores_3d")),
                                     tuple(z["f%d_%s" % (fi, k)] for k in ("labels_3d", "boxes_3d", "scores_3d")), "frame %d" % fi)
+
+
+@pytest.mark.parametrize("mode", ["graph", "pipeline"])
+def test_capacity_overflow_on_a_replayed_frame_of_each_buffer_set(hip_lib, mode):
+    """the overflow flag lives in the frame's own buffer set; a REPLAYED graph never runs the Python line that recorded it
+    at capture time, so the engine binds it per frame.  Five frames that fit (scene start, both captures, both first replays), then
+    two replays -- one per buffer set in pipeline mode -- whose 29 proposals exceed the 27 reserved rows: each must raise, the
+    frames before must not."""
+    from far3d_amd import lib
+    eng, z, rc = _golden_engine("fp32", "far3d_small_seq", proposal_topk=None, proposal_capacity=27)
+    assert len(z["f1_valid_idx"]) <= 27 < len(z["f0_valid_idx"])
+    eng.use_graph = True
+    eng.pipeline = mode == "pipeline"
+    for step, fi in enumerate([1, 1, 1, 1, 1, 0, 0]):
+        data, metas = synth.recipe_frame(rc, fi)      # frames 0 and 1 belong to the same scene
+        eng.forward_frame(data, metas)
+        eng.wait_outputs()
+        if fi == 1:
+            eng.check_proposal_overflow()
+        else:
+            with pytest.raises(lib.Far3dHipError):
+                eng.check_proposal_overflow()
+    if mode == "pipeline":
+        assert sorted(eng._pipe["g_head"]) == [0, 1]

@@ -112,3 +112,61 @@ def test_channel_sum_fusion_is_offered_exactly_where_the_gemm_epilogue_can_produ
     assert not ops.conv_can_fuse_sums(torch.empty(7, 160, 240, 128, dtype=torch.bfloat16), pc3)
     odd = ops.PackedConv(torch.zeros(96, 352, 1, 1), torch.zeros(96), dtype=torch.bfloat16, device="cpu")       # no entry in the table
     assert not ops.conv_can_fuse_sums(torch.empty(7, 40, 60, 352, dtype=torch.bfloat16), odd)
+
+
+def test_bench_launch_plan():
+    """`python bench.py --gpus N` starts its own N ranks (the reference wraps its test script in a launcher the
+    same way, tools/dist_test.sh:11-23): one torch.distributed.run process group on 127.0.0.1, the flags passed through; under a
+    launcher (WORLD_SIZE set) the process is a rank and must agree with --gpus."""
+    import importlib.util
+    import os
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("far3d_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_plan(1, {}, []) is None
+    assert bench.launch_plan(4, {"WORLD_SIZE": "4"}, ["--gpus", "4"]) is None
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {"WORLD_SIZE": "1"}, ["--gpus", "8"])
+    cmd = bench.launch_plan(8, {}, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+
+
+def test_ida_matrix_against_a_stepwise_float32_chain():
+    """ida_matrix is a float64 closed form rounded once; the reference (datasets/pipelines/custom_pipeline.py:294-311)
+    composes scale, crop, flip and rotation step by step in float32.  Equal when rotate == 0 (the reference's only supported
+    value), float32-rounding close otherwise."""
+    import numpy as np
+    import torch
+    from far3d_amd.data_pipeline.preprocess import ida_matrix
+
+    def stepwise(resize, crop, flip, rotate):
+        rot = torch.eye(2) * resize
+        tran = -torch.tensor(crop[:2], dtype=torch.float32)
+        if flip:
+            A = torch.tensor([[-1.0, 0.0], [0.0, 1.0]])
+            b = torch.tensor([crop[2] - crop[0], 0.0])
+            rot, tran = A.matmul(rot), A.matmul(tran) + b
+        th = rotate / 180 * np.pi
+        A = torch.tensor([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]], dtype=torch.float32)
+        b = torch.tensor([crop[2] - crop[0], crop[3] - crop[1]], dtype=torch.float32) / 2
+        b = A.matmul(-b) + b
+        rot, tran = A.matmul(rot), A.matmul(tran) + b
+        M = torch.eye(3)
+        M[:2, :2], M[:2, 2] = rot, tran
+        return M
+
+    rng = np.random.RandomState(3)
+    for _ in range(50):
+        resize = float(np.float32(rng.uniform(0.3, 1.2)))
+        left, top = int(rng.randint(0, 400)), int(rng.randint(0, 300))
+        crop = (left, top, left + 960, top + 640)
+        for flip in (False, True):
+            assert torch.equal(ida_matrix(resize, crop, flip, 0.0), stepwise(resize, crop, flip, 0.0))
+            ang = float(rng.uniform(-25, 25))
+            a, b = ida_matrix(resize, crop, flip, ang), stepwise(resize, crop, flip, ang)
+            assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()

@@ -86,3 +86,25 @@ def test_multihead_attention_module_matches_mmcv_semantics(rig):
     key, kpos = torch.cat([x, mem], 1), torch.cat([qpos, mpos], 1)
     got = mha.to(DEV)(x.to(DEV), key.to(DEV), key.to(DEV), None, query_pos=qpos.to(DEV), key_pos=kpos.to(DEV))
     assert got.shape == want.shape and (got.cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_backbone_module_takes_more_images_than_cameras_in_bf16(rig):
+    """the registry VoVNet runs its engine with the default 7-camera configuration and must take any batch of images
+    (ref models/backbones/vovnet.py:349-360 -- cameras are just the batch dimension).  In bf16 mode the eSE channel sums come from
+    the concat GEMM's epilogue into a per-image scratch sized for the configured cameras: 9 images must run, and give image by image
+    what 3 + 3 + 3 give."""
+    det, orc, rc = rig
+    bb = det.img_backbone
+    old = bb.precision
+    bb.precision = "bf16"
+    try:
+        g = torch.Generator().manual_seed(11)
+        imgs = torch.randn(9, 3, rc["pad_hw"][0], rc["pad_hw"][1], generator=g).to(DEV)
+        all9 = [t.float().clone() for t in bb(imgs)]
+        for k in range(3):
+            part = bb(imgs[3 * k:3 * k + 3])
+            for a, b in zip(all9, part):      # the tile table may pick another tile for another pixel count: bf16 rounding, not bits
+                d = (a[3 * k:3 * k + 3] - b.float()).abs().max().item()
+                assert d <= 2e-2 * max(1.0, a.abs().max().item()), d
+    finally:
+        bb.precision = old

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-run() { d=$1; shift; timeout 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$d -o run -- python $R/tools/run_conv_once.py > $R/gpurun_out/$d.log 2>&1 || echo "pass $d failed"; }
+run() { d=$1; shift; timeout 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$d -o run -- python $R/tools/probe/run_conv_once.py > $R/gpurun_out/$d.log 2>&1 || echo "pass $d failed"; }
 mkdir -p $R/gpurun_out
 run cpmc1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU
 run cpmc2 SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS

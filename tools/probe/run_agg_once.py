@@ -1,7 +1,7 @@
 """Launch the fused aggregation kernel a few times eagerly (for rocprofv3 --pmc passes)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from far3d_amd import ops
 from tests import cases
 dev = "cuda:0"

@@ -1,7 +1,7 @@
 """Launch a few representative convolutions eagerly (for rocprofv3 --pmc passes).  Cases are told apart by grid size."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from far3d_amd import ops
 dev = "cuda:0"
 CASES = [("s2.c1", 7, 160, 240, 128, 128, 3, 60), ("s4.c1", 7, 40, 60, 192, 192, 3, 60), ("s4.c0", 7, 40, 60, 768, 192, 3, 64),
