@@ -369,10 +369,10 @@ class Far3DEngine:
         scratch = self._buf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
         # fixed-point channel sums the concat convolutions accumulate in their epilogue (the eSE pooling without a second pass over the
         # map); zero at rest: every eSE call consumes and re-zeroes them, and a scene start re-zeroes them in case a frame was aborted
-        # (plain bf16 maps only.  The pair-stored mode keeps the fp32 pooling pass: its full-size streaming parity check
-        # -- tests/test_engine_full_gpu.py, three frames against the oracle -- sits on near-tie discrete decisions, and the 1e-7-level
-        # change of the pooled means moved one of them on frame 1)
-        esums = self._esums if (act == torch.bfloat16 and not pair) else None
+        # (plain bf16 AND pair-stored maps.  Round 3 switched the pair mode back to its fp32 pooling pass after its full-size streaming
+        # check lost one query to a flipped depth-bin argmax; the rig now adopts that near-tie like the other discrete decisions --
+        # tests/test_engine_full_gpu.py::_resolve_depth_ties -- and the pair mode takes the sums again)
+        esums = self._esums if act == torch.bfloat16 else None
         if esums is not None and esums.shape[0] < N:
             # more images than cfg["num_cams"] (a standalone / batched backbone call, plugin VoVNet.forward): grow the zero-initialised
             # sums once -- the kernels leave them zero after every use

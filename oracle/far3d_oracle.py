@@ -148,7 +148,8 @@ class Far3DOracle:
     # ------------------------------------------------------------------ a5: 2D proposals (yolox_head.py:355-501)
     def get_bboxes(self, outs, forced_valid=None):
         """forced_valid: optional (BN,S,1) bool mask that replaces the peak selection (test rigs use it to resolve K-th-place
-        near-ties of the build-defined static top-K mode the same way as the device did; the weights are returned for the check)."""
+        near-ties of the build-defined static top-K mode the same way as the device did; the weights are returned for the check),
+        or a tuple (mask, peak mask (BN,S,1) bool): the cells of `mask` outside `peak mask` weigh zero (zero-weight fillers)."""
         cls, reg, obj = outs["enc_cls_scores"], outs["enc_bbox_preds"], outs["objectnesses"]
         n_img = cls[0].shape[0]
         priors, weights, raws = [], [], []
@@ -166,6 +167,11 @@ class Far3DOracle:
             weights.append(sw * (sw == nms).to(sw.dtype))
         weight = torch.cat(weights, dim=1)                    # (BN, S, 1)
         K = self.cfg["proposal_topk"]
+        if isinstance(forced_valid, tuple):
+            # (selection mask, peak mask): the rig also hands over the device's outcome of the 3x3 peak test for the selected cells
+            # (an equality test on near-equal scores: a cell the device counts as a zero-weight filler must weigh zero here too)
+            forced_valid, peak = forced_valid
+            weight = torch.cat(raws, dim=1) * peak.to(self.dtype)
         if forced_valid is not None:
             valid = forced_valid
         elif K is None:

@@ -43,7 +43,7 @@ def _neighbour_max(raw):
     return torch.cat(out, dim=1)
 
 
-def _resolve_topk_ties(sel, tag, tol=2e-5):
+def _resolve_topk_ties(sel, tag, tol=2e-5, dev_scores=None):
     """The static top-K proposal mode keeps the K best 2D peaks per camera (peak: score == maxpool3x3(score)); both the peak test
     and the K-th place are decisions on near-equal numbers that rounding noise can turn either way -- and one flipped peak test
     shifts the K-th place by a whole rank.  Returns a callback for the oracle: it checks that the device's set D is one the
@@ -51,7 +51,11 @@ def _resolve_topk_ties(sel, tag, tol=2e-5):
     frames stay comparable row by row.  In the oracle's scores a cell is a ROBUST peak if it exceeds its 8 neighbours by more
     than tol, a NON-peak if it is below their maximum by more than tol, FRAGILE otherwise.  D is allowed iff
       * |D| = K and D contains no non-peak;
-      * every robust peak outside D scores no higher than the lowest score in D (up to tol)."""
+      * every robust peak outside D scores no higher than the lowest score in D (up to tol).
+    dev_scores (M,), the device's 2D score of every selected cell in row order (camera-major, ascending cell): a selected cell whose
+    peak test FAILED on the device is a zero-weight filler there (score 0 -> the context's log-odds term sits at its clamp, 14 below
+    a real score: found in round 4 as the single 0.19-off query of the pair-stored mode).  The oracle must count the same cells as
+    fillers: allowed iff such a cell is not a robust peak, and a cell the device scores is not a non-peak (checked above)."""
     def pick(own):
         raw = own["raw_weight"][..., 0]                      # (N,S) score before the 3x3 peak test
         N = raw.shape[0]
@@ -69,7 +73,16 @@ def _resolve_topk_ties(sel, tag, tol=2e-5):
             low = raw[n][D[n]].min().item()
             miss = (robust[n] & ~D[n] & (raw[n] > (1 + tol) * low)).nonzero().flatten().tolist()
             assert not miss, "%s camera %d: the device skipped robust peaks %s that outscore its lowest pick %.6f" % (tag, n, miss, low)
-        return mask
+        if dev_scores is None:
+            return mask
+        peak = mask.clone()
+        cells = D.nonzero()                                   # row order of the adaptive queries: camera-major, ascending cell
+        assert cells.shape[0] == dev_scores.numel(), (cells.shape, dev_scores.shape)
+        filler = dev_scores.flatten() <= 0
+        for (n, i) in cells[filler].tolist():
+            assert not bool(robust[n, i]), "%s camera %d: the device weighs cell %d zero although it is a robust peak" % (tag, n, i)
+            peak[n, i, 0] = False
+        return mask, peak
     return pick
 
 
@@ -92,6 +105,26 @@ def _resolve_memory_ties(idx_dev, tag, tol=1e-2):
     return pick
 
 
+def _resolve_depth_ties(depth_logit_dev, tag, tol=1e-3):
+    """The adaptive queries take their depth from the argmax over the 51 depth bins at the proposal's cell (farhead.py:736-766,
+    topk = 1): a discrete choice per cell that rounding noise flips where the two best bins are near-equal -- and a flipped bin
+    replaces a whole query (it bit in round 3: one query 0.19 off with every continuous quantity within 3e-5).  The callback
+    makes the oracle adopt the device's per-cell argmax (first maximum of the device's own logits, what far3d_proposal_gather
+    computes) after checking that every cell where the two differ IS a near-tie in the oracle's own probabilities: the device's
+    bin within a relative `tol` of the oracle's best."""
+    dev = depth_logit_dev.argmax(dim=-1)                          # (N, h, w) from the NHWC logits
+    def pick(pred_depth, own):                                    # (BN, D, h, w) softmax, (BN, h, w, 1)
+        d = dev.view(own.shape).to(own.device)
+        diff = d != own
+        if diff.any():
+            p = pred_depth.permute(0, 2, 3, 1)
+            p_own, p_dev = p.gather(-1, own)[diff], p.gather(-1, d)[diff]
+            gap = ((p_own - p_dev) / p_own).max().item()
+            assert gap < tol, "%s: %d depth-bin choices differ beyond near-ties (relative probability gap %.2e)" % (tag, int(diff.sum()), gap)
+        return d
+    return pick
+
+
 def _run_engine(sd, precision):
     """3 streaming frames through the engine; everything the comparisons need, on the host."""
     eng = _engine(sd, precision)
@@ -100,7 +133,9 @@ def _run_engine(sd, precision):
         o = eng.forward_frame(data, metas)
         cnt = o["sel_cnt"].cpu().numpy()
         got.append(dict(sel=[(n, int(i)) for n in range(7) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()],
-                        memory_topk=o["memory_topk"].cpu().clone(),
+                        memory_topk=o["memory_topk"].cpu().clone(), depth_logit=o["depth_logit"].float().cpu().clone(),
+                        ref=o["reference_points"].float().cpu().clone(), bbox2d=o["bbox2d"].float().cpu().clone(),
+                        score2d=o["bbox2d_scores"].float().cpu().clone(),
                         all_cls_scores=o["all_cls_scores"].cpu().clone(), all_bbox_preds=o["all_bbox_preds"].cpu().clone(),
                         outs_dec=o["outs_dec"].cpu().clone(), feat_flatten=o["feat_flatten"].float().cpu().clone(),
                         fpn=[eng.act_to_nchw(f).permute(0, 2, 3, 1).cpu().clone() for f in o["fpn"]],   # NHWC f32 (pair storage decoded)
@@ -123,12 +158,14 @@ def _run_oracle(sd, got, with_f64, tie_tol=2e-5):
     outs = []
     with torch.no_grad():
         for fi, (data, metas) in enumerate(_frames()):
-            w = keep(orc.simple_test(data, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d" % fi, tie_tol),
-                                     forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d" % fi)))
+            w = keep(orc.simple_test(data, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d" % fi, tie_tol, got[fi]["score2d"]),
+                                     forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d" % fi),
+                                     forced_depth=_resolve_depth_ties(got[fi]["depth_logit"], "frame %d" % fi, max(1e-4, 20 * tie_tol))))
             if with_f64:
                 d64 = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
-                w["f64"] = keep(o64.simple_test(d64, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d (fp64)" % fi, tie_tol),
-                                                forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d (fp64)" % fi)))
+                w["f64"] = keep(o64.simple_test(d64, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d (fp64)" % fi, tie_tol, got[fi]["score2d"]),
+                                                forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d (fp64)" % fi),
+                                                forced_depth=_resolve_depth_ties(got[fi]["depth_logit"], "frame %d (fp64)" % fi, max(1e-4, 20 * tie_tol))))
             outs.append(w)
     return outs
 
@@ -274,15 +311,19 @@ def test_split_bf16_modes_against_the_logit_tolerance(hip_lib, oracle_run, preci
     on the bf16 MFMA with fp32 accumulation; far3d_hip.h FAR3D_DT_F32_BF16X3) against the oracle at the benchmarked size.
 
     What holds (asserted): on a single frame (frame 0, what the north star describes) EVERY logit is within 2e-4, five times
-    inside the 1e-3 bar.  On the streaming frames the propagated queries feed each frame's rounding noise into the next one; the
-    reference arithmetic itself (oracle fp32 vs fp64) disagrees by 4.6e-4 there, the exact-fp32 engine by 3e-4, and the split
-    modes stay within 1e-3 at the 99.9th percentile with the worst logits at 1-2e-3 (asserted: < 4e-3), i.e. 2-4x the
-    reference's own rounding ambiguity.  Where the near-tie decisions (K-th 2D peak, memory top-256 cut) coincide with the fp32
-    engine's, the fixture's oracle run is reused; otherwise the oracle is run again on this engine's decisions."""
+    inside the 1e-3 bar, and on the streaming frames -- where the propagated queries feed each frame's rounding noise into the
+    next one and the reference arithmetic itself (oracle fp32 vs fp64) disagrees by 4.6e-4 -- EVERY logit is within the 1e-3 bar
+    too (observed 3.0e-4 / 7.6e-4).  Rounds 2-3 allowed 4e-3 on the worst streaming logit: that slack was an artifact of the rig,
+    not of the arithmetic -- one selected 2D cell whose 3x3 peak test (an equality on near-equal scores) came out differently on
+    the two sides, so one side carried a zero-weight filler where the other carried a scored proposal (the context's log-odds
+    term 14 apart); the oracle now adopts the device's outcome like the other near-tie decisions (_resolve_topk_ties).  Where the
+    decisions (K-th 2D peak, peak test, depth-bin argmax, memory top-256 cut) coincide with the fp32 engine's, the fixture's oracle
+    run is reused; otherwise the oracle is run again on this engine's decisions."""
     sd, want, got32 = oracle_run
     got = _run_engine(sd, precision)
-    same = all(sorted(got[fi]["sel"]) == sorted(got32[fi]["sel"]) and torch.equal(got[fi]["memory_topk"], got32[fi]["memory_topk"])
-               for fi in range(FRAMES))
+    same = all(sorted(got[fi]["sel"]) == sorted(got32[fi]["sel"]) and torch.equal(got[fi]["memory_topk"], got32[fi]["memory_topk"]) and
+               torch.equal(got[fi]["depth_logit"].argmax(-1), got32[fi]["depth_logit"].argmax(-1)) and
+               torch.equal(got[fi]["score2d"] > 0, got32[fi]["score2d"] > 0) for fi in range(FRAMES))
     if not same:
         want = _run_oracle(sd, got, with_f64=False, tie_tol=5e-4)     # 2D scores carry ~2e-5 mean / 2e-4 max relative noise in this mode
     report = []
@@ -297,13 +338,21 @@ def test_split_bf16_modes_against_the_logit_tolerance(hip_lib, oracle_run, preci
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_full_%s.json" % precision), "w") as f:
         json.dump(report, f, indent=1)
+    for fi in range(FRAMES):      # where do the worst rows come from?  (a whole-query replacement is the signature of a discrete decision)
+        o, w = got[fi], want[fi]
+        d0 = (o["outs_dec"][0] - w["outs_dec"][0, 0]).abs().max(dim=-1).values          # (A,) first decoder layer
+        worst = torch.topk(d0, 5).indices.tolist()
+        dref = (o["ref"].view(-1, 3) - w["ref"].view(-1, 3)).abs().max(dim=-1).values
+        print("\n%s frame %d: worst rows of decoder layer 0 %s (644..1287 adaptive, 1288.. propagated); their errors %s; their "
+              "reference-point differences %s; max reference-point difference overall %.3e at row %d" %
+              (precision, fi, worst, [round(d0[i].item(), 5) for i in worst], [round(dref[i].item(), 6) for i in worst], dref.max().item(), int(dref.argmax())))
     for fi, rep in enumerate(report):
         assert rep["value_maps_rel_max"] < 2e-4 and all(rep["fpn%d_rel_max" % l] < 2e-4 for l in range(4)), rep
         e = rep["logit_abs_err_vs_oracle32"]
         if fi == 0:
             assert e["max"] < 2e-4, "frame 0: max abs logit error %.3e; %s" % (e["max"], e)
         else:
-            assert e["p999"] < 1e-3 and e["max"] < 4e-3, "frame %d: %s" % (fi, e)
+            assert e["p999"] < 1e-3 and e["max"] < 1e-3, "frame %d: %s" % (fi, e)      # the north-star bar itself, streaming frames included
         r = got[fi]["result"]
         keep = r["keep"].numpy()
         assert_detections_match(tuple(r[k].numpy()[keep] for k in ("labels_3d", "boxes_3d", "scores_3d")),

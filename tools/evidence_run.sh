@@ -34,7 +34,7 @@ if [ -n "$PMC" ]; then
     timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o run -- python $R/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_$c.log 2>&1 || echo "pmc pass $c failed"
   done
   timeout 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_tcc -o run -- python $R/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_tcc.log 2>&1 || echo "pmc pass tcc failed"
-  python $R/tools/pmc_to_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc aggregate_v7_kernel $O/aggregate_pmc.json
+  python $R/tools/pmc_to_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc aggregate_v8_kernel $O/aggregate_pmc.json
   # SQ counters of the aggregation kernel: where the wave cycles go (VALU issue vs waiting)
   timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python $R/tools/probe/run_agg_once.py > $O/pmc_sq.log 2>&1 || echo "pmc pass sq failed"
   for f in $(find $O/pmc_sq -name '*counter_collection.csv'); do (head -1 $f; grep aggregate $f) > $O/aggregate_sq_counters.csv; done
