@@ -388,7 +388,7 @@ class ShardedFrame:
         input staging -> camera graph -> exchange.  Stream s_head: [wait for the exchange] -> head graph."""
         eng = self.eng
         if self._pipe is None:
-            self._pipe = dict(s_cam=torch.cuda.Stream(eng.dev), s_head=torch.cuda.Stream(eng.dev), cam_done={}, head_done={})
+            self._pipe = dict(s_cam=torch.cuda.Stream(eng.dev, priority=eng.cam_priority), s_head=torch.cuda.Stream(eng.dev), cam_done={}, head_done={})
         P = self._pipe
         p = eng._par
         cur = torch.cuda.current_stream(eng.dev)

@@ -136,10 +136,17 @@ class Far3DEngine:
         # forward_frame are ready on `output_stream()`; a caller that reads them on its own stream calls `wait_outputs()` first
         # (ordering the caller's stream after every head automatically would serialise the next frame's camera stages again).
         self.pipeline = False
-        self.cam_priority = 0       # HIP stream priority of the camera-stage stream in pipeline mode (-1 = high)
+        self.cam_priority = -1      # HIP stream priority of the camera-stage streams in pipeline mode (-1 = high: the head's latency-bound
+                                    # launches must not hold back the throughput-critical camera stages; 0 = default, A/B in bench.py)
         self._overflow = None       # fixed-capacity threshold mode: device flag of the latest frame (check_proposal_overflow)
         self._ready = None          # event of the latest pipelined head (None: outputs are on the caller's stream)
-        self._par = 0               # buffer-set parity currently in use (always 0 without pipelining)
+        self.cam_streams = 3        # pipeline mode: streams the camera stages of consecutive frames alternate between (< pipeline_sets)
+        self.pipeline_sets = 4      # pipeline mode: buffer sets = frames in flight (4: the camera stages of THREE frames run
+                                    # concurrently on three streams under the head of a fourth; 2: round 3's camera || head overlap only).
+                                    # Measured (profiles/r4/pipeline_ab.txt, bf16): 2 sets 164.5, 3 sets 193.1, 4 sets / 2 streams 195.8,
+                                    # 4 sets / 3 streams 200.5 samples/s -- with the camera streams at high priority; at equal priority the
+                                    # head's small launches interleave with the camera stages and the gain is lost (167.0 at 3 sets)
+        self._par = 0               # buffer set currently in use (always 0 without pipelining)
         self._fidx = 0
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
@@ -201,7 +208,6 @@ class Far3DEngine:
             stages.append(blocks)
         bb["stages"] = stages
         self.bb = bb
-        self._esums = torch.zeros((self.cfg["num_cams"], max(self.spec["stage_out_ch"])), dtype=torch.int64, device=dev)
 
     def _prepare_neck(self):
         sd, cfg, dev = self.sd, self.cfg, self.dev
@@ -368,19 +374,18 @@ class Far3DEngine:
         # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
         scratch = self._buf(("ese_scratch",), (ops.ese_scratch_floats(N, max(spec["stage_out_ch"])),), torch.float32)
         # fixed-point channel sums the concat convolutions accumulate in their epilogue (the eSE pooling without a second pass over the
-        # map); zero at rest: every eSE call consumes and re-zeroes them, and a scene start re-zeroes them in case a frame was aborted
+        # map); zero at rest: every eSE call consumes and re-zeroes them, and an eager call re-zeroes them in case a frame was aborted
         # (plain bf16 AND pair-stored maps.  Round 3 switched the pair mode back to its fp32 pooling pass after its full-size streaming
-        # check lost one query to a flipped depth-bin argmax; the rig now adopts that near-tie like the other discrete decisions --
-        # tests/test_engine_full_gpu.py::_resolve_depth_ties -- and the pair mode takes the sums again)
-        esums = self._esums if act == torch.bfloat16 else None
-        if esums is not None and esums.shape[0] < N:
-            # more images than cfg["num_cams"] (a standalone / batched backbone call, plugin VoVNet.forward): grow the zero-initialised
-            # sums once -- the kernels leave them zero after every use
-            # (a second tensor: captured graphs keep the address of the first)
-            big = getattr(self, "_esums_big", None)
-            if big is None or big.shape[0] < N:
-                big = self._esums_big = torch.zeros((N, esums.shape[1]), dtype=torch.int64, device=self.dev)
-            esums = big
+        # check lost one query; the cause was a near-tie of the rig's 3x3 peak test, not the pooling -- tests/test_engine_full_gpu.py --
+        # and the pair mode takes the sums again).  One tensor per BUFFER SET (camera stages of two frames run
+        # concurrently in pipeline mode) and per image count (any batch of images may be passed); created zeroed, and never
+        # replaced once a graph has captured its address.
+        esums = None
+        if act == torch.bfloat16:
+            ek = (self._par, "esums", N)
+            esums = self._bufs.get(ek)
+            if esums is None:
+                esums = self._bufs[ek] = torch.zeros((N, max(spec["stage_out_ch"])), dtype=torch.int64, device=self.dev)
         if esums is not None and not torch.cuda.is_current_stream_capturing():
             esums.zero_()
         x = ops.stem_im2col(img, act, pair=pair)
@@ -799,8 +804,12 @@ class Far3DEngine:
         if self._pipe is None:
             # the camera stages are the throughput-critical half: their stream gets the higher priority so that the head of the
             # previous frame (latency-bound, few CUs) does not delay their workgroups (self.cam_priority, A/B in bench.py)
-            self._pipe = dict(s_cam=torch.cuda.Stream(self.dev, priority=self.cam_priority), s_head=torch.cuda.Stream(self.dev), g_cam={}, g_head={}, outs={},
-                              cam_done={}, head_done={})
+            # pipeline_sets >= 3: two camera-stage streams.  A frame's per-camera stages are ~215 dependent launches, many of them one
+            # or two rounds of workgroups (stages 4-5, FPN, 2D head); the stages of the NEXT frame on a second stream fill their tails:
+            # two camera graphs take 4.66 ms per frame side by side against 5.62 ms back to back (profiles/r4/cam_overlap.txt)
+            ncs = max(1, min(int(self.pipeline_sets) - 1, int(self.cam_streams)))
+            self._pipe = dict(s_cams=[torch.cuda.Stream(self.dev, priority=self.cam_priority) for _ in range(ncs)], s_head=torch.cuda.Stream(self.dev), g_cam={}, g_head={}, outs={},
+                              cam_done={}, head_done={}, n_issued=0)
         P = self._pipe
         p = self._par
         cur = torch.cuda.current_stream(self.dev)
@@ -829,16 +838,18 @@ class Far3DEngine:
             first = True
         else:
             first = False
-        P["s_cam"].wait_event(here)
+        s_cam = P["s_cams"][P["n_issued"] % len(P["s_cams"])]      # consecutive frames alternate between the camera streams
+        P["n_issued"] += 1
+        s_cam.wait_event(here)
         for v in data.values():                           # the caller may free its input tensors right after this call
             if isinstance(v, torch.Tensor) and v.is_cuda:
-                v.record_stream(P["s_cam"])
-        with torch.cuda.stream(P["s_cam"]):
+                v.record_stream(s_cam)
+        with torch.cuda.stream(s_cam):
             if not first:
-                P["s_cam"].wait_event(P["head_done"][p])  # head(i-2) read this buffer set (inputs included)
+                s_cam.wait_event(P["head_done"][p])       # the head of the frame that last used this buffer set (inputs included)
             self._stage_inputs(data)
             P["g_cam"][p].replay()
-            P["cam_done"][p].record(P["s_cam"])
+            P["cam_done"][p].record(s_cam)
         with torch.cuda.stream(P["s_head"]):
             P["s_head"].wait_event(here)
             P["s_head"].wait_event(P["cam_done"][p])
@@ -878,13 +889,15 @@ class Far3DEngine:
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
         if self.pipeline and self.use_graph and self.static_adaptive_rows() is not None:
-            self._par = self._fidx & 1
+            self._par = self._fidx % max(2, int(self.pipeline_sets))
             self._fidx += 1
             if steady:
                 return self._pipelined_frame(data, img_metas, pad_hw)
             if self._pipe is not None:       # scene start: runs eagerly on the caller's stream, after everything in flight
                 cur = torch.cuda.current_stream(self.dev)
-                cur.wait_stream(self._pipe["s_cam"]); cur.wait_stream(self._pipe["s_head"])
+                for sc in self._pipe["s_cams"]:
+                    cur.wait_stream(sc)
+                cur.wait_stream(self._pipe["s_head"])
             self._ready = None
             outs = self._frame_body(self._stage_inputs(data), img_metas, pad_hw)
             self._overflow = outs.get("proposal_overflow")

@@ -154,7 +154,7 @@ def test_fixed_capacity_threshold_mode_reproduces_the_reference_in_graph_and_pip
         eng.pipeline = mode == "pipeline"
         nq = rc["num_query"]
         out = []
-        for fi in list(range(rc["frames"])) + [rc["frames"] - 1] * 2:      # + 2 steady frames so that both pipeline buffer sets replay
+        for fi in list(range(rc["frames"])) + [rc["frames"] - 1] * 5:      # + steady frames so that every pipeline buffer set captures and replays
             data, metas = synth.recipe_frame(rc, fi)
             o = eng.forward_frame(data, metas)
             eng.wait_outputs()
@@ -166,7 +166,7 @@ def test_fixed_capacity_threshold_mode_reproduces_the_reference_in_graph_and_pip
         if mode == "graph":
             assert eng._graph is not None
         if mode == "pipeline":
-            assert sorted(eng._pipe["g_head"]) == [0, 1]
+            assert sorted(eng._pipe["g_head"]) == list(range(eng.pipeline_sets))
         res[mode] = out
     # the reference's own outputs (goldens are generated in threshold mode) on the rows that hold queries
     for fi in range(rc["frames"]):
@@ -234,15 +234,15 @@ def test_detector_from_registry_config_in_capacity_mode(hip_lib):
 @pytest.mark.parametrize("mode", ["graph", "pipeline"])
 def test_capacity_overflow_on_a_replayed_frame_of_each_buffer_set(hip_lib, mode):
     """the overflow flag lives in the frame's own buffer set; a REPLAYED graph never runs the Python line that recorded it
-    at capture time, so the engine binds it per frame.  Five frames that fit (scene start, both captures, both first replays), then
-    two replays -- one per buffer set in pipeline mode -- whose 29 proposals exceed the 27 reserved rows: each must raise, the
-    frames before must not."""
+    at capture time, so the engine binds it per frame.  Frames that fit (scene start, a capture and a first replay per buffer
+    set), then one replay per buffer set whose 29 proposals exceed the 27 reserved rows: each must raise, the frames before must not."""
     from far3d_amd import lib
     eng, z, rc = _golden_engine("fp32", "far3d_small_seq", proposal_topk=None, proposal_capacity=27)
     assert len(z["f1_valid_idx"]) <= 27 < len(z["f0_valid_idx"])
     eng.use_graph = True
     eng.pipeline = mode == "pipeline"
-    for step, fi in enumerate([1, 1, 1, 1, 1, 0, 0]):
+    n = eng.pipeline_sets if mode == "pipeline" else 1
+    for step, fi in enumerate([1] * (1 + 2 * n) + [0] * n):      # scene start, a capture and a replay per buffer set, then an overflowing replay on each
         data, metas = synth.recipe_frame(rc, fi)      # frames 0 and 1 belong to the same scene
         eng.forward_frame(data, metas)
         eng.wait_outputs()
@@ -252,4 +252,4 @@ def test_capacity_overflow_on_a_replayed_frame_of_each_buffer_set(hip_lib, mode)
             with pytest.raises(lib.Far3dHipError):
                 eng.check_proposal_overflow()
     if mode == "pipeline":
-        assert sorted(eng._pipe["g_head"]) == [0, 1]
+        assert sorted(eng._pipe["g_head"]) == list(range(eng.pipeline_sets))

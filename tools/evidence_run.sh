@@ -10,7 +10,7 @@ if [ "${TESTS:-1}" = "1" ]; then
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $O/smoke.txt
 fi
 timeout 900 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-300 $O/bench.json
-timeout 300 python bench.py --cam-priority -1 --no-cpu-baseline --no-in-tolerance 2>/dev/null | tail -1 > $O/bench_cam_priority_high.json; cut -c1-160 $O/bench_cam_priority_high.json
+timeout 300 python bench.py --pipeline-sets 2 --cam-priority 0 --no-cpu-baseline --no-in-tolerance 2>/dev/null | tail -1 > $O/bench_pipeline_r3.json; cut -c1-160 $O/bench_pipeline_r3.json
 timeout 600 python bench.py --precision fp32 --steps 20 --no-cpu-baseline 2>$O/bench_fp32.err | tail -1 > $O/bench_fp32.json; cut -c1-200 $O/bench_fp32.json
 timeout 600 python bench.py --precision bf16x3 --steps 50 2>$O/bench_bf16x3.err | tail -1 > $O/bench_bf16x3.json; cut -c1-200 $O/bench_bf16x3.json
 timeout 600 python bench.py --proposals threshold --capacity 4096 --steps 30 --no-cpu-baseline 2>$O/bench_thr.err | tail -1 > $O/bench_threshold.json; cut -c1-200 $O/bench_threshold.json
