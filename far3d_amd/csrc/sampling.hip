@@ -999,7 +999,11 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
   }
 }
 
-template <typename TV, int PT, int PRIO = 1>
+// Measured A/B of this kernel's knobs (profiles/r4/agg_live_*_ab.jsonl, live operands of a benchmark frame, bf16 rows): without the
+// work-dependent s_setprio 17.9-19.2 us against 16.9-17.8; a flatter work estimate 17.5-18.8; 8 instead of 4 loads per buffer in the
+// in-loop gather spills (128 VGPRs) 23-30 us; 192-entry lists (22.6 KB of LDS: 7 workgroups per CU, no longer every query resident
+// with margin) 17.8-21.1 us.
+template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW>
 __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ tab,
@@ -1010,7 +1014,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int P = PT ? PT : prm.P, L = prm.L, N = prm.N;
   const int n4 = L * P * 2;                                               // float4 per camera row of the tables (<= 128)
-  constexpr int CAPT = AGG8_CAPW + AGG8_PAD;
+  constexpr int CAPT = CAP + AGG8_PAD;
   float2* pxy_s = reinterpret_cast<float2*>(smem);                        // [8][4][16] pixel coordinates per (camera, level, point)
   float* stat_s = reinterpret_cast<float*>(pxy_s + 8 * 4 * 16);           // [8] softmax denominators (+ 8 pad)
   float4* w_all = reinterpret_cast<float4*>(stat_s + 16);                 // [2 waves][WSLOTS][16 points x 2] item weights
@@ -1083,6 +1087,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     d0 = x0 | (y0 << 16);
     d1 = spanx | (spany << 16);
     // work estimate in list entries: rows to gather + the build's own cost (a patch build is ~25 rows' worth, the per-corner one ~10)
+    // (a flatter formula -- items cost about the same, profiles/r4 -- was measured and is not faster: agg_live_est_formula_ab.jsonl)
     est = is_patch ? min(spanx * spany, 4 * P) + 25 : 4 * P + 10;
     // pixel coordinates of this lane's point on every level of camera n (read back by the build loops)
     if (act) {
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     agg8_gather<TV, NB>(feat, off_s, wt_s, cnt + padn, lane, acc);
     cnt = 0;
   };
-  auto flush = [&]() __attribute__((always_inline)) { flush_nb(std::integral_constant<int, 4>{}); };
+  auto flush = [&]() __attribute__((always_inline)) { flush_nb(std::integral_constant<int, LOOPNB>{}); };
   auto append = [&](bool hit, unsigned off, const float (&wa)[8]) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(hit);
     const int c = __popcll(m);
@@ -1227,7 +1232,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
 #endif
       // one item adds at most 64 rows (a patch's tokens; 4 P <= 64 corners): gather what is listed once fewer might fit.  The only
       // flush site inside the loops (the list is private to the wave: LDS is in order per wave, the test is wave-uniform)
-      if (cnt > AGG8_CAPW - 64) flush();
+      if (cnt > CAP - 64) flush();
       const int it = items[k], b = it & 63, second = it >> 6;
       const int n = (b >> 4) + (second << 2), l = b & 15;
       const int Wl = prm.W[l], Hl = prm.H[l];
@@ -1380,13 +1385,13 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11,
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 11,
                   "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
   const size_t esz = feat_dtype == FAR3D_DT_F32 ? 4 : 2;
   const bool v8_ok = cam_tables && N <= 8 && P <= 16 && L <= AGG_MAX_L && (size_t)N * S * C * esz < (1ull << 32);
   if (variant == 0) variant = v8_ok ? 8 : 7;
-  FAR3D_CHECK_ARG((variant != 8 && variant != 9) || (v8_ok && (variant == 8 || P == 13)), "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
-  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
+  FAR3D_CHECK_ARG(variant != 8 || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
+  FAR3D_CHECK_ARG(variant == 8 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -1428,9 +1433,6 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
-  } else if (variant == 9) {      // A/B: 8 without the work-dependent issue priority
-    if (feat_dtype == FAR3D_DT_F32) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
-    else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
   } else if (variant == 8) {      // factored softmax, decoupled waves (default)
     if (feat_dtype == FAR3D_DT_F32) {
       if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);

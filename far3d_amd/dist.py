@@ -172,9 +172,12 @@ class ShardedFrame:
     use_graph: replay the steady-state frame as TWO hipGraphs per rank -- the per-camera stages and the replicated head --
     with the exchange issued eagerly between them (no collective is ever captured).  The graphs survive scene changes:
     the first frame of a scene runs eagerly and resets the engine's streaming memory in place.
-    pipeline (with use_graph): frames of one stream are software-pipelined over two HIP streams and two buffer sets -- camera
-    graph + exchange of frame i+1 under the head of frame i.  Results are bit-identical to the unpipelined runner; outputs are
-    ready on `output_stream()` (call `wait_outputs()` before reading them on another stream)."""
+    pipeline (with use_graph): frames of one stream are software-pipelined like on one GPU (engine.pipeline_sets buffer sets,
+    engine.cam_streams high-priority camera streams): the camera graph + exchange of the next frames run side by side -- a rank
+    with one or two cameras is launch-bound, three frames at once cost 1.08 ms per frame where one costs 2.33 (1 camera;
+    profiles/r4/stage_times_bf16.txt) -- under the head of an earlier frame.  Exchanges are issued in frame order on every rank.
+    Results are bit-identical to the unpipelined runner; outputs are ready on `output_stream()` (call `wait_outputs()` before
+    reading them on another stream)."""
 
     def __init__(self, engine, group=None, use_graph=False, pipeline=False, decoder="replicated"):
         if engine.static_adaptive_rows() is None:
@@ -354,13 +357,15 @@ class ShardedFrame:
         # an idle rank (no cameras) has no camera graph: it only pads the exchange and runs the head, and is never the slowest rank
         steady = self.use_graph and scene == self._scene and eng._mem_valid
         self._scene = scene
-        p = eng._par = (self._fidx & 1) if self.pipeline else 0
+        p = eng._par = (self._fidx % max(2, int(eng.pipeline_sets))) if self.pipeline else 0
         self._fidx += 1
         if self.pipeline and steady:
             return self._pipelined_frame(data, img_metas, pad_hw)
         if self._pipe is not None:      # scene start in pipeline mode: eager on the caller's stream, after everything in flight
             cur = torch.cuda.current_stream(eng.dev)
-            cur.wait_stream(self._pipe["s_cam"]); cur.wait_stream(self._pipe["s_head"])
+            for sc in self._pipe["s_cams"]:
+                cur.wait_stream(sc)
+            cur.wait_stream(self._pipe["s_head"])
         eng._ready = None
         dd = eng._stage_inputs(data)      # every rank keeps the (small) calibration inputs; images are sliced per rank
         self._drop_stale_graphs(p, dd)
@@ -388,7 +393,9 @@ class ShardedFrame:
         input staging -> camera graph -> exchange.  Stream s_head: [wait for the exchange] -> head graph."""
         eng = self.eng
         if self._pipe is None:
-            self._pipe = dict(s_cam=torch.cuda.Stream(eng.dev, priority=eng.cam_priority), s_head=torch.cuda.Stream(eng.dev), cam_done={}, head_done={})
+            ncs = max(1, min(int(eng.pipeline_sets) - 1, int(eng.cam_streams)))
+            self._pipe = dict(s_cams=[torch.cuda.Stream(eng.dev, priority=eng.cam_priority) for _ in range(ncs)], s_head=torch.cuda.Stream(eng.dev),
+                              cam_done={}, head_done={}, n_issued=0)
         P = self._pipe
         p = eng._par
         cur = torch.cuda.current_stream(eng.dev)
@@ -419,18 +426,20 @@ class ShardedFrame:
         else:
             first = False
         st = self._st[p]
-        P["s_cam"].wait_event(here)
+        s_cam = P["s_cams"][P["n_issued"] % len(P["s_cams"])]      # consecutive frames alternate between the camera streams
+        P["n_issued"] += 1
+        s_cam.wait_event(here)
         for v in data.values():
             if isinstance(v, torch.Tensor) and v.is_cuda:
-                v.record_stream(P["s_cam"])
-        with torch.cuda.stream(P["s_cam"]):
+                v.record_stream(s_cam)
+        with torch.cuda.stream(s_cam):
             if not first:
-                P["s_cam"].wait_event(P["head_done"][p])      # head(i-2) read this buffer set (inputs and exchange buffers included)
+                s_cam.wait_event(P["head_done"][p])      # the head that last read this buffer set (inputs and exchange buffers included)
             eng._stage_inputs(data)
             if self.cams:
                 self._g_cam[p].replay()
             works = self._exchange(p, st)
-            P["cam_done"][p].record(P["s_cam"])
+            P["cam_done"][p].record(s_cam)
         with torch.cuda.stream(P["s_head"]):
             P["s_head"].wait_event(here)
             P["s_head"].wait_event(P["cam_done"][p])

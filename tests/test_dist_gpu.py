@@ -28,7 +28,7 @@ def _build(precision="fp32", capacity=None):
 
 
 def _frame_ids(rc, frames):
-    """Golden frames, then the last one repeated: enough steady frames for both pipeline buffer sets to replay their graphs."""
+    """Golden frames, then the last one repeated: enough steady frames for the pipeline buffer sets to capture and replay their graphs."""
     return [min(fi, rc["frames"] - 1) for fi in range(frames)]
 
 
@@ -50,7 +50,7 @@ def _worker(rank, world, port, q, use_graph, frames, pipeline=False, capacity=No
                 eng.check_proposal_overflow()
             outs.append((o["all_cls_scores"].cpu().numpy(), o["all_bbox_preds"].cpu().numpy()))
         if pipeline:
-            assert sorted(runner._g_head) == [0, 1]
+            assert sorted(runner._g_head) == list(range(eng.pipeline_sets))
         q.put((rank, outs))
         dist.barrier()
     finally:
@@ -60,10 +60,11 @@ def _worker(rank, world, port, q, use_graph, frames, pipeline=False, capacity=No
 # 3 cameras on 2 ranks -> (2, 1 + padding slot).  use_graph: frame 0 runs eagerly, frame 1 captures the two per-rank hipGraphs,
 # frames 2-3 replay them (streaming memory updated in place).  FAR3D_TEST_RANKS=4 adds the idle-rank layout (1 camera each + a
 # rank with none: the 8-GPU / 7-camera case); it is off by default because four engine builds take minutes on the one-GPU box.
-# pipeline: camera graph + exchange of frame i+1 under the head of frame i (two streams, two buffer sets per rank); capacity: the
+# pipeline: camera graphs + exchanges of the next frames side by side under the head of an earlier one (engine.pipeline_sets buffer
+# sets per rank: 9 frames let every set capture and three of them replay); capacity: the
 # reference's threshold proposal rule in fixed-capacity form (per-rank blocks + counts gathered, packed by far3d_compact_rows).
-_CASES = [(2, False, 2, False, None), (2, True, 5, False, None), (2, True, 7, True, None), (2, True, 7, True, 48), (2, False, 3, False, 48)] + \
-         ([(4, False, 2, False, None), (4, True, 3, False, None), (4, True, 7, True, 48)] if os.environ.get("FAR3D_TEST_RANKS") == "4" else [])
+_CASES = [(2, False, 2, False, None), (2, True, 5, False, None), (2, True, 9, True, None), (2, True, 9, True, 48), (2, False, 3, False, 48)] + \
+         ([(4, False, 2, False, None), (4, True, 3, False, None), (4, True, 9, True, 48)] if os.environ.get("FAR3D_TEST_RANKS") == "4" else [])
 
 
 @pytest.mark.parametrize("world,use_graph,frames,pipeline,capacity", _CASES)

@@ -60,6 +60,33 @@ def main():
     res = {"precision": precision}
     for n in (7, 4, 2, 1):
         res["camera_stages_%dcam_ms" % n] = timeit(lambda: eng.camera_stage(dd["img"][:n], dd, range(n), pad_hw), iters=2)
+    # the same stages with the frame pipeline's concurrency: K independent frames (one buffer set and one hipGraph each) replayed
+    # side by side on K high-priority streams -- what a rank does in steady state; ms PER FRAME
+    import time
+    for n in (7, 4, 2, 1):
+        graphs = []
+        for j in range(3):
+            eng._par = j
+            eng.camera_stage(dd["img"][:n], dd, range(n), pad_hw)            # allocate this set's buffers outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.camera_stage(dd["img"][:n], dd, range(n), pad_hw)
+            graphs.append(g)
+        eng._par = 0
+        streams = [torch.cuda.Stream(dev, priority=-1) for _ in range(3)]
+        for k in (2, 3):
+            def go():
+                for j in range(k):
+                    with torch.cuda.stream(streams[j]):
+                        graphs[j].replay()
+            go(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                go()
+            torch.cuda.synchronize()
+            res["camera_stages_%dcam_%dstreams_ms_per_frame" % (n, k)] = (time.perf_counter() - t0) / (10 * k) * 1e3
+        del graphs
     st = eng._camera_part(dd, pad_hw)
     res["head_replicated_ms"] = timeit(lambda: eng._head_part(st, dd, metas, pad_hw), iters=2)
     # the decoder alone, on the live buffers of the head (same operands every replay: timing only)
