@@ -73,10 +73,11 @@ def main():
         perm = ops.camera_sorted_order(args[0], args[2], c["pc_range"], c["pad_hw"], spatial=False)
         perm2 = ops.camera_sorted_order(args[0], args[2], c["pc_range"], c["pad_hw"], spatial=True)
         by = agg_bytes(N, S, C, A, 13, 8, 4, ev)
-        for variant in (7, 11, 3):
+        tab = ops.agg_tables(args[4])
+        for variant in (8, 7, 3):
             for name, pm in (("aggregate_fwd", None), ("aggregate_fwd+camsort", perm), ("aggregate_fwd+cam+tile", perm2)):
                 fn = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], out=out, perm=pm,
-                                                   variant=variant)
+                                                   variant=variant, tables=tab)
                 t = timeit(fn, a.iters)
                 rows.append(dict(kernel="v%d:%s" % (variant, name), dtype=str(dt).split(".")[-1], us=t * 1e6, algorithmic_bytes=by,
                                  achieved_GBps=by / t / 1e9, frac_hbm_peak=by / t / HBM_PEAK))

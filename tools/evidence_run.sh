@@ -6,27 +6,35 @@
 R=$GRAFT_REPO_ROOT; TAG=${1:-final}; O=$R/gpurun_out/ev_$TAG; mkdir -p $O
 cd $R
 if [ "${TESTS:-1}" = "1" ]; then
-  timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 | tee $O/pytest_gpu.txt
+  timeout 2700 python -m pytest tests -m gpu -q -x --durations=12 2>&1 | tail -30 | tee $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $O/smoke.txt
 fi
 timeout 900 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-300 $O/bench.json
 timeout 300 python bench.py --pipeline-sets 2 --cam-priority 0 --no-cpu-baseline --no-in-tolerance 2>/dev/null | tail -1 > $O/bench_pipeline_r3.json; cut -c1-160 $O/bench_pipeline_r3.json
 timeout 600 python bench.py --precision fp32 --steps 20 --no-cpu-baseline 2>$O/bench_fp32.err | tail -1 > $O/bench_fp32.json; cut -c1-200 $O/bench_fp32.json
-timeout 600 python bench.py --precision bf16x3 --steps 50 2>$O/bench_bf16x3.err | tail -1 > $O/bench_bf16x3.json; cut -c1-200 $O/bench_bf16x3.json
+timeout 600 python bench.py --precision bf16x3 --steps 50 --no-cpu-baseline 2>$O/bench_bf16x3.err | tail -1 > $O/bench_bf16x3.json; cut -c1-200 $O/bench_bf16x3.json
 timeout 600 python bench.py --proposals threshold --capacity 4096 --steps 30 --no-cpu-baseline 2>$O/bench_thr.err | tail -1 > $O/bench_threshold.json; cut -c1-200 $O/bench_threshold.json
 timeout 300 python tools/stage_times.py bf16 > $O/stage_times_bf16.txt 2>&1; tail -16 $O/stage_times_bf16.txt
-timeout 300 python tools/stage_times.py bf16x3 > $O/stage_times_bf16x3.txt 2>&1
-timeout 300 python tools/agg_phase_times.py > $O/agg_phase_times.txt 2>&1; tail -14 $O/agg_phase_times.txt
+[ -n "$X3STAGES" ] && timeout 300 python tools/stage_times.py bf16x3 > $O/stage_times_bf16x3.txt 2>&1
+timeout 300 python tools/agg_phase_times.py 1544 8 > $O/agg_phase_times.txt 2>&1; tail -14 $O/agg_phase_times.txt
+[ -f tools/_scratch/agg_operands.pt ] && timeout 300 python tools/bench_agg_live.py tools/_scratch/agg_operands.pt 7 8 2>/dev/null | grep layer > $O/agg_live.jsonl
 python tools/bench_kernels.py --iters 50 --out $O/kernels.jsonl > /dev/null 2>&1; cut -c1-160 $O/kernels.jsonl
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-in-tolerance > $O/prof_bench.log 2>&1
+# the per-kernel statistics come from frames that run ONE AT A TIME (--no-pipeline): with the frame pipeline three camera stages and a
+# head share the chip and a kernel's in-trace duration measures its co-runners as much as itself; the pipelined run's stats are kept
+# beside it (bench_kernel_stats_pipelined.csv)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipe -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-in-tolerance > $O/prof_pipe.log 2>&1
+cp $O/prof_pipe/run_kernel_stats.csv $O/bench_kernel_stats_pipelined.csv 2>/dev/null; rm -rf $O/prof_pipe
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o run -- python $R/bench.py --no-pipeline --steps 10 --warmup 3 --no-cpu-baseline --no-in-tolerance > $O/prof_bench.log 2>&1
 python $R/tools/layer_report.py $O/prof_bench/run_kernel_trace.csv v > $O/conv_layers.txt 2>&1; tail -9 $O/conv_layers.txt
 python $R/tools/frame_report.py $O/prof_bench/run_kernel_trace.csv 40 > $O/frame_report.txt 2>&1; head -12 $O/frame_report.txt
 cp $O/prof_bench/run_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null; rm -f $O/prof_bench/run_kernel_trace.csv
+if [ -n "$X3PROF" ]; then
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_x3 -o run -- python $R/bench.py --precision bf16x3 --no-pipeline --steps 10 --warmup 3 --no-cpu-baseline > $O/prof_x3.log 2>&1
 python $R/tools/layer_report.py $O/prof_x3/run_kernel_trace.csv v > $O/conv_layers_bf16x3.txt 2>&1; tail -9 $O/conv_layers_bf16x3.txt
 python $R/tools/frame_report.py $O/prof_x3/run_kernel_trace.csv 45 > $O/frame_report_bf16x3.txt 2>&1
 cp $O/prof_x3/run_kernel_stats.csv $O/bench_kernel_stats_bf16x3.csv 2>/dev/null; rm -rf $O/prof_x3
+fi
 # PMC: one derived counter per pass (FETCH_SIZE + WRITE_SIZE together exceed the hardware), every pass under `timeout` (a failed
 # rocprofv3 does not exit on its own); the eager bench so that every kernel is its own dispatch
 if [ -n "$PMC" ]; then
