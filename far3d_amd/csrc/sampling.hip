@@ -999,54 +999,12 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
   }
 }
 
-// One buffer of the gather as separate halves (EARLY: an item's first rows are requested before the next item is built)
-template <typename TV> struct Agg8Buf {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 v[4];
-  float w[4];
-};
-template <typename TV>
-__device__ __forceinline__ void agg8_issue(const TV* __restrict__ feat, const unsigned* off_s, const float* wt_s, int k0, int lane, Agg8Buf<TV>& b) {
-  const char* base = reinterpret_cast<const char*>(feat);
-  if constexpr (sizeof(TV) == 2) {
-    const int l31 = lane & 31, hi = lane >> 5, g = l31 >> 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      b.v[i] = *reinterpret_cast<const typename Agg8Buf<TV>::u32x4*>(base + (size_t)(off_s[k0 + 2 * i + hi] + (unsigned)l31 * 16u));
-      b.w[i] = wt_s[(k0 + 2 * i + hi) * 8 + g];
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      b.v[i] = *reinterpret_cast<const typename Agg8Buf<TV>::u32x4*>(base + (size_t)(off_s[k0 + i] + (unsigned)lane * 16u));
-      b.w[i] = wt_s[(k0 + i) * 8 + (lane >> 3)];
-    }
-  }
-}
-template <typename TV>
-__device__ __forceinline__ void agg8_consume(const Agg8Buf<TV>& b, float (&acc)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (sizeof(TV) == 2) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const agg_f2 x = {__uint_as_float(b.v[i][k] << 16), __uint_as_float(b.v[i][k] & 0xffff0000u)};
-        agg_f2 a = {acc[2 * k], acc[2 * k + 1]};
-        a = x * b.w[i] + a;
-        acc[2 * k] = a.x; acc[2 * k + 1] = a.y;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += b.w[i] * __uint_as_float(b.v[i][k]);
-    }
-  }
-}
-
 // Measured A/B of this kernel's knobs (profiles/r4/agg_live_*_ab.jsonl, live operands of a benchmark frame, bf16 rows): without the
 // work-dependent s_setprio 17.9-19.2 us against 16.9-17.8; a flatter work estimate 17.5-18.8; 8 instead of 4 loads per buffer in the
 // in-loop gather spills (128 VGPRs) 23-30 us; 192-entry lists (22.6 KB of LDS: 7 workgroups per CU, no longer every query resident
-// with margin) 17.8-21.1 us.
-template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, int EARLY = 0>
+// with margin) 17.8-21.1 us; an "early" gather buffer (an item's first 8 rows requested before the next item is built, consumed after it:
+// 128 VGPRs + 12 B of scratch) 17.9-18.2 us against 17.3-17.9 -- the build and the gather do not wait for each other.
+template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW>
 __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ tab,
@@ -1227,23 +1185,19 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  int cnt = 0, issued = 0;          // list entries written / already requested by an early buffer (EARLY)
-  bool pending = false;             // wave-uniform: an early buffer is in flight
-  Agg8Buf<TV> eb;
-  constexpr int EB = sizeof(TV) == 2 ? 8 : 4;      // entries one early buffer covers
-  // gather the listed rows [issued, cnt): NB loads per buffer in flight (4 inside the item loop, 8 -- all of a typical list at once -- for the last one)
+  int cnt = 0;
+  // gather the listed rows: NB loads per buffer in flight (4 inside the item loop, 8 -- all of a typical list at once -- for the last one)
   auto flush_nb = [&](auto nbtag) __attribute__((always_inline)) {
     constexpr int NB = decltype(nbtag)::value;
     constexpr int GRAN = sizeof(TV) == 2 ? 2 * NB : NB;
-    if constexpr (EARLY) { if (pending) { agg8_consume<TV>(eb, acc); pending = false; } }
-    const int n = cnt - issued, padn = (-n) & (GRAN - 1);
+    const int padn = (-cnt) & (GRAN - 1);
     if (lane < padn) {
       off_s[cnt + lane] = 0u;
       *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8) = Z4;
       *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8 + 4) = Z4;
     }
-    agg8_gather<TV, NB>(feat, off_s + issued, wt_s + issued * 8, n + padn, lane, acc);
-    cnt = 0; issued = 0;
+    agg8_gather<TV, NB>(feat, off_s, wt_s, cnt + padn, lane, acc);
+    cnt = 0;
   };
   auto flush = [&]() __attribute__((always_inline)) { flush_nb(std::integral_constant<int, LOOPNB>{}); };
   auto append = [&](bool hit, unsigned off, const float (&wa)[8]) __attribute__((always_inline)) {
@@ -1279,11 +1233,6 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
 #endif
       // one item adds at most 64 rows (a patch's tokens; 4 P <= 64 corners): gather what is listed once fewer might fit.  The only
       // flush site inside the loops (the list is private to the wave: LDS is in order per wave, the test is wave-uniform)
-      if constexpr (EARLY) {
-        // the rows of the items built so far are requested now and land while the next item is built (one buffer ahead)
-        if (pending) { agg8_consume<TV>(eb, acc); pending = false; }
-        if (cnt - issued >= EB) { agg8_issue<TV>(feat, off_s, wt_s, issued, lane, eb); issued += EB; pending = true; }
-      }
       if (cnt > CAP - 64) flush();
       const int it = items[k], b = it & 63, second = it >> 6;
       const int n = (b >> 4) + (second << 2), l = b & 15;
@@ -1437,13 +1386,13 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11,
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 11,
                   "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
   const size_t esz = feat_dtype == FAR3D_DT_F32 ? 4 : 2;
   const bool v8_ok = cam_tables && N <= 8 && P <= 16 && L <= AGG_MAX_L && (size_t)N * S * C * esz < (1ull << 32);
   if (variant == 0) variant = v8_ok ? 8 : 7;
-  FAR3D_CHECK_ARG((variant != 8 && variant != 9) || (v8_ok && (variant == 8 || P == 13)), "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
-  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
+  FAR3D_CHECK_ARG(variant != 8 || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
+  FAR3D_CHECK_ARG(variant == 8 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -1485,9 +1434,6 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
-  } else if (variant == 9) {      // A/B: 8 with the early gather buffer
-    if (feat_dtype == FAR3D_DT_F32) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, 1>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
-    else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, 1>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
   } else if (variant == 8) {      // factored softmax, decoupled waves (default)
     if (feat_dtype == FAR3D_DT_F32) {
       if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);

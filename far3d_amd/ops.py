@@ -166,7 +166,7 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         _chk(perm, "perm", torch.int32, 1)
         if perm.numel() > A:
             raise ValueError("aggregate_forward: perm has more entries than there are rows")
-    if tables is None and variant in (0, 8, 9) and A > 0 and N <= 8 and P <= 16:
+    if tables is None and variant in (0, 8) and A > 0 and N <= 8 and P <= 16:
         tables = agg_tables(Vc)
     if tables is not None:
         _chk(tables, "tables", torch.float32, 2)
