@@ -150,6 +150,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     eng.pipeline = eng.use_graph and not args.no_pipeline
     eng.pipeline_sets = args.pipeline_sets
     eng.cam_streams = args.cam_streams
+    eng.tile_table = {"auto": None, "latency": "tuning_mi355x.json", "tput": "tuning_mi355x_tput.json"}[args.tile_table]
 
     def sync():
         if world > 1:
@@ -235,13 +236,17 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
             agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
                                                                 num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
                                                                 variant=args.agg_variant, tables=tab_), 24)]
+        # the backbone ALONE: launches one after the other, so with the tile table tuned for that regime (what a non-pipelined engine
+        # uses; the pipelined frames above run the table tuned under their 3-stream concurrency, engine.tile_table)
+        ops.BF16_TILE_TABLE = "tuning_mi355x.json"
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
+        ops.BF16_TILE_TABLE = eng.bf16_tile_table()
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
     n_adapt = int(out["num_adaptive_dev"].item()) if out.get("num_adaptive_dev") is not None else int(out["num_adaptive"])
     overflow = bool(int(out["proposal_overflow"].item())) if out.get("proposal_overflow") is not None else False
     res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
-               timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(runner.pipeline), cfg=cfg,
+               timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(runner.pipeline), cfg=cfg, tile_table=eng.bf16_tile_table(),
                ncam_local=len(runner.cams) if sharded else 7)
     del eng, runner, frames, out
     torch.cuda.empty_cache()
@@ -278,6 +283,7 @@ def backbone_roofline(res):
                "fp32": "igemm_kernel<float, float> (exact fp32 MFMA)"}[mode]
     return {"kernel": kernels + " -- VoV-99 backbone: all launches incl. eSE / pooling", "bound": "mfma",
             "achieved": n * BACKBONE_FLOP_PER_CAM / bb_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "regime": "the backbone's launches alone, one after the other (tile table tuned for launches alone)",
             "frac": n * BACKBONE_FLOP_PER_CAM / bb_t / peak, "backbone_ms": bb_t * 1e3, "cameras_on_this_rank": n,
             "peak_what": "dense bf16 MFMA 2.5 PF" + (" / 3 (three MFMAs per useful product)" if mode == "bf16x3" else "") if mode != "fp32" else "fp32 MFMA"}
 
@@ -334,6 +340,8 @@ def main():
     ap.add_argument("--capacity", type=int, default=1024, help="--proposals threshold: rows reserved for the adaptive queries")
     ap.add_argument("--pipeline-sets", type=int, default=4, help="single GPU: frames in flight = buffer sets of the frame pipeline (4: the camera "
                     "stages of three frames run concurrently under the head of a fourth; 2: camera || head only)")
+    ap.add_argument("--tile-table", default="auto", choices=["auto", "latency", "tput"],
+                    help="bf16 conv tile table: tuned for a launch alone, or under the pipeline's 3-stream concurrency (auto: by mode; A/B)")
     ap.add_argument("--cam-streams", type=int, default=3, help="streams the camera stages of consecutive frames alternate between (A/B)")
     ap.add_argument("--cam-priority", type=int, default=-1, help="HIP stream priority of the camera-stage streams in pipeline mode (-1 = high, 0 = default; A/B)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
@@ -418,6 +426,7 @@ def main():
                                        "frame_overlap": res["pipeline"],
                                        "frames_in_flight": (args.pipeline_sets if world == 1 else 2) if res["pipeline"] else 1,
                                        "camera_streams": args.cam_streams if (world == 1 and res["pipeline"]) else 1,
+                                       "tile_table": res["tile_table"],
                                        "frame_overlap_what": "the per-camera stages of the next frames (one frame per camera stream, high priority) run "
                                                              "concurrently while the head of frame i is in flight (one buffer set per frame in flight, head "
                                                              "graphs ordered on one stream: results identical to the unpipelined engine); "

@@ -140,6 +140,9 @@ class Far3DEngine:
                                     # launches must not hold back the throughput-critical camera stages; 0 = default, A/B in bench.py)
         self._overflow = None       # fixed-capacity threshold mode: device flag of the latest frame (check_proposal_overflow)
         self._ready = None          # event of the latest pipelined head (None: outputs are on the caller's stream)
+        self.tile_table = None      # bf16 conv tile table: None = by mode -- "tuning_mi355x_tput.json" (tiles picked under the pipeline's
+                                    # 3-stream concurrency, where a tile is judged by the CU-time it occupies) when frames are pipelined,
+                                    # "tuning_mi355x.json" (tiles picked for the latency of a launch alone) otherwise
         self.cam_streams = 3        # pipeline mode: streams the camera stages of consecutive frames alternate between (< pipeline_sets)
         self.pipeline_sets = 4      # pipeline mode: buffer sets = frames in flight (4: the camera stages of THREE frames run
                                     # concurrently on three streams under the head of a fourth; 2: round 3's camera || head overlap only).
@@ -337,6 +340,12 @@ class Far3DEngine:
         if K is not None:
             return (self.cfg["num_cams"] if ncam is None else ncam) * K
         return self.cfg.get("proposal_capacity")
+
+    def bf16_tile_table(self):
+        """The tile table the bf16 convolutions of this engine's launches consult (see tile_table)."""
+        if self.tile_table is not None:
+            return self.tile_table
+        return "tuning_mi355x_tput.json" if (self.pipeline and self.use_graph) else "tuning_mi355x.json"
 
     def check_proposal_overflow(self):
         """Fixed-capacity threshold mode: raise if the latest frame had more proposals than rows (or a camera filled its selection
@@ -888,6 +897,7 @@ class Far3DEngine:
         Outputs live in engine-owned buffers that the next frame overwrites: clone what must outlive it."""
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
+        ops.BF16_TILE_TABLE = self.bf16_tile_table()
         if self.pipeline and self.use_graph and self.static_adaptive_rows() is not None:
             self._par = self._fidx % max(2, int(self.pipeline_sets))
             self._fidx += 1

@@ -192,10 +192,15 @@ ACT = {None: 0, "none": 0, "relu": 1, "swish": 2}
 _TUNING = {}
 
 
-def _tuned_tile(Cout, Cin, k, stride, npix, table="tuning_mi355x.json"):
+BF16_TILE_TABLE = "tuning_mi355x.json"      # the bf16 table conv2d_nhwc / linear consult (an engine may point it at the throughput-tuned one)
+
+
+def _tuned_tile(Cout, Cin, k, stride, npix, table=None):
     """Workgroup tile measured fastest on MI355X for this conv shape (tools/tune_conv.py); 0 = kernel heuristic.
     Shapes that were not swept (e.g. fewer cameras per rank in camera-sharded mode) borrow the entry of the same layer
     geometry with the closest pixel count.  table: tuning_mi355x.json (bf16) or tuning_mi355x_bf16x3.json (split mode)."""
+    if table is None:
+        table = BF16_TILE_TABLE
     tab = _TUNING.get(table)
     if tab is None:
         import json

@@ -18,11 +18,16 @@ def _dispatch_ids():
     return ids
 
 
-def test_tuning_table_names_only_implemented_tiles():
+import pytest
+
+
+@pytest.mark.parametrize("name", ["tuning_mi355x.json", "tuning_mi355x_tput.json"])      # tuned alone / under the frame pipeline's 3-stream concurrency
+def test_tuning_table_names_only_implemented_tiles(name):
     ids = _dispatch_ids()
     assert ids["pipe3"] and ids["gemm"] and ids["dma"], ids
-    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x.json")))
+    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))
     assert table, "empty tuning table"
+    assert set(table) == set(json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x.json")))), "the two tables must cover the same layers"
     for key, tile in table.items():
         cout, cin, k, stride, npix = (int(v) for v in key.split(","))
         assert cout > 0 and cin > 0 and npix > 0 and k in (1, 3) and stride in (1, 2), key

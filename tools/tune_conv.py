@@ -55,8 +55,38 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / (3 * iters)
 
+def timeit_concurrent(make_fn, nstreams=3, iters=8):
+    """Time per launch when `nstreams` independent copies of the launch sequence run side by side on high-priority streams -- the
+    regime of the frame pipeline (engine.cam_streams), where a tile is judged by the CU-time it occupies, not by its own latency."""
+    import time
+    fns = [make_fn(j) for j in range(nstreams)]
+    graphs = []
+    for fn in fns:
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        graphs.append(g)
+    streams = [torch.cuda.Stream("cuda:0", priority=-1) for _ in range(nstreams)]
+
+    def go():
+        for g, st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                g.replay()
+    go(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        go()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (4 * nstreams * iters)
+
+
 def main():
     dev = "cuda:0"
+    conc = int(os.environ.get("CONCURRENT", "0"))      # CONCURRENT=3: sweep under the frame pipeline's concurrency -> tuning_mi355x_tput.json
     table, seen = {}, set()
     only = os.environ.get("ONLY_K")
     x3 = os.environ.get("MODE") == "bf16x3"
@@ -94,9 +124,13 @@ def main():
         sums = torch.zeros(N, Cout, dtype=torch.int64, device=dev) if (os.environ.get("SUMS") and k == 1 and Ho * Wo >= 512 and Cout % 8 == 0) else None
         if sums is not None:
             tiles = tuple(tl for tl in tiles if tl in ops._GEMM_TILES)
+        ys = [torch.empty_like(y) for _ in range(conc)] if conc else None
         for tile in tiles:
             try:
-                t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums))
+                if conc:
+                    t = timeit_concurrent(lambda j: (lambda: ops.conv2d_nhwc(x, pc, out=ys[j], act="relu", tile=tile, sums=sums)), conc)
+                else:
+                    t = timeit(lambda: ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums))
             except Exception:      # a tile that refuses the channel sums (no LDS left, map smaller than the tile)
                 if sums is None:
                     raise
@@ -110,6 +144,8 @@ def main():
         print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %4.0f" % (tl, res[tl] * 1e6) for tl in tiles if tl) +
               " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
     name = "tuning_mi355x_pair" if pair else ("tuning_mi355x_bf16x3" if x3 else "tuning_mi355x")
+    if conc:
+        name += "_tput"
     if os.environ.get("NCAM", "7") != "7":
         name += "_n" + os.environ["NCAM"]
     json.dump(table, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", name + ".json"), "w"), indent=0, sort_keys=True)
