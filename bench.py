@@ -238,9 +238,10 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
                                                                 variant=args.agg_variant, tables=tab_), 24)]
         # the backbone ALONE: launches one after the other, so with the tile table tuned for that regime (what a non-pipelined engine
         # uses; the pipelined frames above run the table tuned under their 3-stream concurrency, engine.tile_table)
-        ops.BF16_TILE_TABLE = "tuning_mi355x.json"
+        ops.BF16_TILE_TABLE, ops.PAIR_TILE_TABLE = "tuning_mi355x.json", "tuning_mi355x_pair.json"
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
         ops.BF16_TILE_TABLE = eng.bf16_tile_table()
+        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
     n_adapt = int(out["num_adaptive_dev"].item()) if out.get("num_adaptive_dev") is not None else int(out["num_adaptive"])

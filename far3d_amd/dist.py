@@ -354,6 +354,7 @@ class ShardedFrame:
         eng = self.eng
         from . import ops
         ops.BF16_TILE_TABLE = eng.tile_table or ("tuning_mi355x_tput.json" if self.pipeline else "tuning_mi355x.json")
+        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         scene = img_metas[0]["scene_token"]
         # an idle rank (no cameras) has no camera graph: it only pads the exchange and runs the head, and is never the slowest rank

@@ -898,6 +898,7 @@ class Far3DEngine:
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
         ops.BF16_TILE_TABLE = self.bf16_tile_table()
+        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
         if self.pipeline and self.use_graph and self.static_adaptive_rows() is not None:
             self._par = self._fidx % max(2, int(self.pipeline_sets))
             self._fidx += 1

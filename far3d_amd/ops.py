@@ -193,6 +193,7 @@ _TUNING = {}
 
 
 BF16_TILE_TABLE = "tuning_mi355x.json"      # the bf16 table conv2d_nhwc / linear consult (an engine may point it at the throughput-tuned one)
+PAIR_TILE_TABLE = "tuning_mi355x_pair.json"  # the same for pair-stored activations (the bf16x3 engine mode)
 
 
 def _tuned_tile(Cout, Cin, k, stride, npix, table=None):
@@ -288,7 +289,7 @@ def _pair_tile(pc, Cin, npix, tile):
     library default), mapped to a hi-planes-only kernel when the layer is assigned a single bf16 product (pc.terms == 1)."""
     fast = pc.stride == 1 and ((pc.KH == 3 and pc.pad == 1) or (pc.KH == 1 and pc.pad == 0))
     if tile == 0:
-        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, "tuning_mi355x_pair.json")
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, PAIR_TILE_TABLE)
     if pc.terms == 1 and fast and (tile == 0 or 150 <= tile < 200):
         tile = _HI_ONLY_TILE.get(tile, 260 if pc.KH == 3 else 279)
     return tile

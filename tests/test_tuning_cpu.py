@@ -57,14 +57,16 @@ def test_tuned_tile_lookup_borrows_nearest_pixel_count():
     assert ops._tuned_tile(191, 192, 3, 1, hi[0]) == 0                        # unknown layer -> kernel heuristic
 
 
-def test_pair_tuning_table_names_only_implemented_tiles():
+@pytest.mark.parametrize("name", ["tuning_mi355x_pair.json", "tuning_mi355x_pair_tput.json"])
+def test_pair_tuning_table_names_only_implemented_tiles(name):
     """Same for the pair-storage (bf16x3) table: ids 150+ of igemm_pair.hip, 1..5 for the register-staged kernel."""
     src = open(os.path.join(ROOT, "far3d_amd", "csrc", "igemm_pair.hip")).read()
     ids = {"igemm": set(), "pipe3": set(), "gemm": set()}
     for m in re.finditer(r"case (\d+): (?:rc = |return )?(launch_[a-z0-9_]+)<", src):
         ids[{"launch_igemm": "igemm", "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm"}[m.group(2)]].add(int(m.group(1)))
-    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json")))
+    table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))
     assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5}
+    assert set(table) == set(json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json"))))
     for key, tile in table.items():
         cout, cin, k, stride, npix = (int(v) for v in key.split(","))
         assert cin % 32 == 0, key
