@@ -22,7 +22,12 @@ import subprocess
 import sys
 import time
 
-import torch
+# The frame pipeline keeps 3 camera streams + a head stream busy and this process builds two engines one after the other: with HIP's
+# default of 4 hardware queues the second engine's streams end up sharing queues (in_tolerance 79.5 instead of 85.9 samples/s,
+# profiles/r4/hw_queues_ab.txt).  Must be set before the HIP runtime initialises; far3d_amd.lib sets the same default on import.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -238,10 +243,9 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
                                                                 variant=args.agg_variant, tables=tab_), 24)]
         # the backbone ALONE: launches one after the other, so with the tile table tuned for that regime (what a non-pipelined engine
         # uses; the pipelined frames above run the table tuned under their 3-stream concurrency, engine.tile_table)
-        ops.BF16_TILE_TABLE, ops.PAIR_TILE_TABLE = "tuning_mi355x.json", "tuning_mi355x_pair.json"
+        keep_table, eng.tile_table = eng.tile_table, "tuning_mi355x.json"
         bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
-        ops.BF16_TILE_TABLE = eng.bf16_tile_table()
-        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
+        eng.tile_table = keep_table
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
     n_adapt = int(out["num_adaptive_dev"].item()) if out.get("num_adaptive_dev") is not None else int(out["num_adaptive"])

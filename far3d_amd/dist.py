@@ -191,6 +191,8 @@ class ShardedFrame:
         self.cams = [c for c in self.slots if c >= 0]
         self.use_graph = use_graph
         self.pipeline = bool(pipeline and use_graph)
+        if self.pipeline and engine.tile_table is None:
+            engine.tile_table = "tuning_mi355x_tput.json"      # tiles picked under the pipeline's concurrency (Far3DEngine.tile_table)
         # decoder="query_sharded": every rank runs A / world of the queries through the six layers (one small all-gather per layer)
         # instead of the whole replicated decoder; the graphs of the head are then captured as segments between the exchanges
         if decoder not in ("replicated", "query_sharded"):
@@ -352,9 +354,6 @@ class ShardedFrame:
     @torch.no_grad()
     def forward_frame(self, data, img_metas):
         eng = self.eng
-        from . import ops
-        ops.BF16_TILE_TABLE = eng.tile_table or ("tuning_mi355x_tput.json" if self.pipeline else "tuning_mi355x.json")
-        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         scene = img_metas[0]["scene_token"]
         # an idle rank (no cameras) has no camera graph: it only pads the exchange and runs the head, and is never the slowest rank

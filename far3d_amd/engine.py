@@ -347,6 +347,12 @@ class Far3DEngine:
             return self.tile_table
         return "tuning_mi355x_tput.json" if (self.pipeline and self.use_graph) else "tuning_mi355x.json"
 
+    def _select_tile_tables(self):
+        """Point the conv wrappers at this engine's tile tables (module state of far3d_amd.ops, consulted when a launch is issued or
+        captured): every entry point that issues convolutions calls this first, so engines with different settings can share a process."""
+        ops.BF16_TILE_TABLE = self.bf16_tile_table()
+        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
+
     def check_proposal_overflow(self):
         """Fixed-capacity threshold mode: raise if the latest frame had more proposals than rows (or a camera filled its selection
         capacity).  Synchronises; call it when the outputs are read, not between pipelined frames."""
@@ -378,6 +384,7 @@ class Far3DEngine:
     def backbone(self, img):
         """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps (pair mode: 2C stored bf16 channels each)."""
         act, spec, cs, pair = self.prec["act"], self.spec, self.cs, self.pair
+        self._select_tile_tables()
         N = img.shape[0]
         Lb = spec["layer_per_block"]
         # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
@@ -447,6 +454,7 @@ class Far3DEngine:
     # ------------------------------------------------------------------------------------------ a3 + MLN: FPN
     def fpn(self, feats, mln_scale, mln_shift):
         """Returns (raw levels [NHWC act; pair mode: 512 stored channels], feat_flatten (N,S,256) value dtype, level_hw, level_start)."""
+        self._select_tile_tables()
         act, val = self.prec["act"], self.prec["value"]
         ins = feats[1:]
         N = ins[0].shape[0]
@@ -471,6 +479,7 @@ class Far3DEngine:
     def roi_head(self, raw, centers2d=None):
         """YOLOX towers + depth head on the raw FPN maps.  centers2d: optional list that receives the (N,h,w,2) centre-offset maps
         (a loss input the inference path never reads; the stand-alone YOLOXHeadCustom.forward returns them like the reference)."""
+        self._select_tile_tables()
         cls, reg = [], []
         for l, x in enumerate(raw):
             lv = self.roi[l]
@@ -636,6 +645,7 @@ class Far3DEngine:
     def camera_stage(self, img, dd, cam_ids, pad_hw, block_rows=None):
         """Everything that is independent per camera: backbone, FPN (+MLN), 2D head, depth, proposal
         selection and adaptive-query construction.  img (n,3,H,W) on device for the contiguous camera block `cam_ids`."""
+        self._select_tile_tables()
         cfg = self.cfg
         n = img.shape[0]
         cam_ids = list(cam_ids)
@@ -699,6 +709,7 @@ class Far3DEngine:
         """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12).
         M: adaptive-query ROWS.  m_dev (int32 device scalar; fixed-capacity threshold mode): only the first m_dev of them are
         queries, rows [nq + m_dev, nq + M) are the masked hole (their inputs are zero-filled by proposal_gather)."""
+        self._select_tile_tables()
         cfg = self.cfg
         E = cfg["embed_dims"]
         lidar2img = dd["lidar2img"][0]
@@ -897,8 +908,7 @@ class Far3DEngine:
         Outputs live in engine-owned buffers that the next frame overwrites: clone what must outlive it."""
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
-        ops.BF16_TILE_TABLE = self.bf16_tile_table()
-        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
+        self._select_tile_tables()
         if self.pipeline and self.use_graph and self.static_adaptive_rows() is not None:
             self._par = self._fidx % max(2, int(self.pipeline_sets))
             self._fidx += 1

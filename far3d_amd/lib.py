@@ -6,6 +6,11 @@ without a HIP device, this raises.  PyTorch is only used for device memory and s
 import ctypes
 import os
 
+# The engine's frame pipeline drives several HIP streams at once (3 camera streams + a head stream per engine); HIP multiplexes
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Takes effect only if the
+# HIP runtime has not been initialised yet (import far3d_amd before the first torch.cuda call, or export it yourself).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # torch bundles its own HIP runtime (file libamdhip64.so, SONAME libamdhip64.so.7).  It MUST be mapped before our
 # library so that both share ONE runtime (and therefore streams / device pointers); loading ours first would pull in
 # /opt/rocm's copy and torch would then initialise a second runtime and report "no GPU".
