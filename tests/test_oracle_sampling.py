@@ -61,3 +61,31 @@ def test_tent_patch_form_equals_bilinear_corner_form():
         for k in seen:
             seen[k] += st[k]
     assert seen["patch"] > 0 and seen["wide"] > 0, seen
+
+
+def test_factored_softmax_is_the_softmax():
+    """The identity aggregate_v8_kernel rests on (csrc/agg_tables.hpp): with logit[n][j] = U[j] + V[n][j],
+        softmax_{n,j}(U + V)[n][j] = eU[j] * eV[n][j] / sum_j eU[j] * EV[j],
+        mV[j] = max_n V[n][j],  eV[n][j] = exp(V[n][j] - mV[j]),  EV[j] = sum_n eV[n][j],  eU[j] = exp(U[j] + mV[j] - max_j(U[j] + mV[j])).
+    The largest term is exactly 1, so it neither overflows nor underflows where the plain max-subtracted softmax does not -- checked
+    on ordinary logits and on logits 200 apart (a naive exp(U) * exp(V) factorisation returns NaN there), in float32."""
+    g = torch.Generator().manual_seed(0)
+    for scale in (1.0, 30.0, 200.0):
+        U = torch.randn(52, 8, generator=g) * scale                       # (L*P, G) query part
+        V = torch.randn(7, 52, 8, generator=g) * scale                    # (N, L*P, G) camera part
+        want = (U[None] + V).double().reshape(-1, 8).softmax(0).reshape(7, 52, 8)
+        mV = V.max(0).values
+        eV = torch.exp(V - mV)
+        EV = eV.sum(0)
+        Up = U + mV
+        eU = torch.exp(Up - Up.max(0).values)
+        S = (eU * EV).sum(0)
+        got = eU[None] * eV / S
+        assert torch.isfinite(got).all() and (S >= 1).all()
+        assert (got.double() - want).abs().max().item() < 5e-6, scale
+        assert abs(got.double().sum().item() - 8.0) < 1e-4               # every group's weights sum to 1
+    # the naive factorisation the kernel does NOT use: exp(U - max U) * exp(V - max V) underflows to 0 / 0
+    U = torch.tensor([[200.0], [0.0]])
+    V = torch.tensor([[[0.0], [200.0]]])
+    naive = torch.exp(U - U.max()) * torch.exp(V - V.max())
+    assert (naive == 0).all() or not torch.isfinite(naive / naive.sum()).all()
