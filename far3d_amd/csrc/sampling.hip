@@ -128,7 +128,7 @@ struct AggParams {
 };
 
 // ------------------------------------------------------------------------------------------
-// v3 of the fused aggregation (the shipped kernel).  PMC counters on v1 showed the kernel VALU-bound (2.5k VALU
+// v3 of the fused aggregation (round 1's kernel; kept as variant 3 for A/B).  PMC counters on v1 showed the kernel VALU-bound (2.5k VALU
 // instructions per wave, L2 hit 60 %, HBM fetch == the 46 MB of value maps): every lane recomputed wave-uniform sample
 // geometry.  v3 computes each visible (camera, point, level) sample ONCE (one thread per camera-point in phase 1), stores a
 // 32-byte record {clamped top-left offset, dx, dy, weight row, 4 bilinear weights} in a compacted LDS list (deterministic
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void aggregate_v3_kernel(const TV* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Tap-merging aggregation (default kernel, `aggregate_v7_kernel`): two waves per query, no atomics.
+// Tap-merging aggregation, `aggregate_v7_kernel` (the default of rounds 2-3; variant 7 since v8): two waves per query, no atomics.
 //
 // Why: the v3 counters (profiles/r1) showed no HBM over-fetch at all -- the kernel sat on (i) ~11 us of block-wide fixed
 // phases (3 barriers per query for the scan / softmax statistics) and (ii) L2 -> CU gather volume: every visible sample moved
@@ -911,8 +911,10 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
 //    only: far3d_agg_tables computes them once per frame for all layers.  Per query that leaves 2 float4 loads of U, 8 exp per lane
 //    and S[g] = sum_j eU[j][g] * EV[j][g]; the largest term is exactly 1 (same overflow / underflow behaviour as the plain
 //    max-subtracted softmax).  Weights are formed only for the (camera, level) items that are visible: w = eU * eV[n].
-//  * lets each of the two waves compute the (cheap) statistics and the 91 projections itself: no barrier before the final
-//    cross-wave sum, nothing shared but identical LDS writes;
+//  * specialises the two waves' front ends: wave 0 projects the 91 (camera, point) pairs, builds the item descriptors and deals
+//    the items; wave 1 computes the softmax statistics; they swap results through each other's (still unused) row-list regions
+//    and meet at ONE barrier (v7: two barriers with both waves doing both halves; a fully redundant front end without any
+//    barrier was built first and is 6 % slower: profiles/r4/agg_live_specialised_front_ab.jsonl);
 //  * deals the visible (camera, level) items to the two waves by estimated work (greedy, computed identically by both) instead
 //    of by level parity, and raises the issue priority of waves that got a lot of it (the launch ends with its slowest wave);
 //  * projects with one v_rcp instead of four IEEE divisions, stores PIXEL coordinates per (camera, level, point) for the build
@@ -1098,32 +1100,82 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     }
     return vis;
   };
-  int dA0, dA1, estA, dB0, dB1, estB;
-  bool patA, patB;
-  const bool visA_ = project(mA0, mA1, mA2, r, dA0, dA1, estA, patA);
-  const bool visB_ = project(mB0, mB1, mB2, r + 4, dB0, dB1, estB, patB);
-  const unsigned long long visA = __ballot(visA_), visB = __ballot(visB_);
-  const unsigned long long patchA = __ballot(patA), patchB = __ballot(patB);
-  // ---- deal the items to the two waves: greedy on the running work estimates (both waves compute the same partition)
-  unsigned long long mineA = 0ull, mineB = 0ull;
-  int myload;
-  {
+  int dA0 = 0, dA1 = 0, estA = 0, dB0 = 0, dB1 = 0, estB = 0;
+  unsigned long long visA, visB, patchA, patchB, mineA = 0ull, mineB = 0ull;
+  int myload = 0;
+  float4 S4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto softmax_stats = [&]() __attribute__((always_inline)) {
+    // eU = exp(U + mV - max), S[g] = sum_j eU[j][g] EV[j][g]  (detr3d_transformer.py:539-540, factored)
+    constexpr float LOG2E = 1.4426950408889634f;
+    eu0 = make_float4(eu0.x + mv0.x, eu0.y + mv0.y, eu0.z + mv0.z, eu0.w + mv0.w);
+    eu1 = make_float4(eu1.x + mv1.x, eu1.y + mv1.y, eu1.z + mv1.z, eu1.w + mv1.w);
+    float4 mx = make_float4(fmaxf(eu0.x, eu1.x), fmaxf(eu0.y, eu1.y), fmaxf(eu0.z, eu1.z), fmaxf(eu0.w, eu1.w));
+    mx.x = agg8_wave_max_parity(mx.x); mx.y = agg8_wave_max_parity(mx.y);
+    mx.z = agg8_wave_max_parity(mx.z); mx.w = agg8_wave_max_parity(mx.w);
+    eu0 = make_float4(__builtin_amdgcn_exp2f((eu0.x - mx.x) * LOG2E), __builtin_amdgcn_exp2f((eu0.y - mx.y) * LOG2E),
+                      __builtin_amdgcn_exp2f((eu0.z - mx.z) * LOG2E), __builtin_amdgcn_exp2f((eu0.w - mx.w) * LOG2E));
+    eu1 = make_float4(__builtin_amdgcn_exp2f((eu1.x - mx.x) * LOG2E), __builtin_amdgcn_exp2f((eu1.y - mx.y) * LOG2E),
+                      __builtin_amdgcn_exp2f((eu1.z - mx.z) * LOG2E), __builtin_amdgcn_exp2f((eu1.w - mx.w) * LOG2E));
+    S4 = make_float4(eu0.x * es0.x + eu1.x * es1.x, eu0.y * es0.y + eu1.y * es1.y, eu0.z * es0.z + eu1.z * es1.z, eu0.w * es0.w + eu1.w * es1.w);
+    S4.x = agg8_wave_sum_parity(S4.x); S4.y = agg8_wave_sum_parity(S4.y);
+    S4.z = agg8_wave_sum_parity(S4.z); S4.w = agg8_wave_sum_parity(S4.w);
+  };
+  auto deal = [&](int w, unsigned long long& mA, unsigned long long& mB, int& load) __attribute__((always_inline)) {
+    // greedy on the running work estimates; w = the wave whose share is returned
     int ld0 = 0, ld1 = 0;
+    mA = 0ull; mB = 0ull;
     for (unsigned long long m = visA; m; m &= m - 1ull) {
       const int b = __builtin_ctzll(m);
       const int e = __builtin_amdgcn_readlane(estA, b);
       const bool to1 = ld1 < ld0;
       if (to1) ld1 += e; else ld0 += e;
-      if ((int)to1 == wv) mineA |= 1ull << b;
+      if ((int)to1 == w) mA |= 1ull << b;
     }
     for (unsigned long long m = visB; m; m &= m - 1ull) {
       const int b = __builtin_ctzll(m);
       const int e = __builtin_amdgcn_readlane(estB, b);
       const bool to1 = ld1 < ld0;
       if (to1) ld1 += e; else ld0 += e;
-      if ((int)to1 == wv) mineB |= 1ull << b;
+      if ((int)to1 == w) mB |= 1ull << b;
     }
-    myload = wv ? ld1 : ld0;
+    load = w ? ld1 : ld0;
+  };
+  {
+    // SPECIALISED front end: wave 0 projects and deals, wave 1 computes the softmax statistics; they swap results through the
+    // (still unused) row-list regions of each other and meet at one barrier
+    int4* xd = reinterpret_cast<int4*>(wt_all + CAPT * 8);       // wave 1's list region <- wave 0: descriptors, dealing
+    float4* xe = reinterpret_cast<float4*>(wt_all);              // wave 0's list region <- wave 1: eU
+    if (wv == 0) {
+      bool patA, patB;
+      const bool visA_ = project(mA0, mA1, mA2, r, dA0, dA1, estA, patA);
+      const bool visB_ = project(mB0, mB1, mB2, r + 4, dB0, dB1, estB, patB);
+      visA = __ballot(visA_); visB = __ballot(visB_); patchA = __ballot(patA); patchB = __ballot(patB);
+      unsigned long long oA, oB;
+      int oload;
+      deal(0, mineA, mineB, myload);
+      oA = visA & ~mineA; oB = visB & ~mineB; oload = 0;
+      for (unsigned long long m = oA; m; m &= m - 1ull) oload += __builtin_amdgcn_readlane(estA, __builtin_ctzll(m));
+      for (unsigned long long m = oB; m; m &= m - 1ull) oload += __builtin_amdgcn_readlane(estB, __builtin_ctzll(m));
+      xd[lane] = make_int4(dA0, dA1, dB0, dB1);
+      if (lane == 0) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(xd + 64);
+        q[0] = oA; q[1] = oB; q[2] = patchA; q[3] = patchB; q[4] = (unsigned long long)oload;
+      }
+    } else {
+      softmax_stats();
+      xe[lane] = eu0; xe[64 + lane] = eu1;
+      if (lane < 2) *reinterpret_cast<float4*>(stat_s + (lane & 1) * 4) = S4;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      eu0 = xe[lane]; eu1 = xe[64 + lane];
+    } else {
+      const int4 d = xd[lane];
+      dA0 = d.x; dA1 = d.y; dB0 = d.z; dB1 = d.w;
+      const unsigned long long* q = reinterpret_cast<const unsigned long long*>(xd + 64);
+      mineA = q[0]; mineB = q[1]; patchA = q[2]; patchB = q[3]; myload = (int)q[4];
+      visA = mineA; visB = mineB;
+    }
   }
   // the launch ends with its slowest wave: waves that drew a lot of work get the issue slots first
   if constexpr (PRIO) {
@@ -1160,24 +1212,6 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   take_batch();
   issue_ev();
 
-  // ---- softmax statistics of the query factor (detr3d_transformer.py:539-540): eU = exp(U + mV - max), S[g] = sum_j eU[j][g] EV[j][g]
-  float4 S4;
-  {
-    constexpr float LOG2E = 1.4426950408889634f;
-    eu0 = make_float4(eu0.x + mv0.x, eu0.y + mv0.y, eu0.z + mv0.z, eu0.w + mv0.w);
-    eu1 = make_float4(eu1.x + mv1.x, eu1.y + mv1.y, eu1.z + mv1.z, eu1.w + mv1.w);
-    float4 mx = make_float4(fmaxf(eu0.x, eu1.x), fmaxf(eu0.y, eu1.y), fmaxf(eu0.z, eu1.z), fmaxf(eu0.w, eu1.w));
-    mx.x = agg8_wave_max_parity(mx.x); mx.y = agg8_wave_max_parity(mx.y);
-    mx.z = agg8_wave_max_parity(mx.z); mx.w = agg8_wave_max_parity(mx.w);
-    eu0 = make_float4(__builtin_amdgcn_exp2f((eu0.x - mx.x) * LOG2E), __builtin_amdgcn_exp2f((eu0.y - mx.y) * LOG2E),
-                      __builtin_amdgcn_exp2f((eu0.z - mx.z) * LOG2E), __builtin_amdgcn_exp2f((eu0.w - mx.w) * LOG2E));
-    eu1 = make_float4(__builtin_amdgcn_exp2f((eu1.x - mx.x) * LOG2E), __builtin_amdgcn_exp2f((eu1.y - mx.y) * LOG2E),
-                      __builtin_amdgcn_exp2f((eu1.z - mx.z) * LOG2E), __builtin_amdgcn_exp2f((eu1.w - mx.w) * LOG2E));
-    S4 = make_float4(eu0.x * es0.x + eu1.x * es1.x, eu0.y * es0.y + eu1.y * es1.y, eu0.z * es0.z + eu1.z * es1.z, eu0.w * es0.w + eu1.w * es1.w);
-    S4.x = agg8_wave_sum_parity(S4.x); S4.y = agg8_wave_sum_parity(S4.y);
-    S4.z = agg8_wave_sum_parity(S4.z); S4.w = agg8_wave_sum_parity(S4.w);
-    if (wv == 0 && lane < 2) *reinterpret_cast<float4*>(stat_s + (lane & 1) * 4) = S4;     // lanes of equal parity hold the same 4 groups
-  }
   AGG_TS(1);
   AGG_TS(2);
   AGG_TS(3);
@@ -1347,7 +1381,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     *reinterpret_cast<float4*>(red + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
   __builtin_amdgcn_s_setprio(0);
-  __syncthreads();                                                                        // the kernel's only barrier
+  __syncthreads();                                                                        // the second and last barrier
   AGG_TS(6);
   {
     const int c = t * 2, g = c >> 5;       // channels 2t, 2t+1 belong to group 2t / 32
@@ -1424,7 +1458,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       hipLaunchKernelGGL((aggregate_v3_kernel<float, 2>), grid, dim3(256), lds3, st, (const float*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     else
       hipLaunchKernelGGL((aggregate_v3_kernel<bf16_t, 2, 1>), grid, dim3(256), lds3, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
-  } else if (variant == 11) {     // v7 with DPP / permlane reductions, early matrix loads, packed FMAs; A/B against the default
+  } else if (variant == 11) {     // v7 with DPP / permlane reductions, early matrix loads, packed FMAs; A/B
     const int NP = N * P;
     const size_t lds7 = (size_t)NP * L * 32 + (size_t)((NP + 1) & ~1) * 8 + AGG4_MAX_N * 16 + 32 * 4 + AGG4_MAX_N * 4 + (size_t)2 * AGG7_CAPW * 36;
     if (feat_dtype == FAR3D_DT_F32) {
@@ -1434,7 +1468,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
-  } else if (variant == 8) {      // factored softmax, decoupled waves (default)
+  } else if (variant == 8) {      // factored softmax, specialised front ends, work-dealt items (default)
     if (feat_dtype == FAR3D_DT_F32) {
       if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
