@@ -899,7 +899,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// v8 (default since round 4): the tap-merging algorithm of v7 with a FACTORED softmax and DECOUPLED waves.
+// v8 (default since round 4): the tap-merging algorithm of v7 with a FACTORED softmax and SPECIALISED front ends.
 //
 // What the round-3 stamps said about v7 (profiles/r3/agg_phase_times.txt, profiles/r4): 40 % of a wave's life is its front end
 // (2 x 6 float4 logit loads, 24 exp, two block barriers for the softmax statistics), the launch lasts as long as its slowest wave,
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
 //    the items; wave 1 computes the softmax statistics; they swap results through each other's (still unused) row-list regions
 //    and meet at ONE barrier (v7: two barriers with both waves doing both halves; a fully redundant front end without any
 //    barrier was built first and is 6 % slower: profiles/r4/agg_live_specialised_front_ab.jsonl);
-//  * deals the visible (camera, level) items to the two waves by estimated work (greedy, computed identically by both) instead
+//  * deals the visible (camera, level) items to the two waves by estimated work (greedy, by wave 0) instead
 //    of by level parity, and raises the issue priority of waves that got a lot of it (the launch ends with its slowest wave);
 //  * projects with one v_rcp instead of four IEEE divisions, stores PIXEL coordinates per (camera, level, point) for the build
 //    loops, evaluates the tent weights with clamp modifiers, pads the row list so that the gather needs no bounds checks, and

@@ -85,8 +85,8 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * N*P<=256, N*P*L<=384.
  * cam_tables: the per-layer softmax factors of Vc from far3d_agg_tables / far3d_agg_order ((2+N)*L*P*G floats), or NULL.
  * variant: 0 = default: kernel 8 when cam_tables is given and N<=8, P<=16, value maps < 4 GiB, else kernel 7.
- *   8: two DECOUPLED waves per query (one barrier), softmax factored into a query part (8 exp per lane) and the per-frame camera
- *      tables, (camera, level) items dealt to the waves by estimated work, bilinear taps merged per token row through the tent
+ *   8: two waves per query with specialised front ends (wave 0 projects and deals, wave 1 does the softmax statistics; two
+ *      barriers), softmax factored into a query part (8 exp per lane) and the per-frame camera tables, (camera, level) items dealt to the waves by estimated work, bilinear taps merged per token row through the tent
  *      form of the interpolation weights (no atomics), padded LDS row lists, 16-byte row gathers from 32-bit byte offsets;
  *   7: round 2/3's kernel (two waves, levels split by parity, full 7-camera softmax from Vc, three barriers); 11 = 7 with its
  *      cross-lane reductions on the VALU and packed FMAs; 3 = round-1 kernel (workgroup per query, one gather per sample corner
