@@ -153,6 +153,10 @@ class Far3DEngine:
         self._fidx = 0
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
+        self.fused_rows = False     # bf16 decoder: run the row-local parts of a decoder layer as two row-resident chains
+                                    # (far3d_rowchain_attn_out / far3d_rowchain_ffn: 4 launches per layer instead of 11).  Opt-in until
+                                    # measured on the GPU; ignored where the chains do not apply (other decoder dtypes / geometries,
+                                    # the query-sharded decoder)
         self.mem = None
         self.prev_scene = None
         self._prepare()
@@ -275,6 +279,8 @@ class Far3DEngine:
         self.cls_b = (L("cls_branches.0.0"), L("cls_branches.0.3"), L("cls_branches.0.6"))
         self.cls_ln = [(f32(sd[h + "cls_branches.0.%d.weight" % j]), f32(sd[h + "cls_branches.0.%d.bias" % j])) for j in (1, 4)]
         self.reg_b = (L("reg_branches.0.0"), L("reg_branches.0.2"), L("reg_branches.0.4"))
+        cls_pcs, reg_pcs = tuple(l.pc for l in self.cls_b), tuple(l.pc for l in self.reg_b)
+        self.branch_rc = ops.RowChainBranches(cls_pcs, self.cls_ln, reg_pcs) if ops.RowChainBranches.supported(cls_pcs, reg_pcs, E, dw) else None
         self.ref_fixed = f32(sd[h + "reference_points.weight"])
         self.pseudo_ref = f32(sd[h + "pseudo_reference_points.weight"]) if cfg["num_propagated"] > 0 else None
         # ---- decoder layers (a7, a8).  Merged GEMMs over the [x+pos | x] operand (K = 2E, block weights):
@@ -302,6 +308,8 @@ class Far3DEngine:
                 ffn1=pk(sd[lp + "ffns.0.layers.0.0.weight"], sd[lp + "ffns.0.layers.0.0.bias"]),
                 ffn2=pk(sd[lp + "ffns.0.layers.1.weight"], sd[lp + "ffns.0.layers.1.bias"]),
                 norms=[(f32(sd[lp + "norms.%d.weight" % j]), f32(sd[lp + "norms.%d.bias" % j])) for j in range(3)])
+            # packed operands of the row-resident chains (csrc/rowchain.hip; used when fused_rows is set)
+            ly["rc"] = ops.RowChainLayer(ly) if ops.RowChainLayer.supported(ly, E, dw) else None
             self.layers.append(ly)
         self.memkv = pk(torch.cat(memkv_w), torch.cat(memkv_b))
         cl = []
@@ -547,6 +555,8 @@ class Far3DEngine:
         perm, tabs = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32), hole=hole,
                                            Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32))
         x = x0
+        if self.fused_rows and fast and all(ly["rc"] is not None for ly in self.layers):
+            return self._decoder_fused(X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs)
         for li, ly in enumerate(self.layers):
             c0 = li * 3 * E
             # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
@@ -570,6 +580,37 @@ class Far3DEngine:
             hdn = ops.linear(x2b if fast else x2, ly["ffn1"], act="relu", out_dtype=at)
             y = ops.linear(hdn, ly["ffn2"], res=x2)
             ops.layernorm(y, *ly["norms"][2], out=outs[li], add=qpos, y2=X2[:A, :E], yb=X2[:A, E:])
+            x = outs[li]
+        return outs
+
+    def _decoder_fused(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs):
+        """The decoder layers with their row-local parts as two row-resident chains (csrc/rowchain.hip): per layer the attention
+        core, far3d_rowchain_attn_out (out-projection + residual + LN0 + the aggregation's logit / offset linears), the
+        aggregation kernel, far3d_rowchain_ffn (output projection + residual + LN1 + FFN + LN2 + the NEXT layer's q / k / v) --
+        4 launches instead of 11; only layer 0's in-projection is a GEMM launch of its own.  Same operands and arithmetic as the
+        unfused loop in decoder() (bf16 operands, fp32 accumulation and LayerNorms), a different K order inside the GEMMs."""
+        cfg = self.cfg
+        E = cfg["embed_dims"]
+        at = self.prec["dec"]
+        nJ = cfg["num_groups"] * cfg["num_levels"] * cfg["num_pts"]
+        nO = cfg["num_pts"] * 3
+        nL = len(self.layers)
+        agg = self._buf(("agg_out",), (A, E), at)
+        att = self._buf(("att_out",), (A, E), at)
+        ops.linear(X2[:A], self.layers[0]["qkv"], out=QKV[:A, :3 * E], out_dtype=at)
+        x = x0
+        for li, ly in enumerate(self.layers):
+            c0 = li * 3 * E
+            ops.attention_forward(QKV[:A, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
+                                  num_heads=cfg["num_heads"], out=att, hole=hole)
+            ops.rowchain_attn_out(att, x, qpos, ly["rc"], x1, UL)
+            ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
+                                  cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg,
+                                  variant=self.agg_variant, tables=tabs[li])
+            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li])
+            last = li + 1 == nL
+            ops.rowchain_ffn(agg, x1, qpos, ly["rc"], outs[li], nxt=None if last else self.layers[li + 1]["rc"],
+                             qkv=None if last else QKV[:A, c0 + 3 * E:c0 + 6 * E])
             x = outs[li]
         return outs
 
@@ -763,10 +804,16 @@ class Far3DEngine:
         flatb = ops.nan_to_num_(flat, bf16_copy=fast)
         hin = flatb if fast else flat
         nl = cfg["num_layers"]
-        r1 = ops.layernorm(self.cls_b[0](hin), *self.cls_ln[0], act="relu", bf16_copy=fast)
-        r2 = ops.layernorm(self.cls_b[1](r1[1] if fast else r1), *self.cls_ln[1], act="relu", bf16_copy=fast)
-        all_cls = self.cls_b[2](r2[1] if fast else r2).view(nl, 1, A, cfg["num_classes"])
-        rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](hin, act="relu", out_dtype=at), act="relu", out_dtype=at))
+        if self.fused_rows and fast and self.branch_rc is not None:      # both branches in one row-resident launch (csrc/rowchain.hip)
+            cls_flat = self._buf(("cls_flat",), (nl * A, cfg["num_classes"]), torch.float32)
+            rr = self._buf(("reg_flat",), (nl * A, cfg["code_size"]), torch.float32)
+            ops.rowchain_branches(hin, self.branch_rc, cls_flat, rr)
+            all_cls = cls_flat.view(nl, 1, A, cfg["num_classes"])
+        else:
+            r1 = ops.layernorm(self.cls_b[0](hin), *self.cls_ln[0], act="relu", bf16_copy=fast)
+            r2 = ops.layernorm(self.cls_b[1](r1[1] if fast else r1), *self.cls_ln[1], act="relu", bf16_copy=fast)
+            all_cls = self.cls_b[2](r2[1] if fast else r2).view(nl, 1, A, cfg["num_classes"])
+            rr = self.reg_b[2](self.reg_b[1](self.reg_b[0](hin, act="relu", out_dtype=at), act="relu", out_dtype=at))
         box_flat, sc = ops.head_finalize(rr, ref, all_cls, cfg["pc_range"], nl, cfg["num_classes"], hole=hole)
         all_box = box_flat.view(nl, 1, A, cfg["code_size"])
         # ---- a11: memory post-update (farhead.py:479-508): top-k by max-class score, push, truncate, ego warp -- in place

@@ -406,6 +406,141 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
 
 
 # --------------------------------------------------------------------------------------------------
+# row-resident decoder chains (csrc/rowchain.hip)
+# --------------------------------------------------------------------------------------------------
+ROWCHAIN_E, ROWCHAIN_FF, ROWCHAIN_WL_TILES = 256, 1024, 29
+
+
+def pack_rowchain(pc, cols=None):
+    """A PackedConv's (rows, K) bf16 weight in the MFMA fragment order the row chains stream (include/far3d_hip.h):
+    [ceil(cols / 16)][K / 32][64][8], element j of lane l of (tile t, step s) = W[16 t + (l & 15)][32 s + 8 (l >> 4) + j].
+    Returns (packed weight, f32 bias covering the padded columns)."""
+    w = pc.w
+    if w.dtype != torch.bfloat16 or pc.KH * pc.KW != 1 or pc.w_code != DT_BF16:
+        raise ValueError("pack_rowchain: plain bf16 linear weights only")
+    K = w.shape[1]
+    if K % 256 != 0:
+        raise ValueError("pack_rowchain: K=%d must be a multiple of 256" % K)
+    cols = pc.Cout if cols is None else cols
+    nt = -(-cols // 16)
+    if nt * 16 > w.shape[0]:
+        raise ValueError("pack_rowchain: %d columns exceed the packed weight's %d rows" % (nt * 16, w.shape[0]))
+    frag = w[:nt * 16].reshape(nt, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()      # [t][s][l >> 4][l & 15][j]
+    bias = pc.bias[:nt * 16].contiguous() if pc.bias is not None else torch.zeros(nt * 16, dtype=torch.float32, device=w.device)
+    return frag.reshape(nt, K // 32, 64, 8), bias
+
+
+class RowChainLayer:
+    """The packed operands of one decoder layer's two row chains.  ly: the engine's layer dict (PackedConvs out / wl / oproj /
+    ffn1 / ffn2 / qkv and the three (gamma, beta) pairs)."""
+
+    def __init__(self, ly):
+        self.out, self.b_out = pack_rowchain(ly["out"])
+        self.wl, self.b_wl = pack_rowchain(ly["wl"])
+        self.n_wl = ly["wl"].Cout
+        self.oproj, self.b_oproj = pack_rowchain(ly["oproj"])
+        self.ffn1, self.b_ffn1 = pack_rowchain(ly["ffn1"])
+        self.ffn2, self.b_ffn2 = pack_rowchain(ly["ffn2"])
+        self.qkv, self.b_qkv = pack_rowchain(ly["qkv"])
+        self.norms = [(g.contiguous(), b.contiguous()) for g, b in ly["norms"]]
+
+    @staticmethod
+    def supported(ly, E, dtype):
+        """The chains are built for the benchmark's decoder geometry (E = 256, FFN 1024, 449..464 aggregation outputs, bf16)."""
+        return (dtype == torch.bfloat16 and E == ROWCHAIN_E and ly["ffn1"].Cout == ROWCHAIN_FF and ly["ffn2"].Cin == ROWCHAIN_FF and
+                16 * (ROWCHAIN_WL_TILES - 1) < ly["wl"].Cout <= 16 * ROWCHAIN_WL_TILES and ly["wl"].Cin == 2 * E and
+                ly["qkv"].Cin == 2 * E and ly["qkv"].Cout == 3 * E and all(ly[k].w.dtype == torch.bfloat16 and ly[k].w_code == DT_BF16
+                                                                           for k in ("out", "wl", "oproj", "ffn1", "ffn2", "qkv")))
+
+
+class RowChainBranches:
+    """Packed operands of far3d_rowchain_branches.  cls / reg: the three PackedConvs of each branch; cls_ln: two (gamma, beta)."""
+
+    def __init__(self, cls, cls_ln, reg):
+        (self.c0, self.b_c0), (self.c1, self.b_c1) = (pack_rowchain(pc) for pc in cls[:2])
+        (self.r0, self.b_r0), (self.r1, self.b_r1) = (pack_rowchain(pc) for pc in reg[:2])
+        (self.c2, self.b_c2), (self.r2, self.b_r2) = pack_rowchain(cls[2], cols=32), pack_rowchain(reg[2], cols=32)   # two tiles each
+        self.cls_ln = [(g.contiguous(), b.contiguous()) for g, b in cls_ln]
+        self.n_cls, self.n_reg = cls[2].Cout, reg[2].Cout
+
+    @staticmethod
+    def supported(cls, reg, E, dtype):
+        pcs = list(cls) + list(reg)
+        return (dtype == torch.bfloat16 and E == ROWCHAIN_E and all(pc.w.dtype == torch.bfloat16 and pc.w_code == DT_BF16 and pc.Cin == E for pc in pcs) and
+                all(pc.Cout == E for pc in (cls[0], cls[1], reg[0], reg[1])) and 1 <= cls[2].Cout <= 32 and 1 <= reg[2].Cout <= 32)
+
+
+def _rows(t, name, dtype, cols):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != dtype or t.shape[1] < cols or not t.is_cuda:
+        raise ValueError("%s must be a (M, >=%d) %s device tensor with unit inner stride" % (name, cols, dtype))
+    return t
+
+
+def rowchain_attn_out(att, x, qpos, rc, x1, ul, eps=1e-5):
+    """x1 = LN0(att @ W_out^T + b + x); ul[:, :n_wl] = [x1 + qpos | x1] @ W_wl^T + b  -- one launch (far3d_rowchain_attn_out).
+    att (M,E) bf16; x, qpos (M,E) f32; x1 (M,E) f32 out; ul (M, >= n_wl) f32 out.  rc: RowChainLayer."""
+    lib = _lib.require_device()
+    E = ROWCHAIN_E
+    M = att.shape[0]
+    _rows(att, "att", torch.bfloat16, E); _rows(x, "x", torch.float32, E); _rows(qpos, "qpos", torch.float32, E)
+    _rows(x1, "x1", torch.float32, E); _rows(ul, "ul", torch.float32, rc.n_wl)
+    for t in (x, qpos, x1, ul):
+        if t.shape[0] != M:
+            raise ValueError("rowchain_attn_out: row counts differ")
+    g0, be0 = rc.norms[0]
+    _lib.check(lib.far3d_rowchain_attn_out(_ptr(att), att.stride(0), _ptr(x), x.stride(0), _ptr(qpos), qpos.stride(0),
+                                           _ptr(rc.out), _ptr(rc.b_out), _ptr(g0), _ptr(be0), _ptr(rc.wl), _ptr(rc.b_wl), rc.n_wl,
+                                           _ptr(x1), x1.stride(0), _ptr(ul), ul.stride(0), M, float(eps), _stream(att)),
+               "far3d_rowchain_attn_out")
+    return x1, ul
+
+
+def rowchain_ffn(agg, x1, qpos, rc, out, nxt=None, qkv=None, xop=None, eps=1e-5):
+    """x2 = LN1(agg @ W_o^T + b + x1); out = LN2(relu(x2 @ W_1^T + b) @ W_2^T + b + x2); with nxt (the NEXT layer's
+    RowChainLayer): qkv = [out + qpos | out] @ W_qkv^T + b (bf16, (M, 3E)) -- one launch (far3d_rowchain_ffn).
+    xop: optional (M, 2E) bf16 out, [out + qpos | out]."""
+    lib = _lib.require_device()
+    E = ROWCHAIN_E
+    M = agg.shape[0]
+    _rows(agg, "agg", torch.bfloat16, E); _rows(x1, "x1", torch.float32, E); _rows(qpos, "qpos", torch.float32, E)
+    _rows(out, "out", torch.float32, E)
+    if (nxt is None) != (qkv is None):
+        raise ValueError("rowchain_ffn: nxt and qkv go together")
+    if qkv is not None:
+        _rows(qkv, "qkv", torch.bfloat16, 3 * E)
+    if xop is not None:
+        _rows(xop, "xop", torch.bfloat16, 2 * E)
+    for t in (x1, qpos, out, qkv, xop):
+        if t is not None and t.shape[0] != M:
+            raise ValueError("rowchain_ffn: row counts differ")
+    (g1, be1), (g2, be2) = rc.norms[1], rc.norms[2]
+    _lib.check(lib.far3d_rowchain_ffn(_ptr(agg), agg.stride(0), _ptr(x1), x1.stride(0), _ptr(qpos), qpos.stride(0),
+                                      _ptr(rc.oproj), _ptr(rc.b_oproj), _ptr(g1), _ptr(be1), _ptr(rc.ffn1), _ptr(rc.b_ffn1),
+                                      _ptr(rc.ffn2), _ptr(rc.b_ffn2), _ptr(g2), _ptr(be2),
+                                      _ptr(nxt.qkv) if nxt is not None else None, _ptr(nxt.b_qkv) if nxt is not None else None,
+                                      _ptr(out), out.stride(0), _ptr(qkv) if qkv is not None else None,
+                                      qkv.stride(0) if qkv is not None else 0, _ptr(xop) if xop is not None else None,
+                                      xop.stride(0) if xop is not None else 0, M, float(eps), _stream(agg)), "far3d_rowchain_ffn")
+    return out
+
+
+def rowchain_branches(h, rb, cls_out, reg_out, eps=1e-5):
+    """cls_out (M, n_cls), reg_out (M, n_reg) f32 = the classification / regression branches of h (M,E) bf16 in one launch
+    (far3d_rowchain_branches).  rb: RowChainBranches."""
+    lib = _lib.require_device()
+    M = h.shape[0]
+    _rows(h, "h", torch.bfloat16, ROWCHAIN_E); _rows(cls_out, "cls_out", torch.float32, rb.n_cls); _rows(reg_out, "reg_out", torch.float32, rb.n_reg)
+    if cls_out.shape[0] != M or reg_out.shape[0] != M:
+        raise ValueError("rowchain_branches: row counts differ")
+    (g0, be0), (g1, be1) = rb.cls_ln
+    _lib.check(lib.far3d_rowchain_branches(_ptr(h), h.stride(0), _ptr(rb.c0), _ptr(rb.b_c0), _ptr(g0), _ptr(be0), _ptr(rb.c1), _ptr(rb.b_c1),
+                                           _ptr(g1), _ptr(be1), _ptr(rb.c2), _ptr(rb.b_c2), rb.n_cls, _ptr(rb.r0), _ptr(rb.b_r0),
+                                           _ptr(rb.r1), _ptr(rb.b_r1), _ptr(rb.r2), _ptr(rb.b_r2), rb.n_reg, _ptr(cls_out), cls_out.stride(0),
+                                           _ptr(reg_out), reg_out.stride(0), M, float(eps), _stream(h)), "far3d_rowchain_branches")
+    return cls_out, reg_out
+
+
+# --------------------------------------------------------------------------------------------------
 # attention / normalisation / pooling
 # --------------------------------------------------------------------------------------------------
 def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32, hole=None):

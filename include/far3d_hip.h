@@ -170,6 +170,51 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
                     int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2, int y2_dt, void* yb, int ldyb,
                     int yb_dt, void* stream);
 
+/* ROW-RESIDENT CHAINS of a decoder layer (bf16 decoder, embed dims 256, FFN hidden 1024): the row-local work between the
+ * attention core and the aggregation kernel, and between the aggregation kernel and the next layer's attention core, in one
+ * launch each -- a workgroup owns 16 query rows, keeps them in LDS across projections / residuals / LayerNorms and streams the
+ * weights from L2 in MFMA fragment order.  They replace sequences of far3d_conv2d_nhwc + far3d_layernorm calls (the default
+ * path of far3d_amd.engine, which stays available) and compute the same arithmetic: bf16 operands, fp32 accumulation, epilogue
+ * order bias -> activation -> residual, far3d_layernorm's reduction tree; only the K order of the fp32 accumulation differs.
+ * Rows never interact: a row's result does not depend on M or on the rows launched with it.
+ * Packed weights: a (N, K) bf16 row-major weight (K % 256 == 0, rows zero-padded to a multiple of 16) re-ordered to
+ * [N / 16][K / 32][64 lanes][8]: element j of lane l of (tile t, step s) is W[16 t + (l & 15)][32 s + 8 (l >> 4) + j]
+ * (far3d_amd.ops.pack_rowchain).  Biases are f32 and cover the padded rows.  All pointers 16-byte aligned, row strides in
+ * elements (bf16 rows: multiples of 8, f32 rows: multiples of 4).
+ *
+ * far3d_rowchain_attn_out: x1 = LN0(att W_out^T + b_out + x);  ul = [x1 + qpos | x1] W_wl^T + b_wl.
+ *   Replaces the self-attention output projection + residual + norm (ref models/utils/detr3d_transformer.py:385-400) and the
+ *   attention-weight / key-point-offset linears of the aggregation (:522-531; merged into one (n_wl, 512) weight whose first
+ *   256 input columns see query + query_pos and whose last 256 see the query, as in the unfused path).
+ *   att (M,256) bf16; x, qpos (M,256) f32; x1 (M,256) f32 out; ul (M, n_wl) f32 out, 448 < n_wl <= 464. */
+int far3d_rowchain_attn_out(const void* att, int ld_att, const float* x, int ldx, const float* qpos, int ldq,
+                            const void* w_out, const float* b_out, const float* g0, const float* be0,
+                            const void* w_wl, const float* b_wl, int n_wl, float* x1, int ldx1, float* ul, int ldu,
+                            int M, float eps, void* stream);
+
+/* far3d_rowchain_ffn: x2 = LN1(agg W_o^T + b_o + x1);  out = LN2(relu(x2 W_1^T + b_1) W_2^T + b_2 + x2);
+ *   with w_qkv: qkv = [out + qpos | out] W_qkv^T + b_qkv (bf16; the NEXT layer's merged q / k / v in-projection).
+ *   Replaces the aggregation's output projection + residual (ref detr3d_transformer.py:566-569), norm, FFN, norm (:398-422)
+ *   and the next layer's in-projection (:378-384).  agg (M,256) bf16; x1, qpos (M,256) f32; out (M,256) f32;
+ *   qkv (M,768) bf16 or NULL with w_qkv NULL; xop (optional, M x 512 bf16): [out + qpos | out], the operand the unfused
+ *   in-projection reads. */
+int far3d_rowchain_ffn(const void* agg, int ld_agg, const float* x1, int ldx1, const float* qpos, int ldq,
+                       const void* w_o, const float* b_o, const float* g1, const float* be1,
+                       const void* w_1, const float* b_1, const void* w_2, const float* b_2,
+                       const float* g2, const float* be2, const void* w_qkv, const float* b_qkv,
+                       float* out, int ldo, void* qkv, int ldqkv, void* xop, int ldxop, int M, float eps, void* stream);
+
+/* far3d_rowchain_branches: the shared classification and regression branches over the decoder outputs of all layers,
+ *   cls = L2(relu(LN(L1(relu(LN(L0(h)))))));  reg = L2'(relu(L1'(relu(L0'(h)))))   (L: 256 -> 256 linears, the last ones -> n_cls / n_reg)
+ *   Replaces 6 far3d_conv2d_nhwc + 2 far3d_layernorm launches (ref models/dense_heads/farhead.py:230-245, applied at :646-664).
+ *   h (M,256) bf16; cls (M, n_cls) f32, reg (M, n_reg) f32, n_cls, n_reg <= 32; weights packed as above (the last linears as TWO
+ *   16-row tiles, zero rows past their outputs), biases covering 32 rows. */
+int far3d_rowchain_branches(const void* h, int ldh, const void* w_c0, const float* b_c0, const float* g_c0, const float* be_c0,
+                            const void* w_c1, const float* b_c1, const float* g_c1, const float* be_c1,
+                            const void* w_c2, const float* b_c2, int n_cls, const void* w_r0, const float* b_r0,
+                            const void* w_r1, const float* b_r1, const void* w_r2, const float* b_r2, int n_reg,
+                            float* cls, int ld_cls, float* reg, int ld_reg, int M, float eps, void* stream);
+
 /* VoVNet eSE block on NHWC maps: y = x * hsigmoid(fc(mean_hw(x))) (+ identity).
  * Replaces eSEModule + the identity add, ref models/backbones/vovnet.py:173-185,232-236.
  * x,identity,y: NHWC `dt` with (pixel stride, image stride) pairs; fcw (C,C) f32 row-major, fcb (C) f32;
