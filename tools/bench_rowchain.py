@@ -36,8 +36,11 @@ def main():
     ap.add_argument("--rows", type=int, default=1544)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-engine", action="store_true")
+    ap.add_argument("--engine-only", action="store_true")
     a = ap.parse_args()
     M = a.rows
+    if a.engine_only:
+        return head_stage()
     ly, nxt = layer(1), layer(2)
     att = torch.randn(M, E, device=DEV).to(torch.bfloat16)
     x, qpos = torch.randn(M, E, device=DEV), torch.randn(M, E, device=DEV) * 0.5
@@ -96,9 +99,14 @@ def main():
     tf, tu = timeit(lambda: ops.rowchain_branches(h, rb, co, ro), a.iters), timeit(unfused_br, a.iters)
     print(json.dumps(dict(chain="cls + reg branches", rows=Mb, fused_us=round(tf * 1e6, 2), unfused_us=round(tu * 1e6, 2), unfused_launches=8,
                           workgroups=-(-Mb // 16), speedup=round(tu / tf, 2))), flush=True)
-    if a.no_engine:
-        return
-    # the head stage of a steady benchmark frame, unfused vs fused (hipGraph replay, no launch gaps)
+    if not a.no_engine:
+        head_stage()
+
+
+def head_stage():
+    """The head stage of a steady benchmark frame, unfused vs fused: device time (hipGraph replay, no launch gaps), C-ABI calls per
+    stage (one call = one kernel launch, far3d_agg_order / decode aside), logits of the two engines on the same frame."""
+    from far3d_amd import lib as _lib
     cfg = engine.default_cfg(proposal_topk=92)
     sd = weights.init_state_dict(weights.detector_spec(cfg["backbone"]), seed=0)
     res = {}
@@ -106,18 +114,29 @@ def main():
         eng = engine.Far3DEngine(sd, cfg, device=DEV, precision="bf16", parts=("backbone", "neck", "roi", "head"))
         eng.fused_rows = fused
         frames = [synth.make_frame(7, (640, 960), seed=0, frame_index=fi, device=DEV, ego_motion=True) for fi in range(2)]
-        for f in frames:
-            o = eng.forward_frame(*f)
+        o = eng.forward_frame(*frames[0])          # frame 0 (no streaming memory yet) is what the two engines are compared on:
+        logits0 = o["all_cls_scores"].clone()      # later frames also differ by whatever a flipped memory top-k entry does downstream
+        eng.forward_frame(*frames[1])
         data, metas = frames[1]
         pad_hw = tuple(metas[0]["pad_shape"][0][:2])
         dd = eng._stage_inputs(data)
         st = eng._camera_part(dd, pad_hw)
         torch.cuda.synchronize()
+        calls, real_check = [0], _lib.check
+
+        def counting_check(status, what):
+            calls[0] += 1
+            return real_check(status, what)
+        _lib.check = ops._lib.check = counting_check
+        try:
+            eng._head_part(st, dd, metas, pad_hw)
+        finally:
+            _lib.check = ops._lib.check = real_check
         t = timeit(lambda: eng._head_part(st, dd, metas, pad_hw), 3, warmup=2)
-        res[fused] = (t, o["all_cls_scores"].clone())
-        print(json.dumps(dict(stage="head", fused_rows=fused, ms=round(t * 1e3, 4))), flush=True)
+        res[fused] = (t, logits0)
+        print(json.dumps(dict(stage="head", fused_rows=fused, ms=round(t * 1e3, 4), c_abi_calls=calls[0])), flush=True)
     d = (res[False][1] - res[True][1]).abs()
-    print(json.dumps(dict(stage="head", logits_max_abs_diff=round(d.max().item(), 6), logits_mean_abs_diff=round(d.mean().item(), 7),
+    print(json.dumps(dict(stage="head", frame=0, logits_max_abs_diff=round(d.max().item(), 6), logits_mean_abs_diff=round(d.mean().item(), 7),
                           speedup=round(res[False][0] / res[True][0], 3))))
 
 
