@@ -143,6 +143,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     eng = engine.Far3DEngine(sd, cfg, device=dev, precision=precision)
     eng.agg_variant = args.agg_variant
     eng.cam_priority = args.cam_priority
+    eng.fused_rows = args.fused_rows        # opt-in A/B: row-resident decoder chains (bf16 decoder only; csrc/rowchain.hip)
     del sd
     frames = []
     for fi in range(4):   # a few distinct frames (ego motion on), resident in HBM before the timed region
@@ -349,6 +350,8 @@ def main():
                     help="bf16 conv tile table: tuned for a launch alone, or under the pipeline's 3-stream concurrency (auto: by mode; A/B)")
     ap.add_argument("--cam-streams", type=int, default=3, help="streams the camera stages of consecutive frames alternate between (A/B)")
     ap.add_argument("--cam-priority", type=int, default=-1, help="HIP stream priority of the camera-stage streams in pipeline mode (-1 = high, 0 = default; A/B)")
+    ap.add_argument("--fused-rows", action="store_true", help="A/B: run the row-local parts of the decoder layers and the cls / reg branches "
+                    "as row-resident chains (engine.fused_rows; bf16 decoder only; not the default path)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N ranks on fewer than N GPUs (test rig only): ranks share devices and exchange over gloo; the line says so and "
                          "is not a scaling measurement")
@@ -421,7 +424,7 @@ def main():
                                    ("BASELINE configs[1] with the reference's threshold proposal rule: 7 cameras 3x640x960, VoV-99, %d query rows (644 "
                                     "learned + %d adaptive rows of which %d hold a proposal in the last frame + 256 propagated), fixed capacity, "
                                     "count on the device, overflow=%s" % (A, args.capacity, res["n_adaptive"], res["proposal_overflow"])),
-                       "proposals": args.proposals,
+                       "proposals": args.proposals, "fused_rows": bool(args.fused_rows),
                        "parallelism": "single GPU" if world == 1 else ("camera-sharded x%d + 1 all-gather" % world if sharded else
                                                                        "%d independent scene streams (replicas, no collective)" % world),
                        "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res["prec"].items()},

@@ -243,6 +243,32 @@ __global__ __launch_bounds__(RC_THREADS) void rowchain_attn_out_kernel(RowAttnOu
   }
 }
 
+// [q | k | v] = A0[16 x 2E] W_qkv^T + b -> bf16 rows of the layer's column block (staged through A1 for 16-byte row stores).
+// Shared by far3d_rowchain_ffn's tail and far3d_rowchain_qkv; the caller has issued rc_prefetch for w_qkv and a barrier after
+// writing A0.
+__device__ __forceinline__ void rc_qkv_tail(const bf16_t* A0, bf16_t* A1, const uint4* __restrict__ w_qkv, const float* __restrict__ b_qkv,
+                                            uint4 (&wb)[RC_NB][8], bf16_t* __restrict__ qkv, int ldqkv, int row0, int M, int tid) {
+  constexpr int NT = 3 * RC_E / 16, TW = NT / RC_WAVES, SLD = 3 * RC_E + 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  float bq[TW];
+  rc_bias<NT>(b_qkv, bq, wave, lane);
+  f32x4_t acc[TW];
+  rc_gemm<2 * RC_E, NT, RC_A0LD>(A0, w_qkv, wb, acc, wave, lane);
+#pragma unroll
+  for (int i = 0; i < TW; ++i) {
+    const int c = (wave + RC_WAVES * i) * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A1[(4 * (lane >> 4) + j) * SLD + c] = f32_to_bf16(acc[i][j] + bq[i]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {                        // 16 rows x 96 pieces of 16 bytes
+    const int idx = tid + RC_THREADS * j, r = idx / 96, ch = idx - r * 96;
+    if (row0 + r < M)
+      *reinterpret_cast<uint4*>(qkv + (long)(row0 + r) * ldqkv + ch * 8) = *reinterpret_cast<const uint4*>(A1 + r * SLD + ch * 8);
+  }
+}
+
 struct RowFfnParams {
   const bf16_t* agg; int ld_agg;        // (M, E) aggregation output
   const float* x1; int ldx1;            // (M, E) residual: LN0 rows
@@ -331,26 +357,41 @@ __global__ __launch_bounds__(RC_THREADS) void rowchain_ffn_kernel(RowFfnParams P
   }
   if (!P.w_qkv) return;                                // uniform over the launch
   __syncthreads();
-  {
-    constexpr int NT = 3 * RC_E / 16, TW = NT / RC_WAVES, SLD = 3 * RC_E + 8;
-    float bq[TW];
-    rc_bias<NT>(P.b_qkv, bq, wave, lane);
-    f32x4_t acc[TW];
-    rc_gemm<2 * RC_E, NT, RC_A0LD>(A0, P.w_qkv, wb, acc, wave, lane);
+  rc_qkv_tail(A0, A1, P.w_qkv, P.b_qkv, wb, P.qkv, P.ldqkv, row0, P.M, tid);
+}
+
+struct RowQkvParams {
+  const float* x; int ldx;              // (M, E) layer input rows (the previous layer's LN2 output)
+  const float* qpos; int ldq;
+  const uint4* w_qkv; const float* b_qkv;
+  bf16_t* qkv; int ldqkv;
+  int M;
+};
+
+// The in-projection alone: qkv = [x + pos | x] W_qkv^T + b with the operand built exactly as far3d_rowchain_ffn builds it from its
+// LN2 rows and the GEMM / store code shared with that kernel's tail -- given the same x and pos the result is BIT-IDENTICAL to the
+// tail's.  The query-sharded decoder needs it: the layer outputs of all ranks exist only after the exchange.
+__global__ __launch_bounds__(RC_THREADS) void rowchain_qkv_kernel(RowQkvParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* A0 = reinterpret_cast<bf16_t*>(smem + RC_F_BYTES);
+  bf16_t* A1 = reinterpret_cast<bf16_t*>(smem + RC_F_BYTES + RC_A0_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * RC_R;
+  uint4 wb[RC_NB][8];
+  rc_prefetch<2 * RC_E, 3 * RC_E / 16>(P.w_qkv, wb, wave, lane);
 #pragma unroll
-    for (int i = 0; i < TW; ++i) {
-      const int c = (wave + RC_WAVES * i) * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) A1[(4 * (lane >> 4) + j) * SLD + c] = f32_to_bf16(acc[i][j] + bq[i]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {                      // 16 rows x 96 pieces of 16 bytes
-      const int idx = tid + RC_THREADS * j, r = idx / 96, ch = idx - r * 96;
-      if (row0 + r < P.M)
-        *reinterpret_cast<uint4*>(P.qkv + (long)(row0 + r) * P.ldqkv + ch * 8) = *reinterpret_cast<const uint4*>(A1 + r * SLD + ch * 8);
-    }
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wave + rr, rowc = min(row0 + r, P.M - 1);
+    float4 o = rc_ld4(P.x + (long)rowc * P.ldx + lane * 4);
+    const float4 pos = rc_ld4(P.qpos + (long)rowc * P.ldq + lane * 4);
+    const bool ok = row0 + r < P.M;
+    o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+    const float4 op = make_float4(o.x + pos.x, o.y + pos.y, o.z + pos.z, o.w + pos.w);
+    *reinterpret_cast<uint2*>(A0 + r * RC_A0LD + lane * 4) = rc_pack4(op);
+    *reinterpret_cast<uint2*>(A0 + r * RC_A0LD + RC_E + lane * 4) = rc_pack4(o);
   }
+  __syncthreads();
+  rc_qkv_tail(A0, A1, P.w_qkv, P.b_qkv, wb, P.qkv, P.ldqkv, row0, P.M, tid);
 }
 
 struct RowBranchParams {
@@ -574,5 +615,26 @@ extern "C" int far3d_rowchain_branches(const void* h, int ldh, const void* w_c0,
   }
   hipLaunchKernelGGL(rowchain_branches_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);
   FAR3D_CHECK_LAUNCH("far3d_rowchain_branches");
+  return FAR3D_OK;
+}
+
+extern "C" int far3d_rowchain_qkv(const float* x, int ldx, const float* qpos, int ldq, const void* w_qkv, const float* b_qkv,
+                                  void* qkv, int ldqkv, int M, void* stream) {
+  FAR3D_CHECK_ARG(x && qpos && w_qkv && b_qkv && qkv, "far3d_rowchain_qkv: null pointer");
+  FAR3D_CHECK_ARG(M >= 0 && ldx % 4 == 0 && ldq % 4 == 0 && ldx >= RC_E && ldq >= RC_E && ldqkv >= 3 * RC_E && ldqkv % 8 == 0,
+                  "far3d_rowchain_qkv: M=%d, row strides %d / %d / %d", M, ldx, ldq, ldqkv);
+  FAR3D_CHECK_ARG(rc_aligned16(x) && rc_aligned16(qpos) && rc_aligned16(w_qkv) && rc_aligned16(qkv),
+                  "far3d_rowchain_qkv: pointers must be 16-byte aligned");
+  if (M == 0) return FAR3D_OK;
+  RowQkvParams P;
+  P.x = x; P.ldx = ldx; P.qpos = qpos; P.ldq = ldq; P.w_qkv = (const uint4*)w_qkv; P.b_qkv = b_qkv; P.qkv = (bf16_t*)qkv; P.ldqkv = ldqkv;
+  P.M = M;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rowchain_qkv_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);
+  FAR3D_CHECK_LAUNCH("far3d_rowchain_qkv");
   return FAR3D_OK;
 }

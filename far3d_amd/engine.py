@@ -655,10 +655,25 @@ class Far3DEngine:
         vc_all = ops.cam_embed_chain(lidar2img, self.cam_chain)
         tabs = ops.agg_tables(vc_all, out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32))
         x = x0
+        # fused_rows: the same row-resident chains as the replicated decoder (_decoder_fused) on this rank's rows -- their results do
+        # not depend on the rows launched together -- with the in-projection of layers > 0 as far3d_rowchain_qkv over ALL rows
+        # after the exchange (bit-identical to the chain's tail): the replicated and the sharded decoder stay equal bit for bit
+        fused = self.fused_rows and fast and all(ly["rc"] is not None for ly in self.layers)
         for li, ly in enumerate(self.layers):
             c0 = li * 3 * E
-            ops.linear(X2[:A], ly["qkv"], out=QKV[:A, c0:c0 + 3 * E], out_dtype=at)          # all rows: every rank needs every K / V
-            if nr > 0:
+            if fused and li > 0:
+                ops.rowchain_qkv(outs[li - 1], qpos, ly["rc"], QKV[:A, c0:c0 + 3 * E])
+            else:
+                ops.linear(X2[:A], ly["qkv"], out=QKV[:A, c0:c0 + 3 * E], out_dtype=at)      # all rows: every rank needs every K / V
+            if nr > 0 and fused:
+                att = ops.attention_forward(QKV[a0:a1, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
+                                            num_heads=cfg["num_heads"], out_dtype=at, hole=hole)
+                ops.rowchain_attn_out(att, x[a0:a1], qpos[a0:a1], ly["rc"], x1[a0:a1], UL[a0:a1])
+                ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
+                                      cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg, variant=self.agg_variant,
+                                      tables=tabs[li])
+                ops.rowchain_ffn(agg[a0:a1], x1[a0:a1], qpos[a0:a1], ly["rc"], gsrc[:nr])
+            elif nr > 0:
                 att = ops.attention_forward(QKV[a0:a1, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
                                             num_heads=cfg["num_heads"], out_dtype=at, hole=hole)
                 y = ops.linear(att, ly["out"], res=x[a0:a1])
@@ -677,8 +692,10 @@ class Far3DEngine:
                 ops.layernorm(y, *ly["norms"][2], out=gsrc[:nr])
             qs.gather(gsrc, gdst)                                       # the layer's ONE exchange (never captured into a graph)
             outs[li].copy_(gdst[:A])       # rank r owns rows [r * per, (r + 1) * per): the blocks are already in row order, padding last
-            # next layer's operand [x + pos | x] for ALL rows (what the fused LayerNorm epilogue writes in the replicated decoder)
-            ops.add_cast(outs[li], qpos, at, out_sum=X2[:A, :E], out_a=X2[:A, E:])
+            # next layer's operand [x + pos | x] for ALL rows (what the fused LayerNorm epilogue writes in the replicated decoder;
+            # the row chains build it inside far3d_rowchain_qkv)
+            if not fused:
+                ops.add_cast(outs[li], qpos, at, out_sum=X2[:A, :E], out_a=X2[:A, E:])
             x = outs[li]
         return outs
 

@@ -40,6 +40,7 @@ SIGNATURES = {
     "far3d_rowchain_attn_out": (c_int, [_p, c_int, _p, c_int, _p, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_int, _p, c_int,
                                         c_int, c_float, _p]),
     "far3d_rowchain_ffn": (c_int, [_p, c_int, _p, c_int, _p, c_int] + [_p] * 12 + [_p, c_int, _p, c_int, _p, c_int, c_int, c_float, _p]),
+    "far3d_rowchain_qkv": (c_int, [_p, c_int, _p, c_int, _p, _p, _p, c_int, c_int, _p]),
     "far3d_rowchain_branches": (c_int, [_p, c_int] + [_p] * 10 + [c_int] + [_p] * 6 + [c_int, _p, c_int, _p, c_int, c_int, c_float, _p]),
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
                                c_int, c_long, _p, _p]),

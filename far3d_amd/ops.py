@@ -524,6 +524,20 @@ def rowchain_ffn(agg, x1, qpos, rc, out, nxt=None, qkv=None, xop=None, eps=1e-5)
     return out
 
 
+def rowchain_qkv(x, qpos, rc, qkv):
+    """qkv (M,3E) bf16 = [x + qpos | x] @ W_qkv^T + b of layer `rc` (RowChainLayer) -- bit-identical to what rowchain_ffn(..., nxt=rc)
+    writes for the same rows (far3d_rowchain_qkv)."""
+    lib = _lib.require_device()
+    E = ROWCHAIN_E
+    M = x.shape[0]
+    _rows(x, "x", torch.float32, E); _rows(qpos, "qpos", torch.float32, E); _rows(qkv, "qkv", torch.bfloat16, 3 * E)
+    if qpos.shape[0] != M or qkv.shape[0] != M:
+        raise ValueError("rowchain_qkv: row counts differ")
+    _lib.check(lib.far3d_rowchain_qkv(_ptr(x), x.stride(0), _ptr(qpos), qpos.stride(0), _ptr(rc.qkv), _ptr(rc.b_qkv), _ptr(qkv), qkv.stride(0),
+                                      M, _stream(x)), "far3d_rowchain_qkv")
+    return qkv
+
+
 def rowchain_branches(h, rb, cls_out, reg_out, eps=1e-5):
     """cls_out (M, n_cls), reg_out (M, n_reg) f32 = the classification / regression branches of h (M,E) bf16 in one launch
     (far3d_rowchain_branches).  rb: RowChainBranches."""

@@ -204,6 +204,13 @@ int far3d_rowchain_ffn(const void* agg, int ld_agg, const float* x1, int ldx1, c
                        const float* g2, const float* be2, const void* w_qkv, const float* b_qkv,
                        float* out, int ldo, void* qkv, int ldqkv, void* xop, int ldxop, int M, float eps, void* stream);
 
+/* far3d_rowchain_qkv: qkv = [x + qpos | x] W_qkv^T + b_qkv (bf16), the in-projection alone -- the operand is built and the GEMM
+ *   run by the code of far3d_rowchain_ffn's tail, so for the same x (that kernel's `out`) and qpos the result is BIT-IDENTICAL
+ *   to the tail's.  For the query-sharded decoder, where a layer's output rows exist on every rank only after the exchange.
+ *   x, qpos (M,256) f32; qkv (M,768) bf16. */
+int far3d_rowchain_qkv(const float* x, int ldx, const float* qpos, int ldq, const void* w_qkv, const float* b_qkv,
+                       void* qkv, int ldqkv, int M, void* stream);
+
 /* far3d_rowchain_branches: the shared classification and regression branches over the decoder outputs of all layers,
  *   cls = L2(relu(LN(L1(relu(LN(L0(h)))))));  reg = L2'(relu(L1'(relu(L0'(h)))))   (L: 256 -> 256 linears, the last ones -> n_cls / n_reg)
  *   Replaces 6 far3d_conv2d_nhwc + 2 far3d_layernorm launches (ref models/dense_heads/farhead.py:230-245, applied at :646-664).

@@ -163,14 +163,16 @@ def test_sharded_frame_over_rccl_world_of_one(hip_lib, pipeline):
         assert np.array_equal(outs[fi], want[fi]), "frame %d: sharded-over-RCCL (world 1) differs from the plain engine" % fi
 
 
-def _qs_worker(rank, world, port, q, use_graph, pipeline, capacity, frames):
+def _qs_worker(rank, world, port, q, use_graph, pipeline, capacity, frames, precision="fp32", fused_rows=False):
     import torch.distributed as dist
     from far3d_amd import synth
     from far3d_amd import dist as fdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng, rc = _build(capacity=capacity)
+        eng, rc = _build(precision=precision, capacity=capacity)
+        eng.fused_rows = fused_rows
+        assert not fused_rows or all(ly["rc"] is not None for ly in eng.layers)
         res = {}
         for mode in ("replicated", "query_sharded"):
             eng.reset_memory()
@@ -198,6 +200,31 @@ def _qs_worker(rank, world, port, q, use_graph, pipeline, capacity, frames):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_query_sharded_decoder_with_row_chains_is_bitwise_the_replicated_one(hip_lib):
+    """The same identity for the bf16 decoder with engine.fused_rows: each rank runs the row-resident chains (csrc/rowchain.hip) on
+    its rows and far3d_rowchain_qkv over all rows after the exchange, the replicated decoder runs the chains over all rows with the
+    in-projection as the FFN chain's tail -- bit for bit the same logits, boxes, decoder states and memory (graph segments,
+    pipelined)."""
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_qs_worker, args=(r, world, port, q, True, True, None, 6, "bf16", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=400) for _ in procs), key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+    assert [r[0] for r in res] == [0, 1]
+    assert all(r[1] for r in res), "query-sharded decoder (row chains) differs from the replicated decoder"
+    assert np.array_equal(res[0][2], res[1][2])
 
 
 @pytest.mark.parametrize("use_graph,pipeline,capacity,frames", [(False, False, None, 3), (True, True, None, 7), (True, False, 48, 5)])

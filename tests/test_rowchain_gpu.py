@@ -184,6 +184,22 @@ def test_chains_give_a_row_the_same_bits_in_any_launch(hip_lib):
             assert torch.equal(f[a0:a1], p)
 
 
+@pytest.mark.parametrize("M", [1544, 21])
+def test_in_projection_alone_is_bitwise_the_ffn_chains_tail(hip_lib, M):
+    """far3d_rowchain_qkv (what the query-sharded decoder runs after its exchange) == the tail of far3d_rowchain_ffn, bit for bit."""
+    ly, nxt = _layer(14), _layer(15)
+    agg, x1, qpos = _inputs(M, 31)
+    out = torch.empty(M, E, device=DEV)
+    tail = torch.empty(M, 3 * E, dtype=torch.bfloat16, device=DEV)
+    ops.rowchain_ffn(agg, x1, qpos, ly["rc"], out, nxt=nxt["rc"], qkv=tail)
+    out2 = torch.empty(M, E, device=DEV)
+    ops.rowchain_ffn(agg, x1, qpos, ly["rc"], out2)                     # the chain without its tail: same rows
+    assert torch.equal(out, out2)
+    alone = torch.zeros(M, 6 * E, dtype=torch.bfloat16, device=DEV)
+    ops.rowchain_qkv(out, qpos, nxt["rc"], alone[:, 3 * E:])
+    assert torch.equal(alone[:, 3 * E:], tail) and not alone[:, :3 * E].any()
+
+
 def test_bad_arguments_are_refused(hip_lib):
     from far3d_amd.lib import Far3dHipError
     ly = _layer(2)
