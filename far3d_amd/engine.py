@@ -11,6 +11,7 @@ raw (for the 2D head) and camera-modulated, token-major (N, S, 256), which IS `f
 """
 import fnmatch
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -153,10 +154,10 @@ class Far3DEngine:
         self._fidx = 0
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
-        self.fused_rows = False     # bf16 decoder: run the row-local parts of a decoder layer as two row-resident chains
+        self.fused_rows = os.environ.get("FAR3D_FUSED_ROWS") == "1"   # bf16 decoder: run the row-local parts of a decoder layer as two row-resident chains
                                     # (far3d_rowchain_attn_out / far3d_rowchain_ffn: 4 launches per layer instead of 11).  Opt-in until
-                                    # measured on the GPU; ignored where the chains do not apply (other decoder dtypes / geometries,
-                                    # the query-sharded decoder)
+                                    # the full GPU suite has run on it; ignored where the chains do not apply (other decoder dtypes /
+                                    # geometries).  FAR3D_FUSED_ROWS=1 turns it on for every engine of the process (to run the suite on it)
         self.mem = None
         self.prev_scene = None
         self._prepare()

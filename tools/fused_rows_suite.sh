@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round-5 opener (one GPU call, ~13 min): the whole GPU suite with the row-resident decoder chains switched on for every engine
+# (FAR3D_FUSED_ROWS=1), then the default bench line with them -- the evidence needed before engine.fused_rows becomes the default.
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/fused_rows_suite.sh r5a'
+cd "${GRAFT_REPO_ROOT:-.}" || exit 1
+O=gpurun_out/ev_${1:-r5a}
+mkdir -p "$O"
+FAR3D_FUSED_ROWS=1 timeout 900 python -m pytest tests -q -m gpu --durations=10 > "$O/pytest_gpu_fused_rows.txt" 2>&1; echo "rc=$?" >> "$O/pytest_gpu_fused_rows.txt"
+tail -4 "$O/pytest_gpu_fused_rows.txt"
+timeout 170 python bench.py --fused-rows > "$O/bench_fused_rows.json" 2> "$O/bench_fused_rows.err"; echo "bench rc=$?"
+tail -c 600 "$O/bench_fused_rows.json"
