@@ -12,6 +12,7 @@
 // bf16 MFMA A-fragment is ONE ds_read_b128); the next tile's global loads are in flight during the MFMAs.
 // T = bf16: v_mfma_f32_32x32x16_bf16.  T = float: exact-fp32 v_mfma_f32_32x32x2_f32 (parity mode).
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
@@ -57,7 +58,11 @@ __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict_
   constexpr int KROW = ACfg<T>::KROW, VROW = ACfg<T>::VROW, KSUB = ACfg<T>::KSUB, CH = ACfg<T>::CH;
   constexpr int E = 16 / sizeof(T);
   constexpr int KBYTES = ATT_KT * KROW, VBYTES = (sizeof(T) == 2 ? ATT_D : ATT_KT) * VROW;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * KBYTES + NS * VBYTES];
+  // static LDS up to the 64 KB static limit (the shipped NS = 2 / 4 instantiations, unchanged); the 8-part variant's 78 KB are dynamic
+  constexpr int LDS_TOTAL = NS * KBYTES + NS * VBYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_st[LDS_TOTAL <= 65536 ? LDS_TOTAL : 16];
+  unsigned char* smem = LDS_TOTAL <= 65536 ? smem_st : smem_dyn;
   static_assert((NS - 1) * 2 * 18 * 64 * 4 <= NS * (KBYTES + VBYTES), "merge buffer must fit the tile buffers");
   unsigned char* KsAll = smem;
   unsigned char* VsAll = smem + NS * KBYTES;
@@ -278,12 +283,26 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
                   "far3d_attention_forward: pointers / row strides must be 16-byte aligned");
   dim3 grid((Aq + 63) / 64, heads);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FAR3D_DT_F32)
+  // key parts per workgroup (2 waves each): fp32 2, bf16 4.  FAR3D_ATTN_PARTS=8 (bf16 only, read once) selects 8 parts = 16 waves,
+  // 5 serial key tiles per wave instead of 9 at 2312 keys -- an A/B switch until it has been measured (the partition changes the
+  // fp32 summation order, i.e. the result's last bits).
+  static const int bf16_parts = [] { const char* e = getenv("FAR3D_ATTN_PARTS"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  constexpr size_t lds_bf16 = ATT_KT * ACfg<bf16_t>::KROW + ATT_D * ACfg<bf16_t>::VROW;      // per part
+  if (dtype == FAR3D_DT_F32) {
     hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                        Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
-  else
+  } else if (bf16_parts == 8) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * lds_bf16));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 8>), grid, dim3(1024), 8 * lds_bf16, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
+  } else {
     hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
+  }
   FAR3D_CHECK_LAUNCH("far3d_attention_forward");
   return FAR3D_OK;
 }

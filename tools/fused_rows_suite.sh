@@ -9,3 +9,5 @@ FAR3D_FUSED_ROWS=1 timeout 900 python -m pytest tests -q -m gpu --durations=10 >
 tail -4 "$O/pytest_gpu_fused_rows.txt"
 timeout 170 python bench.py --fused-rows > "$O/bench_fused_rows.json" 2> "$O/bench_fused_rows.err"; echo "bench rc=$?"
 tail -c 600 "$O/bench_fused_rows.json"
+# experimental A/B variants (not part of the default suite): the 8-part bf16 attention kernel, with its device time
+FAR3D_TEST_EXPERIMENTAL=1 timeout 120 python -m pytest tests/test_attn_norm_gpu.py -q -s -k eight_key_parts > "$O/pytest_attn_parts8.txt" 2>&1; tail -4 "$O/pytest_attn_parts8.txt"
