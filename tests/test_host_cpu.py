@@ -170,3 +170,33 @@ def test_ida_matrix_against_a_stepwise_float32_chain():
             ang = float(rng.uniform(-25, 25))
             a, b = ida_matrix(resize, crop, flip, ang), stepwise(resize, crop, flip, ang)
             assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()
+
+
+def test_rowchain_weight_packing_is_the_documented_fragment_order():
+    """ops.pack_rowchain (include/far3d_hip.h "Packed weights"): element j of lane l of (column tile t, k step s) is
+    W[16 t + (l & 15)][32 s + 8 (l >> 4) + j]; the bias covers the padded columns; the geometry gate of the chains."""
+    import torch
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(0)
+    pc = ops.PackedConv(torch.randn(455, 512, generator=g), torch.randn(455, generator=g), dtype=torch.bfloat16, device="cpu")
+    frag, bias = ops.pack_rowchain(pc)
+    assert tuple(frag.shape) == (29, 16, 64, 8) and tuple(bias.shape) == (464,) and frag.is_contiguous()
+    t, s_, l, j = torch.meshgrid(torch.arange(29), torch.arange(16), torch.arange(64), torch.arange(8), indexing="ij")
+    assert torch.equal(frag, pc.w[16 * t + (l & 15), 32 * s_ + 8 * (l >> 4) + j])
+    assert torch.equal(bias[:455], pc.bias[:455]) and not bias[455:].any() and not frag[28, :, 7:16].any()       # rows past Cout are zero
+    two, b2 = ops.pack_rowchain(ops.PackedConv(torch.randn(10, 256, generator=g), None, dtype=torch.bfloat16, device="cpu"), cols=32)
+    assert tuple(two.shape) == (2, 8, 64, 8) and tuple(b2.shape) == (32,) and not b2.any() and not two[1].any()
+    import pytest
+    with pytest.raises(ValueError):
+        ops.pack_rowchain(ops.PackedConv(torch.randn(16, 384, generator=g), None, dtype=torch.bfloat16, device="cpu"))     # K % 256
+    with pytest.raises(ValueError):
+        ops.pack_rowchain(ops.PackedConv(torch.randn(16, 256, generator=g), None, dtype=torch.float32, device="cpu"))      # bf16 only
+    mk = lambda co, ci: ops.PackedConv(torch.randn(co, ci, generator=g), torch.zeros(co), dtype=torch.bfloat16, device="cpu")
+    ly = dict(out=mk(256, 256), wl=mk(455, 512), oproj=mk(256, 256), ffn1=mk(1024, 256), ffn2=mk(256, 1024), qkv=mk(768, 512))
+    assert ops.RowChainLayer.supported(ly, 256, torch.bfloat16)
+    assert not ops.RowChainLayer.supported(ly, 256, torch.float32)
+    assert not ops.RowChainLayer.supported(dict(ly, wl=mk(300, 512)), 256, torch.bfloat16)          # 19 column tiles: not the 29 the kernel is built for
+    assert not ops.RowChainLayer.supported(dict(ly, ffn1=mk(512, 256), ffn2=mk(256, 512)), 256, torch.bfloat16)
+    cls, reg = [mk(256, 256), mk(256, 256), mk(26, 256)], [mk(256, 256), mk(256, 256), mk(8, 256)]
+    assert ops.RowChainBranches.supported(cls, reg, 256, torch.bfloat16)
+    assert not ops.RowChainBranches.supported(cls[:2] + [mk(40, 256)], reg, 256, torch.bfloat16)    # > 32 classes: two tiles do not cover it
