@@ -212,6 +212,32 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         step_i += 1
     per_frame.sort()
 
+    # ---- opt-in: the same per-frame protocol with the frame's cameras split into groups that run side by side (far3d_amd.latency)
+    lat_groups = None
+    if args.latency_groups > 1 and world == 1 and not sharded and proposals == "topk":
+        from far3d_amd.latency import CameraGroupFrame
+        sync()
+        was = eng.pipeline
+        eng.pipeline = False
+        lat = CameraGroupFrame(eng, groups=args.latency_groups, use_graph=not args.eager)
+        for _ in range(4):                                   # one eager frame (buffers), the captures, two replays
+            lat.forward_frame(*frames[step_i % len(frames)])
+            step_i += 1
+        pf = []
+        for _ in range(min(steps, 50)):
+            sync()
+            t1 = time.perf_counter()
+            out_l = lat.forward_frame(*frames[step_i % len(frames)])
+            sync()
+            pf.append((time.perf_counter() - t1) * 1e3)
+            step_i += 1
+        pf.sort()
+        assert not torch.isnan(out_l["all_cls_scores"]).any()
+        lat_groups = {"groups": [list(b) for b in lat.blocks], "frames": len(pf), "mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2],
+                      "what": "sync before and after every frame; the frame's per-camera stages as camera groups on parallel streams "
+                              "(far3d_amd.latency.CameraGroupFrame), head after all groups"}
+        eng.pipeline = was
+
     # Kernel durations for the rooflines: HIP events (on the launch stream) around hipGraph replays that contain ONLY
     # that kernel, fed with this run's live tensors (last decoder layer's operands / the staged images) -- a launch-gap-free
     # device time that agrees with rocprofv3's per-kernel average (profiles/).
@@ -251,7 +277,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
     n_adapt = int(out["num_adaptive_dev"].item()) if out.get("num_adaptive_dev") is not None else int(out["num_adaptive"])
     overflow = bool(int(out["proposal_overflow"].item())) if out.get("proposal_overflow") is not None else False
-    res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
+    res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, lat_groups=lat_groups, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
                timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(runner.pipeline), cfg=cfg, tile_table=eng.bf16_tile_table(),
                ncam_local=len(runner.cams) if sharded else 7)
     del eng, runner, frames, out
@@ -350,6 +376,8 @@ def main():
                     help="bf16 conv tile table: tuned for a launch alone, or under the pipeline's 3-stream concurrency (auto: by mode; A/B)")
     ap.add_argument("--cam-streams", type=int, default=3, help="streams the camera stages of consecutive frames alternate between (A/B)")
     ap.add_argument("--cam-priority", type=int, default=-1, help="HIP stream priority of the camera-stage streams in pipeline mode (-1 = high, 0 = default; A/B)")
+    ap.add_argument("--latency-groups", type=int, default=0, help="single GPU, opt-in: also time the sync-per-frame protocol with the frame's "
+                    "cameras split into this many groups on parallel streams (far3d_amd.latency; reported as protocol.sync_per_frame_groups)")
     ap.add_argument("--fused-rows", action="store_true", help="A/B: run the row-local parts of the decoder layers and the cls / reg branches "
                     "as row-resident chains (engine.fused_rows; bf16 decoder only; not the default path)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
@@ -447,6 +475,8 @@ def main():
         }
         if res["timing_error"]:
             line["kernel_timing_error"] = res["timing_error"]
+        if res.get("lat_groups"):
+            line["protocol"]["sync_per_frame_groups"] = res["lat_groups"]
 
         def finite(o):           # strict JSON: no NaN / Infinity (a missing kernel timing becomes null)
             if isinstance(o, dict):

@@ -11,3 +11,5 @@ timeout 170 python bench.py --fused-rows > "$O/bench_fused_rows.json" 2> "$O/ben
 tail -c 600 "$O/bench_fused_rows.json"
 # experimental A/B variants (not part of the default suite): the 8-part bf16 attention kernel, with its device time
 FAR3D_TEST_EXPERIMENTAL=1 timeout 120 python -m pytest tests/test_attn_norm_gpu.py -q -s -k eight_key_parts > "$O/pytest_attn_parts8.txt" 2>&1; tail -4 "$O/pytest_attn_parts8.txt"
+FAR3D_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_latency_gpu.py -q -s > "$O/pytest_latency_groups.txt" 2>&1; tail -4 "$O/pytest_latency_groups.txt"
+timeout 170 python bench.py --latency-groups 2 --fused-rows --no-cpu-baseline --no-in-tolerance --steps 40 > "$O/bench_latency_groups.json" 2> "$O/bench_latency_groups.err"; echo "latency bench rc=$?"
