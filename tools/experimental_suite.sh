@@ -1,7 +1,9 @@
 #!/bin/bash
-# Round-5 opener (one GPU call, ~13 min): the whole GPU suite with the row-resident decoder chains switched on for every engine
-# (FAR3D_FUSED_ROWS=1), then the default bench line with them -- the evidence needed before engine.fused_rows becomes the default.
-#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/fused_rows_suite.sh r5a'
+# The opt-in paths built at the end of round 4, in one GPU call (~17 min):
+#  1. the whole GPU suite with the row-resident decoder chains switched on for every engine (FAR3D_FUSED_ROWS=1) and the default
+#     bench line with them -- the evidence needed before engine.fused_rows becomes the default;
+#  2. the gated tests of the A/B variants (8-part attention, camera-group latency runner) and the latency bench line.
+#   /usr/local/graft/bin/gpurun --timeout 1300 -- 'bash tools/experimental_suite.sh r5a'
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 O=gpurun_out/ev_${1:-r5a}
 mkdir -p "$O"
