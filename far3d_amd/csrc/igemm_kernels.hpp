@@ -1398,12 +1398,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
   }
   auto issue = [&](int step, int stage_off, bool half) __attribute__((always_inline)) {
     const int kb = step * 128;                                   // bytes along K
+    if constexpr (!(FAR3D_ABLATE & 32)) {                        // ablation 32: no weight stream
 #pragma unroll
-    for (int i = 0; i < AW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + stage_off + (wv + NW * i) * 1024), 16, half ? avoff_h[i] : avoff[i], kb, 0, 0);
+      for (int i = 0; i < AW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + stage_off + (wv + NW * i) * 1024), 16, half ? avoff_h[i] : avoff[i], kb, 0, 0);
+    }
+    if constexpr (!(FAR3D_ABLATE & 64)) {                        // ablation 64: no activation stream
 #pragma unroll
-    for (int i = 0; i < BW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + stage_off + BM * 128 + (wv + NW * i) * 1024), 16, half ? bvoff_h[i] : bvoff[i], kb, 0, 0);
+      for (int i = 0; i < BW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + stage_off + BM * 128 + (wv + NW * i) * 1024), 16, half ? bvoff_h[i] : bvoff[i], kb, 0, 0);
+    }
   };
 
   f32x16_t acc[WM][WN];
@@ -1436,7 +1440,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
     if (s < nsteps) issue(s, s * STAGE, s >= nfull);
 #define FAR3D_WIDE_SYNC(S)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if constexpr (D == 1) {                                                                                  \
+    if constexpr (FAR3D_ABLATE & 16) {                                                                       \
+    } else if constexpr (D == 1) {                                                                           \
       wait_vmcnt<0>();                                                                                       \
     } else {                                                                                                 \
       int units_ = 0;                                                                                        \
@@ -1445,14 +1450,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
         if ((S) + q_ < nsteps) units_ += 1;                                                                  \
       wait_vmcnt_units<UNIT, D - 1>(units_);                                                                 \
     }                                                                                                        \
-    __builtin_amdgcn_s_barrier();                                                                            \
+    if constexpr (!(FAR3D_ABLATE & 16)) __builtin_amdgcn_s_barrier();                                        \
     asm volatile("" ::: "memory");                                                                           \
     __builtin_amdgcn_sched_barrier(0);
 #define FAR3D_WIDE_STEP(STG, S)                                                                              \
   {                                                                                                          \
     FAR3D_WIDE_SYNC(S)                                                                                       \
+    if constexpr (!(FAR3D_ABLATE & 2)) {                                                                     \
     if ((S) + D < nsteps) issue((S) + D, (((STG) + D) % NS) * STAGE, (S) + D >= nfull);                      \
-    gemm_step_wide<WM, WN, (STG) * STAGE, BM, 4>(smem, aaddr, baddr, acc);                                   \
+    }                                                                                                        \
+    if constexpr (!(FAR3D_ABLATE & 4)) gemm_step_wide<WM, WN, (STG) * STAGE, BM, 4>(smem, aaddr, baddr, acc);   \
   }
   for (int s0 = 0; s0 < nfull; s0 += NS) {
     FAR3D_WIDE_STEP(0, s0)
@@ -1472,6 +1479,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
   }
 #undef FAR3D_WIDE_STEP
 #undef FAR3D_WIDE_SYNC
+  if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
     constexpr int RING = NS * (BM + BP) * 128, OUTB = BP * (BM * 2 + 16);
     epilogue_rows16<NW, WM, WN, BM, BP, false>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {

@@ -16,12 +16,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {0: "shipped", 1: "no epilogue", 2: "no in-loop DMA", 4: "no MFMA / fragment reads", 8: "no fragment reads", 16: "no barrier / vmcnt wait",
-            26: "MFMA loop + epilogue", 27: "bare MFMA loop", 21: "bare DMA stream", 5: "DMA + barriers, no epilogue", 11: "MFMA + barriers"}
-# (name, N, H, W, Cin, Cout, k, tile): the shipped tile of each layer at the benchmarked size (far3d_amd/data/tuning_mi355x.json)
-LAYERS = [("s2.c1", 7, 160, 240, 128, 128, 3, 60), ("s3.c1", 7, 80, 120, 160, 160, 3, 92), ("s3.c0", 7, 80, 120, 512, 160, 3, 101),
-          ("s4.c1", 7, 40, 60, 192, 192, 3, 100), ("s4.c0", 7, 40, 60, 768, 192, 3, 100), ("s5.c1", 7, 20, 30, 224, 224, 3, 102),
-          ("s2.cat", 7, 160, 240, 768, 256, 1, 70), ("s3.cat", 7, 80, 120, 1312, 512, 1, 79), ("s4.cat", 7, 40, 60, 1728, 768, 1, 79),
-          ("s5.cat", 7, 20, 30, 2144, 1024, 1, 79)]
+            26: "MFMA loop + epilogue", 27: "bare MFMA loop", 21: "bare DMA stream", 5: "DMA + barriers, no epilogue", 11: "MFMA + barriers",
+            # GEMM kernels with full-line DMA (gemm1x1_wide_kernel: the concat layers' shipped tiles) only -- which of the two streams is
+            # the slow one: 32 = no weight stream (L2-resident, re-read by every workgroup), 64 = no activation stream (HBM / MALL, read once)
+            37: "activation stream alone (bare DMA, no weights)", 69: "weight stream alone (bare DMA, no activations)",
+            32: "no weight stream", 64: "no activation stream"}
+# (name, N, H, W, Cin, Cout, k, tile): tile 0 = the shipped tile of the layer at the benchmarked size (far3d_amd/data/tuning_mi355x.json;
+# FAR3D_ABL_TABLE=tuning_mi355x_tput.json for the table of the pipelined engines); a fixed tile id pins a kernel for an experiment
+LAYERS = [("s2.c1", 7, 160, 240, 128, 128, 3, 0), ("s3.c1", 7, 80, 120, 160, 160, 3, 0), ("s3.c0", 7, 80, 120, 512, 160, 3, 0),
+          ("s4.c1", 7, 40, 60, 192, 192, 3, 0), ("s4.c0", 7, 40, 60, 768, 192, 3, 0), ("s5.c1", 7, 20, 30, 224, 224, 3, 0),
+          ("s2.cat", 7, 160, 240, 768, 256, 1, 0), ("s3.cat", 7, 80, 120, 1312, 512, 1, 0), ("s4.cat", 7, 40, 60, 1728, 768, 1, 0),
+          ("s5.cat", 7, 20, 30, 2144, 1024, 1, 0)]
 
 
 def lib_path(k):
@@ -51,6 +56,8 @@ def run(k):
     from tune_conv import timeit
     dev = "cuda:0"
     out = {}
+    if os.environ.get("FAR3D_ABL_TABLE"):
+        ops.BF16_TILE_TABLE = os.environ["FAR3D_ABL_TABLE"]
     for name, N, H, W, Cin, Cout, ks, tile in LAYERS:
         x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
         pc = ops.PackedConv(torch.randn(Cout, Cin, ks, ks) * 0.05, torch.randn(Cout), stride=1, pad=ks // 2, dtype=torch.bfloat16, device=dev)
