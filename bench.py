@@ -101,7 +101,9 @@ def parity_block(precision, eng_frames, orc_frames):
         qs = torch.quantile(d.flatten()[::2].double(), torch.tensor([0.5, 0.99], dtype=torch.float64))
         par.append(dict(frame=fi, logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(), logit_p50_abs=qs[0].item(), logit_p99_abs=qs[1].item(),
                         last_layer_logit_max_abs=d[-1].max().item(), proposals_in_common=common, proposals=M,
-                        rows_compared=len(rows_g), engine_path=got["path"]))
+                        rows_compared=len(rows_g), rows_excluded=(A - len(rows_g)),
+                        rows_excluded_what="adaptive-query rows whose 2D peak (camera, cell) the other side did not select: different queries, not compared",
+                        engine_path=got["path"]))
     # Frame 0 is the clean comparison.  From frame 1 on the two sides also differ through the streaming memory: which 256 queries
     # are kept is a discrete top-k on scores ~1e-4 apart, so any rounding difference (let alone bf16) changes the memory contents
     # and the frames stop being the same computation (tests/test_engine_full_gpu.py quantifies this with an fp64 oracle).
@@ -143,20 +145,22 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     eng = engine.Far3DEngine(sd, cfg, device=dev, precision=precision)
     eng.agg_variant = args.agg_variant
     eng.cam_priority = args.cam_priority
-    eng.fused_rows = args.fused_rows        # opt-in A/B: row-resident decoder chains (bf16 decoder only; csrc/rowchain.hip)
+    eng.fused_rows = args.fused_rows        # row-resident decoder chains (bf16 decoder only; csrc/rowchain.hip); --no-fused-rows for A/B
     del sd
     frames = []
     for fi in range(4):   # a few distinct frames (ego motion on), resident in HBM before the timed region
         frames.append(synth.make_frame(7, (640, 960), seed=0 if not (world > 1 and not sharded) else rank, frame_index=fi, device=dev,
                                        ego_motion=True))
     # N > 1 sharded: per-rank hipGraphs for the per-camera stages and the replicated head, collectives eager in between
+    # the tile table is settled BEFORE the sharded runner is built: ShardedFrame picks the throughput-tuned table for its pipelined
+    # frames when none was asked for, and `auto` must not undo that afterwards
+    eng.tile_table = {"auto": None, "latency": "tuning_mi355x.json", "tput": "tuning_mi355x_tput.json"}[args.tile_table]
+    eng.pipeline_sets = args.pipeline_sets
+    eng.cam_streams = args.cam_streams
     runner = fdist.ShardedFrame(eng, use_graph=not args.eager, pipeline=not args.no_pipeline) if sharded else eng
     eng.use_graph = (not sharded) and not args.eager   # whole steady-state frame as ONE hipGraph (no host launch gaps)
     # frames of one stream are software-pipelined: the per-camera stages of frame i+1 overlap the head of frame i (engine.py)
     eng.pipeline = eng.use_graph and not args.no_pipeline
-    eng.pipeline_sets = args.pipeline_sets
-    eng.cam_streams = args.cam_streams
-    eng.tile_table = {"auto": None, "latency": "tuning_mi355x.json", "tput": "tuning_mi355x_tput.json"}[args.tile_table]
 
     def sync():
         if world > 1:
@@ -279,7 +283,10 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     overflow = bool(int(out["proposal_overflow"].item())) if out.get("proposal_overflow") is not None else False
     res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, lat_groups=lat_groups, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
                timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(runner.pipeline), cfg=cfg, tile_table=eng.bf16_tile_table(),
-               ncam_local=len(runner.cams) if sharded else 7)
+               ncam_local=len(runner.cams) if sharded else 7,
+               # what the runner actually did (read back, not assumed): frames in flight and camera streams of its pipeline
+               frames_in_flight=int(eng.pipeline_sets) if runner.pipeline else 1,
+               camera_streams=len(runner._pipe["s_cams"]) if (runner.pipeline and getattr(runner, "_pipe", None)) else 1)
     del eng, runner, frames, out
     torch.cuda.empty_cache()
     return res
@@ -378,8 +385,11 @@ def main():
     ap.add_argument("--cam-priority", type=int, default=-1, help="HIP stream priority of the camera-stage streams in pipeline mode (-1 = high, 0 = default; A/B)")
     ap.add_argument("--latency-groups", type=int, default=0, help="single GPU, opt-in: also time the sync-per-frame protocol with the frame's "
                     "cameras split into this many groups on parallel streams (far3d_amd.latency; reported as protocol.sync_per_frame_groups)")
-    ap.add_argument("--fused-rows", action="store_true", help="A/B: run the row-local parts of the decoder layers and the cls / reg branches "
-                    "as row-resident chains (engine.fused_rows; bf16 decoder only; not the default path)")
+    ap.add_argument("--no-fused-rows", dest="fused_rows", action="store_false", help="A/B: run the row-local parts of the decoder layers and the "
+                    "cls / reg branches as separate GEMM / LayerNorm launches instead of the row-resident chains (engine.fused_rows, the default "
+                    "since round 5; bf16 decoder only)")
+    ap.add_argument("--fused-rows", dest="fused_rows", action="store_true", help="(default) kept so that round 4's command lines still parse")
+    ap.set_defaults(fused_rows=True)
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N ranks on fewer than N GPUs (test rig only): ranks share devices and exchange over gloo; the line says so and "
                          "is not a scaling measurement")
@@ -460,8 +470,8 @@ def main():
             "protocol": {"pipelined": {"frames": args.steps, "mean_ms": dt / args.steps * 1e3, "p50_ms_device_events": dev_ms[len(dev_ms) // 2],
                                        "what": "frames issued back to back, one sync at each end (this file's contract -> `value`)",
                                        "frame_overlap": res["pipeline"],
-                                       "frames_in_flight": (args.pipeline_sets if world == 1 else 2) if res["pipeline"] else 1,
-                                       "camera_streams": args.cam_streams if (world == 1 and res["pipeline"]) else 1,
+                                       "p50_samples_per_s": 1e3 / dev_ms[len(dev_ms) // 2],
+                                       "frames_in_flight": res["frames_in_flight"], "camera_streams": res["camera_streams"],
                                        "tile_table": res["tile_table"],
                                        "frame_overlap_what": "the per-camera stages of the next frames (one frame per camera stream, high priority) run "
                                                              "concurrently while the head of frame i is in flight (one buffer set per frame in flight, head "

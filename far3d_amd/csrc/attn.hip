@@ -283,22 +283,11 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
                   "far3d_attention_forward: pointers / row strides must be 16-byte aligned");
   dim3 grid((Aq + 63) / 64, heads);
   hipStream_t st = (hipStream_t)stream;
-  // key parts per workgroup (2 waves each): fp32 2, bf16 4.  FAR3D_ATTN_PARTS=8 (bf16 only, read once) selects 8 parts = 16 waves,
-  // 5 serial key tiles per wave instead of 9 at 2312 keys -- an A/B switch until it has been measured (the partition changes the
-  // fp32 summation order, i.e. the result's last bits).
-  static const int bf16_parts = [] { const char* e = getenv("FAR3D_ATTN_PARTS"); return (e && atoi(e) == 8) ? 8 : 4; }();
-  constexpr size_t lds_bf16 = ATT_KT * ACfg<bf16_t>::KROW + ATT_D * ACfg<bf16_t>::VROW;      // per part
+  // key parts per workgroup (2 waves each): fp32 2, bf16 4 (an 8-part bf16 instantiation was measured in round 4 -- 27.4 vs 28 us,
+  // profiles/r4/attn_parts8.txt: the per-tile MFMA -> exp -> MFMA chain is what a wave waits on -- and removed)
   if (dtype == FAR3D_DT_F32) {
     hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                        Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
-  } else if (bf16_parts == 8) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * lds_bf16));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 8>), grid, dim3(1024), 8 * lds_bf16, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
   } else {
     hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 #define FAR3D_OK 0
 #define FAR3D_ERR_ARG (-1)      // bad argument (null pointer, unsupported size/dtype)
@@ -35,6 +36,23 @@ void far3d_set_error(const char* fmt, ...);
       return FAR3D_ERR_LAUNCH;                                              \
     }                                                                       \
   } while (0)
+
+// Dynamic LDS above 64 KiB has to be allowed per kernel AND per device (hipFuncSetAttribute acts on the current device): `mask` is the
+// launcher's function-local set of devices already done (one bit per device ordinal; a duplicate call from a racing thread is harmless).
+// A failure is an error of the call, not something to launch through.
+static inline int far3d_allow_lds(const void* fn, int bytes, std::atomic<unsigned long long>& mask, const char* who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_relaxed) & bit) return FAR3D_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    far3d_set_error("%s: hipFuncSetAttribute(max dynamic LDS = %d bytes) failed on device %d: %s", who, bytes, dev, hipGetErrorString(e));
+    return FAR3D_ERR_LAUNCH;
+  }
+  mask.fetch_or(bit, std::memory_order_relaxed);
+  return FAR3D_OK;
+}
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 

@@ -54,9 +54,9 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   hipStream_t st = (hipStream_t)stream;
   if (chan_sums) {       // only the pipelined GEMM kernels accumulate them; anything else is an error, not a silent fallback
     const bool gemm_tile = pair_in ? (tile == 0 || (tile >= 170 && tile <= 181) || tile == 279 || tile == 280)
-                                   : ((tile >= 70 && tile <= 89) || (tile >= 110 && tile <= 129));
+                                   : ((tile >= 70 && tile <= 89) || (tile >= 110 && tile <= 129) || (tile >= 140 && tile <= 149));
     FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && gemm_tile && (pair_in || (x_dt == FAR3D_DT_BF16 && Cin % 32 == 0 && P.x_vec)),
-                    "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-129; pair: 170-181, 279, 280); got k=%d tile=%d", KH, tile);
+                    "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-129, 140-149; pair: 170-181, 279, 280); got k=%d tile=%d", KH, tile);
   }
   if (pair_in) {
     FAR3D_CHECK_ARG(aligned(x, 16) && ldx % 8 == 0 && x_img_stride % 8 == 0 && (!pair_out || (aligned(y, 8) && ldy % 4 == 0 && y_img_stride % 4 == 0)),
@@ -90,16 +90,16 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     bool done = true;
     int rc = 0;
     switch (tile) {
-      case 1: launch_igemm_dma<2, 2, 2, 2, 3>(P, st); break;
-      case 2: launch_igemm_dma<2, 2, 1, 2, 4>(P, st); break;
-      case 3: launch_igemm_dma<2, 2, 1, 1, 4>(P, st); break;
-      case 4: launch_igemm_dma<2, 2, 2, 1, 4>(P, st); break;
+      case 1: rc = launch_igemm_dma<2, 2, 2, 2, 3>(P, st); break;
+      case 2: rc = launch_igemm_dma<2, 2, 1, 2, 4>(P, st); break;
+      case 3: rc = launch_igemm_dma<2, 2, 1, 1, 4>(P, st); break;
+      case 4: rc = launch_igemm_dma<2, 2, 2, 1, 4>(P, st); break;
       // several 32-channel K chunks per barrier step
-      case 18: launch_igemm_dma<2, 2, 1, 1, 3, 3>(P, st); break;   // 64x64, 3 chunks/step
+      case 18: rc = launch_igemm_dma<2, 2, 1, 1, 3, 3>(P, st); break;   // 64x64, 3 chunks/step
       // 2-deep rings: less LDS -> more resident workgroups per CU
-      case 43: launch_igemm_dma<2, 2, 2, 2, 2>(P, st); break;      // 128x128
-      case 46: launch_igemm_dma<2, 2, 2, 1, 2>(P, st); break;      // 128x64
-      case 48: launch_igemm_dma<2, 2, 1, 1, 2>(P, st); break;      // 64x64
+      case 43: rc = launch_igemm_dma<2, 2, 2, 2, 2>(P, st); break;      // 128x128
+      case 46: rc = launch_igemm_dma<2, 2, 2, 1, 2>(P, st); break;      // 128x64
+      case 48: rc = launch_igemm_dma<2, 2, 1, 1, 2>(P, st); break;      // 64x64
       default: done = false;
     }
     if (!done && KH == 1 && KW == 1 && stride == 1 && pad == 0) {   // pipelined GEMM kernel (channels x pixels, waves)
@@ -146,6 +146,13 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         case 127: rc = launch_gemm1x1_wide<2, 4, 1, 2>(P, st); break;   // 64 x 256, 8 waves
         case 128: rc = launch_gemm1x1_wide<4, 4, 1, 1>(P, st); break;   // 128 x 128, 16 waves
         case 129: rc = launch_gemm1x1_wide<4, 2, 1, 2, 3>(P, st); break;   // 128 x 128, 8 waves, 3 stages
+        // split rings, wave-specialised DMA issue (round 5): weight ring NSA deep, activation ring NSB deep (channels x pixels)
+        case 140: rc = launch_gemm1x1_split<4, 2, 2, 4, 2, 3>(P, st); break;   // 256 x 256, 8 waves of 64 ch x 128 px, rings 2 + 3 (160 KiB)
+        case 141: rc = launch_gemm1x1_split<2, 2, 4, 4, 2, 3>(P, st); break;   // 256 x 256, 4 waves of 128 ch x 128 px (256 accumulator registers), rings 2 + 3
+        case 142: rc = launch_gemm1x1_split<2, 4, 2, 2, 2, 4>(P, st); break;   // 128 x 256, 8 waves of 64 x 64, rings 2 + 4 (160 KiB)
+        case 143: rc = launch_gemm1x1_split<4, 2, 2, 2, 2, 4>(P, st); break;   // 256 x 128, 8 waves of 64 x 64, rings 2 + 4 (128 KiB)
+        case 144: rc = launch_gemm1x1_split<4, 2, 2, 4, 2, 2>(P, st); break;   // 256 x 256, rings 2 + 2: tile 123 with the specialised issue (control)
+        case 145: rc = launch_gemm1x1_split<4, 4, 2, 2, 2, 3>(P, st); break;   // 256 x 256, 16 waves of 64 x 64, rings 2 + 3
         default: done = false;
       }
     }
@@ -154,49 +161,62 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
       done = true;
       switch (tile) {
         // software-pipelined kernel (register double-buffered fragments, immediate-offset LDS addressing)
-        case 50: launch_conv3x3_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 4 rows
-        case 51: launch_conv3x3_pipe<1, 4, 2, 1>(P, st); break;   // 64 x 4 rows (1x4 waves)
-        case 52: launch_conv3x3_pipe<1, 4, 1, 1>(P, st); break;   // 32 x 4 rows
-        case 53: launch_conv3x3_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 4 rows
-        case 54: launch_conv3x3_pipe<1, 4, 1, 2>(P, st); break;   // 32 x 8 rows
-        case 55: launch_conv3x3_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 2 rows
-        case 57: launch_conv3x3_pipe<2, 2, 1, 4>(P, st); break;   // 64 x 8 rows
-        case 58: launch_conv3x3_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 2 rows
-        case 59: launch_conv3x3_pipe<1, 4, 3, 1>(P, st); break;   // 96 x 4 rows
+        case 50: rc = launch_conv3x3_pipe<2, 2, 1, 2>(P, st); break;   // 64 x 4 rows
+        case 51: rc = launch_conv3x3_pipe<1, 4, 2, 1>(P, st); break;   // 64 x 4 rows (1x4 waves)
+        case 52: rc = launch_conv3x3_pipe<1, 4, 1, 1>(P, st); break;   // 32 x 4 rows
+        case 53: rc = launch_conv3x3_pipe<2, 2, 2, 2>(P, st); break;   // 128 x 4 rows
+        case 54: rc = launch_conv3x3_pipe<1, 4, 1, 2>(P, st); break;   // 32 x 8 rows
+        case 55: rc = launch_conv3x3_pipe<2, 2, 1, 1>(P, st); break;   // 64 x 2 rows
+        case 57: rc = launch_conv3x3_pipe<2, 2, 1, 4>(P, st); break;   // 64 x 8 rows
+        case 58: rc = launch_conv3x3_pipe<2, 2, 2, 1>(P, st); break;   // 128 x 2 rows
+        case 59: rc = launch_conv3x3_pipe<1, 4, 3, 1>(P, st); break;   // 96 x 4 rows
         // 8 / 16 waves per workgroup sharing one patch + weight slab
-        case 60: launch_conv3x3_pipe<2, 4, 1, 2>(P, st); break;   // 64 x 8 rows, 8 waves
-        case 61: launch_conv3x3_pipe<2, 4, 1, 1>(P, st); break;   // 64 x 4 rows, 8 waves
-        case 62: launch_conv3x3_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 4 rows, 8 waves
-        case 63: launch_conv3x3_pipe<2, 8, 1, 1>(P, st); break;   // 64 x 8 rows, 16 waves
-        case 64: launch_conv3x3_pipe<1, 8, 2, 1>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
-        case 65: launch_conv3x3_pipe<1, 8, 1, 1>(P, st); break;   // 32 x 8 rows, 8 waves
-        case 66: launch_conv3x3_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 4 rows, 16 waves
-        case 67: launch_conv3x3_pipe<4, 2, 1, 1>(P, st); break;   // 128 x 2 rows, 8 waves
+        case 60: rc = launch_conv3x3_pipe<2, 4, 1, 2>(P, st); break;   // 64 x 8 rows, 8 waves
+        case 61: rc = launch_conv3x3_pipe<2, 4, 1, 1>(P, st); break;   // 64 x 4 rows, 8 waves
+        case 62: rc = launch_conv3x3_pipe<4, 2, 1, 2>(P, st); break;   // 128 x 4 rows, 8 waves
+        case 63: rc = launch_conv3x3_pipe<2, 8, 1, 1>(P, st); break;   // 64 x 8 rows, 16 waves
+        case 64: rc = launch_conv3x3_pipe<1, 8, 2, 1>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
+        case 65: rc = launch_conv3x3_pipe<1, 8, 1, 1>(P, st); break;   // 32 x 8 rows, 8 waves
+        case 66: rc = launch_conv3x3_pipe<4, 4, 1, 1>(P, st); break;   // 128 x 4 rows, 16 waves
+        case 67: rc = launch_conv3x3_pipe<4, 2, 1, 1>(P, st); break;   // 128 x 2 rows, 8 waves
         // 3-deep weight ring (kernel rows prefetched two steps ahead)
-        case 90: launch_conv3x3_pipe<2, 4, 1, 2, 3>(P, st); break;   // 64 x 8 rows, 8 waves
-        case 91: launch_conv3x3_pipe<2, 4, 1, 1, 3>(P, st); break;   // 64 x 4 rows, 8 waves
-        case 92: launch_conv3x3_pipe<1, 8, 1, 1, 3>(P, st); break;   // 32 x 8 rows, 8 waves
-        case 93: launch_conv3x3_pipe<1, 4, 1, 1, 3>(P, st); break;   // 32 x 4 rows, 4 waves
-        case 94: launch_conv3x3_pipe<2, 2, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 4 waves
-        case 95: launch_conv3x3_pipe<2, 8, 1, 1, 3>(P, st); break;   // 64 x 8 rows, 16 waves
-        case 96: launch_conv3x3_pipe<1, 8, 2, 1, 3>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
-        case 97: launch_conv3x3_pipe<2, 2, 1, 1, 3>(P, st); break;   // 64 x 2 rows, 4 waves
+        case 90: rc = launch_conv3x3_pipe<2, 4, 1, 2, 3>(P, st); break;   // 64 x 8 rows, 8 waves
+        case 91: rc = launch_conv3x3_pipe<2, 4, 1, 1, 3>(P, st); break;   // 64 x 4 rows, 8 waves
+        case 92: rc = launch_conv3x3_pipe<1, 8, 1, 1, 3>(P, st); break;   // 32 x 8 rows, 8 waves
+        case 93: rc = launch_conv3x3_pipe<1, 4, 1, 1, 3>(P, st); break;   // 32 x 4 rows, 4 waves
+        case 94: rc = launch_conv3x3_pipe<2, 2, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 4 waves
+        case 95: rc = launch_conv3x3_pipe<2, 8, 1, 1, 3>(P, st); break;   // 64 x 8 rows, 16 waves
+        case 96: rc = launch_conv3x3_pipe<1, 8, 2, 1, 3>(P, st); break;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
+        case 97: rc = launch_conv3x3_pipe<2, 2, 1, 1, 3>(P, st); break;   // 64 x 2 rows, 4 waves
         // whole-chunk steps (9 taps per barrier) for the layers with a single workgroup per CU
-        case 100: launch_conv3x3_pipe<2, 4, 1, 2, 2, 3>(P, st); break;   // 64 x 8 rows, 8 waves
-        case 101: launch_conv3x3_pipe<1, 8, 1, 1, 2, 3>(P, st); break;   // 32 x 8 rows, 8 waves
-        case 102: launch_conv3x3_pipe<1, 4, 1, 1, 2, 3>(P, st); break;   // 32 x 4 rows, 4 waves
-        case 103: launch_conv3x3_pipe<2, 4, 1, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 8 waves
+        case 100: rc = launch_conv3x3_pipe<2, 4, 1, 2, 2, 3>(P, st); break;   // 64 x 8 rows, 8 waves
+        case 101: rc = launch_conv3x3_pipe<1, 8, 1, 1, 2, 3>(P, st); break;   // 32 x 8 rows, 8 waves
+        case 102: rc = launch_conv3x3_pipe<1, 4, 1, 1, 2, 3>(P, st); break;   // 32 x 4 rows, 4 waves
+        case 103: rc = launch_conv3x3_pipe<2, 4, 1, 1, 2, 3>(P, st); break;   // 64 x 4 rows, 8 waves
         // whole-chunk steps, deeper rings (NSW - 1 chunks in flight, counted vmcnt).  Measured in round 4 and NOT faster anywhere
         // (profiles/r4/tune_bf16_3x3_deep_rings.log: stage-4 c1 21 -> 22 us, stage-5 c1 9.2 -> 10 us): the K-short layers are not
         // waiting for their DMA round trips; kept as tested tiles
-        case 104: launch_conv3x3_pipe<2, 4, 1, 1, 3, 3>(P, st); break;   // 64 x 4 rows, 8 waves, 3 chunks (150 KB)
-        case 105: launch_conv3x3_pipe<1, 4, 1, 1, 3, 3>(P, st); break;   // 32 x 4 rows, 4 waves, 3 chunks (94 KB)
-        case 106: launch_conv3x3_pipe<1, 4, 1, 1, 4, 3>(P, st); break;   // 32 x 4 rows, 4 waves, 4 chunks (126 KB)
+        case 104: rc = launch_conv3x3_pipe<2, 4, 1, 1, 3, 3>(P, st); break;   // 64 x 4 rows, 8 waves, 3 chunks (150 KB)
+        case 105: rc = launch_conv3x3_pipe<1, 4, 1, 1, 3, 3>(P, st); break;   // 32 x 4 rows, 4 waves, 3 chunks (94 KB)
+        case 106: rc = launch_conv3x3_pipe<1, 4, 1, 1, 4, 3>(P, st); break;   // 32 x 4 rows, 4 waves, 4 chunks (126 KB)
+        // fat tiles (round 5): 2x2 .. 2x4 / 4x2 / 5x1 MFMA tiles per wave -- half to a third of the L2 -> LDS bytes and of the
+        // fragment reads per MFMA of the 1x2 tiles above, workgroups that live 4-8x longer (per-workgroup set-up, first fill and
+        // epilogue amortised); for the layers with >= 4 rounds of workgroups (stem2, stage 2, stage 3, FPN / 2D-head level 0)
+        case 130: rc = launch_conv3x3_pipe<2, 4, 2, 2>(P, st); break;      // 128 x 8 rows, 8 waves of 64 ch x 2 rows
+        case 131: rc = launch_conv3x3_pipe<2, 4, 2, 4>(P, st); break;      // 128 x 16 rows, 8 waves of 64 ch x 4 rows
+        case 132: rc = launch_conv3x3_pipe<1, 8, 4, 1>(P, st); break;      // 128 x 8 rows, 8 waves of 128 ch x 1 row
+        case 133: rc = launch_conv3x3_pipe<2, 4, 1, 4>(P, st); break;      // 64 x 16 rows, 8 waves of 32 ch x 4 rows
+        case 134: rc = launch_conv3x3_pipe<1, 8, 5, 1>(P, st); break;      // 160 x 8 rows, 8 waves of 160 ch x 1 row (stage 3: all channels)
+        case 135: rc = launch_conv3x3_pipe<1, 8, 5, 1, 3>(P, st); break;   // 134 with a 3-deep weight ring
+        case 136: rc = launch_conv3x3_pipe<2, 2, 2, 4>(P, st); break;      // 128 x 8 rows, 4 waves of 64 ch x 4 rows
+        case 137: rc = launch_conv3x3_pipe<2, 4, 2, 2, 3>(P, st); break;   // 130 with a 3-deep weight ring
+        case 138: rc = launch_conv3x3_pipe<1, 8, 2, 2>(P, st); break;      // 64 x 16 rows, 8 waves of 64 ch x 2 rows (stem2: Cout 64)
+        case 139: rc = launch_conv3x3_pipe<1, 8, 3, 1>(P, st); break;      // 96 x 8 rows, 8 waves of 96 ch x 1 row
         default: done = false;
       }
     }
     if (done) {
-      if (rc) return FAR3D_ERR_ARG;
+      if (rc) return rc;
       FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
       return FAR3D_OK;
     }

@@ -699,11 +699,9 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
   const long Npix = (long)P.N * P.Ho * P.Wo;
   dim3 grid((unsigned)((Npix + BP - 1) / BP), (unsigned)((P.Cout + BM - 1) / BM));
   constexpr size_t lds = (size_t)NS * KPS * (BM + BP) * 64;
-  static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if constexpr (lds > 65536)
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
   hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, WM, WN, NS, KPS>), grid, dim3(256), lds, st, P);
   return 0;
 }
@@ -1027,11 +1025,9 @@ static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   static_assert(lds <= 163840, "LDS budget");
   const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
   dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
-  static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if constexpr (lds > 65536)
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
   hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
   return 0;
 }
@@ -1304,13 +1300,11 @@ static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   static_assert(lds_ring <= 163840, "LDS budget");
   constexpr size_t lds0 = lds_ring > lds_out ? lds_ring : lds_out, lds_sums = lds0 + 2 * BM * sizeof(long long);
   const size_t lds = P.chan_sums ? lds_sums : lds0;
-  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return 1;
-  static bool attr_set = false;
-  if (!attr_set && lds_sums > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(lds_sums <= 163840 ? lds_sums : lds0));
-    attr_set = true;
-  }
+  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return FAR3D_ERR_ARG;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if constexpr (lds_sums > 65536)
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>),
+                                       (int)(lds_sums <= 163840 ? lds_sums : lds0), lds_ok, "far3d_conv2d_nhwc")) return rc;
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
   hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
   return 0;
@@ -1503,14 +1497,214 @@ static int launch_gemm1x1_wide(const IgemmParams& P, hipStream_t st) {
   static_assert(lds_ring <= 163840, "LDS budget");
   constexpr size_t lds0 = lds_ring > lds_out ? lds_ring : lds_out, lds_sums = lds0 + 2 * BM * sizeof(long long);
   const size_t lds = P.chan_sums ? lds_sums : lds0;
-  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return 1;
-  static bool attr_set = false;
-  if (!attr_set && lds_sums > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_wide_kernel<WGM, WGN, WM, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(lds_sums <= 163840 ? lds_sums : lds0));
-    attr_set = true;
-  }
+  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return FAR3D_ERR_ARG;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if constexpr (lds_sums > 65536)
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_wide_kernel<WGM, WGN, WM, WN, NS>),
+                                       (int)(lds_sums <= 163840 ? lds_sums : lds0), lds_ok, "far3d_conv2d_nhwc")) return rc;
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
   hipLaunchKernelGGL((gemm1x1_wide_kernel<WGM, WGN, WM, WN, NS>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the full-line GEMM with SPLIT RINGS and WAVE-SPECIALISED LDS-DMA issue.
+// The concat GEMMs run at the speed of their DMA stream, and the stream is bound by latency x bytes in flight (profiles/r3-r4: a
+// 256 x 256 tile spends 3.4 us per 64-channel step against 0.86 us of MFMA work; the weights are L2 hits, ~0.5 us, the activation
+// slab comes from HBM / Infinity Cache, 2+ us).  One ring for both operands gives both the same depth, and the LDS holds only two
+// 64 KiB stages of a 256 x 256 tile.  Here the weight ring is NSA stages deep and the activation ring NSB (2 + 3 stages of 32 KiB =
+// all 160 KiB for a 256 x 256 tile): two activation steps in flight instead of one.  A wave's `vmcnt` retires in order, so one wave
+// cannot keep an old activation piece in flight behind a younger weight piece -- therefore half of the waves issue ONLY weight pieces
+// and the other half ONLY activation pieces, each waiting on its own counter for its own ring depth before the step's barrier.
+// Everything else (128-byte LDS rows, source-side slot permutation, fragment double buffering, epilogue, channel sums, XCD-aware
+// numbering) is gemm1x1_wide_kernel's.  The K loop is unrolled over lcm(NSA, NSB) steps so that every LDS offset is an immediate.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NIT>
+__device__ __forceinline__ void gemm_step_wide_rt(const unsigned char* smem, const int (&aaddr)[WM], const int (&baddr)[WN], int aoff, int boff,
+                                                  f32x16_t (&acc)[WM][WN]) {
+  // Stage offsets at RUN time (wave-uniform, multiples of 1 KiB): WM + WN adds per step, and the K loop stays ONE rolled loop -- no
+  // per-stage copies of the step, no conditional blocks around the MFMAs (every such block is a merge point for all accumulators and
+  // cost the unrolled form of this kernel hundreds of spills at 2 x 4 tiles per wave).  k16 sub-step kk of the 64-channel row flips
+  // bits 5-6 of the slot-permuted byte address: one v_xor per fragment read instead of four address registers per tile row.
+  int aa[WM], bb[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) aa[i] = aaddr[i] + aoff;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bb[j] = baddr[j] + boff;
+  u32x4_t af[2][WM], bf[2][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const u32x4_t*>(smem + aa[i]);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bf[0][j] = *reinterpret_cast<const u32x4_t*>(smem + bb[j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int cur = it & 1, nxt = cur ^ 1;
+    if (it + 1 < NIT) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[nxt][i] = *reinterpret_cast<const u32x4_t*>(smem + (aa[i] ^ ((it + 1) << 5)));
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[nxt][j] = *reinterpret_cast<const u32x4_t*>(smem + (bb[j] ^ ((it + 1) << 5)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][i], bf[cur][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int V> struct ic_t { static constexpr int value = V; };
+constexpr int far3d_gcd(int a, int b) { return b == 0 ? a : far3d_gcd(b, a % b); }
+// f(ic_t<I>{}) for I = 0 .. N-1, unconditionally (compile-time loop: I is a constant inside f)
+template <int I, int N, typename F>
+__device__ __forceinline__ void far3d_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(ic_t<I>{});
+    far3d_static_for<I + 1, N>(f);
+  }
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSA, int NSB>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmParams P, int npt, int nct) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WGM * WGN, NWA = NW / 2, NWB = NW - NWA;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int GA = BM / 8, GB = BP / 8;                       // 1 KB DMA pieces (8 rows x 128 B) per 64-channel step
+  static_assert(NW >= 2 && GA % NWA == 0 && GB % NWB == 0, "every wave of a role issues the same number of pieces (counted vmcnt)");
+  static_assert(NWA % 2 == 0 && NWB % 2 == 0, "a lane's slot permutation must not depend on the piece index (rows 8 * nr apart, nr even)");
+  constexpr int APW = GA / NWA, BPW = GB / NWB, PWMAX = APW > BPW ? APW : BPW;
+  constexpr int ASTG = BM * 128, BSTG = BP * 128, BBASE = NSA * ASTG;
+  constexpr int DA = NSA - 1, DB = NSB - 1;
+  static_assert(NSA >= 2 && NSB >= 2 && NSA <= 4 && NSB <= 5, "ring depths");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;          // XCD-aware numbering as in gemm1x1_pipe_kernel
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= npt) return;
+  const int p0 = pt * BP, m0 = ct * BM;
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int Ktot = P.cin_pad;
+  const int rr = lane >> 3, sl = lane & 7;                       // row of the piece, 16-byte slot of the 128-byte LDS row
+  constexpr unsigned OOB = 0x80000000u;
+  const bool is_a = wv < NWA;                                    // wave-uniform role: weight pieces / activation pieces
+  const int dw = is_a ? wv : wv - NWA, nr = is_a ? NWA : NWB, npw = is_a ? APW : BPW;
+  const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
+  const long w_bytes = (long)BM * Ktot * 2;
+  const void* base = is_a ? (const void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot) : P.x;
+  const long nbytes = is_a ? w_bytes : x_bytes;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nbytes < 0x7fffffffL ? nbytes : 0x7fffffffL), 0x00020000);
+  unsigned voff[PWMAX];
+  const int col = sl ^ ((dw * 4 + (rr >> 1)) & 7);               // = sl ^ ((row >> 1) & 7) for every piece of this lane (nr even)
+  const bool lowcol = col < 4;                                   // the half step fetches slots 0..3 only (upper half out of range -> zeros)
+#pragma unroll
+  for (int i = 0; i < PWMAX; ++i) {
+    const int row = (dw + nr * i) * 8 + rr;
+    if (is_a) {
+      voff[i] = (unsigned)((row * Ktot + col * 8) * 2);
+    } else {
+      const long p = (long)p0 + row;
+      if (p < Npix) {
+        const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+        voff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + col * 8) * 2);
+      } else {
+        voff[i] = OOB;
+      }
+    }
+  }
+  auto issue = [&](int step, bool half, int so) __attribute__((always_inline)) {      // so: LDS byte offset of the stage of this wave's ring
+    const int kb = step * 128;                                   // bytes along K
+#pragma unroll
+    for (int i = 0; i < PWMAX; ++i)
+      if (i < npw)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + so + (dw + nr * i) * 1024), 16, (half && !lowcol) ? OOB : voff[i], kb, 0, 0);
+  };
+
+  f32x16_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aaddr[WM], baddr[WN];                                      // k16 sub-step 0 of the 64-channel row (sub-step kk: ^ kk << 5)
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    aaddr[i] = r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int r = (wn * WN + j) * 32 + l31;
+    baddr[j] = r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
+  }
+  const int nsub = P.cin_pad / 32, nfull = nsub >> 1, tail = nsub & 1, nsteps = nfull + tail;
+  const int dmine = is_a ? DA : DB;
+#pragma unroll
+  for (int s = 0; s < (DA > DB ? DA : DB); ++s)
+    if (s < dmine && s < nsteps) issue(s, s >= nfull, is_a ? s * ASTG : BBASE + s * BSTG);
+  // ONE rolled loop over the steps; the half step (K % 64 == 32) runs the full four sub-steps on a row whose upper half the DMA filled
+  // with zeros (out-of-range slots), so it needs no code of its own
+  const int ring_lo = is_a ? 0 : BBASE, ring_hi = is_a ? NSA * ASTG : BBASE + NSB * BSTG, ring_stg = is_a ? ASTG : BSTG;
+  int iss_off = is_a ? (DA % NSA) * ASTG : BBASE + (DB % NSB) * BSTG;        // stage of THIS wave's ring the next issue goes into
+  int sa_off = 0, sb_off = BBASE;                                            // stages of the step being computed
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    // wait until this wave's pieces of step s have landed: the steps s+1 .. s+D-1 it issued later may stay in flight
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      int ahead = nsteps - 1 - s;
+      if (ahead > dmine - 1) ahead = dmine - 1;
+      if (is_a) wait_vmcnt_units<APW, DA - 1>(ahead);
+      else wait_vmcnt_units<BPW, DB - 1>(ahead);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the barrier also says that every wave is done with step s-1, whose stages the steps s+DA / s+DB go into
+    if (s + dmine < nsteps) issue(s + dmine, s + dmine >= nfull, iss_off);
+    iss_off += ring_stg;
+    if (iss_off == ring_hi) iss_off = ring_lo;
+    gemm_step_wide_rt<WM, WN, 4>(smem, aaddr, baddr, sa_off, sb_off, acc);
+    sa_off += ASTG;
+    if (sa_off == NSA * ASTG) sa_off = 0;
+    sb_off += BSTG;
+    if (sb_off == BBASE + NSB * BSTG) sb_off = BBASE;
+  }
+  if (P.y_rows16) {
+    constexpr int RING = NSA * ASTG + NSB * BSTG, OUTB = BP * (BM * 2 + 16);
+    __syncthreads();         // the ring may fill the whole LDS: the epilogue's sum scratch (zeroed before its first barrier) lies inside it
+    epilogue_rows16<NW, WM, WN, BM, BP, false>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
+      const long p = (long)p0 + pl;
+      if (p >= Npix) return -1L;
+      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      return (long)n * P.y_img_stride + (long)rem * P.ldy;
+    }, (long)p0, OUTB);      // the sum scratch sits right behind the staged tile (the ring is dead by then)
+    (void)RING;
+    return;
+  }
+  igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
+#endif
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSA, int NSB>
+static int launch_gemm1x1_split(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
+  constexpr size_t lds_ring = (size_t)NSA * BM * 128 + (size_t)NSB * BP * 128, lds_out = (size_t)BP * (BM * 2 + 16);
+  static_assert(lds_ring <= 163840, "LDS budget");
+  constexpr size_t lds_out_sums = lds_out + 2 * BM * sizeof(long long);
+  static_assert(lds_out_sums <= 163840, "LDS budget (epilogue)");
+  constexpr size_t lds = lds_ring > lds_out_sums ? lds_ring : lds_out_sums;
+  if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds)) return FAR3D_ERR_ARG;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if constexpr (lds > 65536)
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_split_kernel<WGM, WGN, WM, WN, NSA, NSB>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
+  const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
+  hipLaunchKernelGGL((gemm1x1_split_kernel<WGM, WGN, WM, WN, NSA, NSB>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
   return 0;
 }

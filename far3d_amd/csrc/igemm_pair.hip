@@ -31,50 +31,50 @@ int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
   }
   if (k1) {
     switch (tile) {
-      case 170: return launch_gemm1x1_pipe<2, 2, 2, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 4 waves
-      case 171: return launch_gemm1x1_pipe<2, 4, 2, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 8 waves
-      case 172: return launch_gemm1x1_pipe<2, 4, 2, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 256, 8 waves
-      case 173: return launch_gemm1x1_pipe<4, 2, 2, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 256 x 128, 8 waves
-      case 174: return launch_gemm1x1_pipe<2, 2, 1, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 128, 4 waves
-      case 175: return launch_gemm1x1_pipe<2, 4, 1, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 128, 8 waves
-      case 176: return launch_gemm1x1_pipe<2, 2, 2, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 64, 4 waves
-      case 177: return launch_gemm1x1_pipe<4, 4, 2, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 256 x 128, 16 waves
-      case 178: return launch_gemm1x1_pipe<2, 4, 1, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 256, 8 waves
-      case 179: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 8 waves (1x2 tiles per wave)
-      case 180: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 64 x 64, 4 waves
-      case 181: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // 128 x 128, 16 waves
-      case 279: return launch_gemm1x1_pipe<4, 2, 1, 2, 1, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // hi only: 128 x 128, 8 waves
-      case 280: return launch_gemm1x1_pipe<2, 2, 1, 1, 1, true>(P, st) ? FAR3D_ERR_ARG : FAR3D_OK;   // hi only: 64 x 64, 4 waves
+      case 170: return launch_gemm1x1_pipe<2, 2, 2, 2, 3, true>(P, st);   // 128 x 128, 4 waves
+      case 171: return launch_gemm1x1_pipe<2, 4, 2, 1, 3, true>(P, st);   // 128 x 128, 8 waves
+      case 172: return launch_gemm1x1_pipe<2, 4, 2, 2, 3, true>(P, st);   // 128 x 256, 8 waves
+      case 173: return launch_gemm1x1_pipe<4, 2, 2, 2, 3, true>(P, st);   // 256 x 128, 8 waves
+      case 174: return launch_gemm1x1_pipe<2, 2, 1, 2, 3, true>(P, st);   // 64 x 128, 4 waves
+      case 175: return launch_gemm1x1_pipe<2, 4, 1, 1, 3, true>(P, st);   // 64 x 128, 8 waves
+      case 176: return launch_gemm1x1_pipe<2, 2, 2, 1, 3, true>(P, st);   // 128 x 64, 4 waves
+      case 177: return launch_gemm1x1_pipe<4, 4, 2, 1, 3, true>(P, st);   // 256 x 128, 16 waves
+      case 178: return launch_gemm1x1_pipe<2, 4, 1, 2, 3, true>(P, st);   // 64 x 256, 8 waves
+      case 179: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true>(P, st);   // 128 x 128, 8 waves (1x2 tiles per wave)
+      case 180: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true>(P, st);   // 64 x 64, 4 waves
+      case 181: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true>(P, st);   // 128 x 128, 16 waves
+      case 279: return launch_gemm1x1_pipe<4, 2, 1, 2, 1, true>(P, st);   // hi only: 128 x 128, 8 waves
+      case 280: return launch_gemm1x1_pipe<2, 2, 1, 1, 1, true>(P, st);   // hi only: 64 x 64, 4 waves
       default: break;
     }
   }
   if (k3) {
     switch (tile) {
-      case 150: launch_conv3x3_pipe<2, 2, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 4 rows
-      case 152: launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 4 rows
-      case 153: launch_conv3x3_pipe<2, 2, 2, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows
-      case 154: launch_conv3x3_pipe<1, 4, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 8 rows
-      case 155: launch_conv3x3_pipe<2, 2, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 2 rows
-      case 157: launch_conv3x3_pipe<2, 2, 1, 4, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 4 waves
-      case 159: launch_conv3x3_pipe<1, 4, 3, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 96 x 4 rows
-      case 160: launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 8 waves
-      case 161: launch_conv3x3_pipe<2, 4, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 4 rows, 8 waves
-      case 162: launch_conv3x3_pipe<4, 2, 1, 2, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows, 8 waves
-      case 163: launch_conv3x3_pipe<2, 8, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 16 waves
-      case 164: launch_conv3x3_pipe<1, 8, 2, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 8 waves of 64 ch x 1 row
-      case 165: launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 8 rows, 8 waves
-      case 166: launch_conv3x3_pipe<4, 4, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows, 16 waves
-      case 167: launch_conv3x3_pipe<4, 2, 1, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 2 rows, 8 waves
-      case 168: launch_conv3x3_pipe<2, 4, 2, 1, 2, 1, 3, true>(P, st); return FAR3D_OK;   // 128 x 4 rows, 8 waves of 64 ch x 1 row
+      case 150: return launch_conv3x3_pipe<2, 2, 1, 2, 2, 1, 3, true>(P, st);   // 64 x 4 rows
+      case 152: return launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 3, true>(P, st);   // 32 x 4 rows
+      case 153: return launch_conv3x3_pipe<2, 2, 2, 2, 2, 1, 3, true>(P, st);   // 128 x 4 rows
+      case 154: return launch_conv3x3_pipe<1, 4, 1, 2, 2, 1, 3, true>(P, st);   // 32 x 8 rows
+      case 155: return launch_conv3x3_pipe<2, 2, 1, 1, 2, 1, 3, true>(P, st);   // 64 x 2 rows
+      case 157: return launch_conv3x3_pipe<2, 2, 1, 4, 2, 1, 3, true>(P, st);   // 64 x 8 rows, 4 waves
+      case 159: return launch_conv3x3_pipe<1, 4, 3, 1, 2, 1, 3, true>(P, st);   // 96 x 4 rows
+      case 160: return launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 3, true>(P, st);   // 64 x 8 rows, 8 waves
+      case 161: return launch_conv3x3_pipe<2, 4, 1, 1, 2, 1, 3, true>(P, st);   // 64 x 4 rows, 8 waves
+      case 162: return launch_conv3x3_pipe<4, 2, 1, 2, 2, 1, 3, true>(P, st);   // 128 x 4 rows, 8 waves
+      case 163: return launch_conv3x3_pipe<2, 8, 1, 1, 2, 1, 3, true>(P, st);   // 64 x 8 rows, 16 waves
+      case 164: return launch_conv3x3_pipe<1, 8, 2, 1, 2, 1, 3, true>(P, st);   // 64 x 8 rows, 8 waves of 64 ch x 1 row
+      case 165: return launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 3, true>(P, st);   // 32 x 8 rows, 8 waves
+      case 166: return launch_conv3x3_pipe<4, 4, 1, 1, 2, 1, 3, true>(P, st);   // 128 x 4 rows, 16 waves
+      case 167: return launch_conv3x3_pipe<4, 2, 1, 1, 2, 1, 3, true>(P, st);   // 128 x 2 rows, 8 waves
+      case 168: return launch_conv3x3_pipe<2, 4, 2, 1, 2, 1, 3, true>(P, st);   // 128 x 4 rows, 8 waves of 64 ch x 1 row
       // 3-deep weight ring
-      case 191: launch_conv3x3_pipe<2, 4, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 4 rows, 8 waves
-      case 192: launch_conv3x3_pipe<1, 8, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 8 rows, 8 waves
-      case 193: launch_conv3x3_pipe<1, 4, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 32 x 4 rows, 4 waves
-      case 197: launch_conv3x3_pipe<2, 2, 1, 1, 3, 1, 3, true>(P, st); return FAR3D_OK;   // 64 x 2 rows, 4 waves
+      case 191: return launch_conv3x3_pipe<2, 4, 1, 1, 3, 1, 3, true>(P, st);   // 64 x 4 rows, 8 waves
+      case 192: return launch_conv3x3_pipe<1, 8, 1, 1, 3, 1, 3, true>(P, st);   // 32 x 8 rows, 8 waves
+      case 193: return launch_conv3x3_pipe<1, 4, 1, 1, 3, 1, 3, true>(P, st);   // 32 x 4 rows, 4 waves
+      case 197: return launch_conv3x3_pipe<2, 2, 1, 1, 3, 1, 3, true>(P, st);   // 64 x 2 rows, 4 waves
       // hi planes only
-      case 260: launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 1, true>(P, st); return FAR3D_OK;   // 64 x 8 rows, 8 waves
-      case 265: launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 1, true>(P, st); return FAR3D_OK;   // 32 x 8 rows, 8 waves
-      case 252: launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 1, true>(P, st); return FAR3D_OK;   // 32 x 4 rows, 4 waves
+      case 260: return launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 1, true>(P, st);   // 64 x 8 rows, 8 waves
+      case 265: return launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 1, true>(P, st);   // 32 x 8 rows, 8 waves
+      case 252: return launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 1, true>(P, st);   // 32 x 4 rows, 4 waves
       default: break;
     }
   }

@@ -540,11 +540,8 @@ extern "C" int far3d_rowchain_attn_out(const void* att, int ld_att, const float*
   P.att = (const bf16_t*)att; P.ld_att = ld_att; P.x = x; P.ldx = ldx; P.qpos = qpos; P.ldq = ldq;
   P.w_out = (const uint4*)w_out; P.b_out = b_out; P.g0 = g0; P.be0 = be0;
   P.w_wl = (const uint4*)w_wl; P.b_wl = b_wl; P.n_wl = n_wl; P.x1 = x1; P.ldx1 = ldx1; P.ul = ul; P.ldu = ldu; P.M = M; P.eps = eps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_attn_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int rc_ = far3d_allow_lds(reinterpret_cast<const void*>(&rowchain_attn_out_kernel), RC_LDS, lds_ok, "rowchain_attn_out_kernel")) return rc_;
   hipLaunchKernelGGL(rowchain_attn_out_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);
   FAR3D_CHECK_LAUNCH("far3d_rowchain_attn_out");
   return FAR3D_OK;
@@ -573,11 +570,8 @@ extern "C" int far3d_rowchain_ffn(const void* agg, int ld_agg, const float* x1, 
   P.w_o = (const uint4*)w_o; P.b_o = b_o; P.g1 = g1; P.be1 = be1; P.w_1 = (const uint4*)w_1; P.b_1 = b_1;
   P.w_2 = (const uint4*)w_2; P.b_2 = b_2; P.g2 = g2; P.be2 = be2; P.w_qkv = (const uint4*)w_qkv; P.b_qkv = b_qkv;
   P.out = out; P.ldo = ldo; P.qkv = (bf16_t*)qkv; P.ldqkv = ldqkv; P.xop = (bf16_t*)xop; P.ldxop = ldxop; P.M = M; P.eps = eps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int rc_ = far3d_allow_lds(reinterpret_cast<const void*>(&rowchain_ffn_kernel), RC_LDS, lds_ok, "rowchain_ffn_kernel")) return rc_;
   hipLaunchKernelGGL(rowchain_ffn_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);
   FAR3D_CHECK_LAUNCH("far3d_rowchain_ffn");
   return FAR3D_OK;
@@ -608,11 +602,8 @@ extern "C" int far3d_rowchain_branches(const void* h, int ldh, const void* w_c0,
   P.w_r0 = (const uint4*)w_r0; P.b_r0 = b_r0; P.w_r1 = (const uint4*)w_r1; P.b_r1 = b_r1;
   P.w_r2 = (const uint4*)w_r2; P.b_r2 = b_r2; P.n_reg = n_reg;
   P.cls = cls; P.ld_cls = ld_cls; P.reg = reg; P.ld_reg = ld_reg; P.M = M; P.eps = eps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_branches_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int rc_ = far3d_allow_lds(reinterpret_cast<const void*>(&rowchain_branches_kernel), RC_LDS, lds_ok, "rowchain_branches_kernel")) return rc_;
   hipLaunchKernelGGL(rowchain_branches_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);
   FAR3D_CHECK_LAUNCH("far3d_rowchain_branches");
   return FAR3D_OK;
@@ -629,11 +620,8 @@ extern "C" int far3d_rowchain_qkv(const float* x, int ldx, const float* qpos, in
   RowQkvParams P;
   P.x = x; P.ldx = ldx; P.qpos = qpos; P.ldq = ldq; P.w_qkv = (const uint4*)w_qkv; P.b_qkv = b_qkv; P.qkv = (bf16_t*)qkv; P.ldqkv = ldqkv;
   P.M = M;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (const int rc_ = far3d_allow_lds(reinterpret_cast<const void*>(&rowchain_qkv_kernel), RC_LDS, lds_ok, "rowchain_qkv_kernel")) return rc_;
   hipLaunchKernelGGL(rowchain_qkv_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);
   FAR3D_CHECK_LAUNCH("far3d_rowchain_qkv");
   return FAR3D_OK;

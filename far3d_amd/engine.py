@@ -154,10 +154,10 @@ class Far3DEngine:
         self._fidx = 0
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
-        self.fused_rows = os.environ.get("FAR3D_FUSED_ROWS") == "1"   # bf16 decoder: run the row-local parts of a decoder layer as two row-resident chains
-                                    # (far3d_rowchain_attn_out / far3d_rowchain_ffn: 4 launches per layer instead of 11).  Opt-in until
-                                    # the full GPU suite has run on it; ignored where the chains do not apply (other decoder dtypes /
-                                    # geometries).  FAR3D_FUSED_ROWS=1 turns it on for every engine of the process (to run the suite on it)
+        self.fused_rows = True      # bf16 decoder: the row-local parts of a decoder layer and the cls / reg branches run as row-resident
+                                    # chains (far3d_rowchain_attn_out / _ffn / _branches: 4 launches per layer instead of 11).  Default since
+                                    # round 5 (the full GPU suite ran on it); False selects the unfused kernels (A/B: bench.py --no-fused-rows).
+                                    # Ignored where the chains do not apply (other decoder dtypes / geometries)
         self.mem = None
         self.prev_scene = None
         self._prepare()

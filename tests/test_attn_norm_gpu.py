@@ -59,32 +59,6 @@ def test_attention_bf16_mode(hip_lib):
     assert (got - want).abs().mean().item() < 1e-3
 
 
-@pytest.mark.skipif(os.environ.get("FAR3D_TEST_EXPERIMENTAL") != "1", reason="A/B variant not measured yet (FAR3D_TEST_EXPERIMENTAL=1 runs it)")
-def test_attention_bf16_eight_key_parts(hip_lib):
-    """FAR3D_ATTN_PARTS=8 (read once per process, so this runs in a child): the bf16 kernel with 8 key parts per workgroup, same
-    bounds as the shipped 4-part form, on sizes with empty parts, a key hole and the benchmark's 2312 keys; prints its device time."""
-    code = r'''
-import torch, sys
-sys.path.insert(0, %r)
-from far3d_amd import ops
-from tests.test_attn_norm_gpu import _mha_core
-from tools.bench_kernels import timeit
-for Aq, Nk in ((37, 50), (300, 333), (1544, 2312)):
-    g = torch.Generator().manual_seed(Aq)
-    q, k, v = (torch.randn(n, 256, generator=g).to(torch.bfloat16) for n in (Aq, Nk, Nk))
-    want = _mha_core(q.float(), k.float(), v.float(), 8)
-    d = [t.cuda() for t in (q, k, v)]
-    got = ops.attention_forward(*d).cpu()
-    e = (got - want).abs()
-    assert e.max().item() < 1e-2 and e.mean().item() < 1e-3, (Aq, Nk, e.max().item(), e.mean().item())
-out = torch.empty(1544, 256, dtype=torch.bfloat16, device="cuda")
-print("attention 1544 x 2312, 8 parts: %%.2f us" %% (timeit(lambda: ops.attention_forward(*d, out=out), 20) * 1e6))
-''' % ROOT
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FAR3D_ATTN_PARTS="8"), capture_output=True, text=True, timeout=300)
-    print(r.stdout[-500:])
-    assert r.returncode == 0, r.stderr[-2000:]
-
-
 def test_attention_strided_views_of_one_buffer(hip_lib):
     """q/k/v produced by one GEMM into a (rows, 768) buffer are consumed in place."""
     from far3d_amd import ops

@@ -163,6 +163,74 @@ def test_sharded_frame_over_rccl_world_of_one(hip_lib, pipeline):
         assert np.array_equal(outs[fi], want[fi]), "frame %d: sharded-over-RCCL (world 1) differs from the plain engine" % fi
 
 
+def _rccl2_worker(rank, port, q, pipeline):
+    """One of two ranks, each on ITS OWN GPU, exchanging over RCCL (what the multi-GPU bench does)."""
+    import traceback
+    import torch.distributed as dist
+    from far3d_amd import engine, synth, weights
+    from far3d_amd import dist as fdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", rank))
+        z = np.load(os.path.join(GOLD, "far3d_small_seq.npz"))
+        rc = json.loads(bytes(z["recipe"]).decode())
+        spec = weights.detector_spec(rc["backbone"], num_query=rc["num_query"], num_propagated=rc["num_propagated"])
+        cfg = engine.default_cfg(backbone=rc["backbone"], num_cams=rc["num_cams"], num_query=rc["num_query"], num_propagated=rc["num_propagated"],
+                                 memory_len=rc["memory_len"], topk_proposals=rc["topk_proposals"], proposal_topk=6)
+        eng = engine.Far3DEngine(weights.init_state_dict(spec, seed=rc["weight_seed"]), cfg, device="cuda:%d" % rank, precision="fp32")
+        runner = fdist.ShardedFrame(eng, use_graph=True, pipeline=pipeline)
+        outs = []
+        for fi in _frame_ids(rc, 7):
+            data, metas = synth.recipe_frame(rc, fi)
+            o = runner.forward_frame(data, metas)
+            runner.wait_outputs()
+            outs.append(o["all_cls_scores"].cpu().numpy())
+        q.put((rank, dist.get_backend(), dist.get_world_size(), outs))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:   # noqa: BLE001
+        q.put((rank, "error", 0, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_sharded_frame_over_rccl_with_two_gpus(hip_lib, pipeline):
+    """`ShardedFrame` over RCCL with a world of TWO ranks on two GPUs: the first multi-GPU box exercises the
+    coalesced all-gather over xGMI, the per-rank hipGraphs and the frame pipeline before the scaling bench does.  Both ranks must
+    reproduce the single-rank engine on the same streaming sequence (replicated heads: bit-identical across ranks).  Skips, with
+    the reason, on a box with one GPU (the 2-rank logic runs there over gloo, the RCCL branch with a world of one: tests above)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d): RCCL with a world of 2 cannot run here" % torch.cuda.device_count())
+    import torch.multiprocessing as mp
+    from far3d_amd import synth
+    eng, rc = _build()
+    want = []
+    for fi in _frame_ids(rc, 7):
+        data, metas = synth.recipe_frame(rc, fi)
+        want.append(eng.forward_frame(data, metas)["all_cls_scores"].cpu().numpy())
+    del eng
+    torch.cuda.empty_cache()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl2_worker, args=(r, port, q, pipeline)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    for r in res:
+        assert r[1] == "nccl" and r[2] == 2, r[3] if r[1] == "error" else r[:3]
+    for fi in range(7):
+        assert np.array_equal(res[0][3][fi], res[1][3][fi]), "frame %d: the two ranks' replicated heads differ" % fi
+        tol = 1e-3 * max(1.0, np.abs(want[fi]).max() / 10.0)
+        assert np.abs(res[0][3][fi] - want[fi]).max() < tol, "frame %d: sharded over RCCL vs the single-rank engine" % fi
+
+
 def _qs_worker(rank, world, port, q, use_graph, pipeline, capacity, frames, precision="fp32", fused_rows=False):
     import torch.distributed as dist
     from far3d_amd import synth

@@ -139,7 +139,7 @@ def test_conv_asymmetric_weights_catch_transposes(hip_lib):
         assert torch.allclose(y, want, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("tile", [50, 51, 52, 53, 54, 55, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 90, 91, 92, 93, 94, 95, 96, 97, 100, 101, 102, 103, 104, 105, 106])
+@pytest.mark.parametrize("tile", [50, 51, 52, 53, 54, 55, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 90, 91, 92, 93, 94, 95, 96, 97, 100, 101, 102, 103, 104, 105, 106, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139])
 def test_conv3x3_pipelined_patch_kernel(hip_lib, tile):
     """3x3/s1/p1 bf16 kernel with the LDS-resident halo patch: ragged sizes (W % 32 != 0, H % TH != 0, Cout % BM != 0)."""
     from far3d_amd import ops
@@ -156,7 +156,7 @@ def test_conv3x3_pipelined_patch_kernel(hip_lib, tile):
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin * 9)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 18, 43, 46, 48, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 110, 111, 112, 113, 114, 115, 116, 117, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 18, 43, 46, 48, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 110, 111, 112, 113, 114, 115, 116, 117, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129, 140, 141, 142, 143, 144, 145])
 def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
     """1x1 conv over K = 160 / 1056 / 2144 channels: K chunk counts (5, 33, 67) that do not divide the chunks-per-step."""
     from far3d_amd import ops
@@ -171,7 +171,7 @@ def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin)
 
 
-@pytest.mark.parametrize("tile", [50, 52, 53, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67, 90, 92, 93, 95, 100, 101, 102, 103, 104, 105, 106, 70, 71, 72, 73, 74, 75, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 110, 111, 112, 113, 114, 115, 116, 117, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129])
+@pytest.mark.parametrize("tile", [50, 52, 53, 57, 59, 60, 61, 62, 63, 64, 65, 66, 67, 90, 92, 93, 95, 100, 101, 102, 103, 104, 105, 106, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 70, 71, 72, 73, 74, 75, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 110, 111, 112, 113, 114, 115, 116, 117, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129, 140, 141, 142, 143, 144, 145])
 def test_pipelined_kernels_bf16_output_coalesced_rows(hip_lib, tile):
     """bf16 outputs of the pipelined kernels leave through the LDS-transposed 16-byte row stores: ragged tiles
     (Cout % BM != 0, W % 32 != 0, pixel count % BP != 0), output written into a channel slice of a wider buffer whose

@@ -21,7 +21,7 @@ def _expected(stored, C, pair):
     return q
 
 
-@pytest.mark.parametrize("tile", [70, 73, 75, 79, 80, 81, 85, 110, 116, 120, 122, 123, 125, 128])
+@pytest.mark.parametrize("tile", [70, 73, 75, 79, 80, 81, 85, 110, 116, 120, 122, 123, 125, 128, 140, 142, 143, 145])
 def test_bf16_gemm_tiles_accumulate_exact_channel_sums(hip_lib, tile):
     from far3d_amd import ops
     g = torch.Generator().manual_seed(tile)

@@ -13,7 +13,7 @@ def _dispatch_ids():
     for m in re.finditer(r"case (\d+): (?:rc = |return )?(launch_[a-z0-9_]+)<", src):
         tile, fn = int(m.group(1)), m.group(2)
         key = {"launch_igemm": "igemm", "launch_igemm_dma": "dma", "launch_conv3x3_patch": "patch",
-               "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm", "launch_gemm1x1_wide": "gemm"}[fn]
+               "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm", "launch_gemm1x1_wide": "gemm", "launch_gemm1x1_split": "gemm"}[fn]
         ids[key].add(tile)
     return ids
 

@@ -37,14 +37,16 @@ def build():
     from far3d_amd import build as fbuild
     fbuild.build(verbose=False)
     objs = [os.path.join(fbuild.OBJ, f) for f in os.listdir(fbuild.OBJ) if f.endswith(".o") and f != "igemm.o"]
-    procs = []
-    for k in [v for v in VARIANTS if v]:
-        o = os.path.join("/tmp", "igemm_abl%d.o" % k)
-        procs.append((k, o, subprocess.Popen([fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_ABLATE=%d" % k, "-c", os.path.join(fbuild.CSRC, "igemm.hip"), "-o", o])))
-    for k, o, p in procs:
-        assert p.wait() == 0
-        subprocess.run([fbuild.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(k), o] + objs, check=True)
-        print("built", lib_path(k))
+    todo = [v for v in VARIANTS if v]
+    for i in range(0, len(todo), 5):          # five compiles at a time (fourteen at once ran the container out of memory)
+        procs = []
+        for k in todo[i:i + 5]:
+            o = os.path.join("/tmp", "igemm_abl%d.o" % k)
+            procs.append((k, o, subprocess.Popen([fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_ABLATE=%d" % k, "-c", os.path.join(fbuild.CSRC, "igemm.hip"), "-o", o])))
+        for k, o, p in procs:
+            assert p.wait() == 0, "variant %d failed to compile" % k
+            subprocess.run([fbuild.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(k), o] + objs, check=True)
+            print("built", lib_path(k), flush=True)
 
 
 def run(k):
