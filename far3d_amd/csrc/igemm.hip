@@ -4,6 +4,12 @@
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 
+#ifdef FAR3D_PROFILING
+// tools/conv_phase_times.py: where the per-workgroup stamps of the pipelined conv / GEMM kernels go (8 x uint64 per workgroup)
+static unsigned long long* g_conv_ts = nullptr;
+extern "C" int far3d_prof_set_conv_timestamps(void* buf) { g_conv_ts = (unsigned long long*)buf; return 0; }
+#endif
+
 // See include/far3d_hip.h for the argument contract.
 extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const float* bias, void* y,
                                  int y_dt, int N, int H, int W, int Cin, int ldx, long x_img_stride, int Ho,
@@ -50,6 +56,9 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.y_vec = aligned(y, 16) && (ldy % 4 == 0) && (y_img_stride % 4 == 0);
   P.y2_vec = y2 && aligned(y2, 16) && (ldy2 % 4 == 0) && (y2_img_stride % 4 == 0);
   P.chan_sums = chan_sums; P.sums_hw = Ho * Wo;
+#ifdef FAR3D_PROFILING
+  P.prof = g_conv_ts;
+#endif
   P.y_rows16 = (y_dt == FAR3D_DT_BF16 || pair_out) && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   if (chan_sums) {       // only the pipelined GEMM kernels accumulate them; anything else is an error, not a silent fallback

@@ -66,7 +66,43 @@ struct IgemmParams {
   int y_rows16;         // plain bf16 output whose pixel rows take 16-byte stores (LDS-transposed coalesced epilogue)
   long long* chan_sums; // optional [N][Cout] fixed-point sums over the pixels of the STORED output (GEMM kernels, rows16 epilogue)
   int sums_hw;          // Ho * Wo (>= the pixel tile: a tile then spans at most two images)
+#ifdef FAR3D_PROFILING
+  unsigned long long* prof;   // tools/conv_phase_times.py: 8 x 64-bit stamps per workgroup (never in libfar3d_hip.so)
+#endif
 };
+
+// Profiling build only (-DFAR3D_PROFILING, libfar3d_hip_prof.so): thread 0 of every workgroup records s_memtime at the phase boundaries
+// -- slot 0 hardware id (HW_ID | XCC_ID << 32), 1 kernel entry, 2 set-up done (addresses, descriptors, first DMA issued), 3 first step's
+// operands in LDS, 4 K loop done, 5 epilogue stores retired, 6 s_memrealtime at entry (100 MHz: clock rate and cross-CU ordering).
+#ifdef FAR3D_PROFILING
+#define FAR3D_CONV_TS(P, slot)                                                                                          \
+  do {                                                                                                                  \
+    if ((P).prof && threadIdx.x == 0) {                                                                                 \
+      const unsigned long long wg_ = (unsigned long long)blockIdx.x + (unsigned long long)blockIdx.y * gridDim.x;        \
+      (P).prof[wg_ * 8 + (slot)] = (unsigned long long)__builtin_amdgcn_s_memtime();                                    \
+    }                                                                                                                   \
+  } while (0)
+#define FAR3D_CONV_TS_ENTRY(P)                                                                                          \
+  do {                                                                                                                  \
+    if ((P).prof && threadIdx.x == 0) {                                                                                 \
+      const unsigned long long wg_ = (unsigned long long)blockIdx.x + (unsigned long long)blockIdx.y * gridDim.x;        \
+      unsigned hw_, xcc_;                                                                                               \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                                 \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                               \
+      (P).prof[wg_ * 8 + 0] = (unsigned long long)hw_ | ((unsigned long long)xcc_ << 32);                               \
+      (P).prof[wg_ * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_memrealtime();                                     \
+      (P).prof[wg_ * 8 + 1] = (unsigned long long)__builtin_amdgcn_s_memtime();                                         \
+    }                                                                                                                   \
+  } while (0)
+#define FAR3D_CONV_TS_FIRST(P) do { wait_vmcnt_all_(); __syncthreads(); FAR3D_CONV_TS(P, 3); } while (0)
+#define FAR3D_CONV_TS_END(P) do { wait_vmcnt_all_(); FAR3D_CONV_TS(P, 5); } while (0)
+__device__ __forceinline__ void wait_vmcnt_all_() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+#define FAR3D_CONV_TS(P, slot) do { } while (0)
+#define FAR3D_CONV_TS_ENTRY(P) do { } while (0)
+#define FAR3D_CONV_TS_FIRST(P) do { } while (0)
+#define FAR3D_CONV_TS_END(P) do { } while (0)
+#endif
 
 template <typename TC> struct Cfg;
 template <> struct Cfg<bf16_t> { static constexpr int E = 8, ROWB = 80, KSUB = 2; };
@@ -783,6 +819,7 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
 template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParams P, int tiles_x, int tiles_y) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
+  FAR3D_CONV_TS_ENTRY(P);
   constexpr int NW = WGM * WGN;                      // waves per workgroup (4, 8 or 16)
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
   constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + NW - 1) / NW;
@@ -916,6 +953,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
 #pragma unroll
     for (int c = 0; c < AHEAD; ++c)
       if (c < nchunks) { issue_w(c, 0, c); issue_patch(c, c); }
+    FAR3D_CONV_TS(P, 2);
+    FAR3D_CONV_TS_FIRST(P);
 #define FAR3D_PIPE_CHUNK(STG, CH)                                                                                      \
   {                                                                                                                    \
     const bool more = (CH) + AHEAD < nchunks;                                                                          \
@@ -953,6 +992,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     issue_patch(0, 0);
     issue_w(0, 1, 1);
   }
+  FAR3D_CONV_TS(P, 2);
+  FAR3D_CONV_TS_FIRST(P);
   // step s = 3c + ky reads weight stage s % NSW and patch buffer c & 1; after its barrier it issues the weights of step
   // s + NSW - 1 and (ky == 0) the next chunk's patch.  Pieces issued after W(s), which may stay in flight at the top of
   // step s:  NSW 2: the patch when ky == 1;  NSW 3: W(s+1), plus the patch when ky != 0.
@@ -996,12 +1037,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   }   // RPS == 1
 #undef FAR3D_WAITC
 #undef FAR3D_DMA_PIECES
+  FAR3D_CONV_TS(P, 4);
   if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
     epilogue_rows16<NW, WM, WN, BM, TH * 32, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
       return (y < P.H && x < P.W) ? (long)n * P.y_img_stride + ((long)y * P.W + x) * P.ldy : -1L;
     });
+    FAR3D_CONV_TS_END(P);
     return;
   }
   int pn[WN], ppix[WN];
@@ -1349,6 +1392,7 @@ __device__ __forceinline__ void gemm_step_wide(const unsigned char* smem, const 
 template <int WGM, int WGN, int WM, int WN, int NS = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParams P, int npt, int nct) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  FAR3D_CONV_TS_ENTRY(P);
   constexpr int NW = WGM * WGN;
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   constexpr int GA = BM / 8, GB = BP / 8;                       // 1 KB DMA pieces (8 rows x 128 B) per 64-channel step
@@ -1432,6 +1476,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < nsteps) issue(s, s * STAGE, s >= nfull);
+  FAR3D_CONV_TS(P, 2);
+  FAR3D_CONV_TS_FIRST(P);
 #define FAR3D_WIDE_SYNC(S)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if constexpr (FAR3D_ABLATE & 16) {                                                                       \
@@ -1473,6 +1519,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
   }
 #undef FAR3D_WIDE_STEP
 #undef FAR3D_WIDE_SYNC
+  FAR3D_CONV_TS(P, 4);
   if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
     constexpr int RING = NS * (BM + BP) * 128, OUTB = BP * (BM * 2 + 16);
@@ -1482,6 +1529,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
       const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
     }, (long)p0, RING > OUTB ? RING : OUTB);
+    FAR3D_CONV_TS_END(P);
     return;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);
@@ -1569,6 +1617,7 @@ __device__ __forceinline__ void far3d_static_for(F&& f) {
 template <int WGM, int WGN, int WM, int WN, int NSA, int NSB>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmParams P, int npt, int nct) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  FAR3D_CONV_TS_ENTRY(P);
   constexpr int NW = WGM * WGN, NWA = NW / 2, NWB = NW - NWA;
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   constexpr int GA = BM / 8, GB = BP / 8;                       // 1 KB DMA pieces (8 rows x 128 B) per 64-channel step
@@ -1646,6 +1695,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
 #pragma unroll
   for (int s = 0; s < (DA > DB ? DA : DB); ++s)
     if (s < dmine && s < nsteps) issue(s, s >= nfull, is_a ? s * ASTG : BBASE + s * BSTG);
+  FAR3D_CONV_TS(P, 2);
   // ONE rolled loop over the steps; the half step (K % 64 == 32) runs the full four sub-steps on a row whose upper half the DMA filled
   // with zeros (out-of-range slots), so it needs no code of its own
   const int ring_lo = is_a ? 0 : BBASE, ring_hi = is_a ? NSA * ASTG : BBASE + NSB * BSTG, ring_stg = is_a ? ASTG : BSTG;
@@ -1676,6 +1726,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
   }
   if (P.y_rows16) {
     constexpr int RING = NSA * ASTG + NSB * BSTG, OUTB = BP * (BM * 2 + 16);
+    FAR3D_CONV_TS(P, 4);
     __syncthreads();         // the ring may fill the whole LDS: the epilogue's sum scratch (zeroed before its first barrier) lies inside it
     epilogue_rows16<NW, WM, WN, BM, BP, false>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const long p = (long)p0 + pl;
@@ -1684,6 +1735,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
     }, (long)p0, OUTB);      // the sum scratch sits right behind the staged tile (the ring is dead by then)
     (void)RING;
+    FAR3D_CONV_TS_END(P);
     return;
   }
   igemm_epilogue<WM, WN>(P, acc, p0, m0, wm, wn, l31, hi, HoWo, Npix);

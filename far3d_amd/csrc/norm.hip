@@ -311,6 +311,253 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   return FAR3D_OK;
 }
 
+// ---------------------------------------------------------------- eSE, ONE launch (round 5): gate + apply (+ stage-end max-pool)
+// far3d_ese_nhwc with fixed-point channel sums is two launches -- the gate (a C x C mat-vec per image, ~5 us of latency) and the apply
+// pass -- followed, at the end of a stage, by the 3x3/s2 max-pool that re-reads the map the apply pass just wrote.  Here
+//   * workgroups (x < GP, n) of the launch compute the gates of image n (16 channels each, ese_gate_kernel's arithmetic instruction for
+//     instruction), publish them with a release fence and count themselves on sync[n];
+//   * the data workgroups (x >= GP, n) issue their first loads, THEN wait until sync[n] == GP (the producers have lower workgroup ids,
+//     are dispatched first and never wait: no deadlock), acquire, and stream x * g (+ identity) in 16-byte pieces: a thread keeps ONE
+//     group of 8 channels (its gates live in registers, no division in the loop);
+//   * pooled != null: the same launch writes maxpool3x3s2(ceil)(y) from x directly -- every tap is re-evaluated as x * g (+ identity),
+//     ROUNDED TO THE STORAGE FORMAT first, so the result is bit-identical to pooling the stored y; y == null: only the pooled map is
+//     wanted (VoVNet stage 2 inside the detector: nothing else reads its output) and the full-resolution map is never written;
+//   * the last data workgroup of an image (a ticket on sync[N + n]) returns both counters to zero; the consumed channel sums are zeroed
+//     by the data workgroups once every producer has read them.
+// The counters are device-scope atomics, the fences agent-scope: gates written on one XCD are visible on the others (L2 is per XCD).
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u); v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  }
+  static __device__ __forceinline__ void round(float (&v)[8]) {      // what a store followed by a load returns
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) { const uint32_t q = pack_bf16x2(v[e], v[e + 1]); v[e] = __uint_as_float(q << 16); v[e + 1] = __uint_as_float(q & 0xffff0000u); }
+  }
+};
+template <> struct Vec8<pair_t> {        // p -> hi of 8 consecutive channels of one 32-block; lo 32 elements on
+  static __device__ __forceinline__ void ld(const pair_t* p, float (&v)[8]) {
+    float h[8], l[8];
+    Vec8<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p), h);
+    Vec8<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p) + 32, l);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = h[e] + l[e];
+  }
+  static __device__ __forceinline__ void split(const float (&v)[8], uint4& h, uint4& l) {
+    uint2 h0, l0, h1, l1;
+    split4f(v[0], v[1], v[2], v[3], h0, l0);
+    split4f(v[4], v[5], v[6], v[7], h1, l1);
+    h = make_uint4(h0.x, h0.y, h1.x, h1.y); l = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+  static __device__ __forceinline__ void st(pair_t* p, const float (&v)[8]) {
+    uint4 h, l;
+    split(v, h, l);
+    *reinterpret_cast<uint4*>(p) = h;
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p) + 32) = l;
+  }
+  static __device__ __forceinline__ void round(float (&v)[8]) {
+    uint4 h, l;
+    split(v, h, l);
+    const uint32_t hh[4] = {h.x, h.y, h.z, h.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(hh[e] << 16) + __uint_as_float(ll[e] << 16);
+      v[2 * e + 1] = __uint_as_float(hh[e] & 0xffff0000u) + __uint_as_float(ll[e] & 0xffff0000u);
+    }
+  }
+};
+
+struct EseFusedParams {
+  const void* x; const void* idn; void* y; void* pooled;
+  const float* fcw; const float* fcb; float* gate; int* sync; long long* sums;
+  int N, H, W, C, ldx, ldi, ldy, ldp, Hp, Wp, GP, DB;
+  long xs, is, ys, ps;
+  float inv_hw;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
+  const int n = blockIdx.y, tid = threadIdx.x, C = P.C;
+  if ((int)blockIdx.x < P.GP) {
+    // ---- gate producer: 16 output channels of image n (ese_gate_kernel with fixed-point sums)
+    __shared__ float mean[1024];
+    const int lane = tid & 63, wv = tid >> 6;
+    const int c0 = blockIdx.x * 16 + wv * 4;
+    float4 w[4][4];
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[j] = c0 + j < C ? P.fcb[c0 + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = lane * 4 + i * 256;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        w[i][j] = (k < C && c0 + j < C) ? *reinterpret_cast<const float4*>(P.fcw + (long)(c0 + j) * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tid + j * 256 < C)
+        mean[tid + j * 256] = (float)((double)P.sums[(long)n * C + tid + j * 256] * (1.0 / (1 << FAR3D_SUMS_FRAC_BITS)) * (double)P.inv_hw);
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = lane * 4 + i * 256;
+      if (k < C) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += (w[i][j].x * m.x + w[i][j].y * m.y) + (w[i][j].z * m.z + w[i][j].w * m.w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = wave_sum(acc[j]);
+      if (lane == 0 && c0 + j < C) {
+        const float z = a + bias[j];
+        P.gate[(long)n * C + c0 + j] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
+      }
+    }
+    __threadfence();                       // release: the gates (and this workgroup's reads of the sums) before the count
+    __syncthreads();
+    if (tid == 0) atomicAdd(P.sync + n, 1);
+    return;
+  }
+  // ---- data workgroup b of image n
+  const int b = blockIdx.x - P.GP, cq = C / 8;
+  const int HW = P.H * P.W;
+  const int stride = P.DB * 256;                           // a multiple of cq: a thread's channel group is the same for all its items
+  const int i0 = b * 256 + tid;
+  const int cg = i0 % cq, pstep = stride / cq;
+  const int co = chan_off<T>(cg * 8);
+  const T* x = reinterpret_cast<const T*>(P.x) + (long)n * P.xs + co;
+  const T* idn = P.idn ? reinterpret_cast<const T*>(P.idn) + (long)n * P.is + co : nullptr;
+  T* y = P.y ? reinterpret_cast<T*>(P.y) + (long)n * P.ys + co : nullptr;
+  int pix = i0 / cq;
+  float xv[8], dv[8];
+  const bool first = y && pix < HW;
+  if (first) {                                             // the first item's loads go out before the wait for the gates
+    Vec8<T>::ld(x + (long)pix * P.ldx, xv);
+    if (idn) Vec8<T>::ld(idn + (long)pix * P.ldi, dv);
+  }
+  if (tid == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(P.sync + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.GP) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 24)) break;                      // a producer can only be late, never missing; never hang the device on a bug
+    }
+  }
+  __syncthreads();
+  __threadfence();                                         // acquire: the gates of other CUs / XCDs
+  float g[8];
+  {
+    const float4 g0 = *reinterpret_cast<const float4*>(P.gate + (long)n * C + cg * 8), g1 = *reinterpret_cast<const float4*>(P.gate + (long)n * C + cg * 8 + 4);
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+  }
+  // every producer of this image has read the channel sums: return them to zero for their next producer
+  for (int i = i0; i < C; i += stride) P.sums[(long)n * C + i] = 0;
+  if (y) {
+    for (; pix < HW; pix += pstep) {
+      const int nxt = pix + pstep;
+      float xn[8], dn[8];
+      if (nxt < HW) {
+        Vec8<T>::ld(x + (long)nxt * P.ldx, xn);
+        if (idn) Vec8<T>::ld(idn + (long)nxt * P.ldi, dn);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = idn ? xv[e] * g[e] + dv[e] : xv[e] * g[e];
+      Vec8<T>::st(y + (long)pix * P.ldy, xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xv[e] = xn[e]; dv[e] = dn[e]; }
+    }
+  }
+  if (P.pooled) {
+    T* pd = reinterpret_cast<T*>(P.pooled) + (long)n * P.ps + co;
+    const int HWp = P.Hp * P.Wp;
+    for (int q = i0 / cq; q < HWp; q += pstep) {
+      const int oy = q / P.Wp, ox = q - oy * P.Wp;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 + ky;
+        if (iy >= P.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ox * 2 + kx;
+          if (ix >= P.W) continue;
+          const long pp = (long)iy * P.W + ix;
+          float v[8];
+          Vec8<T>::ld(x + pp * P.ldx, v);
+          if (idn) {
+            float d[8];
+            Vec8<T>::ld(idn + pp * P.ldi, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + d[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e];
+          }
+          Vec8<T>::round(v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+      }
+      Vec8<T>::st(pd + (long)q * P.ldp, m);
+    }
+  }
+  // ---- the last data workgroup of the image resets the two counters
+  __syncthreads();
+  if (tid == 0 && atomicAdd(P.sync + P.N + n, 1) == P.DB - 1) {
+    atomicExch(P.sync + n, 0);
+    atomicExch(P.sync + P.N + n, 0);
+  }
+}
+
+extern "C" int far3d_ese_fused_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y, void* pooled,
+                                    float* gate, int* sync, int N, int H, int W, int C, int ldx, long x_img_stride, int ldi,
+                                    long i_img_stride, int ldy, long y_img_stride, int Hp, int Wp, int ldp, long p_img_stride,
+                                    long long* chan_sums, void* stream) {
+  FAR3D_CHECK_ARG(x && fcw && fcb && gate && sync && chan_sums && (y || pooled), "far3d_ese_fused_nhwc: null pointer argument (y or pooled must be given)");
+  FAR3D_CHECK_ARG(dt == FAR3D_DT_BF16 || dt == FAR3D_DT_BF16_PAIR, "far3d_ese_fused_nhwc: bf16 or pair-stored maps (the fixed-point channel sums describe those)");
+  FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C <= 1024 && C % (dt == FAR3D_DT_BF16_PAIR ? 32 : 8) == 0, "far3d_ese_fused_nhwc: bad sizes (C=%d)", C);
+  auto al = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  FAR3D_CHECK_ARG(al(x) && ldx % 8 == 0 && x_img_stride % 8 == 0 && (!identity || (al(identity) && ldi % 8 == 0 && i_img_stride % 8 == 0)) &&
+                  (!y || (al(y) && ldy % 8 == 0 && y_img_stride % 8 == 0)) && (!pooled || (al(pooled) && ldp % 8 == 0 && p_img_stride % 8 == 0)),
+                  "far3d_ese_fused_nhwc: pointers and strides must be multiples of 16 bytes");
+  if (pooled) {      // ceil_mode output size: ceil((H-3)/2)+1, last window must start inside the input
+    int eh = (H - 3 + 1) / 2 + 1; if ((eh - 1) * 2 >= H) --eh;
+    int ew = (W - 3 + 1) / 2 + 1; if ((ew - 1) * 2 >= W) --ew;
+    FAR3D_CHECK_ARG(Hp == eh && Wp == ew, "far3d_ese_fused_nhwc: pooled size %dx%d != ceil-mode size %dx%d", Hp, Wp, eh, ew);
+  }
+  EseFusedParams P;
+  P.x = x; P.idn = identity; P.y = y; P.pooled = pooled; P.fcw = fcw; P.fcb = fcb; P.gate = gate; P.sync = sync; P.sums = chan_sums;
+  P.N = N; P.H = H; P.W = W; P.C = C; P.ldx = ldx; P.ldi = ldi; P.ldy = ldy; P.ldp = ldp; P.Hp = Hp; P.Wp = Wp;
+  P.xs = x_img_stride; P.is = i_img_stride; P.ys = y_img_stride; P.ps = p_img_stride; P.inv_hw = 1.f / ((float)H * W);
+  P.GP = (C + 15) / 16;
+  // data workgroups per image: one 8-channel piece per thread and ~4 passes, the thread stride a multiple of C / 8 (unit: the smallest
+  // workgroup count whose 256 * unit threads are a multiple of C / 8 -- 1 for C = 256 / 512 / 1024, 3 for C = 768)
+  const int cq = C / 8;
+  int unit = 1;
+  while ((256 * unit) % cq) ++unit;
+  const long items = (long)(y ? H * W : Hp * Wp) * cq;
+  long db = (items + 4 * 256 - 1) / (4 * 256);
+  if (db > 640) db = 640;
+  db = (db + unit - 1) / unit * unit;
+  P.DB = (int)db;
+  dim3 grid((unsigned)(P.GP + P.DB), (unsigned)N);
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == FAR3D_DT_BF16_PAIR) hipLaunchKernelGGL(ese_fused_kernel<pair_t>, grid, dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(ese_fused_kernel<bf16_t>, grid, dim3(256), 0, st, P);
+  FAR3D_CHECK_LAUNCH("far3d_ese_fused_nhwc");
+  return FAR3D_OK;
+}
+
 // ---------------------------------------------------------------- GroupNorm + ReLU (NHWC)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int C,
                                                        int groups, float inv_cnt, float eps, int nparts) {

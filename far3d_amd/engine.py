@@ -390,8 +390,10 @@ class Far3DEngine:
         return b
 
     # ------------------------------------------------------------------------------------------ a2: backbone
-    def backbone(self, img):
-        """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps (pair mode: 2C stored bf16 channels each)."""
+    def backbone(self, img, keep_stage2=True):
+        """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps (pair mode: 2C stored bf16 channels each).
+        keep_stage2=False (the detector's own frames): nothing but the stage-3 pooling reads the stage-2 map, so its last eSE writes
+        the pooled map only and the first entry of the result is None (the stand-alone VoVNet module returns all four maps)."""
         act, spec, cs, pair = self.prec["act"], self.spec, self.cs, self.pair
         self._select_tile_tables()
         N = img.shape[0]
@@ -413,6 +415,17 @@ class Far3DEngine:
                 esums = self._bufs[ek] = torch.zeros((N, max(spec["stage_out_ch"])), dtype=torch.int64, device=self.dev)
         if esums is not None and not torch.cuda.is_current_stream_capturing():
             esums.zero_()
+        # one-launch eSE (far3d_ese_fused_nhwc: gate + apply + stage-end pooling): gates workspace and the launch's two counters per image
+        # (zero at rest; like the sums, created zeroed once per buffer set and never replaced)
+        egate = esync = None
+        if esums is not None:
+            egate = self._buf(("ese_gate", N), (N * max(spec["stage_out_ch"]),), torch.float32)
+            sk = (self._par, "esync", N)
+            esync = self._bufs.get(sk)
+            if esync is None:
+                esync = self._bufs[sk] = torch.zeros((2 * N,), dtype=torch.int32, device=self.dev)
+            if not torch.cuda.is_current_stream_capturing():
+                esync.zero_()
         x = ops.stem_im2col(img, act, pair=pair)
         x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
@@ -420,6 +433,7 @@ class Far3DEngine:
         in_ch = spec["stem"][2]
         outs = []
         stage_in = None   # dense input of the stage (stem3 output is written straight into the first concat buffer)
+        pooled_by_ese = False      # the previous stage's last eSE launch already wrote this stage's pooled input
         for si, blocks in enumerate(self.bb["stages"]):
             sc, oc = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
             if si > 0:
@@ -432,8 +446,9 @@ class Far3DEngine:
             cat = self._buf(("cat", si, 0), (N, H, W, (in_ch + Lb * sc) * cs), act)
             if si == 0:
                 ops.conv2d_nhwc(x, self.bb["stem3"], out=cat[..., :in_ch * cs], act="relu")
-            else:
+            elif not pooled_by_ese:
                 ops.maxpool3x3s2_nhwc(stage_in, out=cat[..., :in_ch * cs], pair=pair)
+            pooled_by_ese = False
             cur_in = in_ch
             for bi, blk in enumerate(blocks):
                 last = bi == len(blocks) - 1
@@ -445,17 +460,30 @@ class Far3DEngine:
                 fuse = esums is not None and ops.conv_can_fuse_sums(cat, blk["concat"])
                 xt = ops.conv2d_nhwc(cat, blk["concat"], out=self._buf(("xt", si), (N, H, W, oc * cs), act), act="relu",
                                      sums=esums if fuse else None)
+                idn = cat[..., :cur_in * cs] if bi > 0 else None
+                will_fuse = fuse and ops.ese_fused_ok(xt, pair) and (idn is None or ops.ese_fused_ok(idn, pair))
+                pooled = None
+                if will_fuse and last and si + 1 < len(self.bb["stages"]):   # the next stage's input slice: MaxPool2d(3, 2, ceil) of this output
+                    Hn, Wn = ops.maxpool_out_hw(H, W)
+                    nsc = spec["stage_conv_ch"][si + 1]
+                    pooled = self._buf(("cat", si + 1, 0), (N, Hn, Wn, (oc + Lb * nsc) * cs), act)[..., :oc * cs]
+                skip_out = pooled is not None and si == 0 and not keep_stage2     # nothing but the pooling reads the stage-2 map
                 if last:
-                    out = self._buf(("stage", si), (N, H, W, oc * cs), act)
+                    out = None if skip_out else self._buf(("stage", si), (N, H, W, oc * cs), act)
                     nxt = None
                 else:
                     nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, (oc + Lb * sc) * cs), act)
                     out = nxt[..., :oc * cs]
-                ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=cat[..., :cur_in * cs] if bi > 0 else None, out=out, scratch=scratch,
-                             pair=pair, sums=esums if fuse else None)
+                if will_fuse and (out is None or ops.ese_fused_ok(out, pair)):
+                    ops.ese_fused_nhwc(xt, blk["fcw"], blk["fcb"], esums, egate, esync, identity=idn, out=out, pooled=pooled, pair=pair)
+                    pooled_by_ese = pooled is not None
+                else:
+                    if out is None:
+                        out = self._buf(("stage", si), (N, H, W, oc * cs), act)
+                    ops.ese_nhwc(xt, blk["fcw"], blk["fcb"], identity=idn, out=out, scratch=scratch, pair=pair, sums=esums if fuse else None)
                 if not last:
                     cat, cur_in = nxt, oc
-            stage_in = self._bufs[(self._par, "stage", si)]
+            stage_in = out
             outs.append(stage_in)
             in_ch = oc
         return outs
@@ -716,7 +744,7 @@ class Far3DEngine:
         img2lidar, c14 = ops.camera_prep(lidar2img, dd["intrinsics"][0, lo:hi], dd["extrinsics"][0, lo:hi])
         hh = self.sa["reduce"](c14, act="relu")
         mln_scale, mln_shift = self.sa["gamma"](hh), self.sa["beta"](hh)           # (n, E) each
-        feats = self.backbone(img)
+        feats = self.backbone(img, keep_stage2=False)
         raw, tokens, hw, starts = self.fpn(feats, mln_scale, mln_shift)
         st = dict(tokens=tokens, hw=hw, starts=starts, raw=raw, lidar2img=lidar2img)
         cls, reg, depth_logit = self.roi_head(raw)

@@ -635,6 +635,54 @@ def ese_nhwc(x, fcw, fcb, identity=None, out=None, scratch=None, pair=False, sum
     return out
 
 
+def ese_fused_ok(x, pair=False):
+    """Whether ese_fused_nhwc takes this map: bf16 / pair storage, 8-channel (16-byte) pieces everywhere."""
+    C = x.shape[-1] // (2 if pair else 1)
+    return x.dtype == torch.bfloat16 and C % (32 if pair else 8) == 0 and C <= 1024 and x.stride(2) % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+
+
+def maxpool_out_hw(H, W):
+    """MaxPool2d(3, 2, ceil_mode=True) output size (ref models/backbones/vovnet.py:249-250)."""
+    Ho, Wo = -(-(H - 3) // 2) + 1, -(-(W - 3) // 2) + 1
+    if (Ho - 1) * 2 >= H:
+        Ho -= 1
+    if (Wo - 1) * 2 >= W:
+        Wo -= 1
+    return Ho, Wo
+
+
+def ese_fused_nhwc(x, fcw, fcb, sums, gate, sync, identity=None, out=None, pooled=None, pair=False):
+    """eSE in ONE launch (far3d_ese_fused_nhwc): gates from the fixed-point channel sums `sums` of the concat convolution, y = x * gate
+    (+ identity) into `out` (None: not written) and, optionally, MaxPool2d(3, 2, ceil_mode=True)(y) into `pooled` (an NHWC view, e.g. the
+    input slice of the next stage's concat buffer).  gate: >= N*C floats of workspace; sync: 2*N int32, zero at rest."""
+    lib = _lib.require_device()
+    N, H, W, C = x.shape
+    if pair:
+        C //= 2
+    if out is None and pooled is None:
+        raise ValueError("ese_fused_nhwc: nothing to write (out and pooled are both None)")
+    ldx, xs = _nhwc_view(x, "x")
+    ldy, ys, yp = 0, 0, None
+    if out is not None:
+        ldy, ys = _nhwc_view(out, "out")
+        yp = _ptr(out)
+    ldi, isd, ip = 0, 0, None
+    if identity is not None:
+        ldi, isd = _nhwc_view(identity, "identity")
+        ip = _ptr(identity)
+    Hp = Wp = ldp = ps = 0
+    pp = None
+    if pooled is not None:
+        Hp, Wp = pooled.shape[1], pooled.shape[2]
+        ldp, ps = _nhwc_view(pooled, "pooled")
+        pp = _ptr(pooled)
+    if gate.numel() < N * C or gate.dtype != torch.float32 or sync.numel() < 2 * N or sync.dtype != torch.int32:
+        raise ValueError("ese_fused_nhwc: gate needs N*C floats, sync 2*N int32")
+    _lib.check(lib.far3d_ese_fused_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(fcw), _ptr(fcb), ip, yp, pp, _ptr(gate), _ptr(sync), N, H, W, C,
+                                        ldx, xs, ldi, isd, ldy, ys, Hp, Wp, ldp, ps, _sums_ptr(sums, N, C), _stream(x)), "far3d_ese_fused_nhwc")
+    return out if out is not None else pooled
+
+
 def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, relu=True, out=None, scratch=None, pair=False):
     lib = _lib.require_device()
     _chk(x, "x", ndim=4)

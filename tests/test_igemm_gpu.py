@@ -178,7 +178,7 @@ def test_pipelined_kernels_bf16_output_coalesced_rows(hip_lib, tile):
     neighbours must stay untouched."""
     from far3d_amd import ops
     g = torch.Generator().manual_seed(500 + tile)
-    k = 1 if (70 <= tile < 90 or 110 <= tile < 130) else 3
+    k = 1 if (70 <= tile < 90 or 110 <= tile < 130 or 140 <= tile < 150) else 3
     for (N, Cin, Cout, H, W) in ((2, 64, 200, 13, 45), (3, 96, 40, 9, 37), (1, 32, 64, 5, 33)):
         x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
         w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05

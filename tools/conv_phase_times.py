@@ -1,0 +1,117 @@
+"""Where does a workgroup of the pipelined conv / GEMM kernels spend its life?  Builds libfar3d_hip_prof.so (-DFAR3D_PROFILING: thread 0 of
+every workgroup stamps s_memtime at the phase boundaries, csrc/igemm_kernels.hpp FAR3D_CONV_TS), runs single launches of the VoV-99 layers
+at the benchmarked size and prints, per (layer, tile): the phase medians, the workgroup lifetime, how many workgroups a CU ran and how many
+of them overlapped.  Tools only -- the shipped libfar3d_hip.so has no such hooks.
+
+  python tools/conv_phase_times.py build            # here (no GPU needed)
+  python tools/conv_phase_times.py [layer ...]      # on the GPU box
+"""
+import ctypes
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from far3d_amd import build as fbuild  # noqa: E402
+
+PROF = os.path.join(ROOT, "far3d_amd", "libfar3d_hip_prof.so")
+# (name, N, H, W, Cin, Cout, k, tiles)
+LAYERS = [("s2.c1", 7, 160, 240, 128, 128, 3, (60, 130)), ("s3.c1", 7, 80, 120, 160, 160, 3, (92,)), ("s3.c0", 7, 80, 120, 512, 160, 3, (101,)),
+          ("s4.c1", 7, 40, 60, 192, 192, 3, (60, 100)), ("s4.c0", 7, 40, 60, 768, 192, 3, (100,)), ("s5.c1", 7, 20, 30, 224, 224, 3, (102,)),
+          ("s2.cat", 7, 160, 240, 768, 256, 1, (123, 145)), ("s3.cat", 7, 80, 120, 1312, 512, 1, (120,)), ("s4.cat", 7, 40, 60, 1728, 768, 1, (123, 145, 120))]
+
+
+def build_prof():
+    objs = []
+    os.makedirs("/tmp/far3d_prof_obj", exist_ok=True)
+
+    def one(src):
+        o = os.path.join("/tmp/far3d_prof_obj", src[:-4] + ".o")
+        subprocess.run([fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_PROFILING", "-c", os.path.join(fbuild.CSRC, src), "-o", o], check=True)
+        return o
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(one, fbuild._sources()))
+    subprocess.run([fbuild.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROF] + objs, check=True)
+    print("built", PROF)
+
+
+def main():
+    import torch
+    from far3d_amd import lib as flib
+    flib.LIB_PATH = PROF
+    lib = flib.load()
+    from far3d_amd import ops
+    fn = lib.far3d_prof_set_conv_timestamps
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    dev = "cuda:0"
+    only = sys.argv[1:]
+    for name, N, H, W, Cin, Cout, k, tiles in LAYERS:
+        if only and name not in only:
+            continue
+        x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
+        pc = ops.PackedConv(torch.randn(Cout, Cin, k, k) * 0.05, torch.randn(Cout), stride=1, pad=k // 2, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(N, H, W, Cout, device=dev, dtype=torch.bfloat16)
+        sums = torch.zeros(N, Cout, dtype=torch.int64, device=dev) if k == 1 else None
+        for tile in tiles:
+            ts = torch.zeros(1 << 20, dtype=torch.int64, device=dev)       # 128 Ki workgroups x 8 stamps
+            fn(None)
+            for _ in range(3):
+                ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums)
+            torch.cuda.synchronize()
+            fn(ctypes.c_void_p(ts.data_ptr()))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums)
+            e1.record()
+            torch.cuda.synchronize()
+            fn(None)
+            t = ts.cpu().numpy().astype(np.uint64).reshape(-1, 8)
+            t = t[t[:, 1] != 0]
+            if not len(t):
+                print("%-7s tile %3d: no stamps (kernel without hooks)" % (name, tile))
+                continue
+            hw, xcc = (t[:, 0] & np.uint64(0xffffffff)).astype(np.int64), (t[:, 0] >> np.uint64(32)).astype(np.int64) & 0xf
+            cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)      # cu_id, sh_id, se_id, xcc
+            tt = t[:, 1:6].astype(np.int64)
+            real = t[:, 6].astype(np.int64)
+            # shader clock per 100 MHz tick, from the spread of the entry stamps
+            o = np.argsort(real)
+            dr, dt = real[o][-1] - real[o][0], tt[o, 0][-1] - tt[o, 0][0]
+            mhz = 100.0 * dt / max(dr, 1)
+            us = lambda ticks: ticks / max(mhz, 1.0)
+            ph = np.diff(tt, axis=1)                    # set-up, first fill, K loop, epilogue
+            life = tt[:, 4] - tt[:, 0]
+            span = tt[:, 4].max() - tt[:, 0].min()
+            med = lambda a: float(np.median(a))
+            ncu = len(np.unique(cu))
+            per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
+            # overlap: for every CU, the time with >= 1 / >= 2 workgroups alive
+            busy1 = busy2 = 0.0
+            for c in np.unique(cu):
+                m = cu == c
+                ev = sorted([(a, 1) for a in tt[m, 0]] + [(b, -1) for b in tt[m, 4]])
+                alive, last = 0, ev[0][0]
+                for when, d in ev:
+                    if alive >= 1:
+                        busy1 += when - last
+                    if alive >= 2:
+                        busy2 += when - last
+                    alive += d
+                    last = when
+            print("%-7s tile %3d: launch %6.1f us (events) | %5d workgroups on %3d CUs (%.1f per CU, max %d) | clock %4.0f MHz | span %6.1f us | "
+                  "median per workgroup: set-up %5.2f  first fill %5.2f  K loop %6.2f  epilogue %5.2f  life %6.2f us (p10 %.2f p90 %.2f) | "
+                  "a CU has >=1 workgroup alive %4.1f %% of the span, >=2 alive %4.1f %%" %
+                  (name, tile, e0.elapsed_time(e1) * 1e3, len(t), ncu, len(t) / ncu, per_cu.max(), mhz, us(span), us(med(ph[:, 0])), us(med(ph[:, 1])),
+                   us(med(ph[:, 2])), us(med(ph[:, 3])), us(med(life)), us(np.percentile(life, 10)), us(np.percentile(life, 90)),
+                   100.0 * busy1 / (ncu * span), 100.0 * busy2 / (ncu * span)), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build_prof()
+    else:
+        main()
