@@ -253,6 +253,19 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
   }
 }
 
+// x * g rounded, THEN + d (two fp32 operations as in the reference, vovnet.py:185,232-236): never contracted into an fma, so that
+// far3d_ese_nhwc and far3d_ese_fused_nhwc -- two kernels evaluating the same expression -- give the same bits whatever the compiler
+// would have chosen to fuse in each (HIP's __fmul_rn is a plain `*` and contracts like one)
+__device__ __forceinline__ float ese_mul(float x, float g) {
+#pragma clang fp contract(off)
+  return x * g;
+}
+__device__ __forceinline__ float ese_mul_add(float x, float g, float d) {
+#pragma clang fp contract(off)
+  const float p = x * g;
+  return p + d;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x, const float* __restrict__ gate,
                                                         const T* __restrict__ idn, T* __restrict__ y, long total4, int C,
@@ -270,10 +283,11 @@ __global__ __launch_bounds__(256) void ese_apply_kernel(const T* __restrict__ x,
     const int co = chan_off<T>(c);
     float4 v = load4(x + n * xs + pix * ldx + co);
     const float4 g = *reinterpret_cast<const float4*>(gate + (long)n * C + c);
-    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
     if (idn) {
       const float4 d = load4(idn + n * is + pix * ldi + co);
-      v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+      v.x = ese_mul_add(v.x, g.x, d.x); v.y = ese_mul_add(v.y, g.y, d.y); v.z = ese_mul_add(v.z, g.z, d.z); v.w = ese_mul_add(v.w, g.w, d.w);
+    } else {
+      v.x = ese_mul(v.x, g.x); v.y = ese_mul(v.y, g.y); v.z = ese_mul(v.z, g.z); v.w = ese_mul(v.w, g.w);
     }
     store4(y + n * ys + pix * ldy + co, v);
   }
@@ -324,7 +338,8 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
 //     wanted (VoVNet stage 2 inside the detector: nothing else reads its output) and the full-resolution map is never written;
 //   * the last data workgroup of an image (a ticket on sync[N + n]) returns both counters to zero; the consumed channel sums are zeroed
 //     by the data workgroups once every producer has read them.
-// The counters are device-scope atomics, the fences agent-scope: gates written on one XCD are visible on the others (L2 is per XCD).
+// The counters and the gates travel as device-scope atomics (sc1: through to memory): gates written on one XCD are visible on the others
+// (L2 is per XCD) without any agent-scope fence.
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
   static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
@@ -419,10 +434,14 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
       const float a = wave_sum(acc[j]);
       if (lane == 0 && c0 + j < C) {
         const float z = a + bias[j];
-        P.gate[(long)n * C + c0 + j] = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;   // F.relu6(x + 3) / 6
+        // device-scope (sc1) store: written through to memory, where the other XCDs' loads below find it
+        __hip_atomic_store(P.gate + (long)n * C + c0 + j, fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // F.relu6(x + 3) / 6
       }
     }
-    __threadfence();                       // release: the gates (and this workgroup's reads of the sums) before the count
+    // The hand-over uses device-scope ATOMIC stores / loads for the gates and a workgroup-scope release (= wait until this wave's stores are
+    // acknowledged), NOT __threadfence(): on a multi-XCD part an agent-scope fence is `buffer_wbl2 sc1` + `buffer_inv sc1` -- a write-back
+    // and an invalidation of the XCD's whole L2 -- and one of those per workgroup doubled the backbone's time (measured, profiles/r5).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) atomicAdd(P.sync + n, 1);
     return;
@@ -452,12 +471,9 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
     }
   }
   __syncthreads();
-  __threadfence();                                         // acquire: the gates of other CUs / XCDs
-  float g[8];
-  {
-    const float4 g0 = *reinterpret_cast<const float4*>(P.gate + (long)n * C + cg * 8), g1 = *reinterpret_cast<const float4*>(P.gate + (long)n * C + cg * 8 + 4);
-    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-  }
+  float g[8];                                              // device-scope loads: past this XCD's L2, which may hold a stale line of the workspace
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = __hip_atomic_load(P.gate + (long)n * C + cg * 8 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // every producer of this image has read the channel sums: return them to zero for their next producer
   for (int i = i0; i < C; i += stride) P.sums[(long)n * C + i] = 0;
   if (y) {
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
         if (idn) Vec8<T>::ld(idn + (long)nxt * P.ldi, dn);
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[e] = idn ? xv[e] * g[e] + dv[e] : xv[e] * g[e];
+      for (int e = 0; e < 8; ++e) xv[e] = idn ? ese_mul_add(xv[e], g[e], dv[e]) : ese_mul(xv[e], g[e]);
       Vec8<T>::st(y + (long)pix * P.ldy, xv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { xv[e] = xn[e]; dv[e] = dn[e]; }
@@ -498,10 +514,10 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
             float d[8];
             Vec8<T>::ld(idn + pp * P.ldi, d);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + d[e];
+            for (int e = 0; e < 8; ++e) v[e] = ese_mul_add(v[e], g[e], d[e]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e];
+            for (int e = 0; e < 8; ++e) v[e] = ese_mul(v[e], g[e]);
           }
           Vec8<T>::round(v);
 #pragma unroll

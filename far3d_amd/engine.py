@@ -426,8 +426,11 @@ class Far3DEngine:
                 esync = self._bufs[sk] = torch.zeros((2 * N,), dtype=torch.int32, device=self.dev)
             if not torch.cuda.is_current_stream_capturing():
                 esync.zero_()
-        x = ops.stem_im2col(img, act, pair=pair)
-        x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
+        if act == torch.bfloat16 and not pair:
+            x = ops.stem_conv(img, self.bb["stem1"], act="relu")      # im2col folded into the convolution (bit-identical, csrc/stem.hip)
+        else:
+            x = ops.stem_im2col(img, act, pair=pair)
+            x = ops.conv2d_nhwc(x, self.bb["stem1"], act="relu")
         x = ops.conv2d_nhwc(x, self.bb["stem2"], act="relu")
         H, W = self.bb["stem3"].out_hw(x.shape[1], x.shape[2])
         in_ch = spec["stem"][2]

@@ -50,6 +50,7 @@ SIGNATURES = {
     "far3d_groupnorm_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p]),
     "far3d_maxpool3x3s2_nhwc": (c_int, [_p, c_int, _p] + [c_int] * 7 + [c_long, _p]),
     "far3d_stem_im2col": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p]),
+    "far3d_stem_conv": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, _p]),
     "far3d_proposal_select": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_float, c_int, _p]),
     "far3d_proposal_gather": (c_int, [_p, c_int, c_int, c_int, _p, _p, _p, _p, c_int, _p, _p, c_int, c_int, c_int, c_int,
                                       c_float, c_float, c_int, _p, _p, c_int, c_int, _p, c_float, _p, _p, _p, _p, c_int, _p, _p, _p]),

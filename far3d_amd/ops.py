@@ -739,6 +739,23 @@ def stem_im2col(img, out_dtype=torch.bfloat16, out=None, pair=False):
     return out
 
 
+def stem_conv(img, pc, act="relu", out=None):
+    """VoVNet's first stem convolution (3 -> 64, 3x3, stride 2, pad 1) straight from the (N,3,H,W) f32 NCHW image: bf16 NHWC output,
+    bit-identical to conv2d_nhwc(stem_im2col(img), pc).  pc: the layer packed as a 1x1 conv over the 32-channel im2col rows (bf16)."""
+    lib = _lib.require_device()
+    _chk(img, "img", torch.float32, 4)
+    N, C, H, W = img.shape
+    if C != 3 or pc.Cout != 64 or pc.Cin != 32 or pc.KH != 1 or pc.w.dtype != torch.bfloat16:
+        raise ValueError("stem_conv: 3-channel image and the 64 x 32 bf16 packing of the stem layer")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, 64), dtype=torch.bfloat16, device=img.device)
+    ldy, ys = _nhwc_view(out, "out")
+    _lib.check(lib.far3d_stem_conv(_ptr(img), _ptr(pc.w), _ptr(pc.bias) if pc.bias is not None else None, _ptr(out), N, H, W, ldy, ys,
+                                   {None: 0, "relu": 1}[act], _stream(img)), "far3d_stem_conv")
+    return out
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr

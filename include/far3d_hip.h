@@ -264,6 +264,14 @@ int far3d_maxpool3x3s2_nhwc(const void* x, int dt, void* y, int N, int H, int W,
  * a K=32 far3d_conv2d_nhwc 1x1. */
 int far3d_stem_im2col(const float* img, void* out, int out_dt, int N, int H, int W, void* stream);
 
+/* The same convolution in ONE launch for bf16 engines: y = act(conv3x3 / stride 2 / pad 1 (img) + bias) with the folded-BN weights of
+ * VoVNet's first stem layer, read straight from the NCHW fp32 image -- the im2col map is never written.  w: bf16 [>= 64][32] rows of the
+ * layer packed like far3d_stem_im2col's consumer (k = (ky*3 + kx)*3 + c, 5 zero columns), bias [64] f32 or NULL; y: bf16 NHWC
+ * (N, Ho, Wo, 64 channels) with pixel stride ldy, Ho = (H-1)/2+1, Wo = (W-1)/2+1; act 0 none / 1 ReLU.  Same products in the same order as
+ * far3d_stem_im2col + far3d_conv2d_nhwc (bit-identical output).  Replaces ref models/backbones/vovnet.py:306-311 (stem_1). */
+int far3d_stem_conv(const float* img, const void* w, const float* bias, void* y, int N, int H, int W, int ldy, long y_img_stride,
+                    int act, void* stream);
+
 /* 2D proposal scoring + ordered fixed-capacity selection (no host sync).
  * Replaces YOLOXHeadCustom.get_bboxes' score / 3x3-peak / threshold steps, ref models/dense_heads/yolox_head.py:426-438,
  * and its boolean-mask indexing :452-467.  cls[l] (N,h,w,ncls) f32 logits, reg[l] (N,h,w,nreg) f32 with channels

@@ -32,6 +32,31 @@ def test_proposal_select_topk_matches_stable_sort(hip_lib, K):
         assert np.array_equal(idx[n], np.sort(order)), "camera %d" % n
 
 
+@pytest.mark.parametrize("geom", [(2, 22, 38), (1, 64, 96), (3, 37, 131), (7, 640, 960)])
+def test_stem_conv_from_the_image_is_bitwise_im2col_plus_gemm(hip_lib, geom):
+    """far3d_stem_conv (VoVNet stem_1 read straight from the NCHW image, csrc/stem.hip) against far3d_stem_im2col + far3d_conv2d_nhwc:
+    same bf16 products in the same order -> bit-identical; and against F.conv2d on bf16-rounded operands; odd sizes (Wo % 32 != 0, odd H / W),
+    an output written into a channel slice of a wider buffer whose neighbours must stay untouched."""
+    import torch.nn.functional as F
+    from far3d_amd import ops
+    N, H, W = geom
+    g = torch.Generator().manual_seed(H * W)
+    img = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    pc = ops.PackedConv(F.pad(w.permute(0, 2, 3, 1).reshape(64, 27), (0, 5)), b, dtype=torch.bfloat16, device=DEV)
+    d = img.to(DEV)
+    want = ops.conv2d_nhwc(ops.stem_im2col(d, torch.bfloat16), pc, act="relu")
+    got = ops.stem_conv(d, pc, act="relu")
+    assert got.shape == want.shape and torch.equal(got, want)
+    ref = F.conv2d(img.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), b, stride=2, padding=1).relu().permute(0, 2, 3, 1)
+    assert (got.float().cpu() - ref).abs().max().item() < 2e-5 * 27 ** 0.5 * max(1.0, ref.abs().max().item()) + ref.abs().max().item() * 2 ** -8
+    Ho, Wo = got.shape[1], got.shape[2]
+    buf = torch.full((N, Ho, Wo, 96), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.stem_conv(d, pc, act=None, out=buf[..., 16:80])
+    assert torch.equal(buf[..., 16:80], ops.conv2d_nhwc(ops.stem_im2col(d, torch.bfloat16), pc)) and bool((buf[..., :16] == 7.0).all()) and bool((buf[..., 80:] == 7.0).all())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_stem_im2col_matches_unfold(hip_lib, dt):
     """Stem conv input: (n, oy, ox, tap*3 + c) = img[n, c, 2*oy-1+ky, 2*ox-1+kx], zero padded, 5 zero pad channels."""

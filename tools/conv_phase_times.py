@@ -63,10 +63,7 @@ def main():
                 ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums)
             torch.cuda.synchronize()
             fn(ctypes.c_void_p(ts.data_ptr()))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
             ops.conv2d_nhwc(x, pc, out=y, act="relu", tile=tile, sums=sums)
-            e1.record()
             torch.cuda.synchronize()
             fn(None)
             t = ts.cpu().numpy().astype(np.uint64).reshape(-1, 8)
@@ -78,21 +75,22 @@ def main():
             cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)      # cu_id, sh_id, se_id, xcc
             tt = t[:, 1:6].astype(np.int64)
             real = t[:, 6].astype(np.int64)
-            # shader clock per 100 MHz tick, from the spread of the entry stamps
-            o = np.argsort(real)
-            dr, dt = real[o][-1] - real[o][0], tt[o, 0][-1] - tt[o, 0][0]
-            mhz = 100.0 * dt / max(dr, 1)
-            us = lambda ticks: ticks / max(mhz, 1.0)
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "conv_phases"), exist_ok=True)
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", "conv_phases", "%s_t%d.npz" % (name, tile)), stamps=t)
+            # s_memtime is a per-XCD counter: clock rate, spans and overlaps are evaluated per CU and then combined
             ph = np.diff(tt, axis=1)                    # set-up, first fill, K loop, epilogue
             life = tt[:, 4] - tt[:, 0]
-            span = tt[:, 4].max() - tt[:, 0].min()
             med = lambda a: float(np.median(a))
-            ncu = len(np.unique(cu))
-            per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
-            # overlap: for every CU, the time with >= 1 / >= 2 workgroups alive
-            busy1 = busy2 = 0.0
-            for c in np.unique(cu):
+            cus = np.unique(cu)
+            rates, spans, busy1, busy2, nper = [], [], 0.0, 0.0, []
+            for c in cus:
                 m = cu == c
+                nper.append(int(m.sum()))
+                sp = tt[m, 4].max() - tt[m, 0].min()
+                spans.append(sp)
+                dr = real[m].max() - real[m].min()
+                if dr > 50:                              # >= 0.5 us between the first and the last entry stamp of this CU
+                    rates.append(100.0 * (tt[m, 0].max() - tt[m, 0].min()) / dr)
                 ev = sorted([(a, 1) for a in tt[m, 0]] + [(b, -1) for b in tt[m, 4]])
                 alive, last = 0, ev[0][0]
                 for when, d in ev:
@@ -102,12 +100,14 @@ def main():
                         busy2 += when - last
                     alive += d
                     last = when
-            print("%-7s tile %3d: launch %6.1f us (events) | %5d workgroups on %3d CUs (%.1f per CU, max %d) | clock %4.0f MHz | span %6.1f us | "
-                  "median per workgroup: set-up %5.2f  first fill %5.2f  K loop %6.2f  epilogue %5.2f  life %6.2f us (p10 %.2f p90 %.2f) | "
-                  "a CU has >=1 workgroup alive %4.1f %% of the span, >=2 alive %4.1f %%" %
-                  (name, tile, e0.elapsed_time(e1) * 1e3, len(t), ncu, len(t) / ncu, per_cu.max(), mhz, us(span), us(med(ph[:, 0])), us(med(ph[:, 1])),
-                   us(med(ph[:, 2])), us(med(ph[:, 3])), us(med(life)), us(np.percentile(life, 10)), us(np.percentile(life, 90)),
-                   100.0 * busy1 / (ncu * span), 100.0 * busy2 / (ncu * span)), flush=True)
+            mhz = float(np.median(rates)) if rates else float("nan")
+            us = (lambda ticks: ticks / mhz) if rates else (lambda ticks: float("nan"))
+            tot = float(np.sum(spans))
+            print("%-7s tile %3d: %5d workgroups on %3d CUs (max %d per CU) | s_memtime %5.0f MHz | per-CU span median %6.1f us (%d ticks) | median per "
+                  "workgroup [ticks]: set-up %5.0f  first fill %5.0f  K loop %6.0f  epilogue %5.0f  life %6.0f (p10 %.0f p90 %.0f) = %.2f us | "
+                  "a CU has >=1 workgroup alive %4.1f %% of its span, >=2 alive %4.1f %%" %
+                  (name, tile, len(t), len(cus), max(nper), mhz, us(med(spans)), med(spans), med(ph[:, 0]), med(ph[:, 1]), med(ph[:, 2]), med(ph[:, 3]),
+                   med(life), np.percentile(life, 10), np.percentile(life, 90), us(med(life)), 100.0 * busy1 / tot, 100.0 * busy2 / tot), flush=True)
 
 
 if __name__ == "__main__":
