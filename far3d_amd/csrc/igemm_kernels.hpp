@@ -1567,9 +1567,9 @@ static int launch_gemm1x1_wide(const IgemmParams& P, hipStream_t st) {
 // Everything else (128-byte LDS rows, source-side slot permutation, fragment double buffering, epilogue, channel sums, XCD-aware
 // numbering) is gemm1x1_wide_kernel's.  The K loop is unrolled over lcm(NSA, NSB) steps so that every LDS offset is an immediate.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NIT>
+template <int WM, int WN, int NIT, typename Dma>
 __device__ __forceinline__ void gemm_step_wide_rt(const unsigned char* smem, const int (&aaddr)[WM], const int (&baddr)[WN], int aoff, int boff,
-                                                  f32x16_t (&acc)[WM][WN]) {
+                                                  f32x16_t (&acc)[WM][WN], Dma dma) {
   // Stage offsets at RUN time (wave-uniform, multiples of 1 KiB): WM + WN adds per step, and the K loop stays ONE rolled loop -- no
   // per-stage copies of the step, no conditional blocks around the MFMAs (every such block is a merge point for all accumulators and
   // cost the unrolled form of this kernel hundreds of spills at 2 x 4 tiles per wave).  k16 sub-step kk of the 64-channel row flips
@@ -1599,6 +1599,8 @@ __device__ __forceinline__ void gemm_step_wide_rt(const unsigned char* smem, con
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[cur][i], bf[cur][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    dma(it);           // this sub-step's share of the LDS-DMA pieces of a later step: their issue cost hides under the MFMAs above
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -1664,13 +1666,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
       }
     }
   }
-  auto issue = [&](int step, bool half, int so) __attribute__((always_inline)) {      // so: LDS byte offset of the stage of this wave's ring
+  // pieces [i0, i1) of this wave's share of `step`; so: LDS byte offset of the stage of this wave's ring
+  auto issue_part = [&](int step, bool half, int so, int i0, int i1) __attribute__((always_inline)) {
     const int kb = step * 128;                                   // bytes along K
 #pragma unroll
     for (int i = 0; i < PWMAX; ++i)
-      if (i < npw)
+      if (i >= i0 && i < i1 && i < npw)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + so + (dw + nr * i) * 1024), 16, (half && !lowcol) ? OOB : voff[i], kb, 0, 0);
   };
+  auto issue = [&](int step, bool half, int so) __attribute__((always_inline)) { issue_part(step, half, so, 0, PWMAX); };
 
   f32x16_t acc[WM][WN];
 #pragma unroll
@@ -1715,10 +1719,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // the barrier also says that every wave is done with step s-1, whose stages the steps s+DA / s+DB go into
-    if (s + dmine < nsteps) issue(s + dmine, s + dmine >= nfull, iss_off);
+    // ... issued in four shares between the MFMA groups of this step (PWMAX / 4 pieces after each k16 sub-step)
+    const bool more = s + dmine < nsteps;
+    const int nstep = s + dmine, ioff = iss_off;
+    constexpr int PPI = (PWMAX + 3) / 4;
+    gemm_step_wide_rt<WM, WN, 4>(smem, aaddr, baddr, sa_off, sb_off, acc, [&](int it) __attribute__((always_inline)) {
+      if (more) issue_part(nstep, nstep >= nfull, ioff, it * PPI, (it + 1) * PPI);
+    });
     iss_off += ring_stg;
     if (iss_off == ring_hi) iss_off = ring_lo;
-    gemm_step_wide_rt<WM, WN, 4>(smem, aaddr, baddr, sa_off, sb_off, acc);
     sa_off += ASTG;
     if (sa_off == NSA * ASTG) sa_off = 0;
     sb_off += BSTG;

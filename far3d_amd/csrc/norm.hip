@@ -325,21 +325,19 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
   return FAR3D_OK;
 }
 
-// ---------------------------------------------------------------- eSE, ONE launch (round 5): gate + apply (+ stage-end max-pool)
-// far3d_ese_nhwc with fixed-point channel sums is two launches -- the gate (a C x C mat-vec per image, ~5 us of latency) and the apply
-// pass -- followed, at the end of a stage, by the 3x3/s2 max-pool that re-reads the map the apply pass just wrote.  Here
-//   * workgroups (x < GP, n) of the launch compute the gates of image n (16 channels each, ese_gate_kernel's arithmetic instruction for
-//     instruction), publish them with a release fence and count themselves on sync[n];
-//   * the data workgroups (x >= GP, n) issue their first loads, THEN wait until sync[n] == GP (the producers have lower workgroup ids,
-//     are dispatched first and never wait: no deadlock), acquire, and stream x * g (+ identity) in 16-byte pieces: a thread keeps ONE
-//     group of 8 channels (its gates live in registers, no division in the loop);
-//   * pooled != null: the same launch writes maxpool3x3s2(ceil)(y) from x directly -- every tap is re-evaluated as x * g (+ identity),
-//     ROUNDED TO THE STORAGE FORMAT first, so the result is bit-identical to pooling the stored y; y == null: only the pooled map is
-//     wanted (VoVNet stage 2 inside the detector: nothing else reads its output) and the full-resolution map is never written;
-//   * the last data workgroup of an image (a ticket on sync[N + n]) returns both counters to zero; the consumed channel sums are zeroed
-//     by the data workgroups once every producer has read them.
-// The counters and the gates travel as device-scope atomics (sc1: through to memory): gates written on one XCD are visible on the others
-// (L2 is per XCD) without any agent-scope fence.
+// ---------------------------------------------------------------- eSE apply + stage-end max-pool in one pass (round 5)
+// far3d_ese_fused_nhwc = the gate launch of far3d_ese_nhwc(chan_sums) + ONE streaming launch that
+//   * applies y = x * g (+ identity) in 16-byte pieces: a thread keeps ONE group of 8 channels (its gates live in registers, no division
+//     in the loop, the next piece's loads in flight while the current one is stored);
+//   * pooled != null: also writes maxpool3x3s2(ceil)(y), computed from x directly -- every tap is re-evaluated as x * g (+ identity) and
+//     ROUNDED TO THE STORAGE FORMAT first, so the result is bit-identical to pooling the stored y; y == null: only the pooled map is wanted
+//     (VoVNet stage 2 inside the detector: nothing else reads its output) and the full-resolution map is never written;
+//   * returns the consumed channel sums to zero.
+// Built first as ONE launch -- the gate workgroups at the head of the grid, the data workgroups spinning on a device-scope counter until
+// the gates were published -- and measured 5x SLOWER than the two launches (profiles/r5/ese_handover.txt): on this 8-XCD part the
+// hand-over needs either agent-scope fences (`buffer_wbl2 sc1` + `buffer_inv sc1`: a write-back and an invalidation of the XCD's whole L2,
+// once per workgroup) or sc1 loads / stores that go past the L2 for every gate of every thread, and a thousand resident workgroups
+// polling seven counters serialise on their cache lines.  A kernel boundary is the cheap device-wide release / acquire here.
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
   static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
@@ -389,65 +387,15 @@ template <> struct Vec8<pair_t> {        // p -> hi of 8 consecutive channels of
 
 struct EseFusedParams {
   const void* x; const void* idn; void* y; void* pooled;
-  const float* fcw; const float* fcb; float* gate; int* sync; long long* sums;
-  int N, H, W, C, ldx, ldi, ldy, ldp, Hp, Wp, GP, DB;
+  const float* gate; long long* sums;
+  int N, H, W, C, ldx, ldi, ldy, ldp, Hp, Wp, DB;
   long xs, is, ys, ps;
-  float inv_hw;
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
   const int n = blockIdx.y, tid = threadIdx.x, C = P.C;
-  if ((int)blockIdx.x < P.GP) {
-    // ---- gate producer: 16 output channels of image n (ese_gate_kernel with fixed-point sums)
-    __shared__ float mean[1024];
-    const int lane = tid & 63, wv = tid >> 6;
-    const int c0 = blockIdx.x * 16 + wv * 4;
-    float4 w[4][4];
-    float bias[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bias[j] = c0 + j < C ? P.fcb[c0 + j] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = lane * 4 + i * 256;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        w[i][j] = (k < C && c0 + j < C) ? *reinterpret_cast<const float4*>(P.fcw + (long)(c0 + j) * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (tid + j * 256 < C)
-        mean[tid + j * 256] = (float)((double)P.sums[(long)n * C + tid + j * 256] * (1.0 / (1 << FAR3D_SUMS_FRAC_BITS)) * (double)P.inv_hw);
-    __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = lane * 4 + i * 256;
-      if (k < C) {
-        const float4 m = *reinterpret_cast<const float4*>(mean + k);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += (w[i][j].x * m.x + w[i][j].y * m.y) + (w[i][j].z * m.z + w[i][j].w * m.w);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a = wave_sum(acc[j]);
-      if (lane == 0 && c0 + j < C) {
-        const float z = a + bias[j];
-        // device-scope (sc1) store: written through to memory, where the other XCDs' loads below find it
-        __hip_atomic_store(P.gate + (long)n * C + c0 + j, fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // F.relu6(x + 3) / 6
-      }
-    }
-    // The hand-over uses device-scope ATOMIC stores / loads for the gates and a workgroup-scope release (= wait until this wave's stores are
-    // acknowledged), NOT __threadfence(): on a multi-XCD part an agent-scope fence is `buffer_wbl2 sc1` + `buffer_inv sc1` -- a write-back
-    // and an invalidation of the XCD's whole L2 -- and one of those per workgroup doubled the backbone's time (measured, profiles/r5).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0) atomicAdd(P.sync + n, 1);
-    return;
-  }
-  // ---- data workgroup b of image n
-  const int b = blockIdx.x - P.GP, cq = C / 8;
+  const int b = blockIdx.x, cq = C / 8;
   const int HW = P.H * P.W;
   const int stride = P.DB * 256;                           // a multiple of cq: a thread's channel group is the same for all its items
   const int i0 = b * 256 + tid;
@@ -457,24 +405,17 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
   const T* idn = P.idn ? reinterpret_cast<const T*>(P.idn) + (long)n * P.is + co : nullptr;
   T* y = P.y ? reinterpret_cast<T*>(P.y) + (long)n * P.ys + co : nullptr;
   int pix = i0 / cq;
+  float g[8];
+  {
+    const float4 g0 = *reinterpret_cast<const float4*>(P.gate + (long)n * C + cg * 8), g1 = *reinterpret_cast<const float4*>(P.gate + (long)n * C + cg * 8 + 4);
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+  }
   float xv[8], dv[8];
-  const bool first = y && pix < HW;
-  if (first) {                                             // the first item's loads go out before the wait for the gates
+  if (y && pix < HW) {
     Vec8<T>::ld(x + (long)pix * P.ldx, xv);
     if (idn) Vec8<T>::ld(idn + (long)pix * P.ldi, dv);
   }
-  if (tid == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(P.sync + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.GP) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1 << 24)) break;                      // a producer can only be late, never missing; never hang the device on a bug
-    }
-  }
-  __syncthreads();
-  float g[8];                                              // device-scope loads: past this XCD's L2, which may hold a stale line of the workspace
-#pragma unroll
-  for (int e = 0; e < 8; ++e) g[e] = __hip_atomic_load(P.gate + (long)n * C + cg * 8 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // every producer of this image has read the channel sums: return them to zero for their next producer
+  // the gate launch has read the channel sums: return them to zero for their next producer
   for (int i = i0; i < C; i += stride) P.sums[(long)n * C + i] = 0;
   if (y) {
     for (; pix < HW; pix += pstep) {
@@ -527,47 +468,42 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
       Vec8<T>::st(pd + (long)q * P.ldp, m);
     }
   }
-  // ---- the last data workgroup of the image resets the two counters
-  __syncthreads();
-  if (tid == 0 && atomicAdd(P.sync + P.N + n, 1) == P.DB - 1) {
-    atomicExch(P.sync + n, 0);
-    atomicExch(P.sync + P.N + n, 0);
-  }
 }
 
 extern "C" int far3d_ese_fused_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y, void* pooled,
-                                    float* gate, int* sync, int N, int H, int W, int C, int ldx, long x_img_stride, int ldi,
+                                    float* gate, int N, int H, int W, int C, int ldx, long x_img_stride, int ldi,
                                     long i_img_stride, int ldy, long y_img_stride, int Hp, int Wp, int ldp, long p_img_stride,
                                     long long* chan_sums, void* stream) {
-  FAR3D_CHECK_ARG(x && fcw && fcb && gate && sync && chan_sums && (y || pooled), "far3d_ese_fused_nhwc: null pointer argument (y or pooled must be given)");
+  FAR3D_CHECK_ARG(x && fcw && fcb && gate && chan_sums && (y || pooled), "far3d_ese_fused_nhwc: null pointer argument (y or pooled must be given)");
   FAR3D_CHECK_ARG(dt == FAR3D_DT_BF16 || dt == FAR3D_DT_BF16_PAIR, "far3d_ese_fused_nhwc: bf16 or pair-stored maps (the fixed-point channel sums describe those)");
   FAR3D_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C <= 1024 && C % (dt == FAR3D_DT_BF16_PAIR ? 32 : 8) == 0, "far3d_ese_fused_nhwc: bad sizes (C=%d)", C);
   auto al = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
   FAR3D_CHECK_ARG(al(x) && ldx % 8 == 0 && x_img_stride % 8 == 0 && (!identity || (al(identity) && ldi % 8 == 0 && i_img_stride % 8 == 0)) &&
-                  (!y || (al(y) && ldy % 8 == 0 && y_img_stride % 8 == 0)) && (!pooled || (al(pooled) && ldp % 8 == 0 && p_img_stride % 8 == 0)),
+                  (!y || (al(y) && ldy % 8 == 0 && y_img_stride % 8 == 0)) && (!pooled || (al(pooled) && ldp % 8 == 0 && p_img_stride % 8 == 0)) && al(gate),
                   "far3d_ese_fused_nhwc: pointers and strides must be multiples of 16 bytes");
   if (pooled) {      // ceil_mode output size: ceil((H-3)/2)+1, last window must start inside the input
     int eh = (H - 3 + 1) / 2 + 1; if ((eh - 1) * 2 >= H) --eh;
     int ew = (W - 3 + 1) / 2 + 1; if ((ew - 1) * 2 >= W) --ew;
     FAR3D_CHECK_ARG(Hp == eh && Wp == ew, "far3d_ese_fused_nhwc: pooled size %dx%d != ceil-mode size %dx%d", Hp, Wp, eh, ew);
   }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, (const float*)nullptr, fcw, fcb, gate, C, 1.f / ((float)H * W), 0,
+                     (const long long*)chan_sums);
   EseFusedParams P;
-  P.x = x; P.idn = identity; P.y = y; P.pooled = pooled; P.fcw = fcw; P.fcb = fcb; P.gate = gate; P.sync = sync; P.sums = chan_sums;
+  P.x = x; P.idn = identity; P.y = y; P.pooled = pooled; P.gate = gate; P.sums = chan_sums;
   P.N = N; P.H = H; P.W = W; P.C = C; P.ldx = ldx; P.ldi = ldi; P.ldy = ldy; P.ldp = ldp; P.Hp = Hp; P.Wp = Wp;
-  P.xs = x_img_stride; P.is = i_img_stride; P.ys = y_img_stride; P.ps = p_img_stride; P.inv_hw = 1.f / ((float)H * W);
-  P.GP = (C + 15) / 16;
-  // data workgroups per image: one 8-channel piece per thread and ~4 passes, the thread stride a multiple of C / 8 (unit: the smallest
+  P.xs = x_img_stride; P.is = i_img_stride; P.ys = y_img_stride; P.ps = p_img_stride;
+  // workgroups per image: one 8-channel piece per thread and ~4 passes, the thread stride a multiple of C / 8 (unit: the smallest
   // workgroup count whose 256 * unit threads are a multiple of C / 8 -- 1 for C = 256 / 512 / 1024, 3 for C = 768)
   const int cq = C / 8;
   int unit = 1;
   while ((256 * unit) % cq) ++unit;
   const long items = (long)(y ? H * W : Hp * Wp) * cq;
   long db = (items + 4 * 256 - 1) / (4 * 256);
-  if (db > 640) db = 640;
+  if (db > 1200) db = 1200;
   db = (db + unit - 1) / unit * unit;
   P.DB = (int)db;
-  dim3 grid((unsigned)(P.GP + P.DB), (unsigned)N);
-  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)P.DB, (unsigned)N);
   if (dt == FAR3D_DT_BF16_PAIR) hipLaunchKernelGGL(ese_fused_kernel<pair_t>, grid, dim3(256), 0, st, P);
   else hipLaunchKernelGGL(ese_fused_kernel<bf16_t>, grid, dim3(256), 0, st, P);
   FAR3D_CHECK_LAUNCH("far3d_ese_fused_nhwc");

@@ -415,17 +415,8 @@ class Far3DEngine:
                 esums = self._bufs[ek] = torch.zeros((N, max(spec["stage_out_ch"])), dtype=torch.int64, device=self.dev)
         if esums is not None and not torch.cuda.is_current_stream_capturing():
             esums.zero_()
-        # one-launch eSE (far3d_ese_fused_nhwc: gate + apply + stage-end pooling): gates workspace and the launch's two counters per image
-        # (zero at rest; like the sums, created zeroed once per buffer set and never replaced)
-        egate = esync = None
-        if esums is not None:
-            egate = self._buf(("ese_gate", N), (N * max(spec["stage_out_ch"]),), torch.float32)
-            sk = (self._par, "esync", N)
-            esync = self._bufs.get(sk)
-            if esync is None:
-                esync = self._bufs[sk] = torch.zeros((2 * N,), dtype=torch.int32, device=self.dev)
-            if not torch.cuda.is_current_stream_capturing():
-                esync.zero_()
+        # eSE with the stage-end pooling fused into its apply pass (far3d_ese_fused_nhwc): the gates' workspace
+        egate = self._buf(("ese_gate", N), (N * max(spec["stage_out_ch"]),), torch.float32) if esums is not None else None
         if act == torch.bfloat16 and not pair:
             x = ops.stem_conv(img, self.bb["stem1"], act="relu")      # im2col folded into the convolution (bit-identical, csrc/stem.hip)
         else:
@@ -478,7 +469,7 @@ class Far3DEngine:
                     nxt = self._buf(("cat", si, 1 + (bi % 2)), (N, H, W, (oc + Lb * sc) * cs), act)
                     out = nxt[..., :oc * cs]
                 if will_fuse and (out is None or ops.ese_fused_ok(out, pair)):
-                    ops.ese_fused_nhwc(xt, blk["fcw"], blk["fcb"], esums, egate, esync, identity=idn, out=out, pooled=pooled, pair=pair)
+                    ops.ese_fused_nhwc(xt, blk["fcw"], blk["fcb"], esums, egate, identity=idn, out=out, pooled=pooled, pair=pair)
                     pooled_by_ese = pooled is not None
                 else:
                     if out is None:

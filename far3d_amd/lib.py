@@ -44,7 +44,7 @@ SIGNATURES = {
     "far3d_rowchain_branches": (c_int, [_p, c_int] + [_p] * 10 + [c_int] + [_p] * 6 + [c_int, _p, c_int, _p, c_int, c_int, c_float, _p]),
     "far3d_ese_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_long, c_int, c_long,
                                c_int, c_long, _p, _p]),
-    "far3d_ese_fused_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_long,
+    "far3d_ese_fused_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_long,
                                      c_int, c_int, c_int, c_long, _p, _p]),
     "far3d_cam_embed_chain": (c_int, [_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_int, _p]),
     "far3d_groupnorm_nhwc": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p]),

@@ -651,10 +651,10 @@ def maxpool_out_hw(H, W):
     return Ho, Wo
 
 
-def ese_fused_nhwc(x, fcw, fcb, sums, gate, sync, identity=None, out=None, pooled=None, pair=False):
-    """eSE in ONE launch (far3d_ese_fused_nhwc): gates from the fixed-point channel sums `sums` of the concat convolution, y = x * gate
-    (+ identity) into `out` (None: not written) and, optionally, MaxPool2d(3, 2, ceil_mode=True)(y) into `pooled` (an NHWC view, e.g. the
-    input slice of the next stage's concat buffer).  gate: >= N*C floats of workspace; sync: 2*N int32, zero at rest."""
+def ese_fused_nhwc(x, fcw, fcb, sums, gate, identity=None, out=None, pooled=None, pair=False):
+    """eSE with the stage-end pooling fused into the apply pass (far3d_ese_fused_nhwc): gates from the fixed-point channel sums `sums` of
+    the concat convolution, y = x * gate (+ identity) into `out` (None: not written) and, optionally, MaxPool2d(3, 2, ceil_mode=True)(y) into
+    `pooled` (an NHWC view, e.g. the input slice of the next stage's concat buffer).  gate: >= N*C floats of workspace."""
     lib = _lib.require_device()
     N, H, W, C = x.shape
     if pair:
@@ -676,9 +676,9 @@ def ese_fused_nhwc(x, fcw, fcb, sums, gate, sync, identity=None, out=None, poole
         Hp, Wp = pooled.shape[1], pooled.shape[2]
         ldp, ps = _nhwc_view(pooled, "pooled")
         pp = _ptr(pooled)
-    if gate.numel() < N * C or gate.dtype != torch.float32 or sync.numel() < 2 * N or sync.dtype != torch.int32:
-        raise ValueError("ese_fused_nhwc: gate needs N*C floats, sync 2*N int32")
-    _lib.check(lib.far3d_ese_fused_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(fcw), _ptr(fcb), ip, yp, pp, _ptr(gate), _ptr(sync), N, H, W, C,
+    if gate.numel() < N * C or gate.dtype != torch.float32:
+        raise ValueError("ese_fused_nhwc: gate needs N*C floats")
+    _lib.check(lib.far3d_ese_fused_nhwc(_ptr(x), DT_BF16_PAIR if pair else _dt(x), _ptr(fcw), _ptr(fcb), ip, yp, pp, _ptr(gate), N, H, W, C,
                                         ldx, xs, ldi, isd, ldy, ys, Hp, Wp, ldp, ps, _sums_ptr(sums, N, C), _stream(x)), "far3d_ese_fused_nhwc")
     return out if out is not None else pooled
 

@@ -234,16 +234,15 @@ int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const float* fcb, co
                    float* scratch, int N, int HW, int C, int ldx, long x_img_stride, int ldi, long i_img_stride,
                    int ldy, long y_img_stride, long long* chan_sums, void* stream);
 
-/* The same block in ONE launch, for maps whose channel sums came out of the concat convolution (chan_sums REQUIRED; dt bf16 or pair):
- * the first workgroups of the launch compute the gates, the others start their loads, wait for the gates (device-scope counter) and
- * stream y = x * gate (+ identity) in 16-byte pieces.  Optionally the stage-end pooling of ref models/backbones/vovnet.py:249-250 in the
- * same launch: pooled != NULL receives MaxPool2d(3, 2, ceil_mode=True)(y), (Hp, Wp) its ceil-mode size, computed from x with every
- * tap rounded to the storage format first -- bit-identical to far3d_maxpool3x3s2_nhwc of the stored y; y == NULL: only the pooled map
- * is written (the caller needs the stage output at half resolution only).
- * gate: N*C floats of workspace; sync: 2*N int32 counters, ZERO at rest (the launch returns them to zero); chan_sums come back zeroed.
+/* The same block for maps whose channel sums came out of the concat convolution (chan_sums REQUIRED; dt bf16 or pair), with the stage-end
+ * pooling of ref models/backbones/vovnet.py:249-250 fused into the apply pass: the gate launch of far3d_ese_nhwc, then ONE streaming launch
+ * that writes y = x * gate (+ identity) in 16-byte pieces and, pooled != NULL, MaxPool2d(3, 2, ceil_mode=True)(y) ((Hp, Wp) its ceil-mode
+ * size) computed from x with every tap rounded to the storage format first -- bit-identical to far3d_maxpool3x3s2_nhwc of the stored y.
+ * y == NULL: only the pooled map is written (the caller needs the stage output at half resolution only).
+ * gate: N*C floats of workspace (16-byte aligned); chan_sums come back zeroed.
  * C % 8 == 0 (pair: % 32), <= 1024; every pointer / stride a multiple of 16 bytes. */
 int far3d_ese_fused_nhwc(const void* x, int dt, const float* fcw, const float* fcb, const void* identity, void* y, void* pooled,
-                         float* gate, int* sync, int N, int H, int W, int C, int ldx, long x_img_stride, int ldi,
+                         float* gate, int N, int H, int W, int C, int ldx, long x_img_stride, int ldi,
                          long i_img_stride, int ldy, long y_img_stride, int Hp, int Wp, int ldp, long p_img_stride,
                          long long* chan_sums, void* stream);
 

@@ -113,11 +113,11 @@ def test_ese_from_epilogue_sums_matches_ese_from_its_own_pooling(hip_lib, pair):
 
 @pytest.mark.parametrize("pair", [False, True])
 @pytest.mark.parametrize("geom", [(3, 20, 30, 256, True), (2, 21, 29, 768, True), (1, 9, 17, 64, False), (7, 40, 60, 512, True)])
-def test_one_launch_ese_is_bitwise_the_gate_apply_and_pool_launches(hip_lib, pair, geom):
-    """far3d_ese_fused_nhwc (gate + apply + stage-end max-pool in one launch, gates handed over through a device-scope counter) against
+def test_fused_ese_pool_is_bitwise_the_apply_and_pool_launches(hip_lib, pair, geom):
+    """far3d_ese_fused_nhwc (the gate launch + ONE pass that applies the gates in 16-byte pieces and writes the stage-end max-pool) against
     far3d_ese_nhwc(chan_sums) followed by far3d_maxpool3x3s2_nhwc: same gate arithmetic, taps rounded to the storage format before the
-    maximum -> BIT-identical maps; the counters and the sums come back zero; repeated launches (the counters' reset) stay identical;
-    channel slices of wider buffers on every operand; the pooled-only form (stage 2 inside the detector) writes no full-resolution map."""
+    maximum -> BIT-identical maps; the sums come back zero; repeated launches stay identical; channel slices of wider buffers on every
+    operand; the pooled-only form (stage 2 inside the detector) writes no full-resolution map."""
     from far3d_amd import ops
     N, H, W, C, with_idn = geom
     g = torch.Generator().manual_seed(11 + pair + C)
@@ -147,31 +147,30 @@ def test_one_launch_ese_is_bitwise_the_gate_apply_and_pool_launches(hip_lib, pai
     Hp, Wp = ops.maxpool_out_hw(H, W)
     assert tuple(want_pool.shape[1:3]) == (Hp, Wp)
     gate = torch.empty(N * C, dtype=torch.float32, device=DEV)
-    sync = torch.zeros(2 * N, dtype=torch.int32, device=DEV)
     obuf = torch.full((N, H, W, (C + 32) * cs), 7.0, dtype=torch.bfloat16, device=DEV)
     pbuf = torch.full((N, Hp, Wp, (C + 96) * cs), 7.0, dtype=torch.bfloat16, device=DEV)
     for rep in range(3):
         sums = s0.clone()
-        ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, sync, identity=idn_d, out=obuf[..., :C * cs], pooled=pbuf[..., 32 * cs:(32 + C) * cs], pair=pair)
+        ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, identity=idn_d, out=obuf[..., :C * cs], pooled=pbuf[..., 32 * cs:(32 + C) * cs], pair=pair)
         assert torch.equal(obuf[..., :C * cs], want), "rep %d: y differs" % rep
         assert torch.equal(pbuf[..., 32 * cs:(32 + C) * cs], want_pool), "rep %d: pooled map differs" % rep
-        assert int(sums.abs().sum()) == 0 and int(sync.abs().sum()) == 0, "the launch returns the sums and its counters to zero"
+        assert int(sums.abs().sum()) == 0, "the launch returns the sums to zero"
     assert bool((obuf[..., C * cs:] == 7.0).all()) and bool((pbuf[..., :32 * cs] == 7.0).all()) and bool((pbuf[..., (32 + C) * cs:] == 7.0).all())
     # y only, pooled only
     sums = s0.clone()
-    y_only = ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, sync, identity=idn_d, out=torch.empty_like(want), pair=pair)
+    y_only = ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, identity=idn_d, out=torch.empty_like(want), pair=pair)
     assert torch.equal(y_only, want)
     sums = s0.clone()
-    p_only = ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, sync, identity=idn_d, pooled=torch.empty_like(want_pool), pair=pair)
-    assert torch.equal(p_only, want_pool) and int(sync.abs().sum()) == 0
-    # as a hipGraph (the engine's steady state): the counters survive replays
+    p_only = ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, identity=idn_d, pooled=torch.empty_like(want_pool), pair=pair)
+    assert torch.equal(p_only, want_pool)
+    # as a hipGraph (the engine's steady state)
     sums = s0.clone()
     static_s = s0.clone()
     gr = torch.cuda.CUDAGraph()
     yg, pg = torch.empty_like(want), torch.empty_like(want_pool)
     with torch.cuda.graph(gr):
         sums.copy_(static_s)
-        ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, sync, identity=idn_d, out=yg, pooled=pg, pair=pair)
+        ops.ese_fused_nhwc(xd, fcw, fcb, sums, gate, identity=idn_d, out=yg, pooled=pg, pair=pair)
     for _ in range(3):
         yg.zero_(); pg.zero_()
         gr.replay()
@@ -179,14 +178,14 @@ def test_one_launch_ese_is_bitwise_the_gate_apply_and_pool_launches(hip_lib, pai
         assert torch.equal(yg, want) and torch.equal(pg, want_pool)
 
 
-def test_one_launch_ese_refuses_what_it_cannot_do(hip_lib):
+def test_fused_ese_pool_refuses_what_it_cannot_do(hip_lib):
     from far3d_amd import ops, lib as flib
     x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=DEV)
     fcw, fcb = torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)
-    sums, gate, sync = torch.zeros(1, 64, dtype=torch.int64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
+    sums, gate = torch.zeros(1, 64, dtype=torch.int64, device=DEV), torch.zeros(64, device=DEV)
     with pytest.raises(ValueError):
-        ops.ese_fused_nhwc(x, fcw, fcb, sums, gate, sync)                                   # nothing to write
+        ops.ese_fused_nhwc(x, fcw, fcb, sums, gate)                                   # nothing to write
     with pytest.raises(flib.Far3dHipError):
-        ops.ese_fused_nhwc(x, fcw, fcb, sums, gate, sync, pooled=torch.zeros(1, 3, 3, 64, dtype=torch.bfloat16, device=DEV))   # ceil-mode size is 2 x 2
+        ops.ese_fused_nhwc(x, fcw, fcb, sums, gate, pooled=torch.zeros(1, 3, 3, 64, dtype=torch.bfloat16, device=DEV))   # ceil-mode size is 2 x 2
     with pytest.raises(flib.Far3dHipError):
-        ops.ese_fused_nhwc(x[..., 4:], fcw[:60, :60].contiguous(), fcb[:60], sums, gate, sync, out=torch.zeros(1, 4, 4, 60, dtype=torch.bfloat16, device=DEV))   # 8-byte pieces
+        ops.ese_fused_nhwc(x[..., 4:], fcw[:60, :60].contiguous(), fcb[:60], sums, gate, out=torch.zeros(1, 4, 4, 60, dtype=torch.bfloat16, device=DEV))   # 8-byte pieces

@@ -2,7 +2,7 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"] or "stem_conv_kernel" in r["Kernel_Name"]]
 segs = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
 # whole benchmark frames only: a real frame has one aggregation launch per decoder layer (6); the segments at the end of
 # a bench.py trace are polluted by the kernel-timing replays (24 aggregation launches each) and are skipped

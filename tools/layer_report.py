@@ -31,14 +31,16 @@ for l in range(4):
 p = N*80*120
 layers += [("depth.c0", p, 256, 2304), ("depth.c1", p, 256, 2304), ("depth.cls", p, 51, 256)]
 rows = list(csv.DictReader(open(sys.argv[1])))
-idx = max(i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"])
-ig = [r for r in rows[idx:] if "igemm" in r["Kernel_Name"] or "conv3x3_p" in r["Kernel_Name"] or "gemm1x1" in r["Kernel_Name"]][:len(layers)]
+# a frame starts with the stem: far3d_stem_im2col (+ a GEMM) in the fp32 / pair modes, stem_conv_kernel (the fused stem_1, itself layer 0) in bf16
+idx = max(i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"] or "stem_conv_kernel" in r["Kernel_Name"])
+ig = [r for r in rows[idx:] if "igemm" in r["Kernel_Name"] or "conv3x3_p" in r["Kernel_Name"] or "gemm1x1" in r["Kernel_Name"] or "stem_conv_kernel" in r["Kernel_Name"]][:len(layers)]
 tot_t = tot_f = 0
 agg = {}
 for (name, npix, cout, K), r in zip(layers, ig):
     t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     fl = 2.0 * npix * cout * K
-    var = ("P" if "conv3x3" in r["Kernel_Name"] else "G" if "gemm1x1" in r["Kernel_Name"] else "D" if "dma" in r["Kernel_Name"] else "R") + r["Kernel_Name"].split("<")[1].split(">")[0].replace("unsigned short", "bf16").replace(" ", "")
+    var = "S(fused stem)" if "stem_conv_kernel" in r["Kernel_Name"] else \
+        ("P" if "conv3x3" in r["Kernel_Name"] else "G" if "gemm1x1" in r["Kernel_Name"] else "D" if "dma" in r["Kernel_Name"] else "R") + r["Kernel_Name"].split("<")[1].split(">")[0].replace("unsigned short", "bf16").replace(" ", "")
     blocks = int(r["Grid_Size_X"]) // 256 * int(r["Grid_Size_Y"])
     key = name.split(".")[0]
     a = agg.setdefault(key, [0.0, 0.0]); a[0] += t; a[1] += fl
