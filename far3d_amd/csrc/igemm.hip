@@ -76,6 +76,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     return FAR3D_OK;
   }
   const long Npix = (long)N * Ho * Wo;
+  FAR3D_CHECK_ARG(Npix < (1L << 31) - 4096 && (long)N * H * W < (1L << 31) - 4096, "far3d_conv2d_nhwc: %ld pixels: the kernels index pixels with 32 bits", Npix);
   // tile: 0 = auto.  (channels x pixels per workgroup) 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64, 5 = 64x256
   if (tile == 0) {   // fallback heuristic; far3d_amd/data/tuning_mi355x.json holds measured per-shape winners
     const long big = ((Npix + 127) / 128) * ((Cout + 127) / 128);

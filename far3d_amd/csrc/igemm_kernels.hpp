@@ -104,6 +104,15 @@ __device__ __forceinline__ void wait_vmcnt_all_() { asm volatile("s_waitcnt vmcn
 #define FAR3D_CONV_TS_END(P) do { } while (0)
 #endif
 
+// pixel index -> (image, pixel of the image).  p < 2^31 (checked at launch): a 32-bit division -- the 64-bit one this replaced costs
+// ~150 VALU instructions per call, and the row-store epilogue of the GEMM kernels called it once per 16-byte piece (16-32 times per thread
+// of a 256 x 256 tile: a third of that epilogue, tools/conv_phase_times.py, round 5)
+__device__ __forceinline__ void pix_split(long p, int HoWo, int& n, int& rem) {
+  const unsigned u = (unsigned)p;
+  n = (int)(u / (unsigned)HoWo);
+  rem = (int)(u - (unsigned)n * (unsigned)HoWo);
+}
+
 template <typename TC> struct Cfg;
 template <> struct Cfg<bf16_t> { static constexpr int E = 8, ROWB = 80, KSUB = 2; };
 template <> struct Cfg<float> { static constexpr int E = 4, ROWB = 144, KSUB = 4; };
@@ -270,7 +279,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& P, f32x16_t (&
   for (int j = 0; j < WN; ++j) {
     const long p = (long)p0 + (wn * WN + j) * 32 + l31;
     pn[j] = -1; ppix[j] = 0;
-    if (p < Npix) { pn[j] = (int)(p / HoWo); ppix[j] = (int)(p - (long)pn[j] * HoWo); }
+    if (p < Npix) pix_split(p, HoWo, pn[j], ppix[j]);
   }
   igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
 }
@@ -468,7 +477,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams P) {
     brow[c] = id / CPR; bcol[c] = id % CPR;
     const long p = (long)p0 + brow[c];
     if (p < Npix) {
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      int n, rem;
+      pix_split(p, HoWo, n, rem);
       bn[c] = n; boy[c] = (rem / P.Wo) * P.stride - P.pad; box[c] = (rem % P.Wo) * P.stride - P.pad;
     } else {
       bn[c] = -1; boy[c] = 0; box[c] = 0;
@@ -646,7 +656,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IgemmParams P) {
       const long p = (long)p0 + row;
       sdst[i] = BM * 64 + (q - GA) * 1024;
       if (p < Npix) {
-        const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+        int n, rem;
+      pix_split(p, HoWo, n, rem);
         sbase_[i] = reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride + lc * 8;
         soy[i] = (rem / P.Wo) * P.stride - P.pad; sox[i] = (rem % P.Wo) * P.stride - P.pad;
       } else {
@@ -1204,7 +1215,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
     const int g = wv + NW * i;
     const long p = (long)p0 + g * 16 + rg;
     if (p < Npix) {
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      int n, rem;
+      pix_split(p, HoWo, n, rem);
       bvoff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + lc * 8) * 2);
     } else {
       bvoff[i] = OOB;
@@ -1312,10 +1324,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
     constexpr int RING = NS * 2 * (BM + BP) * 64, OUTB = BP * (BM * (PAIR ? 4 : 2) + 16);
+    int ep_n0, ep_r0;
+    pix_split((long)p0, HoWo, ep_n0, ep_r0);
     epilogue_rows16<NW, WM, WN, BM, BP, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
-      const long p = (long)p0 + pl;
-      if (p >= Npix) return -1L;
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      if ((long)p0 + pl >= Npix) return -1L;
+      int n = ep_n0, rem = ep_r0 + pl;                 // (image, pixel) of the tile's first pixel + pl: no division per piece
+      while (rem >= HoWo) { rem -= HoWo; ++n; }
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
     }, (long)p0, RING > OUTB ? RING : OUTB);
     return;
@@ -1427,7 +1441,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
     const int row = (wv + NW * i) * 8 + rr, col = sl ^ ((row >> 1) & 7);
     const long p = (long)p0 + row;
     if (p < Npix) {
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      int n, rem;
+      pix_split(p, HoWo, n, rem);
       bvoff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + col * 8) * 2);
     } else {
       bvoff[i] = OOB;
@@ -1523,10 +1538,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
   if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
   if (P.y_rows16) {
     constexpr int RING = NS * (BM + BP) * 128, OUTB = BP * (BM * 2 + 16);
+    int ep_n0, ep_r0;
+    pix_split((long)p0, HoWo, ep_n0, ep_r0);
     epilogue_rows16<NW, WM, WN, BM, BP, false>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
-      const long p = (long)p0 + pl;
-      if (p >= Npix) return -1L;
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      if ((long)p0 + pl >= Npix) return -1L;
+      int n = ep_n0, rem = ep_r0 + pl;                 // (image, pixel) of the tile's first pixel + pl: no division per piece
+      while (rem >= HoWo) { rem -= HoWo; ++n; }
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
     }, (long)p0, RING > OUTB ? RING : OUTB);
     FAR3D_CONV_TS_END(P);
@@ -1659,7 +1676,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
     } else {
       const long p = (long)p0 + row;
       if (p < Npix) {
-        const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+        int n, rem;
+      pix_split(p, HoWo, n, rem);
         voff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + col * 8) * 2);
       } else {
         voff[i] = OOB;
@@ -1737,10 +1755,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
     constexpr int RING = NSA * ASTG + NSB * BSTG, OUTB = BP * (BM * 2 + 16);
     FAR3D_CONV_TS(P, 4);
     __syncthreads();         // the ring may fill the whole LDS: the epilogue's sum scratch (zeroed before its first barrier) lies inside it
+    int ep_n0, ep_r0;
+    pix_split((long)p0, HoWo, ep_n0, ep_r0);
     epilogue_rows16<NW, WM, WN, BM, BP, false>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
-      const long p = (long)p0 + pl;
-      if (p >= Npix) return -1L;
-      const int n = (int)(p / HoWo), rem = (int)(p - (long)n * HoWo);
+      if ((long)p0 + pl >= Npix) return -1L;
+      int n = ep_n0, rem = ep_r0 + pl;                 // (image, pixel) of the tile's first pixel + pl: no division per piece
+      while (rem >= HoWo) { rem -= HoWo; ++n; }
       return (long)n * P.y_img_stride + (long)rem * P.ldy;
     }, (long)p0, OUTB);      // the sum scratch sits right behind the staged tile (the ring is dead by then)
     (void)RING;
