@@ -225,6 +225,19 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
         default: done = false;
       }
     }
+    // 3x3 / stride 2 / pad 1 on the LDS-patch kernel (round 5; de-interleaved patch rows): (channels x output rows of 32 pixels, waves)
+    if (!done && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1) {
+      done = true;
+      switch (tile) {
+        case 30: rc = launch_conv3x3_pipe<4, 2, 1, 2, 2, 1, 1, false, 2>(P, st); break;   // 128 x 4 rows, 8 waves
+        case 31: rc = launch_conv3x3_pipe<2, 2, 1, 1, 2, 1, 1, false, 2>(P, st); break;   // 64 x 2 rows, 4 waves
+        case 32: rc = launch_conv3x3_pipe<4, 2, 1, 1, 2, 1, 1, false, 2>(P, st); break;   // 128 x 2 rows, 8 waves
+        case 33: rc = launch_conv3x3_pipe<2, 4, 1, 1, 2, 1, 1, false, 2>(P, st); break;   // 64 x 4 rows, 8 waves
+        case 34: rc = launch_conv3x3_pipe<2, 2, 1, 2, 2, 1, 1, false, 2>(P, st); break;   // 64 x 4 rows, 4 waves
+        case 35: rc = launch_conv3x3_pipe<4, 2, 1, 2, 3, 1, 1, false, 2>(P, st); break;   // 30 with a 3-deep weight ring
+        default: done = false;
+      }
+    }
     if (done) {
       if (rc) return rc;
       FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");

@@ -772,9 +772,9 @@ static int launch_igemm_dma(const IgemmParams& P, hipStream_t st) {
 // lo*hi' + hi*lo' + hi*hi' (NT = 3) from four fragment sets -- 3 MFMAs per 2+2 fragment reads instead of 1 per 1+1, so the
 // split mode is LESS LDS-bound than plain bf16.  NT = 1 with PAIR reads only the hi planes (a single-bf16 layer inside a
 // pair-stored network; the per-layer precision sweep of tools/precision_sweep.py).
-template <int WM, int WN, int KY, int POFF, int WOFF, int TAPB, int NTAPS, int NT, int PPS, int WPS, typename Dma>   // NTAPS: 3 = one kernel row, 9 = all taps
+template <int WM, int WN, int KY, int POFF, int WOFF, int TAPB, int NTAPS, int NT, int PPS, int WPS, int STRIDE = 1, typename Dma>   // NTAPS: 3 = one kernel row, 9 = all taps
 __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, const int (&aaddr)[2][WM],
-                                                     const int (&baddr)[2][WN + 2][3], f32x16_t (&acc)[WM][WN], Dma dma) {
+                                                     const int (&baddr)[2][STRIDE * (WN - 1) + 3][3], f32x16_t (&acc)[WM][WN], Dma dma) {
   constexpr int PL = NT == 3 ? 2 : 1;          // planes read per chunk: [0] hi (or plain bf16), [1] lo
   u32x4_t af[2][PL][WM], bf[2][PL][WN];
 #pragma unroll
@@ -782,7 +782,7 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
 #pragma unroll
     for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + pl * WPS + aaddr[0][i]);
 #pragma unroll
-    for (int j = 0; j < WN; ++j) bf[0][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + pl * PPS + baddr[0][j + KY][0]);
+    for (int j = 0; j < WN; ++j) bf[0][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + pl * PPS + baddr[0][STRIDE * j + KY][0]);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -795,7 +795,7 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
 #pragma unroll
         for (int i = 0; i < WM; ++i) af[nxt][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + WOFF + tp * TAPB + pl * WPS + aaddr[kk][i]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bf[nxt][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + pl * PPS + baddr[kk][j + KY + tp / 3][tp % 3]);
+        for (int j = 0; j < WN; ++j) bf[nxt][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + POFF + pl * PPS + baddr[kk][STRIDE * j + KY + tp / 3][tp % 3]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the next fragments' reads ahead of this iteration's MFMAs
@@ -827,12 +827,18 @@ __device__ __forceinline__ void patch_step_pipelined(const unsigned char* smem, 
 // chunk, 9 taps: a third of the barriers, for the layers too small to fill the chip with more than one workgroup per CU).
 // NT / PAIR: see patch_step_pipelined; with PAIR the pointers / strides of x, w (and of y when y_dt is the pair code) count bf16
 // elements of the 2C-wide stored rows.
-template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false>
+// STRIDE 2 (round 5; 3x3 / stride 2 / pad 1: VoVNet stem_3, the extra FPN level): the patch is (2 TH + 1) rows of 65 input columns, and
+// the DMA lands every patch row DE-INTERLEAVED -- 33 even columns, then 32 odd ones (the source address of an LDS slot is free: a DMA piece
+// is lane-linear on the LDS side only) -- so that the 32 output pixels of a fragment read 32 CONSECUTIVE slots for every tap (kx = 0: even
+// block at l, kx = 1: odd block at l, kx = 2: even block at l + 1), exactly the conflict-free pattern of the stride-1 kernel.
+template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false, int STRIDE = 1>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParams P, int tiles_x, int tiles_y) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   FAR3D_CONV_TS_ENTRY(P);
   constexpr int NW = WGM * WGN;                      // waves per workgroup (4, 8 or 16)
-  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
+  static_assert(STRIDE == 1 || (STRIDE == 2 && RPS == 1), "stride 2: one kernel row per step");
+  constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = STRIDE == 1 ? 34 : 66, PH = STRIDE * TH + 3 - STRIDE, PPIX = PW * PH;
+  constexpr int RB = STRIDE * (WN - 1) + 3;          // patch rows a wave's WN output rows touch
   constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024, GPL = (PG + NW - 1) / NW;
   constexpr int TPSN = 3 * RPS;                      // taps per barrier step
   constexpr int GA = BM / 16, WSLOTS = TPSN * GA, GWL = (WSLOTS + NW - 1) / NW, WST = BM * 64;
@@ -875,8 +881,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     pdst[i] = q * 1024;
     const int idx = q * 16 + rg;
     const int py = idx / PW, px = idx - py * PW;
-    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool ok = idx < PPIX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    // stride 2: slot px of a patch row holds input column 2 px (px < 33: the even block) or 2 (px - 33) + 1 (the odd block; slot 65 is unused)
+    const int pcol = STRIDE == 1 ? px : (px < 33 ? 2 * px : 2 * (px - 33) + 1);
+    const int iy = STRIDE * y0 - 1 + py, ix = STRIDE * x0 - 1 + pcol;
+    const bool ok = idx < PPIX && pcol <= 64 && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
     pvoff[i] = ok ? (unsigned)((((long)iy * P.W + ix) * P.ldx + lc * 8) * 2) : OOB;
   }
   int wtap[GWL];                        // weight slot = (tap of the kernel row, 16-row group); slots past WSLOTS are skipped
@@ -921,7 +929,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read addresses (bytes from the plane base): [k-half][...]; the k-half flips bit 5 of the swizzled chunk
-  int aaddr[2][WM], baddr[2][WN + 2][3];
+  int aaddr[2][WM], baddr[2][RB][3];
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int r = (wm * WM + i) * 32 + l31;
@@ -929,10 +937,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     aaddr[1][i] = aaddr[0][i] ^ 32;
   }
 #pragma unroll
-  for (int r = 0; r < WN + 2; ++r)
+  for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int idx = (wn * WN + r) * PW + l31 + kx;
+      const int slot = STRIDE == 1 ? l31 + kx : (kx == 1 ? 33 + l31 : l31 + (kx >> 1));
+      const int idx = (STRIDE * wn * WN + r) * PW + slot;
       baddr[0][r][kx] = idx * 64 + ((hi ^ ((idx >> 2) & 3)) << 4);
       baddr[1][r][kx] = baddr[0][r][kx] ^ 32;
     }
@@ -981,7 +990,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     constexpr int NXT = ((STG) + AHEAD) % NSW;                                                                         \
     constexpr int PIECES = (GWL + GPL) * PLD, PPI = (PIECES + 17) / 18;                                                \
-    patch_step_pipelined<WM, WN, 0, (STG) * PLD * PATCH_B, WBASE + (STG) * TPSN * TAPB, TAPB, 9, NT, PATCH_B, WST>(    \
+    patch_step_pipelined<WM, WN, 0, (STG) * PLD * PATCH_B, WBASE + (STG) * TPSN * TAPB, TAPB, 9, NT, PATCH_B, WST, STRIDE>(    \
       smem, aaddr, baddr, acc, [&](int it) __attribute__((always_inline)) {                                            \
         FAR3D_DMA_PIECES(more, w_piece(sl, pl, (CH) + AHEAD, 0, NXT), more, patch_piece(sl, pl, (CH) + AHEAD, NXT))    \
       });                                                                                                              \
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
     constexpr int wk = (KY + NSW - 1) % 3, ws = NSW == 2 ? (STG ^ 1) : wk;                                             \
     const bool do_w = wc < nchunks, do_p = KY == 0 && more;                                                            \
     constexpr int PIECES = (GWL + GPL) * PLD, PPI = (PIECES + 5) / 6;                                                  \
-    patch_step_pipelined<WM, WN, KY, (PAR) * PLD * PATCH_B, WBASE + STG * 3 * TAPB, TAPB, 3, NT, PATCH_B, WST>(        \
+    patch_step_pipelined<WM, WN, KY, (PAR) * PLD * PATCH_B, WBASE + STG * 3 * TAPB, TAPB, 3, NT, PATCH_B, WST, STRIDE>(        \
       smem, aaddr, baddr, acc, [&](int it) __attribute__((always_inline)) {                                            \
         FAR3D_DMA_PIECES(do_w, w_piece(sl, pl, wc, wk, ws), do_p, patch_piece(sl, pl, (CH) + 1, (PAR) ^ 1))            \
       });                                                                                                              \
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   if (P.y_rows16) {
     epilogue_rows16<NW, WM, WN, BM, TH * 32, PAIR>(P, smem, acc, m0, wm, wn, l31, hi, [&](int pl) -> long {
       const int y = y0 + (pl >> 5), x = x0 + (pl & 31);
-      return (y < P.H && x < P.W) ? (long)n * P.y_img_stride + ((long)y * P.W + x) * P.ldy : -1L;
+      return (y < P.Ho && x < P.Wo) ? (long)n * P.y_img_stride + ((long)y * P.Wo + x) * P.ldy : -1L;
     });
     FAR3D_CONV_TS_END(P);
     return;
@@ -1062,27 +1071,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int y = y0 + wn * WN + j, x = x0 + l31;
-    pn[j] = (y < P.H && x < P.W) ? n : -1;
-    ppix[j] = y * P.W + x;
+    pn[j] = (y < P.Ho && x < P.Wo) ? n : -1;
+    ppix[j] = y * P.Wo + x;
   }
   igemm_epilogue_px<WM, WN>(P, acc, pn, ppix, m0, wm, hi);
 #endif
 }
 
-template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false>
+template <int WGM, int WGN, int WM, int WN, int NSW = 2, int RPS = 1, int NT = 1, bool PAIR = false, int STRIDE = 1>
 static int launch_conv3x3_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PLD = NT == 3 ? 2 : 1;
-  constexpr int PG = (34 * (TH + 2) + 15) / 16;
+  constexpr int PG = ((STRIDE == 1 ? 34 : 66) * (STRIDE * TH + 3 - STRIDE) + 15) / 16;
   constexpr size_t lds_ring = (size_t)(RPS == 3 ? NSW : 2) * PLD * PG * 1024 + (size_t)NSW * 3 * RPS * PLD * BM * 64;
   constexpr size_t lds_out = (size_t)TH * 32 * (BM * (PAIR ? 4 : 2) + 16);
   constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   static_assert(lds <= 163840, "LDS budget");
-  const int tiles_x = (P.W + 31) / 32, tiles_y = (P.H + TH - 1) / TH;
+  const int tiles_x = (P.Wo + 31) / 32, tiles_y = (P.Ho + TH - 1) / TH;
   dim3 grid((unsigned)(P.N * tiles_x * tiles_y), (unsigned)((P.Cout + BM - 1) / BM));
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds > 65536)
-    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
-  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR, STRIDE>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
+  hipLaunchKernelGGL((conv3x3_pipe_kernel<WGM, WGN, WM, WN, NSW, RPS, NT, PAIR, STRIDE>), grid, dim3(64 * WGM * WGN), lds, st, P, tiles_x, tiles_y);
   return 0;
 }
 

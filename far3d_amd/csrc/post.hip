@@ -68,31 +68,40 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
     ++pass;                                                                \
     dst = tot_;                                                            \
   }
-  // K-th largest key by bisection; invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
+  // Round 5: the bisection stops as soon as SOME cut keeps between K and CAPW entries (`key >= mid` selects a superset of the top-K that
+  // holds every entry of any tie group it touches), and the winners are ordered by a counting rank instead of a bitonic network: the
+  // top-K is the first K of that order.  32 passes + 45 barrier stages became ~10 passes + 2 barriers on the frame's 40 k logits
+  // (decode 47 -> us, memory top-k 24 -> us; profiles/r5).  A key distribution with no such cut (more than CAPW entries tied at the
+  // K-th place) runs the bisection to its end and takes the exact tie rule below -- same result either way.
+  const int CAPW = min(TOPK_MAXK, max(2 * K, 256));
+  // invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
   unsigned long long lo = 1ull, hi = 0x100000000ull;
   int n_ge = -1;
+  bool window = false;
   while (hi - lo > 1ull) {
     const unsigned mid = (unsigned)(lo + ((hi - lo) >> 1));
     int c;
     TOPK_COUNT(c, key >= mid);
-    if (c == K) { lo = mid; n_ge = K; break; }        // `key >= mid` selects exactly K: the cut need not be a key itself
+    if (c >= K && c <= CAPW) { lo = mid; n_ge = c; window = true; break; }      // block-uniform
     if (c > K) lo = mid; else hi = mid;
   }
   const unsigned kth = (unsigned)lo;
   int n_gt = 0;
-  if (n_ge < 0) TOPK_COUNT(n_ge, key >= kth);
   int idx_cut = 0x7fffffff;                           // among the keys == kth, keep indices <= idx_cut
-  if (n_ge > K) {                                     // ties at the cut (block-uniform): keep the lowest indices
-    if (kth != 0xffffffffu) TOPK_COUNT(n_gt, key > kth);
-    const int need = K - n_gt;
-    int ilo = -1, ihi = n - 1;                        // count(idx <= ilo) < need <= count(idx <= ihi)
-    while (ihi - ilo > 1) {
-      const int mid = ilo + ((ihi - ilo) >> 1);
-      int c;
-      TOPK_COUNT(c, key == kth && idx <= mid);
-      if (c >= need) ihi = mid; else ilo = mid;
+  if (!window) {
+    if (n_ge < 0) TOPK_COUNT(n_ge, key >= kth);
+    if (n_ge > K) {                                   // ties at the cut (block-uniform): keep the lowest indices
+      if (kth != 0xffffffffu) TOPK_COUNT(n_gt, key > kth);
+      const int need = K - n_gt;
+      int ilo = -1, ihi = n - 1;                      // count(idx <= ilo) < need <= count(idx <= ihi)
+      while (ihi - ilo > 1) {
+        const int mid = ilo + ((ihi - ilo) >> 1);
+        int c;
+        TOPK_COUNT(c, key == kth && idx <= mid);
+        if (c >= need) ihi = mid; else ilo = mid;
+      }
+      idx_cut = ihi;
     }
-    idx_cut = ihi;
   }
 #undef TOPK_COUNT
   if (t == 0) s_cnt = 0;
@@ -100,29 +109,29 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int i = t + k * TOPK_THREADS;
-    if (v[k] > kth || (v[k] == kth && i <= idx_cut)) {
+    if (v[k] > kth || (v[k] == kth && (window || i <= idx_cut))) {
       const int pos = atomicAdd(&s_cnt, 1);
       if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)v[k] << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
     }
   }
-  // bitonic sort, descending, of the next power of two >= K entries (padding 0 sorts last)
-  int Kp = 1;
-  while (Kp < K) Kp <<= 1;
-  for (int i = K + t; i < Kp; i += TOPK_THREADS) sel[i] = 0ull;
   __syncthreads();
-  for (int sz = 2; sz <= Kp; sz <<= 1) {
-    for (int st = sz >> 1; st > 0; st >>= 1) {
-      for (int i = t; i < Kp; i += TOPK_THREADS) {
-        const int j = i ^ st;
-        if (j > i) {
-          const unsigned long long a = sel[i], b = sel[j];
-          const bool desc = (i & sz) == 0;
-          if (desc ? (a < b) : (a > b)) { sel[i] = b; sel[j] = a; }
-        }
-      }
-      __syncthreads();
+  // counting rank, descending: entry e goes to position #{e' > e} (the entries are distinct: the index is part of them).  Every thread
+  // of a wave reads the same LDS words (broadcast), 4 entries per iteration; threads past the count pad the tail with zeros first.
+  const int c = min(s_cnt, TOPK_MAXK);
+  __shared__ __attribute__((aligned(16))) unsigned long long s_tmp[TOPK_MAXK + 4];
+  const unsigned long long mine = t < c ? sel[t] : 0ull;
+  if (t < c) s_tmp[t] = mine;
+  if (t < 4) s_tmp[c + t] = 0ull;
+  __syncthreads();
+  if (t < c) {
+    int r = 0;
+    for (int j = 0; j < c; j += 4) {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(s_tmp + j), b = *reinterpret_cast<const ulonglong2*>(s_tmp + j + 2);
+      r += (a.x > mine ? 1 : 0) + (a.y > mine ? 1 : 0) + (b.x > mine ? 1 : 0) + (b.y > mine ? 1 : 0);
     }
+    sel[r] = mine;
   }
+  __syncthreads();
 }
 
 template <int MAXV>

@@ -14,7 +14,9 @@ have produced), and the head -- eager on the first frame of a scene, a hipGraph 
 groups.  Same kernels on the same per-camera data as the plain engine; results equal up to the tile choice of layers whose tile table
 entry depends on the pixel count (fp32: identical accumulation order; tests/test_latency_gpu.py).  Static top-K proposal mode only.
 
-Opt-in and not yet run on a GPU (written after the round's GPU minutes were spent): tests gated by FAR3D_TEST_EXPERIMENTAL=1.
+Opt-in (`bench.py --latency-groups 2` reports it as protocol.sync_per_frame_groups beside the engine's own figure).  Measured in round 5
+(profiles/r5): 6.90 ms per frame against 7.08 ms for the plain engine on the same box -- less than the 0.6 ms the stage times promised:
+two camera groups side by side slow each other down more than two independent jobs did.
 """
 import torch
 

@@ -156,6 +156,31 @@ def test_conv3x3_pipelined_patch_kernel(hip_lib, tile):
         _close(y.cpu().permute(0, 3, 1, 2), want, Cin * 9)
 
 
+@pytest.mark.parametrize("tile", [30, 31, 32, 33, 34, 35])
+def test_conv3x3_stride2_patch_kernel(hip_lib, tile):
+    """3x3 / stride 2 / pad 1 on the LDS-patch kernel (patch rows de-interleaved into even and odd input columns): odd and even input
+    sizes (the last window column / row falls on the padding or not), ragged tiles, Cout % BM != 0, input read as a channel slice of a
+    wider buffer, bf16 output through the coalesced row stores into a channel slice and fp32 output through the direct epilogue."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(900 + tile)
+    for (N, Cin, Cout, H, W) in ((2, 64, 128, 22, 38), (1, 32, 200, 17, 67), (3, 96, 64, 9, 130), (1, 64, 128, 64, 96)):
+        x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        want = _ref_conv(x, w, b, 2, 1, "relu", torch.bfloat16)
+        pc = ops.PackedConv(w, b, stride=2, pad=1, dtype=torch.bfloat16, device=DEV)
+        buf = torch.zeros(N, H, W, Cin + 32, dtype=torch.bfloat16, device=DEV)
+        buf[..., 16:16 + Cin] = x.permute(0, 2, 3, 1).to(torch.bfloat16).to(DEV)
+        y = ops.conv2d_nhwc(buf[..., 16:16 + Cin], pc, act="relu", out_dtype=torch.float32, tile=tile)
+        assert tuple(y.shape) == (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout)
+        _close(y.cpu().permute(0, 3, 1, 2), want, Cin * 9)
+        ob = torch.full((N, y.shape[1], y.shape[2], Cout + 24), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.conv2d_nhwc(buf[..., 16:16 + Cin], pc, out=ob[..., 8:8 + Cout], act="relu", tile=tile)
+        got = ob[..., 8:8 + Cout].float().cpu().permute(0, 3, 1, 2)
+        assert (got - want).abs().max().item() < 2e-6 * (Cin * 9) ** 0.5 * max(1.0, want.abs().max().item()) + 1e-5 + want.abs().max().item() * 2 ** -8
+        assert (ob[..., :8] == 7.0).all() and (ob[..., 8 + Cout:] == 7.0).all()
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 18, 43, 46, 48, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 110, 111, 112, 113, 114, 115, 116, 117, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129, 140, 141, 142, 143, 144, 145])
 def test_conv1x1_bf16_dma_partial_last_step(hip_lib, tile):
     """1x1 conv over K = 160 / 1056 / 2144 channels: K chunk counts (5, 33, 67) that do not divide the chunks-per-step."""

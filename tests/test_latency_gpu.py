@@ -1,14 +1,12 @@
 """GPU: far3d_amd.latency.CameraGroupFrame (one frame's per-camera stages as camera groups on parallel streams) against the plain
 engine on the golden toy sequence (its cameras split into two groups), eager and as hipGraphs, through a scene change.
-Written after round 4's GPU minutes were spent: runs only with FAR3D_TEST_EXPERIMENTAL=1 until it has passed once on a GPU."""
-import os
+First run on a GPU in round 5 (3 passed, profiles/r5); part of the default suite since."""
 
 import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("FAR3D_TEST_EXPERIMENTAL") != "1", reason="not yet run on a GPU (FAR3D_TEST_EXPERIMENTAL=1)")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("precision,use_graph", [("fp32", False), ("fp32", True), ("bf16", True)])

@@ -29,6 +29,18 @@ def test_topk_matches_torch(hip_lib, n, K):
     assert np.array_equal(idx.numpy(), order)
 
 
+@pytest.mark.parametrize("n,K,levels", [(5000, 100, 3), (40000, 300, 2), (1544, 256, 1), (2000, 700, 5)])
+def test_topk_with_huge_tie_groups_takes_the_exact_tie_rule(hip_lib, n, K, levels):
+    """Values drawn from a handful of levels: the K-th place sits inside a tie group far larger than the window of the fast path (no cut
+    keeps between K and max(2K, 256) entries), so the bisection runs to its end and the index bisection decides -- lowest indices first."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(n * 3 + K)
+    v = torch.randint(0, levels, (n,), generator=g).float() * 0.5 - 1.0
+    idx, val = ops.topk(v.to(DEV), K, with_values=True)
+    order = np.lexsort((np.arange(n), -v.numpy()))[:K]
+    assert np.array_equal(idx.cpu().numpy(), order) and torch.equal(val.cpu(), v[torch.as_tensor(order)])
+
+
 def test_decode_topk_matches_oracle_decode(hip_lib):
     from far3d_amd import ops
     from oracle import far3d_oracle

@@ -33,9 +33,11 @@ def test_tuning_table_names_only_implemented_tiles(name):
         assert cout > 0 and cin > 0 and npix > 0 and k in (1, 3) and stride in (1, 2), key
         generic = ids["igemm"] | ids["dma"]                      # any kernel size / stride (bf16, Cin % 32 == 0 for the DMA ring)
         if k == 3 and stride == 1:
-            allowed = generic | ids["patch"] | ids["pipe3"]
+            allowed = generic | ids["patch"] | {t for t in ids["pipe3"] if not 30 <= t <= 39}
         elif k == 1 and stride == 1:
             allowed = generic | ids["gemm"]
+        elif k == 3 and stride == 2:
+            allowed = generic | {t for t in ids["pipe3"] if 30 <= t <= 39}
         else:
             allowed = generic
         assert tile in allowed, "tile %d is not dispatchable for layer %s" % (tile, key)

@@ -113,6 +113,8 @@ def main():
         fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         res = {}
         tiles = ((0, 1, 2, 3, 4, 18, 43, 46, 48) if not (k == 3 and stride == 1) else (0,)) + ((70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 110, 111, 114, 116, 117, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129, 140, 141, 142, 143, 144, 145) if (k == 1 and stride == 1) else ()) + ((50, 52, 60, 61, 63, 64, 65, 90, 92, 93, 96, 100, 101, 102, 103, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139) if (k == 3 and stride == 1) else ())
+        if k == 3 and stride == 2 and not (x3 or pair):
+            tiles = tiles + (30, 31, 32, 33, 34, 35)
         if x3:
             tiles = (0, 1, 2, 3, 4, 5)
         if pair:
