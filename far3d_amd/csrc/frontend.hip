@@ -192,6 +192,7 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
       if (t < c) {
         const unsigned long long mine = s_ent[t];
         int r = 0;
+#pragma unroll 8
         for (int j = 0; j < c; j += 4) {
           const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(s_ent + j), b = *reinterpret_cast<const ulonglong2*>(s_ent + j + 2);
           r += (a.x > mine ? 1 : 0) + (a.y > mine ? 1 : 0) + (b.x > mine ? 1 : 0) + (b.y > mine ? 1 : 0);
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
       if (t < cap) {
         const int mine = s_kidx[t];
         int r = 0;
+#pragma unroll 8
         for (int j = 0; j < cap; ++j) r += s_kidx[j] < mine ? 1 : 0;
         sel_idx[(long)n * cap + r] = mine;                                                   // ascending index order
       }

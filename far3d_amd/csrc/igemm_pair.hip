@@ -4,6 +4,7 @@
 //   100 + t  split products (3 MFMAs per product, NT = 3): 3x3/s1/p1 t in 50..67, 90..97; 1x1/s1 t in 70..81
 //   200 + t  hi planes only (one bf16 product, NT = 1), a subset of the shapes
 //   1..5     register-staged kernel (any kernel size / stride), split products
+//   330, 331 3x3 / stride 2 / pad 1 on the LDS-patch kernel, split products (round 5)
 #include "igemm_kernels.hpp"
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
@@ -75,6 +76,14 @@ int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
       case 260: return launch_conv3x3_pipe<2, 4, 1, 2, 2, 1, 1, true>(P, st);   // 64 x 8 rows, 8 waves
       case 265: return launch_conv3x3_pipe<1, 8, 1, 1, 2, 1, 1, true>(P, st);   // 32 x 8 rows, 8 waves
       case 252: return launch_conv3x3_pipe<1, 4, 1, 1, 2, 1, 1, true>(P, st);   // 32 x 4 rows, 4 waves
+      default: break;
+    }
+  }
+  const bool k3s2 = P.KH == 3 && P.KW == 3 && P.stride == 2 && P.pad == 1 && P.Ho == (P.H - 1) / 2 + 1 && P.Wo == (P.W - 1) / 2 + 1;
+  if (k3s2) {      // 3x3 / stride 2 / pad 1 on the LDS-patch kernel (de-interleaved patch rows), split products: the LDS holds 2 output rows
+    switch (tile) {
+      case 330: return launch_conv3x3_pipe<2, 2, 1, 1, 2, 1, 3, true, 2>(P, st);   // 64 x 2 rows, 4 waves
+      case 331: return launch_conv3x3_pipe<1, 2, 1, 1, 2, 1, 3, true, 2>(P, st);   // 32 x 2 rows, 2 waves
       default: break;
     }
   }

@@ -125,7 +125,8 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
   __syncthreads();
   if (t < c) {
     int r = 0;
-    for (int j = 0; j < c; j += 4) {
+#pragma unroll 8
+    for (int j = 0; j < c; j += 4) {           // unrolled: the broadcast reads of 32 entries are in flight together (LDS latency, not bandwidth)
       const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(s_tmp + j), b = *reinterpret_cast<const ulonglong2*>(s_tmp + j + 2);
       r += (a.x > mine ? 1 : 0) + (a.y > mine ? 1 : 0) + (b.x > mine ? 1 : 0) + (b.y > mine ? 1 : 0);
     }

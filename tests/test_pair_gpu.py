@@ -104,8 +104,8 @@ def test_pair_conv_small_cout_f32_heads_and_swish(hip_lib):
     assert (got.double() - want).abs().max().item() < _bound(2304, x, w)[0] + want.abs().max().item() * 2.0 ** -15
 
 
-def test_pair_conv_stride2_register_staged(hip_lib):
-    """Strided convs (stem 3, the extra FPN level) take the register-staged kernel with pair input."""
+def test_pair_conv_stride2(hip_lib):
+    """Strided convs (stem 3, the extra FPN level) with pair input: the register-staged kernel (1-5) and the LDS-patch kernel (330, 331)."""
     from far3d_amd import ops
     g = torch.Generator().manual_seed(12)
     N, Cin, Cout, H, W = 2, 64, 128, 21, 30
@@ -115,7 +115,7 @@ def test_pair_conv_stride2_register_staged(hip_lib):
     want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1).relu()
     pc = ops.PackedConv(w, b, stride=2, pad=1, dtype=torch.float32, device=DEV, compute="bf16x3")
     xin = ops.pair_from_float(x.permute(0, 2, 3, 1)).to(DEV)
-    for tile in (0, 1, 2, 3, 4, 5):
+    for tile in (0, 1, 2, 3, 4, 5, 330, 331):          # 330 / 331: the LDS-patch kernel with de-interleaved patch rows (round 5)
         got = ops.pair_to_float(ops.conv2d_nhwc(xin, pc, act="relu", tile=tile)).cpu().permute(0, 3, 1, 2)
         assert tuple(got.shape) == (N, Cout, 11, 15)
         assert (got.double() - want).abs().max().item() < _bound(Cin * 9, x, w)[0] + want.abs().max().item() * 2.0 ** -16, tile

@@ -72,5 +72,6 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
     for key, tile in table.items():
         cout, cin, k, stride, npix = (int(v) for v in key.split(","))
         assert cin % 32 == 0, key
-        allowed = ids["igemm"] | (ids["pipe3"] if (k == 3 and stride == 1) else ids["gemm"] if (k == 1 and stride == 1) else set())
+        allowed = ids["igemm"] | ({t for t in ids["pipe3"] if t < 300} if (k == 3 and stride == 1) else ids["gemm"] if (k == 1 and stride == 1) else
+                                  {t for t in ids["pipe3"] if t >= 330} if (k == 3 and stride == 2) else set())
         assert tile in allowed and not 200 <= tile < 300, "tile %d is not a split-product tile for layer %s" % (tile, key)

@@ -119,7 +119,8 @@ def main():
             tiles = (0, 1, 2, 3, 4, 5)
         if pair:
             tiles = (0, 150, 152, 154, 155, 157, 160, 161, 162, 163, 164, 165, 166, 167, 168, 191, 192, 193, 197) if (k == 3 and stride == 1) else \
-                    ((0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181) if (k == 1 and stride == 1) else (0, 1, 2, 3, 4, 5))
+                    ((0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181) if (k == 1 and stride == 1) else
+                     (0, 1, 2, 3, 4, 5, 330, 331) if (k == 3 and stride == 2) else (0, 1, 2, 3, 4, 5))
         if k == 3 and stride == 1 and os.environ.get("EXTRA_TILES"):
             tiles = tiles + tuple(int(v) for v in os.environ["EXTRA_TILES"].split(","))
         # SUMS=1: time the 1x1 layers WITH the channel sums of the eSE fusion in their epilogue (GEMM tiles only, Ho*Wo >= 512)
