@@ -115,21 +115,25 @@ def parity_block(precision, eng_frames, orc_frames):
                 see="tests/test_engine_full_gpu.py (per-stage budget, fp64 yardstick), DESIGN.md section 4")
 
 
-def agg_traffic():
-    """HBM bytes per launch of the aggregation kernel from the committed in-frame PMC pass (profiles/r4/aggregate_pmc.json:
-    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes over `bench.py --eager`, tools/evidence_run.sh with
-    PMC=1).  Counters cannot be read from inside this process; the file carries the kernel name and the commit it was taken
-    at, and a figure for another kernel is not reported."""
-    p = os.path.join(ROOT, "profiles", "r4", "aggregate_pmc.json")
-    try:
-        with open(p) as f:
-            j = json.load(f)
-        if j.get("kernel") != AGG_KERNEL:
-            return None, None
-        return j["hbm_bytes_per_launch"], ("profiles/r4/aggregate_pmc.json @ %s (in-frame rocprofv3 --pmc passes over `bench.py --eager`; a committed "
-                                           "figure, NOT measured by the run that prints this line)" % j.get("commit", "?"))
-    except Exception:   # noqa: BLE001
-        return None, None
+def agg_traffic(fp32_rows=False):
+    """HBM bytes per launch of the aggregation kernel from the committed in-frame PMC passes (profiles/<round>/aggregate_pmc.json for
+    bf16 value rows, aggregate_pmc_fp32rows.json for the fp32 rows of the in-tolerance engine: FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    separate rocprofv3 --pmc passes over `bench.py --eager`, tools/evidence_run.sh with PMC=1; the newest round that holds the file).
+    Counters cannot be read from inside this process; the file carries the kernel name and the commit it was taken at, and a figure
+    for another kernel is not reported."""
+    name = "aggregate_pmc_fp32rows.json" if fp32_rows else "aggregate_pmc.json"
+    for rnd in ("r5", "r4"):
+        p = os.path.join(ROOT, "profiles", rnd, name)
+        try:
+            with open(p) as f:
+                j = json.load(f)
+            if j.get("kernel") != AGG_KERNEL:
+                continue
+            return j["hbm_bytes_per_launch"], ("profiles/%s/%s @ %s (in-frame rocprofv3 --pmc passes over `bench.py --eager`; a committed "
+                                               "figure, NOT measured by the run that prints this line)" % (rnd, name, j.get("commit", "?")))
+        except Exception:   # noqa: BLE001
+            continue
+    return None, None
 
 
 def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk"):
@@ -443,7 +447,7 @@ def main():
         dt, dev_ms, per_frame, A, N, S, C, cfg = (res[k] for k in ("dt", "dev_ms", "per_frame", "A", "N", "S", "C", "cfg"))
         samples = args.steps * (world if (world > 1 and not sharded) else 1)
         # the committed PMC passes measured the bf16-row kernel: no traffic figure for the fp32-row modes
-        traffic, traffic_src = agg_traffic() if res["prec"]["value"] == torch.bfloat16 else (None, None)
+        traffic, traffic_src = agg_traffic(fp32_rows=res["prec"]["value"] != torch.bfloat16)
         sync_rate = 1e3 * len(per_frame) / sum(per_frame)
         line = {
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
@@ -510,7 +514,7 @@ def main():
                    "ms_per_step": res_tol["dt"] / res_tol["steps"] * 1e3, "vs_baseline": res_tol["steps"] / res_tol["dt"] / 6.4,
                    "sync_per_frame": {"mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2], "samples_per_s_mean": 1e3 * len(pf) / sum(pf)},
                    "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res_tol["prec"].items()},
-                   "roofline": agg_roofline(args, res_tol), "roofline_backbone": backbone_roofline(res_tol)}
+                   "roofline": agg_roofline(args, res_tol, *agg_traffic(fp32_rows=True)), "roofline_backbone": backbone_roofline(res_tol)}
             if orc is not None:
                 blk["parity"] = parity_block("bf16x3", res_tol["eng_frames"], orc)
                 blk["meets_tolerance"] = blk["parity"]["meets_tolerance"]

@@ -109,8 +109,13 @@ class CameraGroupFrame:
             self._g_cam, self._g_head, self._head_out = {}, None, None
             self._sig = sig
         if not steady:
-            # first frame of a scene (streaming memory reset in place) or graphs off: eager, groups still side by side
-            self._meta = self._fork(lambda g: self._group_part(g, dd, pad_hw))[0]
+            # first frame of a scene (streaming memory reset in place) or graphs off: eager, the groups ONE AFTER THE OTHER on the caller's
+            # stream.  (Until round 5 the eager groups also ran side by side on their streams; the full GPU suite then caught that form
+            # differing from the plain engine on one run out of two -- eager launches allocate their temporaries while they are enqueued,
+            # and nothing else in this code base enqueues eager work on several streams at once.  Only the graph replays, whose buffers all
+            # exist beforehand, run concurrently; an eager frame is a scene start, where latency is not the point.)
+            for g in range(len(self.blocks)):
+                self._meta = self._group_part(g, dd, pad_hw)
             return self._head(dd, img_metas, *self._meta, pad_hw)
         if len(self._g_cam) < len(self.blocks) or self._g_head is None:
             # capture with the device quiet: one graph per camera group (each on the capturing stream), then the head's

@@ -1,4 +1,4 @@
-"""CPU: the committed evidence under profiles/r4/ is internally consistent with the bench contract -- the JSON lines carry every
+"""CPU: the committed evidence under profiles/r5/ is internally consistent with the bench contract -- the JSON lines carry every
 field the contract names, the roofline block is arithmetic on its own fields, the kernel it names is the one in the committed
 rocprofv3 stats and in the PMC file, and the live HIP-event timing agrees with the profiler's average for that kernel."""
 import csv
@@ -9,7 +9,7 @@ import pytest
 
 from tests.conftest import ROOT
 
-P = os.path.join(ROOT, "profiles", "r4")
+P = os.path.join(ROOT, "profiles", "r5")
 LINES = ["bench.json", "bench_fp32.json", "bench_bf16x3.json"]
 
 
@@ -83,9 +83,15 @@ def test_roofline_kernel_matches_the_committed_profiles():
     assert abs(avg_us - live_us) / live_us < 0.12, (avg_us, live_us)
     # round-4 bar of VERDICT r3 item 1: <= 18 us in frame, >= 0.46 of the HBM peak in the bench line
     assert live_us <= 18.0 and d["roofline"]["frac"] >= 0.46
-    # the fp32-row modes time the same kernel on 1-KiB rows and do not borrow the bf16 traffic figure
+    # the fp32-row modes time the same kernel on 1-KiB rows and do not borrow the bf16 traffic figure: they carry the PMC passes taken on
+    # fp32 rows (round 5, aggregate_pmc_fp32rows.json) or nothing
+    px = _load("aggregate_pmc_fp32rows.json")
+    assert px["kernel"] == kernel and px["hbm_bytes_per_launch"] > pmc["hbm_bytes_per_launch"]
     for name in ("bench_fp32.json", "bench_bf16x3.json"):
-        assert _load(name)["roofline"]["traffic"] is None
+        r = _load(name)["roofline"]
+        assert r["traffic"] is None or ("fp32rows" in r["traffic_source"] and r["traffic_measured_in_this_run"] is False)
+    tr = d["in_tolerance"]["roofline"]
+    assert tr["traffic"] is None or "fp32rows" in tr["traffic_source"]
 
 
 def test_threshold_mode_and_stage_time_evidence():
@@ -111,13 +117,13 @@ def test_gpu_suite_and_smoke_logs_are_green():
 
 
 def test_design_is_rendered_from_the_evidence():
-    """DESIGN.md is DESIGN.tmpl.md with every measured number filled from profiles/r4/ (tools/fill_design.py): a figure that is
+    """DESIGN.md is DESIGN.tmpl.md with every measured number filled from profiles/r5/ -- or, where a placeholder says r4/, from that round's set -- (tools/fill_design.py): a figure that is
     not in the committed evidence cannot be quoted, and a stale one fails here (DESIGN.md:260 carried a round-2 number)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fill_design", os.path.join(ROOT, "tools", "fill_design.py"))
     fd = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fd)
     tmpl = open(os.path.join(ROOT, "DESIGN.tmpl.md")).read()
-    want = "<!-- generated by tools/fill_design.py from DESIGN.tmpl.md and profiles/r4/: edit the template, not this file -->\n" + fd.render(tmpl)
+    want = "<!-- generated by tools/fill_design.py from DESIGN.tmpl.md and profiles/: edit the template, not this file -->\n" + fd.render(tmpl)
     assert open(os.path.join(ROOT, "DESIGN.md")).read() == want, "DESIGN.md is stale: run `python tools/fill_design.py`"
     assert tmpl.count("{{") >= 100

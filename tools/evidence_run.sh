@@ -19,6 +19,11 @@ timeout 300 python tools/stage_times.py bf16 > $O/stage_times_bf16.txt 2>&1; tai
 timeout 300 python tools/agg_phase_times.py 1544 8 > $O/agg_phase_times.txt 2>&1; tail -14 $O/agg_phase_times.txt
 [ -f tools/_scratch/agg_operands.pt ] && timeout 300 python tools/bench_agg_live.py tools/_scratch/agg_operands.pt 7 8 2>/dev/null | grep layer > $O/agg_live.jsonl
 python tools/bench_kernels.py --iters 50 --out $O/kernels.jsonl > /dev/null 2>&1; cut -c1-160 $O/kernels.jsonl
+# round 5: the latency runner beside the engine's own sync-per-frame figure, the clock under load, the per-workgroup phase stamps
+timeout 200 python bench.py --latency-groups 2 --no-cpu-baseline --no-in-tolerance --steps 40 2>/dev/null | tail -1 > $O/bench_latency_groups.json
+timeout 200 python bench.py --no-fused-rows --no-cpu-baseline --no-in-tolerance --steps 40 2>/dev/null | tail -1 > $O/bench_no_fused_rows.json
+[ -x tools/ubench/_bin/clock_probe ] && timeout 60 tools/ubench/_bin/clock_probe > $O/clock_probe.txt 2>&1
+timeout 200 python tools/conv_phase_times.py 2>/dev/null | grep tile > $O/conv_phase_times.txt
 cd /tmp && export TMPDIR=/tmp
 # the per-kernel statistics come from frames that run ONE AT A TIME (--no-pipeline): with the frame pipeline three camera stages and a
 # head share the chip and a kernel's in-trace duration measures its co-runners as much as itself; the pipelined run's stats are kept
@@ -43,6 +48,16 @@ if [ -n "$PMC" ]; then
   done
   timeout 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_tcc -o run -- python $R/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_tcc.log 2>&1 || echo "pmc pass tcc failed"
   python $R/tools/pmc_to_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_tcc aggregate_v8_kernel $O/aggregate_pmc.json
+  # the same traffic passes for the in-tolerance engine (fp32 value rows): in_tolerance.roofline.traffic
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcx3_$c -o run -- python $R/bench.py --precision bf16x3 --eager --steps 5 --warmup 2 --no-cpu-baseline > $O/pmcx3_$c.log 2>&1 || echo "pmc pass x3 $c failed"
+  done
+  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmcx3_tcc -o run -- python $R/bench.py --precision bf16x3 --eager --steps 5 --warmup 2 --no-cpu-baseline > $O/pmcx3_tcc.log 2>&1 || echo "pmc pass x3 tcc failed"
+  python $R/tools/pmc_to_json.py $O/pmcx3_FETCH_SIZE $O/pmcx3_WRITE_SIZE $O/pmcx3_tcc aggregate_v8_kernel $O/aggregate_pmc_fp32rows.json
+  for d in $O/pmcx3_FETCH_SIZE $O/pmcx3_WRITE_SIZE $O/pmcx3_tcc; do
+    for f in $(find $d -name '*counter_collection.csv'); do (head -1 $f; grep aggregate $f) > $f.agg; rm -f $f; done
+    find $d -name '*kernel_trace.csv' -delete
+  done
   # SQ counters of the aggregation kernel: where the wave cycles go (VALU issue vs waiting)
   timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python $R/tools/probe/run_agg_once.py > $O/pmc_sq.log 2>&1 || echo "pmc pass sq failed"
   for f in $(find $O/pmc_sq -name '*counter_collection.csv'); do (head -1 $f; grep aggregate $f) > $O/aggregate_sq_counters.csv; done
