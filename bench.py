@@ -161,6 +161,8 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     sd = weights.init_state_dict(spec, seed=0)
     eng = engine.Far3DEngine(sd, cfg, device=dev, precision=precision)
     eng.agg_variant = args.agg_variant
+    if args.agg_split is not None:
+        eng.agg_split_extra = args.agg_split
     eng.cam_priority = args.cam_priority
     eng.fused_rows = args.fused_rows        # row-resident decoder chains (bf16 decoder only; csrc/rowchain.hip); --no-fused-rows for A/B
     del sd
@@ -290,7 +292,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
             agg_out = torch.empty(ref_.shape[0], 256, device=dev, dtype=eng.prec["dec"])
             agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
                                                                 num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
-                                                                variant=args.agg_variant, tables=tab_), 24)]
+                                                                variant=args.agg_variant, tables=tab_, split=getattr(eng, "last_agg_split", None)), 24)]
         # the backbone ALONE: launches one after the other, so with the tile table tuned for that regime (what a non-pipelined engine
         # uses; the pipelined frames above run the table tuned under their 3-stream concurrency, engine.tile_table)
         keep_table, eng.tile_table = eng.tile_table, "tuning_mi355x.json"
@@ -302,7 +304,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     overflow = bool(int(out["proposal_overflow"].item())) if out.get("proposal_overflow") is not None else False
     res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, lat_groups=lat_groups, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
                timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(runner.pipeline), cfg=cfg, tile_table=eng.bf16_tile_table(),
-               ncam_local=len(runner.cams) if sharded else 7,
+               ncam_local=len(runner.cams) if sharded else 7, agg_split_extra=int(getattr(eng, "agg_split_extra", 0)),
                # what the runner actually did (read back, not assumed): frames in flight and camera streams of its pipeline
                frames_in_flight=int(eng.pipeline_sets) if runner.pipeline else 1,
                camera_streams=len(runner._pipe["s_cams"]) if (runner.pipeline and getattr(runner, "_pipe", None)) else 1)
@@ -318,7 +320,7 @@ def agg_roofline(args, res, traffic=None, traffic_src=None):
     evb = 2 if res["prec"]["value"] == torch.bfloat16 else 4
     by = agg_algorithmic_bytes(res["N"], res["S"], res["C"], res["A"], cfg["num_pts"], cfg["num_groups"], cfg["num_levels"], evb)
     agg_t = (sum(res["agg_ms"]) / len(res["agg_ms"])) * 1e-3 if res["agg_ms"] else float("nan")
-    return {"kernel": AGG_KERNEL + " (fused perspective-aware aggregation, one launch per decoder layer)" if args.agg_variant in (0, 8)
+    return {"kernel": AGG_KERNEL + " (fused perspective-aware aggregation, one launch per decoder layer)" + (" + %d sibling workgroups for heavy queries (variant 9)" % res["agg_split_extra"] if res.get("agg_split_extra") else "") if args.agg_variant in (0, 8, 9)
             else "aggregate_v%d_kernel (A/B variant %d)" % (3 if args.agg_variant == 3 else 7, args.agg_variant),
             "bound": "hbm", "achieved": by / agg_t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": by / agg_t / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
@@ -393,6 +395,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="single GPU: do not overlap the camera stages of frame i+1 with the head of frame i")
     ap.add_argument("--agg-variant", type=int, default=0, help="far3d_aggregate_forward kernel variant (A/B timing)")
+    ap.add_argument("--agg-split", type=int, default=None, help="sibling workgroups for heavy queries in the aggregation kernel (variant 9; 0 = off; "
+                    "default: the engine's setting)")
     ap.add_argument("--proposals", default="topk", choices=["topk", "threshold"],
                     help="adaptive queries: 92 best 2D peaks per camera (static 644), or the reference's score > 0.1 rule with a fixed capacity")
     ap.add_argument("--capacity", type=int, default=1024, help="--proposals threshold: rows reserved for the adaptive queries")

@@ -366,14 +366,28 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
   __syncthreads();
   bf16_t* y = reinterpret_cast<bf16_t*>(P.y);
   constexpr int ES = EB / 2;                            // stored bf16 elements per logical channel
+  // The copy loops below run in batches of RB pieces per thread: the RB staged rows are read unconditionally (clamped index) BEFORE any
+  // of them is stored, so that RB LDS reads are in flight together -- one piece at a time the loop is a chain of LDS round trips, and the
+  // stamps of tools/conv_phase_times.py put this epilogue at a fifth (3x3) to a third (256 x 256 GEMM) of a workgroup's life.
+  // Measured NEUTRAL on the backbone (4.395 ms before and after: profiles/r5/bench.json vs bench_epilogue_batched.json): the second resident workgroup's
+  // K loop already covers this epilogue's LDS latency.  Kept because it is not slower and bounds the chain for single-workgroup CUs.
+  constexpr int RBATCH = 4, NPIECE = BPX * CPP;
   if (!do_sums) {
-#pragma unroll 2
-    for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
-      const int pl = idx / CPP, c = idx - pl * CPP;
-      if (m0 * ES + c * 8 >= P.Cout * ES) continue;
-      const long off = pix_off(pl);
-      if (off < 0) continue;
-      *reinterpret_cast<u32x4_t*>(y + off + m0 * ES + c * 8) = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+    for (int base = threadIdx.x; base < NPIECE; base += RBATCH * NT) {
+      u32x4_t ch[RBATCH];
+      long off[RBATCH];
+      int cu[RBATCH];
+#pragma unroll
+      for (int u = 0; u < RBATCH; ++u) {
+        const int idx = min(base + u * NT, NPIECE - 1);
+        const int pl = idx / CPP, c = idx - pl * CPP;
+        ch[u] = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+        off[u] = (base + u * NT < NPIECE && m0 * ES + c * 8 < P.Cout * ES) ? pix_off(pl) : -1L;
+        cu[u] = c;
+      }
+#pragma unroll
+      for (int u = 0; u < RBATCH; ++u)
+        if (off[u] >= 0) *reinterpret_cast<u32x4_t*>(y + off[u] + m0 * ES + cu[u] * 8) = ch[u];
     }
     return;
   }
@@ -386,15 +400,24 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
     int s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float mx = 0.f;
     int cc = -1;
-#pragma unroll 2
-    for (int idx = threadIdx.x; idx < BPX * CPP; idx += NT) {
-      const int pl = idx / CPP, c = idx - pl * CPP;
-      if (m0 * ES + c * 8 >= P.Cout * ES) continue;
-      const long off = pix_off(pl);
-      if (off < 0) continue;
-      const u32x4_t ch = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
-      if (slot == 0) *reinterpret_cast<u32x4_t*>(y + off + m0 * ES + c * 8) = ch;
-      if ((sums_p0 + pl >= bnd) == (slot == 1)) { sums_add8(s, mx, ch); cc = c; }
+    for (int base = threadIdx.x; base < NPIECE; base += RBATCH * NT) {
+      u32x4_t ch[RBATCH];
+      long off[RBATCH];
+      int cu[RBATCH], plu[RBATCH];
+#pragma unroll
+      for (int u = 0; u < RBATCH; ++u) {
+        const int idx = min(base + u * NT, NPIECE - 1);
+        const int pl = idx / CPP, c = idx - pl * CPP;
+        ch[u] = *reinterpret_cast<const u32x4_t*>(smem + pl * RS + c * 16);
+        off[u] = (base + u * NT < NPIECE && m0 * ES + c * 8 < P.Cout * ES) ? pix_off(pl) : -1L;
+        cu[u] = c; plu[u] = pl;
+      }
+#pragma unroll
+      for (int u = 0; u < RBATCH; ++u) {
+        if (off[u] < 0) continue;
+        if (slot == 0) *reinterpret_cast<u32x4_t*>(y + off[u] + m0 * ES + cu[u] * 8) = ch[u];
+        if ((sums_p0 + plu[u] >= bnd) == (slot == 1)) { sums_add8(s, mx, ch[u]); cc = cu[u]; }
+      }
     }
     // a magnitude the 32-bit per-wave sums cannot hold (|v| >= 2^(24 - FRAC_BITS) = 64 over up to 64 pixels): redo this slot in 64 bits
     const bool wide = __any(mx >= (float)(1 << (24 - FAR3D_SUMS_FRAC_BITS)));

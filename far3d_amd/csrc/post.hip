@@ -309,9 +309,10 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
                                                          int* __restrict__ perm, int A, int N, float lo0, float lo1, float lo2,
                                                          float sp0, float sp1, float sp2, float pad_h, float pad_w,
                                                          const int* __restrict__ hole_count, int hole_start, int hole_end, int row_base,
-                                                         const float* __restrict__ Vc, float* __restrict__ tables, int J) {
+                                                         const float* __restrict__ Vc, float* __restrict__ tables, int J, int split_extra) {
   __shared__ int hist[AGGO_MAX_BINS];
   __shared__ int wsum[16];
+  __shared__ int hsum[16];
   if (blockIdx.x > 0) {      // blocks 1.. : the aggregation softmax factors of decoder layer blockIdx.x - 1 (csrc/agg_tables.hpp)
     agg_tables_body(Vc + (long)(blockIdx.x - 1) * N * J, tables + (long)(blockIdx.x - 1) * (2 + N) * J, N, J, threadIdx.x, 1024);
     return;
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
   __syncthreads();
   constexpr int MAXQ = 8;   // A <= 8192
   int key[MAXQ], rank[MAXQ];
+  unsigned heavy = 0u;      // bit k: query t + 1024 k projects into two or more cameras (twice the items: far3d_aggregate_forward variant 9)
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k) {
     const int a = t + k * 1024;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
       const float* rp = ref + (long)(row_base + a) * 3;      // rows [row_base, row_base + A) of the caller's reference points
       const float X = rp[0] * sp0 + lo0, Y = rp[1] * sp1 + lo1, Z = rp[2] * sp2 + lo2;
       float best = 3.0e9f, bu = 0.f, bv = 0.f;
-      int cam = 0;
+      int cam = 0, nvis = 0;
       for (int n = 0; n < N; ++n) {
         const float* m = l2i + n * 16;
         const float x = m[0] * X + m[1] * Y + m[2] * Z + m[3], y = m[4] * X + m[5] * Y + m[6] * Z + m[7],
@@ -341,7 +343,10 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
         const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
         const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
         if (cost < best) { best = cost; cam = n; bu = u; bv = v; }
+        nvis += (z > 1e-5f && fabsf(u) < 0.55f && fabsf(v) < 0.55f) ? 1 : 0;      // inside the image, 5 % margin for the key-point offsets
       }
+      const int arow = row_base + a;
+      if (nvis >= 2 && !(arow >= hole_lo && arow < hole_end)) heavy |= 1u << k;
       const int ub = (int)(fminf(fmaxf(bu + 0.5f, 0.f), 0.999f) * 8.f), vb = (int)(fminf(fmaxf(bv + 0.5f, 0.f), 0.999f) * 8.f);
       key[k] = (cam * 8 + vb) * 8 + ub;
       rank[k] = atomicAdd(&hist[key[k]], 1);
@@ -362,17 +367,42 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
   __syncthreads();
   if (t < AGGO_MAX_BINS) hist[t] = base + inc - c;
   __syncthreads();
+  // sibling entries (variant 9): the first split_extra heavy queries IN ROW ORDER are split -- a deterministic choice (an atomic counter would
+  // pick a different subset from run to run when there are more heavy queries than slots, and a split query sums in another order) --
+  // query with heavy-rank e gets sibling slot e: perm[A + e] = row | sibling | split, and its main entry carries the split flag
+  unsigned splitm = 0u;
+  if (split_extra > 0) {
+    int before = 0;                                          // heavy queries in the chunks already scanned
+    for (int k = 0; k < MAXQ; ++k) {
+      if (k * 1024 >= A) break;                              // block-uniform
+      const bool h = (heavy >> k) & 1u;
+      const unsigned long long bm = __ballot(h);
+      const int inwave = __popcll(bm & ((1ull << (t & 63)) - 1ull));
+      if ((t & 63) == 0) hsum[t >> 6] = __popcll(bm);
+      __syncthreads();
+      int wb = 0, tot = 0;
+      for (int w = 0; w < 16; ++w) { wb += w < (t >> 6) ? hsum[w] : 0; tot += hsum[w]; }
+      __syncthreads();
+      const int e = before + wb + inwave;
+      if (h && e < split_extra) {
+        splitm |= 1u << k;
+        perm[A + e] = (row_base + t + k * 1024) | (1 << 30) | (1 << 29);
+      }
+      before += tot;
+    }
+    for (int e = before + t; e < split_extra; e += 1024) perm[A + e] = 0x7fffffff;      // unused sibling slots
+  }
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k)
     if (key[k] >= 0) {
       const int a = row_base + t + k * 1024;                 // absolute row
-      perm[hist[key[k]] + rank[k]] = (a >= hole_lo && a < hole_end) ? ~a : a;
+      perm[hist[key[k]] + rank[k]] = (a >= hole_lo && a < hole_end) ? ~a : (((splitm >> k) & 1u) ? (a | (1 << 29)) : a);
     }
 }
 
 extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range,
                                float pad_h, float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
-                               const float* Vc, float* tables, int layers, int J, void* stream) {
+                               const float* Vc, float* tables, int layers, int J, int split_extra, void* stream) {
   FAR3D_CHECK_ARG(ref && lidar2img && perm && pc_range && A >= 0 && N > 0, "far3d_agg_order: bad arguments");
   FAR3D_CHECK_ARG(!tables || (Vc && layers > 0 && J > 0), "far3d_agg_order: tables need Vc, layers > 0 and J > 0");
   if (!tables) layers = 0;
@@ -380,10 +410,11 @@ extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t
   FAR3D_CHECK_ARG(row_base >= 0 && (!hole_count || (0 <= hole_start && hole_start <= hole_end)), "far3d_agg_order: bad hole [%d, %d) / row_base %d",
                   hole_start, hole_end, row_base);
   if (!hole_count) hole_start = hole_end = 0;
-  if (A == 0 && layers == 0) return FAR3D_OK;
+  FAR3D_CHECK_ARG(split_extra >= 0 && row_base + A < (1 << 29), "far3d_agg_order: bad split_extra %d / row range", split_extra);
+  if (A == 0 && layers == 0 && split_extra == 0) return FAR3D_OK;
   hipLaunchKernelGGL(agg_order_kernel, dim3(1 + layers), dim3(1024), 0, (hipStream_t)stream, ref, lidar2img, perm, A, N, pc_range[0],
                      pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], pad_h,
-                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base, Vc, tables, J);
+                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base, Vc, tables, J, split_extra);
   FAR3D_CHECK_LAUNCH("far3d_agg_order");
   return FAR3D_OK;
 }

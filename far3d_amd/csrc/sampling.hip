@@ -125,7 +125,15 @@ struct AggParams {
   int ldU, ldO;   // row strides (floats) of U and of the key-point offsets
   float ipw, iph;                       // 1 / pad_w, 1 / pad_h
   float Wf[AGG_MAX_L], Hf[AGG_MAX_L];   // level sizes as floats
+  // variant 9 (sibling workgroups for heavy queries, round 5): perm holds A main entries + split_extra sibling entries
+  float* split_part;                    // [rows][2][256] partial sums of the two workgroups of a split query
+  int* split_tick;                      // [rows] arrival tickets, zero at rest
+  int split_extra;
 };
+#define AGG_SPLIT_FLAG (1 << 29)        // perm entry: this query is handled by two workgroups (set on both of its entries)
+#define AGG_SIBLING_FLAG (1 << 30)      // perm entry of the second workgroup (part 1)
+#define AGG_ROW_MASK 0x1fffffff
+#define AGG_NO_SIBLING 0x7fffffff       // unused sibling slot
 
 // ------------------------------------------------------------------------------------------
 // v3 of the fused aggregation (round 1's kernel; kept as variant 3 for A/B).  PMC counters on v1 showed the kernel VALU-bound (2.5k VALU
@@ -1006,13 +1014,24 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
 // in-loop gather spills (128 VGPRs) 23-30 us; 192-entry lists (22.6 KB of LDS: 7 workgroups per CU, no longer every query resident
 // with margin) 17.8-21.1 us; an "early" gather buffer (an item's first 8 rows requested before the next item is built, consumed after it:
 // 128 VGPRs + 12 B of scratch) 17.9-18.2 us against 17.3-17.9 -- the build and the gather do not wait for each other.
-template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW>
+// SPLIT (variant 9, round 5): the launch ends with its slowest wave, and the slowest waves belong to the queries two cameras see (twice
+// the (camera, level) items).  far3d_agg_order marks those queries and appends one SIBLING entry per marked query to perm; the extra
+// workgroups at the end of the grid take them.  Both workgroups of a marked query run the same front end and deal its items into FOUR
+// shares (same greedy rule), workgroup `part` taking shares 2 part and 2 part + 1; each publishes its unnormalised 256-float sum with
+// device-scope stores and draws a ticket; the one that arrives second adds the two partials in part order (part 0 + part 1 whoever
+// merges: deterministic), applies 1 / S and writes the row.  An unmarked query takes the two-share path, bit-identical to variant 8.
+template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false>
 __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ tab,
                                                            const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
-  const int a0 = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
-  if (a0 >= prm.A) return;
+  int a0 = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  bool sibling = false;
+  if constexpr (SPLIT) {
+    const int nmain = 8 * prm.q_per_xcd;
+    if ((int)blockIdx.x >= nmain) { sibling = true; a0 = prm.A + ((int)blockIdx.x - nmain); }
+  }
+  if (!sibling && a0 >= prm.A) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int P = PT ? PT : prm.P, L = prm.L, N = prm.N;
@@ -1042,6 +1061,10 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   const float4* mB = reinterpret_cast<const float4*>(l2i + min(r + 4, N - 1) * 16);
   const float4 mA0 = mA[0], mA1 = mA[1], mA2 = mA[2], mB0 = mB[0], mB1 = mB[1], mB2 = mB[2];
   int a = perm ? perm[a0] : a0;
+  bool split = false;
+  if constexpr (SPLIT) {
+    if (sibling && a == AGG_NO_SIBLING) return;      // unused sibling slot
+  }
   if (a < 0) {      // ~a: row a holds no query (far3d_agg_order): zero row, no work
     a = ~a;
     const int c = t * 2;
@@ -1049,6 +1072,11 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = 0u;
     return;
   }
+  if constexpr (SPLIT) {
+    split = (a & AGG_SPLIT_FLAG) != 0;
+    a &= AGG_ROW_MASK;
+  }
+  const int part = sibling ? 1 : 0;
   // ---- query-dependent loads, issued together: reference point, this lane's key-point offset, the query part of the logits
   const float rf0 = ref[a * 3], rf1 = ref[a * 3 + 1], rf2 = ref[a * 3 + 2];
   const float* op_ = offs + (long)a * prm.ldO + min(p, P - 1) * 3;
@@ -1120,25 +1148,38 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     S4.x = agg8_wave_sum_parity(S4.x); S4.y = agg8_wave_sum_parity(S4.y);
     S4.z = agg8_wave_sum_parity(S4.z); S4.w = agg8_wave_sum_parity(S4.w);
   };
-  auto deal = [&](int w, unsigned long long& mA, unsigned long long& mB, int& load) __attribute__((always_inline)) {
-    // greedy on the running work estimates; w = the wave whose share is returned
-    int ld0 = 0, ld1 = 0;
-    mA = 0ull; mB = 0ull;
+  // greedy on the running work estimates into nsh shares (2, or 4 for a split query): an item goes to the least loaded share, ties to
+  // the lower one; returned are the items and loads of shares s0 and s1 (the two waves of this workgroup).  nsh = 2, (s0, s1) = (0, 1)
+  // is variant 8's dealing, decision for decision.
+  auto deal2 = [&](int nsh, int s0, int s1, unsigned long long& a0m, unsigned long long& b0m, int& l0, unsigned long long& a1m,
+                   unsigned long long& b1m, int& l1) __attribute__((always_inline)) {
+    int ld0 = 0, ld1 = 0, ld2 = 0, ld3 = 0;
+    a0m = 0ull; b0m = 0ull; a1m = 0ull; b1m = 0ull;
+    const int big = nsh > 2 ? 0 : 0x3fffffff;        // shares 2 and 3 never win a two-share deal
+    // every update is a select on scalars (an `if (best == k) ld_k += e` chain is turned into a scratch array indexed by `best`)
+    auto place = [&](int e) __attribute__((always_inline)) -> int {
+      const int c2 = ld2 + big, c3 = ld3 + big;
+      int best = 0, lb = ld0;
+      best = ld1 < lb ? 1 : best; lb = min(lb, ld1);
+      best = c2 < lb ? 2 : best; lb = min(lb, c2);
+      best = c3 < lb ? 3 : best;
+      ld0 += best == 0 ? e : 0; ld1 += best == 1 ? e : 0; ld2 += best == 2 ? e : 0; ld3 += best == 3 ? e : 0;
+      return best;
+    };
     for (unsigned long long m = visA; m; m &= m - 1ull) {
       const int b = __builtin_ctzll(m);
-      const int e = __builtin_amdgcn_readlane(estA, b);
-      const bool to1 = ld1 < ld0;
-      if (to1) ld1 += e; else ld0 += e;
-      if ((int)to1 == w) mA |= 1ull << b;
+      const int sh = place(__builtin_amdgcn_readlane(estA, b));
+      a0m |= sh == s0 ? 1ull << b : 0ull;
+      a1m |= sh == s1 ? 1ull << b : 0ull;
     }
     for (unsigned long long m = visB; m; m &= m - 1ull) {
       const int b = __builtin_ctzll(m);
-      const int e = __builtin_amdgcn_readlane(estB, b);
-      const bool to1 = ld1 < ld0;
-      if (to1) ld1 += e; else ld0 += e;
-      if ((int)to1 == w) mB |= 1ull << b;
+      const int sh = place(__builtin_amdgcn_readlane(estB, b));
+      b0m |= sh == s0 ? 1ull << b : 0ull;
+      b1m |= sh == s1 ? 1ull << b : 0ull;
     }
-    load = w ? ld1 : ld0;
+    l0 = s0 == 0 ? ld0 : s0 == 1 ? ld1 : s0 == 2 ? ld2 : ld3;
+    l1 = s1 == 0 ? ld0 : s1 == 1 ? ld1 : s1 == 2 ? ld2 : ld3;
   };
   {
     // SPECIALISED front end: wave 0 projects and deals, wave 1 computes the softmax statistics; they swap results through the
@@ -1152,10 +1193,7 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
       visA = __ballot(visA_); visB = __ballot(visB_); patchA = __ballot(patA); patchB = __ballot(patB);
       unsigned long long oA, oB;
       int oload;
-      deal(0, mineA, mineB, myload);
-      oA = visA & ~mineA; oB = visB & ~mineB; oload = 0;
-      for (unsigned long long m = oA; m; m &= m - 1ull) oload += __builtin_amdgcn_readlane(estA, __builtin_ctzll(m));
-      for (unsigned long long m = oB; m; m &= m - 1ull) oload += __builtin_amdgcn_readlane(estB, __builtin_ctzll(m));
+      deal2(split ? 4 : 2, 2 * part, 2 * part + 1, mineA, mineB, myload, oA, oB, oload);
       xd[lane] = make_int4(dA0, dA1, dB0, dB1);
       if (lane == 0) {
         unsigned long long* q = reinterpret_cast<unsigned long long*>(xd + 64);
@@ -1387,7 +1425,29 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     const int c = t * 2, g = c >> 5;       // channels 2t, 2t+1 belong to group 2t / 32
     const float inv = 1.f / stat_s[g];
     const float2 p0 = *reinterpret_cast<const float2*>(wt_all + c), p1 = *reinterpret_cast<const float2*>(wt_all + CAPT * 8 + c);
-    const float r0 = (p0.x + p1.x) * inv, r1 = (p0.y + p1.y) * inv;
+    float s0 = p0.x + p1.x, s1 = p0.y + p1.y;
+    if constexpr (SPLIT) {
+      if (split) {
+        // publish this workgroup's unnormalised sums (device-scope 8-byte stores: through to where the sibling, on any XCD, reads them),
+        // make sure they have landed, draw a ticket; the second arrival merges in part order
+        unsigned long long* mine = reinterpret_cast<unsigned long long*>(prm.split_part + ((long)a * 2 + part) * 256 + c);
+        const unsigned long long* other = reinterpret_cast<const unsigned long long*>(prm.split_part + ((long)a * 2 + (1 - part)) * 256 + c);
+        __hip_atomic_store(mine, (unsigned long long)__float_as_uint(s0) | ((unsigned long long)__float_as_uint(s1) << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        int* tk = reinterpret_cast<int*>(stat_s + 12);
+        if (t == 0) *tk = atomicAdd(prm.split_tick + a, 1);
+        __syncthreads();
+        if (*tk == 0) return;                        // first to arrive: the sibling finishes the row
+        const unsigned long long o = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o0 = __uint_as_float((unsigned)(o & 0xffffffffull)), o1 = __uint_as_float((unsigned)(o >> 32));
+        s0 = part == 0 ? s0 + o0 : o0 + s0;          // part 0 + part 1, whoever merges
+        s1 = part == 0 ? s1 + o1 : o1 + s1;
+        if (t == 0) atomicExch(prm.split_tick + a, 0);      // zero at rest for the next launch
+      }
+    }
+    const float r0 = s0 * inv, r1 = s1 * inv;
     if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(r0, r1);
     else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = pack_bf16x2(r0, r1);
   }
@@ -1410,7 +1470,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
                                        const float* Vc, const float* cam_tables, const int32_t* perm, void* out, int out_dt, int A, int N,
                                        int S, int C, int G, int P, int L, const int32_t* level_hw, const int32_t* level_start,
                                        const float* pc_range, float pad_h, float pad_w, int ldU, int ldOffs, int variant,
-                                       void* stream) {
+                                       float* split_partials, int32_t* split_tickets, int split_extra, void* stream) {
   FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && (Vc || cam_tables) && out && level_hw && level_start && pc_range,
                   "far3d_aggregate_forward: null pointer argument");
   FAR3D_CHECK_ARG(C == 256 && G == 8, "far3d_aggregate_forward: fused kernel is built for C=256,G=8 (got C=%d G=%d)", C, G);
@@ -1420,13 +1480,16 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 11,
-                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11,
+                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 9 = 8 + sibling workgroups for heavy queries; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
+  FAR3D_CHECK_ARG(variant != 9 || (perm && split_partials && split_tickets && split_extra > 0),
+                  "far3d_aggregate_forward: variant 9 needs perm (A main + split_extra sibling entries from far3d_agg_order), split_partials, split_tickets and split_extra > 0");
   const size_t esz = feat_dtype == FAR3D_DT_F32 ? 4 : 2;
   const bool v8_ok = cam_tables && N <= 8 && P <= 16 && L <= AGG_MAX_L && (size_t)N * S * C * esz < (1ull << 32);
   if (variant == 0) variant = v8_ok ? 8 : 7;
+  FAR3D_CHECK_ARG(variant != 9 || v8_ok, "far3d_aggregate_forward: variant 9 needs what variant 8 needs (cam_tables, N <= 8, P <= 16)");
   FAR3D_CHECK_ARG(variant != 8 || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
-  FAR3D_CHECK_ARG(variant == 8 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
+  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -1443,6 +1506,7 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   prm.ipw = 1.f / pad_w; prm.iph = 1.f / pad_h;
   for (int l = 0; l < AGG_MAX_L; ++l) { prm.Wf[l] = (float)prm.W[l]; prm.Hf[l] = (float)prm.H[l]; }
   prm.q_per_xcd = cdiv(A, 8);
+  prm.split_part = split_partials; prm.split_tick = split_tickets; prm.split_extra = variant == 9 ? split_extra : 0;
   prm.out_dt = out_dt;
   prm.ldU = ldU > 0 ? ldU : L * P * G;
   prm.ldO = ldOffs > 0 ? ldOffs : P * 3;
@@ -1475,6 +1539,15 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
     } else {
       if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+    }
+  } else if (variant == 9) {      // variant 8 + sibling workgroups for the queries far3d_agg_order marked as heavy
+    const dim3 grid9(8 * prm.q_per_xcd + split_extra);
+    if (feat_dtype == FAR3D_DT_F32) {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+    } else {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
     }
   } else if (variant == 7) {     // 2 waves per query, levels split by parity, softmax over all 7 cameras
     const int NP = N * P;

@@ -154,6 +154,8 @@ class Far3DEngine:
         self._fidx = 0
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
+        self.agg_split_extra = 0    # > 0: far3d_aggregate_forward variant 9 -- that many sibling workgroups for the queries two cameras see
+                                    # (far3d_agg_order marks them; ops.AggSplit holds the partial sums / tickets, one per buffer set)
         self.fused_rows = True      # bf16 decoder: the row-local parts of a decoder layer and the cls / reg branches run as row-resident
                                     # chains (far3d_rowchain_attn_out / _ffn / _branches: 4 launches per layer instead of 11).  Default since
                                     # round 5 (the full GPU suite ran on it); False selects the unfused kernels (A/B: bench.py --no-fused-rows).
@@ -575,8 +577,15 @@ class Far3DEngine:
         vc_all = ops.cam_embed_chain(lidar2img, self.cam_chain)             # (layers, N, nJ), bias included
         # per-frame preparations of the aggregation in ONE launch: reference points are fixed across the layers -> one camera-sorted
         # workgroup order (scheduling only); the camera factors of the factored softmax for all layers (include/far3d_hip.h)
-        perm, tabs = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A,), torch.int32), hole=hole,
-                                           Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32))
+        sp = None
+        if self.agg_split_extra > 0 and self.agg_variant in (0, 9):
+            sk = (self._par, "agg_split", A, int(self.agg_split_extra))
+            sp = self._bufs.get(sk)
+            if sp is None:
+                sp = self._bufs[sk] = ops.AggSplit(A, self.agg_split_extra, self.dev)
+        self.last_agg_split = sp
+        perm, tabs = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A + (sp.extra if sp else 0),), torch.int32),
+                                           hole=hole, Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32), split=sp)
         x = x0
         if self.fused_rows and fast and all(ly["rc"] is not None for ly in self.layers):
             return self._decoder_fused(X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs)
@@ -592,7 +601,7 @@ class Far3DEngine:
             ops.linear(XW, ly["wl"], out=UL[:, :nJ + nO])
             agg = ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
                                         cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out_dtype=at,
-                                        variant=self.agg_variant, tables=tabs[li])
+                                        variant=self.agg_variant, tables=tabs[li], split=sp)
             self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li])
             y = ops.linear(agg, ly["oproj"], res=x1)
             if fast:
@@ -629,7 +638,7 @@ class Far3DEngine:
             ops.rowchain_attn_out(att, x, qpos, ly["rc"], x1, UL)
             ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
                                   cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg,
-                                  variant=self.agg_variant, tables=tabs[li])
+                                  variant=self.agg_variant, tables=tabs[li], split=self.last_agg_split)
             self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li])
             last = li + 1 == nL
             ops.rowchain_ffn(agg, x1, qpos, ly["rc"], outs[li], nxt=None if last else self.layers[li + 1]["rc"],

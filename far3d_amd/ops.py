@@ -129,8 +129,18 @@ def agg_tables(Vc, out=None):
     return tab if Vc.dim() == 3 else tab[0]
 
 
+class AggSplit:
+    """Workspace of far3d_aggregate_forward variant 9 (sibling workgroups for heavy queries): partial sums [rows][2][256] f32, arrival
+    tickets [rows] int32 (zero at rest) and the number of sibling slots far3d_agg_order may hand out."""
+
+    def __init__(self, rows, extra=384, device="cuda:0"):
+        self.rows, self.extra = int(rows), int(extra)
+        self.partials = torch.empty((self.rows, 2, 256), dtype=torch.float32, device=device)
+        self.tickets = torch.zeros((self.rows,), dtype=torch.int32, device=device)
+
+
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None):
+                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None, split=None):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
@@ -162,11 +172,17 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
                          (tuple(U.shape), tuple(Vc.shape), tuple(lidar2img.shape), A, N, L, P, G))
     if out is None:
         out = torch.empty((A, C), dtype=out_dtype, device=feat.device)
+    nperm = None
     if perm is not None:
         _chk(perm, "perm", torch.int32, 1)
-        if perm.numel() > A:
+        nperm = perm.numel() - (split.extra if split is not None else 0)        # main entries (the sibling entries follow them)
+        if nperm > A or nperm < 0:
             raise ValueError("aggregate_forward: perm has more entries than there are rows")
-    if tables is None and variant in (0, 8) and A > 0 and N <= 8 and P <= 16:
+    if split is not None:
+        if perm is None or split.rows < A or variant not in (0, 9):
+            raise ValueError("aggregate_forward: split needs the perm of aggregation_order(split=...), a workspace of >= A rows and variant 0 / 9")
+        variant = 9
+    if tables is None and variant in (0, 8, 9) and A > 0 and N <= 8 and P <= 16:
         tables = agg_tables(Vc)
     if tables is not None:
         _chk(tables, "tables", torch.float32, 2)
@@ -178,9 +194,11 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     _lib.check(lib.far3d_aggregate_forward(_ptr(feat), _dt(feat), _ptr(ref), _ptr(offsets), _ptr(lidar2img),
                                            _ptr(U), _ptr(Vc), _ptr(tables) if tables is not None else None,
                                            _ptr(perm) if perm is not None else None, _ptr(out), _dt(out),
-                                           A if perm is None else perm.numel(), N, S, C, G, P, L, hw_p, st_p, pc_p,
+                                           A if perm is None else nperm, N, S, C, G, P, L, hw_p, st_p, pc_p,
                                            float(pad_hw[0]), float(pad_hw[1]), U.stride(0) if A > 0 else 0,
-                                           offsets.stride(0) if A > 0 else 0, int(variant), _stream(feat)),
+                                           offsets.stride(0) if A > 0 else 0, int(variant),
+                                           _ptr(split.partials) if split is not None else None, _ptr(split.tickets) if split is not None else None,
+                                           split.extra if split is not None else 0, _stream(feat)),
                "far3d_aggregate_forward")
     return out
 
@@ -963,7 +981,7 @@ def add_cast(a, b, sum_dtype, a_dtype=None, out_sum=None, out_a=None):
     return osum, oa
 
 
-def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None, Vc=None, tables_out=None):
+def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None, Vc=None, tables_out=None, split=None):
     """Query order for aggregate_forward's `perm` (camera, then 8x8 image cell), one single-workgroup launch.  Groups the
     same way as camera_sorted_order(spatial=True); the order inside a cell is arbitrary (scheduling only).  hole: rows without a
     query are entered as ~a so that aggregate_forward writes zero rows for them (see _hole).  rows=(a0, a1): order only the rows
@@ -973,7 +991,10 @@ def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, row
     _chk(ref, "ref", torch.float32, 2)
     a0, a1 = (0, ref.shape[0]) if rows is None else rows
     A = a1 - a0
-    perm = out if out is not None else torch.empty((A,), dtype=torch.int32, device=ref.device)
+    extra = split.extra if split is not None else 0        # AggSplit: A main entries + `extra` sibling entries (aggregate_forward variant 9)
+    perm = out if out is not None else torch.empty((A + extra,), dtype=torch.int32, device=ref.device)
+    if perm.numel() != A + extra:
+        raise ValueError("aggregation_order: perm needs %d entries (A = %d + %d sibling slots), got %d" % (A + extra, A, extra, perm.numel()))
     pk, pp = _host_f32(list(pc_range))
     tab, layers, J = None, 0, 0
     if Vc is not None:
@@ -984,7 +1005,7 @@ def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, row
         tab = tables_out if tables_out is not None else torch.empty((layers, 2 + Nv, J), dtype=torch.float32, device=ref.device)
     _lib.check(lib.far3d_agg_order(_ptr(ref), _ptr(lidar2img), _ptr(perm), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
                                    *_hole(hole), int(a0), _ptr(Vc) if Vc is not None else None, _ptr(tab) if tab is not None else None,
-                                   layers, J, _stream(ref)), "far3d_agg_order")
+                                   layers, J, int(extra), _stream(ref)), "far3d_agg_order")
     return perm if Vc is None else (perm, tab)
 
 

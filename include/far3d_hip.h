@@ -84,7 +84,8 @@ int far3d_msda_forward(const void* value, int value_dtype, const int64_t* spatia
  * the rows they name may lie anywhere in ref / offsets / U / out (a subset of a larger query set).  Requires C=256, G=8, L<=4, N<=16,
  * N*P<=256, N*P*L<=384.
  * cam_tables: the per-layer softmax factors of Vc from far3d_agg_tables / far3d_agg_order ((2+N)*L*P*G floats), or NULL.
- * variant: 0 = default: kernel 8 when cam_tables is given and N<=8, P<=16, value maps < 4 GiB, else kernel 7.
+ * variant: 0 = default: kernel 8 when cam_tables is given and N<=8, P<=16, value maps < 4 GiB, else kernel 7; 9 = kernel 8 with sibling
+ * workgroups for heavy queries (below).
  *   8: two waves per query with specialised front ends (wave 0 projects and deals, wave 1 does the softmax statistics; two
  *      barriers), softmax factored into a query part (8 exp per lane) and the per-frame camera tables, (camera, level) items dealt to the waves by estimated work, bilinear taps merged per token row through the tent
  *      form of the interpolation weights (no atomics), padded LDS row lists, 16-byte row gathers from 32-bit byte offsets;
@@ -96,7 +97,15 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
                             const int32_t* perm, void* out, int out_dt, int A,
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
-                            int ldU, int ldOffs, int variant, void* stream);
+                            int ldU, int ldOffs, int variant, float* split_partials, int32_t* split_tickets, int split_extra,
+                            void* stream);
+/* variant 9 (round 5) = kernel 8 + SIBLING workgroups for heavy queries: the launch ends with its slowest wave, and the slowest waves
+ * belong to the queries two cameras see.  far3d_agg_order(split_extra) marks those queries (flag 1 << 29 on their perm entry) and appends
+ * one sibling entry per marked query (perm[A + e] = row | 1 << 30 | 1 << 29; unused slots 0x7fffffff); the launch runs split_extra extra
+ * workgroups for them.  The two workgroups of a marked query deal its items into four shares instead of two, each publishes its
+ * unnormalised 256-float sum in split_partials ([rows][2][256] f32) and draws a ticket from split_tickets ([rows] int32, ZERO at rest,
+ * returned to zero); the second arrival adds the partials in part order and writes the row -- deterministic, run to run and graph vs
+ * eager.  Unmarked queries take kernel 8's path unchanged.  The three split_* arguments are ignored by the other variants. */
 
 /* Softmax factors of the aggregation logits' camera part, for `layers` decoder layers in one launch (block = layer):
  * Vc (layers, N, J) f32 (far3d_cam_embed_chain's output, J = L*P*G, J % 4 == 0) -> tables (layers, 2+N, J) f32 =
@@ -361,7 +370,9 @@ int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, vo
  * per-frame preparations of the aggregation; one launch instead of two). */
 int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range, float pad_h,
                     float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
-                    const float* Vc, float* tables, int layers, int J, void* stream);
+                    const float* Vc, float* tables, int layers, int J, int split_extra, void* stream);
+/* split_extra > 0 (far3d_aggregate_forward variant 9): perm has A + split_extra entries; the first split_extra queries IN ROW ORDER whose
+ * reference point projects into two or more cameras are marked and get a sibling entry behind the A main ones (see above). */
 
 /* Descending top-K of n <= 40960 floats (ties -> lower index), one workgroup: idx_out (K) int64, val_out (K) f32 or NULL.
  * Replaces torch.topk in post_update_memory, ref models/dense_heads/farhead.py:488-491 (K <= 1024). */

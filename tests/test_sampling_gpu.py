@@ -141,3 +141,54 @@ def test_aggregate_generic_point_and_level_counts(hip_lib, dtype):
     c["feat"] = c["feat"][:, :S3].contiguous()
     c["U"], c["Vc"] = torch.randn(45, 3 * 6 * 8, generator=g), torch.randn(5, 3 * 6 * 8, generator=g)
     assert cases.run_aggregate_case(c, DEV, dtype) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("extra", [384, 7, 1])
+def test_aggregate_sibling_workgroups_for_heavy_queries(hip_lib, dtype, extra):
+    """Variant 9 (round 5): queries two cameras see are handled by TWO workgroups that deal the items into four shares and merge their
+    partial sums in part order.  Against the oracle at the benchmarked size; rows that were not split are BIT-identical to variant 8;
+    the marked set is the first `extra` heavy queries in row order (few slots: most heavy queries stay unsplit); launch after launch
+    and as a hipGraph the result is bit-identical (the tickets return to zero); sibling slots that are not used do nothing."""
+    from far3d_amd import ops
+    c = cases.config2_aggregate_case(seed=5)
+    A = c["ref"].shape[0]
+    d = lambda t: t.to(DEV).contiguous()
+    feat = d(c["feat"].to(dtype))
+    ref, offs, l2i, U, Vc = d(c["ref"]), d(c["offsets"]), d(c["lidar2img"]), d(c["U"]), d(c["Vc"])
+    want = cases.oracle_aggregate(c, dtype)
+    tab = ops.agg_tables(Vc)
+    perm8 = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"])
+    base = ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm8, variant=8, tables=tab)
+    sp = ops.AggSplit(A, extra, DEV)
+    perm = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"], split=sp)
+    pm = perm.cpu().numpy()
+    main, sib = pm[:A], pm[A:]
+    assert sorted((main & 0x1fffffff).tolist()) == list(range(A))
+    marked = sorted((main[(main & (1 << 29)) != 0] & 0x1fffffff).tolist())
+    used = sib[sib != 0x7fffffff]
+    assert sorted((used & 0x1fffffff).tolist()) == marked and bool(((used >> 29) & 3 == 3).all()), "every marked query has exactly one sibling entry"
+    assert 0 < len(marked) <= extra
+    # the choice is by row order: the marked set is a prefix of the heavy rows
+    sp_all = ops.AggSplit(A, 4096, DEV)
+    pa = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"], split=sp_all).cpu().numpy()[:A]
+    heavy = sorted((pa[(pa & (1 << 29)) != 0] & 0x1fffffff).tolist())
+    assert marked == heavy[:len(marked)] and (len(marked) == extra or len(marked) == len(heavy))
+    run = lambda: ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab, split=sp)
+    got = run()
+    assert (got.float().cpu() - want).abs().max().item() < 5e-5
+    unsplit = torch.ones(A, dtype=torch.bool)
+    unsplit[marked] = False
+    assert torch.equal(got[unsplit.to(DEV)], base[unsplit.to(DEV)]), "rows without a sibling take variant 8's path bit for bit"
+    assert int(sp.tickets.abs().sum()) == 0
+    for _ in range(3):
+        assert torch.equal(run(), got) and int(sp.tickets.abs().sum()) == 0
+    out = torch.empty_like(got)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab, split=sp, out=out)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, got)

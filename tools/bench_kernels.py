@@ -81,6 +81,20 @@ def main():
                 t = timeit(fn, a.iters)
                 rows.append(dict(kernel="v%d:%s" % (variant, name), dtype=str(dt).split(".")[-1], us=t * 1e6, algorithmic_bytes=by,
                                  achieved_GBps=by / t / 1e9, frac_hbm_peak=by / t / HBM_PEAK))
+        # variant 9: kernel 8 + sibling workgroups for the queries two cameras see (the device-side order marks them)
+        for extra in (128, 256, 384, 512):
+            sp = ops.AggSplit(A, extra, dev)
+            pm9 = ops.aggregation_order(args[0], args[2], c["pc_range"], c["pad_hw"], split=sp)
+            nsib = int((pm9[A:] != 0x7fffffff).sum().item())
+            fn = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], out=out, perm=pm9, tables=tab, split=sp)
+            t = timeit(fn, a.iters)
+            rows.append(dict(kernel="v9:aggregate_fwd+device order+%d sibling slots (%d used)" % (extra, nsib), dtype=str(dt).split(".")[-1], us=t * 1e6,
+                             algorithmic_bytes=by, achieved_GBps=by / t / 1e9, frac_hbm_peak=by / t / HBM_PEAK))
+        pm8 = ops.aggregation_order(args[0], args[2], c["pc_range"], c["pad_hw"])
+        fn = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], out=out, perm=pm8, variant=8, tables=tab)
+        t = timeit(fn, a.iters)
+        rows.append(dict(kernel="v8:aggregate_fwd+device order", dtype=str(dt).split(".")[-1], us=t * 1e6, algorithmic_bytes=by,
+                         achieved_GBps=by / t / 1e9, frac_hbm_peak=by / t / HBM_PEAK))
     for r in rows:
         print(json.dumps(r))
     if a.out:
