@@ -142,14 +142,15 @@ __global__ __launch_bounds__(1024) void prop_select_kernel(const float* __restri
   unsigned v[MAXV];
   if (mode == 1) {
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) { const int i = t + k * nt; v[k] = i < S ? __float_as_uint(w[i]) : 0u; }   // padding 0 never counts (mid >= 1)
+    for (int k = 0; k < MAXV; ++k) v[k] = __float_as_uint(w[min(t + k * nt, S - 1)]);        // clamped index: all loads in flight together
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) v[k] = (t + k * nt) < S ? v[k] : 0u;                        // padding 0 never counts (mid >= 1)
     __shared__ int s_part[2][1024 / 64];
     int pass = 0;
 #define PROP_COUNT_GE(dst, keyv)                                           \
     {                                                                      \
-      int c_ = 0;                                                          \
-      _Pragma("unroll") for (int k = 0; k < MAXV; ++k) c_ += (v[k] >= (keyv)) ? 1 : 0; \
-      for (int o = 32; o >= 1; o >>= 1) c_ += __shfl_xor(c_, o);           \
+      int c_ = 0;                        /* wave-uniform: ballot + s_bcnt1, no cross-lane shuffles */ \
+      _Pragma("unroll") for (int k = 0; k < MAXV; ++k) c_ += __popcll(__ballot(v[k] >= (keyv))); \
       if ((t & 63) == 0) s_part[pass & 1][t >> 6] = c_;                    \
       __syncthreads();                                                     \
       int tot_ = 0;                                                        \

@@ -15,6 +15,20 @@
 #include "common.hpp"
 #include "agg_tables.hpp"
 
+#ifdef FAR3D_PROFILING
+// tools/topk_phase_times.py: stage stamps (s_memtime) of block_topk_sorted, written by thread 0 of workgroup 0: 8 x uint64
+__device__ unsigned long long* d_topk_ts = nullptr;
+extern "C" int far3d_prof_set_topk_timestamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(d_topk_ts), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#define TOPK_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && d_topk_ts) d_topk_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TOPK_NOTE(i, v) do { if (threadIdx.x == 0 && blockIdx.x == 0 && d_topk_ts) d_topk_ts[i] = (unsigned long long)(v); } while (0)
+#else
+#define TOPK_STAMP(i) do { } while (0)
+#define TOPK_NOTE(i, v) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------ block-wide top-K
 // order-preserving map float -> uint (larger float <-> larger uint; -0 == +0; every NaN, whatever its sign bit, maps to the
 // largest key and so sorts above +inf, like torch.topk)
@@ -31,50 +45,185 @@ __device__ __forceinline__ float ord_val(unsigned k) {     // inverse of ord_key
 #define TOPK_THREADS 1024
 #define TOPK_MAXV 40          // values per thread held in registers: n <= 40960
 #define TOPK_MAXK 1024
+#define TOPK_CAND 4096        // candidates the single-wave bisection ranks out of LDS
+#define TOPK_SAMPLE 2048      // sample (two register slots per thread) that places the candidate threshold of a large input
 
-// Selects the K largest of vals[0..n) (ties -> lower index first) and leaves them sorted descending in
-// sel[0..K) as (ord_key << 32) | (0xffffffff - index).  All TOPK_THREADS threads must call; sel is LDS [TOPK_MAXK].
-// The values stay in registers (v[k] is only ever indexed by unrolled loops); a pass of the bisection = register compares,
-// one wave reduction, ONE barrier.  The winners are compacted in arbitrary order (LDS counter) and the bitonic sort on the
-// (key, index) pairs restores the order, so no ordered scan is needed.
-template <int MAXV>      // values per thread held in registers: n <= TOPK_THREADS * MAXV
-__device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, unsigned long long* sel) {
-  const int t = threadIdx.x;
-  __shared__ int s_part[2][TOPK_THREADS / 64];
-  __shared__ int s_cnt;
-  unsigned v[MAXV];
+// ---- block-wide top-K (round 5, second form).  Measured on the frame's shapes (tools/topk_phase_times.py, profiles/r5): with 40
+// values per thread EVERY pass over the registers costs ~3 k cycles on the one CU (16 waves on 4 SIMDs), and a 16-wave bisection
+// pass has a floor of ~1.2 k cycles (LDS partials + barrier) even with one value per thread -- 15-21 passes were half the kernel,
+// the 40 serialised global loads (one `s_waitcnt vmcnt(0)` each: the bounds check kept them apart) another third.  Now:
+//   1. all loads in flight together (clamped index, padding applied afterwards);
+//   2. n > TOPK_CAND: a 2048-key sample (every n/2048-th input, LDS) is bisected by ONE wave -- no barrier, no partial sums: ballot + s_bcnt1 over
+//      `ds_read_b128`s -- to a threshold T whose sample rank promises ~2-4 K keys >= T; ONE pass over the registers gathers those
+//      candidates (key, index) into LDS.  n <= TOPK_CAND: every key is a candidate;
+//   3. wave 0 bisects the candidates to a cut that keeps between K and CAPW of them (or, when a tie group straddles every such cut,
+//      to the exact K-th key and the index bound inside its tie group);
+//   4. the kept candidates are ordered by a counting rank (all 16 waves) and the first K are the result.
+// The candidate set holds EVERY key >= T, so steps 3-4 see exactly the order the whole input has; when the sample misleads (fewer
+// than K or more than TOPK_CAND keys >= T: heavy ties, adversarial layouts) the 16-wave bisection over the registers -- the previous
+// form, kept whole -- takes over.  Result and tie rule (lower index first) are those of torch.topk on every path.
+
+// keys[0 .. 1024 * n1024) >= thr, counted by one wave: four b128 per lane and iteration in flight, wave-uniform result
+// (the trip count is in whole groups so that the body can be unrolled by hand: a loop around a ballot is not unrolled by the compiler)
+__device__ __forceinline__ int wave_count_ge(const unsigned* keys, int n1024, unsigned thr, int lane) {
+  int c = 0;
+  for (int j = 0; j < n1024; ++j) {
+    uint4 q[4];
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int i = t + k * TOPK_THREADS;
-    unsigned key = 0u;                              // padding: below every real key (real keys are >= 1)
-    if (i < n) { key = ord_key(vals[i]); key = key < 1u ? 1u : key; }
-    v[k] = key;
+    for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const uint4*>(keys + j * 1024 + u * 256 + lane * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      c += __popcll(__ballot(q[u].x >= thr)) + __popcll(__ballot(q[u].y >= thr)) + __popcll(__ballot(q[u].z >= thr)) + __popcll(__ballot(q[u].w >= thr));
   }
+  return c;
+}
+// #{ j : keys[j] == key && idx[j] <= bound }
+__device__ __forceinline__ int wave_count_eq_idx(const unsigned* keys, const unsigned* idx, int nk256, unsigned key, unsigned bound, int lane) {
+  int c = 0;
+  for (int j = 0; j < nk256; ++j) {
+    const uint4 q = *reinterpret_cast<const uint4*>(keys + j * 256 + lane * 4), d = *reinterpret_cast<const uint4*>(idx + j * 256 + lane * 4);
+    c += __popcll(__ballot(q.x == key && d.x <= bound)) + __popcll(__ballot(q.y == key && d.y <= bound)) +
+         __popcll(__ballot(q.z == key && d.z <= bound)) + __popcll(__ballot(q.w == key && d.w <= bound));
+  }
+  return c;
+}
+
+// wave-wide max of an unsigned (all lanes get it): DPP inside the 16-lane rows, permlane swaps across them -- no LDS round trips
+template <int CTRL> __device__ __forceinline__ unsigned topk_dpp(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  v = max(v, topk_dpp<0xB1>(v));      // quad_perm:[1,0,3,2]
+  v = max(v, topk_dpp<0x4E>(v));      // quad_perm:[2,3,0,1]
+  v = max(v, topk_dpp<0x124>(v));     // row_ror:4
+  v = max(v, topk_dpp<0x128>(v));     // row_ror:8
+  u2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  unsigned rx = r.x, ry = r.y;
+  v = max(rx, ry);
+  r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  rx = r.x; ry = r.y;
+  return max(rx, ry);
+}
+// smallest non-zero and largest key of keys[0 .. 1024 * n1024), by one wave (0 = padding; every lane gets both)
+__device__ __forceinline__ void wave_minmax(const unsigned* keys, int n1024, int lane, unsigned& mn, unsigned& mx) {
+  unsigned hi = 0u, lo_inv = 0u;            // lo_inv = max over (~key) of the real keys
+  for (int j = 0; j < n1024; ++j) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint4 q = *reinterpret_cast<const uint4*>(keys + j * 1024 + u * 256 + lane * 4);
+      hi = max(max(hi, q.x), max(q.y, max(q.z, q.w)));
+      lo_inv = max(lo_inv, q.x ? ~q.x : 0u); lo_inv = max(lo_inv, q.y ? ~q.y : 0u);
+      lo_inv = max(lo_inv, q.z ? ~q.z : 0u); lo_inv = max(lo_inv, q.w ? ~q.w : 0u);
+    }
+  }
+  mx = wave_max_u32(hi);
+  mn = ~wave_max_u32(lo_inv);
+}
+// Binary search by ONE wave (no barriers) for a cut with Klo <= count(key >= cut) <= Khi over keys[0 .. 1024 * n1024), started from the
+// keys' own range [min, max + 1) instead of [1, 2^32): the frame's logits sit in a band 2^23 keys wide, which is 9 passes less.
+// window = true: lo = such a cut.  Otherwise hi - lo == 1 with count(key >= lo) >= Klo > count(key >= hi) = cnt_hi.
+// Needs count(key != 0) >= Klo.  Wave-uniform results.
+__device__ __forceinline__ void wave_search(const unsigned* keys, int n1024, int Klo, int Khi, int lane, unsigned long long& lo,
+                                            unsigned long long& hi, int& cnt_hi, bool& window) {
+  unsigned mn, mx;
+  wave_minmax(keys, n1024, lane, mn, mx);
+  lo = (unsigned long long)__builtin_amdgcn_readfirstlane(mn);
+  hi = (unsigned long long)__builtin_amdgcn_readfirstlane(mx) + 1ull;
+  cnt_hi = 0;
+  window = false;
+  while (hi - lo > 1ull) {
+    const unsigned mid = (unsigned)(lo + ((hi - lo) >> 1));
+    const int c = wave_count_ge(keys, n1024, mid, lane);
+    if (c >= Klo && c <= Khi) { lo = mid; window = true; return; }
+    if (c > Khi) lo = mid; else { hi = mid; cnt_hi = c; }
+  }
+}
+
+// Common tail: sel[0..c) holds the kept entries (any order) -> sorted descending.  Counting rank: entry e goes to position
+// #{e' > e} (entries are distinct: the index is part of them).
+// Stage 1 ranks by the 32-bit keys alone -- 4 keys per 16-byte broadcast read, one v_cmp + one add each -- with all 1024 threads
+// at work: a thread keeps TWO entries (e, e + cp/2; cp = 2^m >= c) against one of 2048 / cp key ranges, the partial ranks meet in
+// LDS atomics.  (The transposed form -- a lane keeps keys, a wave walks entries whose key is a scalar, ballot + s_bcnt1 count 64
+// compares per v_cmp -- has a third of the VALU work and measured 1.6x SLOWER: 11-13 k cycles against 7-8 k, the v_cmp -> s_bcnt1
+// -> s_add chains of one wave do not overlap; profiles/r5/topk_phase_times.txt.)
+// Stage 2: entries with equal keys share their stage-1 position r, and the g of them own sel[r .. r + g): each parks itself in a
+// staging copy of that range (arrival order), then ranks itself among the g by index (lower index = larger entry first).
+// All threads call; s_k32: >= 16 KB of scratch (keys, staging); s_rank / s_slot zeroed by the caller.
+__device__ __forceinline__ void topk_rank_place(unsigned long long* sel, int c, unsigned* s_k32, int* s_rank, int* s_slot) {
+  const int t = threadIdx.x;
+  unsigned long long* stage = reinterpret_cast<unsigned long long*>(s_k32 + 2 * TOPK_MAXK);      // [TOPK_MAXK] entries
+  const unsigned long long mine = t < c ? sel[t] : 0ull;
+  s_k32[t] = (unsigned)(mine >> 32);                  // 0 past the entries: below every real key
+  __syncthreads();
+  {
+    int lg = 6;
+    while ((1 << lg) < c) ++lg;                       // cp = 2^lg >= c, 64 .. 1024
+    const int half = 1 << (lg - 1), P = (2 * TOPK_THREADS) >> lg;
+    const int e0 = t & (half - 1), e1 = e0 + half, part = t >> (lg - 1);
+    const int len = ((c + P - 1) / P + 15) & ~15;
+    const int j0 = part * len, j1 = min(j0 + len, (c + 15) & ~15);
+    if (e0 < c && j0 < j1) {
+      const unsigned k0 = s_k32[e0], k1 = e1 < c ? s_k32[e1] : 0xffffffffu;
+      int r0 = 0, r1 = 0;
+      for (int j = j0; j < j1; j += 16) {
+        const uint4 a = *reinterpret_cast<const uint4*>(s_k32 + j), b = *reinterpret_cast<const uint4*>(s_k32 + j + 4);
+        const uint4 d = *reinterpret_cast<const uint4*>(s_k32 + j + 8), f = *reinterpret_cast<const uint4*>(s_k32 + j + 12);
+        const unsigned q[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { r0 += q[u] > k0 ? 1 : 0; r1 += q[u] > k1 ? 1 : 0; }
+      }
+      if (r0) atomicAdd(&s_rank[e0], r0);
+      if (r1 && e1 < c) atomicAdd(&s_rank[e1], r1);
+    }
+  }
+  __syncthreads();
+  TOPK_STAMP(4);
+  int r = 0;
+  if (t < c) {
+    r = s_rank[t];
+    const int q = atomicAdd(&s_slot[r], 1);           // arrival order inside the group of equal keys
+    stage[r + q] = mine;
+  }
+  __syncthreads();
+  if (t < c) {
+    const int g = s_slot[r];
+    int rr = r;
+#pragma unroll 4
+    for (int j = 0; j < g; ++j) rr += stage[r + j] > mine ? 1 : 0;      // g == 1: nothing is greater
+    sel[rr] = mine;
+  }
+  __syncthreads();
+}
+
+// The 16-wave form over the register-held keys v[] (any input; the fall-back of block_topk_sorted).  A pass of the bisection =
+// one v_cmp per value whose wave-wide result lands in an SGPR pair (ballot), s_bcnt1 + s_add on the scalar unit, one LDS word per
+// wave, ONE barrier.  Leaves the kept entries (K <= count <= CAPW) in sel, unordered, and returns their number.
+// Needs *s_cnt == 0 on entry (visible to all threads).
+template <int MAXV>
+__device__ __forceinline__ int topk_select_registers(const unsigned (&v)[MAXV], int n, int K, int CAPW, unsigned long long* sel, int* s_cnt) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  __shared__ __attribute__((aligned(16))) int s_part[2][TOPK_THREADS / 64];
   int pass = 0;
 #define TOPK_COUNT(dst, pred)                                              \
   {                                                                        \
-    int c_ = 0;                                                            \
+    int c_ = 0;                                   /* wave-uniform */       \
     _Pragma("unroll") for (int k = 0; k < MAXV; ++k) {                     \
       const unsigned key = v[k];                                           \
       const int idx = t + k * TOPK_THREADS;                                \
       (void)idx;                                                           \
-      c_ += (pred) ? 1 : 0;                                                \
+      c_ += __popcll(__ballot(pred));                                      \
     }                                                                      \
-    for (int o = 32; o >= 1; o >>= 1) c_ += __shfl_xor(c_, o);             \
-    if ((t & 63) == 0) s_part[pass & 1][t >> 6] = c_;                      \
+    if (lane == 0) s_part[pass & 1][wv] = c_;                              \
     __syncthreads();                                                       \
+    const int4* pp_ = reinterpret_cast<const int4*>(s_part[pass & 1]);     \
     int tot_ = 0;                                                          \
-    _Pragma("unroll") for (int w = 0; w < TOPK_THREADS / 64; ++w) tot_ += s_part[pass & 1][w]; \
+    _Pragma("unroll") for (int w = 0; w < TOPK_THREADS / 256; ++w) { const int4 q_ = pp_[w]; tot_ += (q_.x + q_.y) + (q_.z + q_.w); } \
     ++pass;                                                                \
     dst = tot_;                                                            \
   }
-  // Round 5: the bisection stops as soon as SOME cut keeps between K and CAPW entries (`key >= mid` selects a superset of the top-K that
-  // holds every entry of any tie group it touches), and the winners are ordered by a counting rank instead of a bitonic network: the
-  // top-K is the first K of that order.  32 passes + 45 barrier stages became ~10 passes + 2 barriers on the frame's 40 k logits
-  // (decode 47 -> us, memory top-k 24 -> us; profiles/r5).  A key distribution with no such cut (more than CAPW entries tied at the
-  // K-th place) runs the bisection to its end and takes the exact tie rule below -- same result either way.
-  const int CAPW = min(TOPK_MAXK, max(2 * K, 256));
-  // invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit)
+  // invariant: count(key >= lo) >= K, count(key >= hi) < K   (hi = 2^32 as 64-bit).  The bisection stops as soon as SOME cut keeps
+  // between K and CAPW entries (`key >= mid` selects a superset of the top-K that holds every entry of any tie group it touches).
   unsigned long long lo = 1ull, hi = 0x100000000ull;
   int n_ge = -1;
   bool window = false;
@@ -104,35 +253,180 @@ __device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals
     }
   }
 #undef TOPK_COUNT
-  if (t == 0) s_cnt = 0;
-  __syncthreads();
+  // compaction, order arbitrary: a wave reserves its range with ONE LDS atomic, lanes take positions from the ballot masks
+#define TOPK_TAKEN(k) (v[k] > kth || (v[k] == kth && (window || (t + (k) * TOPK_THREADS) <= idx_cut)))
+  {
+    int wc = 0;
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int i = t + k * TOPK_THREADS;
-    if (v[k] > kth || (v[k] == kth && (window || i <= idx_cut))) {
-      const int pos = atomicAdd(&s_cnt, 1);
-      if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)v[k] << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+    for (int k = 0; k < MAXV; ++k) wc += __popcll(__ballot(TOPK_TAKEN(k)));
+    int base = 0;
+    if (lane == 0 && wc) base = atomicAdd(s_cnt, wc);
+    int run = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const bool tk = TOPK_TAKEN(k);
+      const unsigned long long m = __ballot(tk);
+      if (m == 0ull) continue;
+      if (tk) {
+        const int pos = run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)v[k] << 32) | (unsigned long long)(0xffffffffu - (unsigned)(t + k * TOPK_THREADS));
+      }
+      run += __popcll(m);
     }
   }
+#undef TOPK_TAKEN
   __syncthreads();
-  // counting rank, descending: entry e goes to position #{e' > e} (the entries are distinct: the index is part of them).  Every thread
-  // of a wave reads the same LDS words (broadcast), 4 entries per iteration; threads past the count pad the tail with zeros first.
-  const int c = min(s_cnt, TOPK_MAXK);
-  __shared__ __attribute__((aligned(16))) unsigned long long s_tmp[TOPK_MAXK + 4];
-  const unsigned long long mine = t < c ? sel[t] : 0ull;
-  if (t < c) s_tmp[t] = mine;
-  if (t < 4) s_tmp[c + t] = 0ull;
-  __syncthreads();
-  if (t < c) {
-    int r = 0;
-#pragma unroll 8
-    for (int j = 0; j < c; j += 4) {           // unrolled: the broadcast reads of 32 entries are in flight together (LDS latency, not bandwidth)
-      const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(s_tmp + j), b = *reinterpret_cast<const ulonglong2*>(s_tmp + j + 2);
-      r += (a.x > mine ? 1 : 0) + (a.y > mine ? 1 : 0) + (b.x > mine ? 1 : 0) + (b.y > mine ? 1 : 0);
+  return min(*s_cnt, TOPK_MAXK);
+}
+
+// Selects the K largest of vals[0..n) (ties -> lower index first) and leaves them sorted descending in
+// sel[0..K) as (ord_key << 32) | (0xffffffff - index).  All TOPK_THREADS threads must call; sel is LDS [TOPK_MAXK].
+template <int MAXV>      // values per thread held in registers: n <= TOPK_THREADS * MAXV
+__device__ __forceinline__ void block_topk_sorted(const float* __restrict__ vals, int n, int K, unsigned long long* sel) {
+  static_assert(TOPK_THREADS == TOPK_MAXK && TOPK_CAND == 4 * TOPK_THREADS && TOPK_SAMPLE == 2 * TOPK_THREADS, "one entry per thread in the rank stage");
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned s_ckey[TOPK_CAND];    // candidate keys;    later the rank stage's keys
+  __shared__ __attribute__((aligned(16))) unsigned s_cidx[TOPK_CAND];    // candidate indices; first the sample, later the rank stage's entries
+  __shared__ int s_rank[TOPK_MAXK], s_slot[TOPK_MAXK];
+  __shared__ int s_cnt;
+  __shared__ unsigned s_ctl[4];
+  TOPK_STAMP(0);
+  unsigned v[MAXV];
+  unsigned smp0 = 0u, smp1 = 0u;                      // n > TOPK_CAND: two entries of an evenly strided sample of the input
+  {
+    float f[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) f[k] = vals[min(t + k * TOPK_THREADS, n - 1)];       // all loads in flight together
+    if (n > TOPK_CAND) {
+      const float a = vals[(long)(2 * t) * n / TOPK_SAMPLE], b = vals[(long)(2 * t + 1) * n / TOPK_SAMPLE];
+      smp0 = ord_key(a); smp1 = ord_key(b);
+      smp0 = smp0 < 1u ? 1u : smp0; smp1 = smp1 < 1u ? 1u : smp1;
     }
-    sel[r] = mine;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      unsigned key = ord_key(f[k]);
+      key = key < 1u ? 1u : key;
+      v[k] = (t + k * TOPK_THREADS) < n ? key : 0u;   // padding: below every real key (real keys are >= 1)
+    }
   }
-  __syncthreads();
+  TOPK_STAMP(1);
+  s_rank[t] = 0;
+  s_slot[t] = 0;
+  if (t == 0) s_cnt = 0;
+  const int CAPW = min(TOPK_MAXK, K + max(K >> 3, 32));
+  int ncand = n;
+  bool registers = false;                             // block-uniform: the 16-wave form over the registers decides
+  if (n <= TOPK_CAND) {
+#pragma unroll
+    for (int k = 0; k < (MAXV < 4 ? MAXV : 4); ++k) { s_ckey[t + k * TOPK_THREADS] = v[k]; s_cidx[t + k * TOPK_THREADS] = (unsigned)(t + k * TOPK_THREADS); }
+    if (MAXV < 4) for (int k = MAXV; k < 4; ++k) s_ckey[t + k * TOPK_THREADS] = 0u;
+    __syncthreads();
+  } else {
+    unsigned* s_smp = s_cidx;
+    s_smp[t] = smp0;
+    s_smp[TOPK_THREADS + t] = smp1;
+    *reinterpret_cast<uint4*>(s_ckey + t * 4) = make_uint4(0u, 0u, 0u, 0u);     // keys past the candidates read as padding
+    __syncthreads();
+    // sample ranks [r_lo, 1.5 r_lo] <-> about [1.3 K + 10 n / S, 2 K + 15 n / S] keys of the input (S = TOPK_SAMPLE entries)
+    if (wv == 0) {
+      const int r_lo = (int)(1.3f * (float)K * (float)TOPK_SAMPLE / (float)n) + 10, r_hi = r_lo + (r_lo >> 1);
+      unsigned long long lo, hi;
+      int cnt_hi;
+      bool win;
+      wave_search(s_smp, TOPK_SAMPLE / 1024, r_lo, r_hi, lane, lo, hi, cnt_hi, win);
+      if (lane == 0) s_ctl[0] = (unsigned)lo;
+    }
+    __syncthreads();
+    const unsigned T = s_ctl[0];
+    {
+      int wc = 0;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) wc += __popcll(__ballot(v[k] >= T));
+      int base = 0;
+      if (lane == 0 && wc) base = atomicAdd(&s_cnt, wc);
+      int run = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const bool tk = v[k] >= T;
+        const unsigned long long m = __ballot(tk);
+        if (m == 0ull) continue;
+        if (tk) {
+          const int pos = run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (pos < TOPK_CAND) { s_ckey[pos] = v[k]; s_cidx[pos] = (unsigned)(t + k * TOPK_THREADS); }
+        }
+        run += __popcll(m);
+      }
+    }
+    __syncthreads();
+    ncand = s_cnt;
+    registers = ncand < K || ncand > TOPK_CAND;
+    __syncthreads();
+    if (t == 0) s_cnt = 0;
+  }
+  TOPK_STAMP(2);
+  TOPK_NOTE(7, ncand + (registers ? (1 << 30) : 0));
+  int c;
+  if (registers) {
+    __syncthreads();                                  // s_cnt = 0
+    c = topk_select_registers<MAXV>(v, n, K, CAPW, sel, &s_cnt);
+  } else {
+    const int nk256 = (ncand + 255) >> 8, nk1024 = (ncand + 1023) >> 10;     // keys past the candidates are 0 up to TOPK_CAND
+    if (wv == 0) {
+      // invariant: count(key >= lo) >= K > count(key >= hi) = cnt_hi
+      unsigned long long lo, hi;
+      int cnt_hi;
+      bool win;
+      wave_search(s_ckey, nk1024, K, CAPW, lane, lo, hi, cnt_hi, win);
+      const unsigned kth = (unsigned)lo;
+      unsigned idx_cut = 0xffffffffu;                 // among the keys == kth, keep indices <= idx_cut
+      if (!win) {
+        const int n_ge = wave_count_ge(s_ckey, nk1024, kth, lane);
+        if (n_ge > K) {                               // ties at the cut: keep the lowest indices (rare: one wave, binary)
+          const int need = K - cnt_hi;                // cnt_hi = count(key > kth)
+          long ilo = -1, ihi = (long)n - 1;           // count(idx <= ilo) < need <= count(idx <= ihi)
+          while (ihi - ilo > 1) {
+            const long mid = ilo + ((ihi - ilo) >> 1);
+            const int cc = wave_count_eq_idx(s_ckey, s_cidx, nk256, kth, (unsigned)mid, lane);
+            if (cc >= need) ihi = mid; else ilo = mid;
+          }
+          idx_cut = (unsigned)ihi;
+        }
+      }
+      if (lane == 0) { s_ctl[0] = kth; s_ctl[1] = win ? 1u : 0u; s_ctl[2] = idx_cut; }
+    }
+    __syncthreads();                                  // also: s_cnt = 0
+    const unsigned kth = s_ctl[0], idx_cut = s_ctl[2];
+    const bool window = s_ctl[1] != 0u;
+    // the kept candidates -> sel, order arbitrary (<= 4 candidates per thread)
+    unsigned ck[4], ci[4];
+    bool tk[4];
+    int wc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p_ = t + j * TOPK_THREADS;
+      ck[j] = s_ckey[p_]; ci[j] = s_cidx[p_];
+      tk[j] = p_ < ncand && (ck[j] > kth || (ck[j] == kth && (window || ci[j] <= idx_cut)));
+      wc += __popcll(__ballot(tk[j]));
+    }
+    int base = 0;
+    if (lane == 0 && wc) base = atomicAdd(&s_cnt, wc);
+    int run = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned long long m = __ballot(tk[j]);
+      if (tk[j]) {
+        const int pos = run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)ck[j] << 32) | (unsigned long long)(0xffffffffu - ci[j]);
+      }
+      run += __popcll(m);
+    }
+    __syncthreads();
+    c = min(s_cnt, TOPK_MAXK);
+  }
+  TOPK_STAMP(3);
+  TOPK_NOTE(6, c);
+  topk_rank_place(sel, c, s_ckey, s_rank, s_slot);
+  TOPK_STAMP(5);
 }
 
 template <int MAXV>
@@ -153,6 +447,8 @@ extern "C" int far3d_topk(const float* vals, int n, int K, int64_t* idx_out, flo
                   "far3d_topk: need 0 < K <= min(n, %d), n <= %d (got n=%d K=%d)", TOPK_MAXK, TOPK_THREADS * TOPK_MAXV, n, K);
   if (n <= TOPK_THREADS * 4)      // the memory update ranks A ~ 1.5k scores: 4 registers per thread instead of 40
     hipLaunchKernelGGL(topk_kernel<4>, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
+  else if (n <= TOPK_THREADS * 16)
+    hipLaunchKernelGGL(topk_kernel<16>, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
   else
     hipLaunchKernelGGL(topk_kernel<TOPK_MAXV>, dim3(1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, vals, n, K, (long*)idx_out, val_out);
   FAR3D_CHECK_LAUNCH("far3d_topk");
@@ -235,7 +531,11 @@ extern "C" int far3d_decode_topk(const float* cls_last, const float* box_last, i
   p.A = A; p.ncls = num_classes; p.code = code_size; p.K = K;
   for (int k = 0; k < 3; ++k) { p.lo[k] = post_center_range[k]; p.hi[k] = post_center_range[3 + k]; }
   hipStream_t st = (hipStream_t)stream;
-  if (n <= DECODE_CHUNK) {
+  if (n <= TOPK_THREADS * 4) {
+    hipLaunchKernelGGL(decode_topk_kernel<4>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)n, (const int*)nullptr);
+  } else if (n <= TOPK_THREADS * 16) {      // the benchmarked frame: 1544 queries x 10 classes
+    hipLaunchKernelGGL(decode_topk_kernel<16>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)n, (const int*)nullptr);
+  } else if (n <= DECODE_CHUNK) {
     hipLaunchKernelGGL(decode_topk_kernel<TOPK_MAXV>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)n, (const int*)nullptr);
   } else {
     const int nchunks = (int)((n + DECODE_CHUNK - 1) / DECODE_CHUNK);

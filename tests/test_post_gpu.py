@@ -32,10 +32,32 @@ def test_topk_matches_torch(hip_lib, n, K):
 @pytest.mark.parametrize("n,K,levels", [(5000, 100, 3), (40000, 300, 2), (1544, 256, 1), (2000, 700, 5)])
 def test_topk_with_huge_tie_groups_takes_the_exact_tie_rule(hip_lib, n, K, levels):
     """Values drawn from a handful of levels: the K-th place sits inside a tie group far larger than the window of the fast path (no cut
-    keeps between K and max(2K, 256) entries), so the bisection runs to its end and the index bisection decides -- lowest indices first."""
+    keeps between K and K + max(K/8, 32) entries), so the search runs to its end and the index bisection decides -- lowest indices first."""
     from far3d_amd import ops
     g = torch.Generator().manual_seed(n * 3 + K)
     v = torch.randint(0, levels, (n,), generator=g).float() * 0.5 - 1.0
+    idx, val = ops.topk(v.to(DEV), K, with_values=True)
+    order = np.lexsort((np.arange(n), -v.numpy()))[:K]
+    assert np.array_equal(idx.cpu().numpy(), order) and torch.equal(val.cpu(), v[torch.as_tensor(order)])
+
+
+@pytest.mark.parametrize("layout", ["top_values_only_at_sampled_positions", "top_values_never_sampled", "plain"])
+@pytest.mark.parametrize("n,K", [(40960, 300), (40144, 300), (9000, 1000), (4097, 64)])
+def test_topk_when_the_strided_sample_misleads(hip_lib, layout, n, K):
+    """Large inputs place the candidate threshold from a strided 2048-entry sample (every n/2048-th input).  Layouts whose sample says
+    nothing true about the input -- the largest values ONLY at the sampled positions (far fewer than K candidates come back) or NEVER
+    there (more candidates than the LDS holds) -- must fall back to the 16-wave bisection over the registers and give the same answer."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(n + K + len(layout))
+    v = torch.randn(n, generator=g) * 0.1 - 4.0
+    sampled = torch.unique((torch.arange(2048, dtype=torch.int64) * n) // 2048)
+    if layout == "top_values_only_at_sampled_positions":
+        v[sampled] += 10.0
+    elif layout == "top_values_never_sampled":
+        mask = torch.ones(n, dtype=torch.bool)
+        mask[sampled] = False
+        pick = torch.nonzero(mask)[:, 0][::3][:6000]
+        v[pick] += 10.0
     idx, val = ops.topk(v.to(DEV), K, with_values=True)
     order = np.lexsort((np.arange(n), -v.numpy()))[:K]
     assert np.array_equal(idx.cpu().numpy(), order) and torch.equal(val.cpu(), v[torch.as_tensor(order)])
