@@ -186,7 +186,13 @@ __device__ __forceinline__ void sum_parts(const float2* __restrict__ src, int np
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        v[j][k] = (c0 + j * cstep < C && b + k < nparts) ? src[(long)(b + k) * C + c0 + j * cstep] : make_float2(0.f, 0.f);
+        v[j][k] = src[(long)min(b + k, nparts - 1) * C + min(c0 + j * cstep, C - 1)];     // clamped, never predicated: a load under a
+                                                                                          // condition waits for the one before it
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (!(c0 + j * cstep < C && b + k < nparts)) v[j][k] = make_float2(0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
   float4 w[4][4];
   float bias[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias[j] = c0 + j < C ? fcb[c0 + j] : 0.f;
+  for (int j = 0; j < 4; ++j) bias[j] = fcb[min(c0 + j, C - 1)];          // clamped (a predicated load waits for the one before it);
+                                                                             // channels past C are never stored
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = lane * 4 + i * 256;
@@ -221,10 +228,13 @@ __global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__
       w[i][j] = (k < C && c0 + j < C) ? *reinterpret_cast<const float4*>(fcw + (long)(c0 + j) * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (fixed) {
+    long long fx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fx[j] = fixed[(long)n * C + min((int)threadIdx.x + j * 256, C - 1)];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (threadIdx.x + j * 256 < C)
-        mean[threadIdx.x + j * 256] = (float)((double)fixed[(long)n * C + threadIdx.x + j * 256] * (1.0 / (1 << FAR3D_SUMS_FRAC_BITS)) * (double)inv_hw);
+        mean[threadIdx.x + j * 256] = (float)((double)fx[j] * (1.0 / (1 << FAR3D_SUMS_FRAC_BITS)) * (double)inv_hw);
   } else {
     float2 sm[4];                                  // C <= 1024: channels t, t + 256, t + 512, t + 768
     sum_parts<4>(src, nparts, C, threadIdx.x, 256, sm);
@@ -340,6 +350,13 @@ extern "C" int far3d_ese_nhwc(const void* x, int dt, const float* fcw, const flo
 // polling seven counters serialise on their cache lines.  A kernel boundary is the cheap device-wide release / acquire here.
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
+  struct Raw { uint4 a; };                             // the 16 bytes as loaded: conversion can wait until every load is issued
+  static __device__ __forceinline__ Raw ldraw(const bf16_t* p) { Raw r; r.a = *reinterpret_cast<const uint4*>(p); return r; }
+  static __device__ __forceinline__ void cvt(const Raw& q, float (&v)[8]) {
+    const uint4 r = q.a;
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u); v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
   static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
     const uint4 r = *reinterpret_cast<const uint4*>(p);
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
@@ -354,6 +371,22 @@ template <> struct Vec8<bf16_t> {
   }
 };
 template <> struct Vec8<pair_t> {        // p -> hi of 8 consecutive channels of one 32-block; lo 32 elements on
+  struct Raw { uint4 h, l; };
+  static __device__ __forceinline__ Raw ldraw(const pair_t* p) {
+    Raw r;
+    r.h = *reinterpret_cast<const uint4*>(p);
+    r.l = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p) + 32);
+    return r;
+  }
+  static __device__ __forceinline__ void cvt(const Raw& q, float (&v)[8]) {
+    float h[8], l[8];
+    Vec8<bf16_t>::Raw a, b;
+    a.a = q.h; b.a = q.l;
+    Vec8<bf16_t>::cvt(a, h);
+    Vec8<bf16_t>::cvt(b, l);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = h[e] + l[e];
+  }
   static __device__ __forceinline__ void ld(const pair_t* p, float (&v)[8]) {
     float h[8], l[8];
     Vec8<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p), h);
@@ -392,8 +425,8 @@ struct EseFusedParams {
   long xs, is, ys, ps;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
+template <typename T, bool POOL>      // POOL = false: the launches without a pooled output (13 of the 16 of a frame) keep their small register file
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void ese_fused_kernel(EseFusedParams P) {
   const int n = blockIdx.y, tid = threadIdx.x, C = P.C;
   const int b = blockIdx.x, cq = C / 8;
   const int HW = P.H * P.W;
@@ -432,34 +465,35 @@ __global__ __launch_bounds__(256) void ese_fused_kernel(EseFusedParams P) {
       for (int e = 0; e < 8; ++e) { xv[e] = xn[e]; dv[e] = dn[e]; }
     }
   }
-  if (P.pooled) {
+  if constexpr (POOL) {
     T* pd = reinterpret_cast<T*>(P.pooled) + (long)n * P.ps + co;
     const int HWp = P.Hp * P.Wp;
     for (int q = i0 / cq; q < HWp; q += pstep) {
       const int oy = q / P.Wp, ox = q - oy * P.Wp;
+      // taps past the edge are clamped onto the last row / column, which lies inside the window (ceil mode: a window starts inside the
+      // input): a duplicate tap leaves the maximum as it is, and the loads are UNCONDITIONAL -- under `if (iy >= H) continue` every
+      // load waited for the one before it (nine dependent round trips per pooled pixel).  A kernel row (3 taps of x and of the
+      // identity) is in flight at a time, kept as loaded (16-byte registers) until all of them are issued.
       float m[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 + ky;
-        if (iy >= P.H) continue;
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) {                 // not unrolled: the compiler otherwise hoists all 18 loads and spills
+        const int iy = min(oy * 2 + ky, P.H - 1);
+        typename Vec8<T>::Raw tv[3], td[3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int ix = ox * 2 + kx;
-          if (ix >= P.W) continue;
-          const long pp = (long)iy * P.W + ix;
-          float v[8];
-          Vec8<T>::ld(x + pp * P.ldx, v);
-          if (idn) {
-            float d[8];
-            Vec8<T>::ld(idn + pp * P.ldi, d);
+          const long pp = (long)iy * P.W + min(ox * 2 + kx, P.W - 1);
+          tv[kx] = Vec8<T>::ldraw(x + pp * P.ldx);
+          if (idn) td[kx] = Vec8<T>::ldraw(idn + pp * P.ldi);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ese_mul_add(v[e], g[e], d[e]);
-          } else {
+        for (int kx = 0; kx < 3; ++kx) {
+          float v[8], d[8];
+          Vec8<T>::cvt(tv[kx], v);
+          if (idn) Vec8<T>::cvt(td[kx], d);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ese_mul(v[e], g[e]);
-          }
+          for (int e = 0; e < 8; ++e) v[e] = idn ? ese_mul_add(v[e], g[e], d[e]) : ese_mul(v[e], g[e]);
           Vec8<T>::round(v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
@@ -504,8 +538,13 @@ extern "C" int far3d_ese_fused_nhwc(const void* x, int dt, const float* fcw, con
   db = (db + unit - 1) / unit * unit;
   P.DB = (int)db;
   dim3 grid((unsigned)P.DB, (unsigned)N);
-  if (dt == FAR3D_DT_BF16_PAIR) hipLaunchKernelGGL(ese_fused_kernel<pair_t>, grid, dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(ese_fused_kernel<bf16_t>, grid, dim3(256), 0, st, P);
+  if (dt == FAR3D_DT_BF16_PAIR) {
+    if (pooled) hipLaunchKernelGGL((ese_fused_kernel<pair_t, true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((ese_fused_kernel<pair_t, false>), grid, dim3(256), 0, st, P);
+  } else {
+    if (pooled) hipLaunchKernelGGL((ese_fused_kernel<bf16_t, true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((ese_fused_kernel<bf16_t, false>), grid, dim3(256), 0, st, P);
+  }
   FAR3D_CHECK_LAUNCH("far3d_ese_fused_nhwc");
   return FAR3D_OK;
 }
