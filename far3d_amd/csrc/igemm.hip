@@ -3,6 +3,7 @@
 #include "igemm_kernels.hpp"
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
+int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 
 #ifdef FAR3D_PROFILING
 // tools/conv_phase_times.py: where the per-workgroup stamps of the pipelined conv / GEMM kernels go (8 x uint64 per workgroup)
@@ -77,6 +78,21 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   }
   const long Npix = (long)N * Ho * Wo;
   FAR3D_CHECK_ARG(Npix < (1L << 31) - 4096 && (long)N * H * W < (1L << 31) - 4096, "far3d_conv2d_nhwc: %ld pixels: the kernels index pixels with 32 bits", Npix);
+  // fp32 activation rows x pre-split weights, 1x1: the pipelined GEMM kernel with in-register hi / lo split of the rows (tiles 479-481;
+  // auto).  32 floats = the 128 bytes of a pair-stored 32-channel block: the rows go in as pair rows of twice the stride.
+  if (x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32_BF16X3 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cin % 32 == 0 && !chan_sums &&
+      aligned(x, 16) && ldx % 4 == 0 && x_img_stride % 4 == 0 && ((long)(N - 1) * x_img_stride + (long)Ho * Wo * ldx) * 4 < 0x7fffffffL &&
+      (tile == 0 || (tile >= 479 && tile <= 481))) {
+    IgemmParams Q = P;
+    Q.ldx = 2 * ldx; Q.x_img_stride = 2 * x_img_stride;
+    // auto: the 64 x 64 tile (measured 7.3-10 us on the decoder's GEMMs against 11-18 for the 128 x 128 ones and 12-19 for the staged
+    // exact-fp32 kernel, profiles/r5/fp32_rows_gemm.txt); the 8-wave 128 x 128 tile only when even that one fills the chip 8 times over
+    const int t = tile ? tile : ((((Npix + 127) / 128) * ((Cout + 127) / 128) >= 2048) ? 479 : 480);
+    const int rc = far3d_conv_f32rows_launch(Q, t, st);
+    if (rc != FAR3D_OK) return rc;
+    FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
+    return FAR3D_OK;
+  }
   // tile: 0 = auto.  (channels x pixels per workgroup) 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x64, 5 = 64x256
   if (tile == 0) {   // fallback heuristic; far3d_amd/data/tuning_mi355x.json holds measured per-shape winners
     const long big = ((Npix + 127) / 128) * ((Cout + 127) / 128);

@@ -1200,13 +1200,68 @@ __device__ __forceinline__ void gemm_step_split(const unsigned char* smem, const
   }
 }
 
+// fp32 activation rows (F32B, round 5: the exact-data decoder GEMMs of the in-tolerance engine on the pipelined kernel): 32 floats are
+// the same 128 bytes as a pair-stored 32-channel block, so the DMA pattern is the pair kernel's -- the two 64-byte sub-tiles of a step
+// are floats 0-15 and 16-31 -- and only the fragment differs: the 8 floats a lane feeds into k-half kk are logical chunks 2*hi and
+// 2*hi + 1 of sub-tile kk, split into their hi / lo bf16 halves in registers (round-to-nearest-even, as pair_from_float stores them).
+// baddr[c][j]: chunk 2*hi + c of the lane's row in pixel tile j.  Products and their order are those of gemm_step_split.
+template <int WM, int WN, int SOFF, int BM, int SUBB>
+__device__ __forceinline__ void gemm_step_split_f32b(const unsigned char* smem, const int (&aaddr)[2][WM], const int (&baddr)[2][WN],
+                                                     f32x16_t (&acc)[WM][WN]) {
+  u32x4_t af[2][2][WM], bx[2][2][WN];       // [register buffer][plane | chunk][tile]
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + pl * SUBB + aaddr[0][i]);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bx[0][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + baddr[pl][j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    if (kk == 0) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[1][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + pl * SUBB + aaddr[1][i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bx[1][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + SUBB + baddr[pl][j]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4_t bh[WN], bl[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      uint2 h0, l0, h1, l1;
+      split4(bx[kk][0][j], h0, l0);
+      split4(bx[kk][1][j], h1, l1);
+      bh[j] = u32x4_t{h0.x, h0.y, h1.x, h1.y};
+      bl[j] = u32x4_t{l0.x, l0.y, l1.x, l1.y};
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[kk][1][i], bh[j]);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[kk][0][i], bl[j]);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], af[kk][0][i], bh[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // NT / PAIR as in conv3x3_pipe_kernel: pair-stored activations + pre-split weights; NT = 3 split products, NT = 1 hi planes only.
 // NS: LDS ring depth in 64-channel steps.  NS = 2: the step that follows the one being computed is in flight (each barrier waits
 // for vmcnt(0)).  NS >= 3: NS - 1 steps are in flight and a barrier waits for the OLDEST one only (counted vmcnt: the LDS-DMAs of a
 // wave retire in order), so a step's HBM / L2 latency has NS - 1 steps of MFMA work to hide under -- for the K-short GEMMs of the
 // decoder (4..16 steps) that is most of the K loop issued up front.
 
-template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2>
+// F32B: the activations are fp32 rows handed over as if pair-stored (the caller doubles ldx / x_img_stride: same bytes), weights pre-split.
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WGM * WGN;
@@ -1226,6 +1281,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   const int HoWo = P.Ho * P.Wo;
   const long Npix = (long)P.N * HoWo;
   static_assert(NT == 1 || (NT == 3 && PAIR), "split products need pair-stored operands");
+  static_assert(!F32B || (NT == 3 && PAIR), "fp32 activation rows: split products, weights pre-split");
   constexpr int PLS = PAIR ? 2 : 1;
   constexpr int KSTR = (PAIR && NT == 1) ? 128 : 64;      // bytes along K between the sub-tiles this kernel consumes
   const int Ktot = P.cin_pad * PLS;
@@ -1292,8 +1348,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int r = (wn * WN + j) * 32 + l31;
-    baddr[0][j] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
-    baddr[1][j] = baddr[0][j] ^ 32;
+    if constexpr (F32B) {     // [c]: logical chunk 2 * hi + c (4 floats) of a sub-tile row
+      baddr[0][j] = r * 64 + (((2 * hi) ^ ((r >> 2) & 3)) << 4);
+      baddr[1][j] = baddr[0][j] ^ 16;
+    } else {
+      baddr[0][j] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+      baddr[1][j] = baddr[0][j] ^ 32;
+    }
   }
   // sub-tiles of 64 bytes along K: NT 1: one per 32 channels, a step takes two; NT 3: the hi and lo plane of one 32-channel block
   const int nsub = NT == 3 ? P.cin_pad / 16 : P.cin_pad / 32, nfull = nsub >> 1, tail = nsub & 1;   // full steps + an optional half one
@@ -1332,7 +1393,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
     if ((S) + D < nfull) issue((S) + D, (((STG) + D) % NS) * STAGE, 2);                                      \
     else if ((S) + D < nsteps) issue((S) + D, (((STG) + D) % NS) * STAGE, 1);                                \
     }                                                                                                        \
-    if constexpr (NT == 3) gemm_step_split<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);         \
+    if constexpr (F32B) gemm_step_split_f32b<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);       \
+    else if constexpr (NT == 3) gemm_step_split<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);    \
     else gemm_step_pipelined<WM, WN, (STG) * STAGE, BM, SUB, 4>(smem, aaddr, baddr, acc);                    \
   }
   for (int s0 = 0; s0 < nfull; s0 += NS) {
@@ -1380,7 +1442,7 @@ static bool gemm_sums_ok(const IgemmParams& P, size_t lds_sums) {
   return true;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2>
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false>
 static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
@@ -1392,10 +1454,10 @@ static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return FAR3D_ERR_ARG;
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds_sums > 65536)
-    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>),
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B>),
                                        (int)(lds_sums <= 163840 ? lds_sums : lds0), lds_ok, "far3d_conv2d_nhwc")) return rc;
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
-  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
+  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
   return 0;
 }
 

@@ -90,3 +90,16 @@ int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
   far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for pair-stored activations with k=%d stride=%d", tile, P.KH, P.stride);
   return FAR3D_ERR_ARG;
 }
+
+// fp32 activation rows x pre-split weights on the pipelined GEMM kernel (F32B: the rows are handed over as if pair-stored -- P.ldx and
+// P.x_img_stride already doubled by the caller; 1x1 / stride 1, Cin % 32 == 0).  Tile ids 479-481 = the pair ids 179-181 + 300.
+int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st) {
+  switch (tile) {
+    case 479: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true, 2, true>(P, st);   // 128 x 128, 8 waves (1x2 tiles per wave)
+    case 480: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 2, true>(P, st);   // 64 x 64, 4 waves
+    case 481: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true, 2, true>(P, st);   // 128 x 128, 16 waves
+    default: break;
+  }
+  far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for fp32 activation rows with split weights (479-481)", tile);
+  return FAR3D_ERR_ARG;
+}

@@ -140,7 +140,11 @@ int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, v
  *    shapes; 252, 260, 265, 279, 280: the hi halves only (ONE bf16 product per term: a single-bf16 layer inside a pair-stored
  *    network).  An id the layer cannot use is an error, not a silent fallback.
  *    bf16, 1x1/s1 only: 82-89 the GEMM tiles with 3- / 4-deep LDS rings, 110-117 256 x 256 (and other large) tiles, 120-129 the
- *    GEMM with full-line LDS-DMA pieces (8 rows x 128 bytes per piece instead of 16 x 64).
+ *    GEMM with full-line LDS-DMA pieces (8 rows x 128 bytes per piece instead of 16 x 64), 140-145 split weight / activation rings;
+ *    30-35 the 3x3 / stride 2 / pad 1 layers on the LDS-patch kernel (pair: 330, 331).
+ *    x_dt = FAR3D_DT_F32 with w_dt = FAR3D_DT_F32_BF16X3, 1x1/s1, Cin % 32 == 0, x 16-byte aligned with strides that are multiples
+ *    of 4 floats: 479-481 (auto) the pipelined GEMM kernel on fp32 rows -- 32 floats are the 128 bytes of a pair-stored block, so
+ *    the LDS-DMA pattern is the pair kernel's and the hi / lo split of the rows happens in registers (same three products).
  * chan_sums (optional, DEVICE int64 [N][Cout]; 1x1/s1 layers on a pipelined GEMM tile with a bf16 or pair output, Ho*Wo >= the
  *    tile's pixel count): every STORED output element v (for a pair output: its hi and its lo half) ADDS
  *    rint(v * 2^FAR3D_SUMS_FRAC_BITS) to chan_sums[n][channel] -- the global average pool of VoVNet's eSE block (ref

@@ -253,6 +253,36 @@ def test_split_bf16_products_track_fp32(hip_lib, tile, case):
     assert bound < 0.1 * bf16_level                   # the assertion is far below what one bf16 product term would give
 
 
+@pytest.mark.parametrize("tile", [0, 479, 480, 481])
+@pytest.mark.parametrize("shape", [(1544, 256, 256), (333, 96, 200), (2568, 1024, 256), (70, 32, 40)])
+@pytest.mark.parametrize("epilogue", ["plain", "relu_residual_strided"])
+def test_fp32_rows_on_the_pipelined_gemm_kernel(hip_lib, tile, shape, epilogue):
+    """fp32 activation rows x pre-split weights, K % 32 == 0: the LDS-DMA pipelined GEMM kernel with the hi / lo split of the rows done
+    in registers (tiles 479-481, auto) -- the decoder / FarHead GEMMs of the in-tolerance engine.  Same three products as the staged
+    kernel: the same error bound as test_split_bf16_products_track_fp32; rows with a stride, a residual and an activation go through
+    the generic epilogue."""
+    from far3d_amd import ops
+    M, Kd, Co = shape
+    g = torch.Generator().manual_seed(M + Kd + Co)
+    xs = torch.randn(M, Kd + 8, generator=g)
+    x = xs[:, 4:4 + Kd]                               # row stride Kd + 8, 16-byte aligned start
+    w = torch.randn(Co, Kd, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    pc = ops.PackedConv(w, b, dtype=torch.float32, device=DEV, compute="bf16x3")
+    xd = xs.to(DEV)[:, 4:4 + Kd]
+    want = F.linear(x.double(), w.double(), b.double())
+    if epilogue == "plain":
+        got = ops.linear(xd, pc, tile=tile).cpu()
+    else:
+        res = torch.randn(M, Co, generator=g)
+        want = want.relu() + res.double()
+        got = ops.linear(xd, pc, act="relu", res=res.to(DEV), tile=tile).cpu()
+    err = (got.double() - want).abs().max().item()
+    scale = (x.abs().mean() * w.abs().mean()).item()
+    bound = 4 * 2.0 ** -16 * Kd ** 0.5 * scale * 3
+    assert err < bound, (err, bound)
+
+
 def test_split_mode_rejects_bf16_operands(hip_lib):
     from far3d_amd import lib, ops
     with pytest.raises(ValueError):
