@@ -24,6 +24,7 @@ timeout 200 python bench.py --latency-groups 2 --no-cpu-baseline --no-in-toleran
 timeout 200 python bench.py --no-fused-rows --no-cpu-baseline --no-in-tolerance --steps 40 2>/dev/null | tail -1 > $O/bench_no_fused_rows.json
 [ -x tools/ubench/_bin/clock_probe ] && timeout 60 tools/ubench/_bin/clock_probe > $O/clock_probe.txt 2>&1
 timeout 200 python tools/conv_phase_times.py 2>/dev/null | grep tile > $O/conv_phase_times.txt
+timeout 200 python tools/topk_phase_times.py 2>/dev/null | grep -v amdgpu.ids > $O/topk_phase_times_final.txt; timeout 100 python tools/topk_phase_times.py --shipped 2>/dev/null | grep -v amdgpu.ids >> $O/topk_phase_times_final.txt
 cd /tmp && export TMPDIR=/tmp
 # the per-kernel statistics come from frames that run ONE AT A TIME (--no-pipeline): with the frame pipeline three camera stages and a
 # head share the chip and a kernel's in-trace duration measures its co-runners as much as itself; the pipelined run's stats are kept
