@@ -10,6 +10,7 @@ writes its channel slice in place, so torch.cat never runs; FPN outputs are writ
 raw (for the 2D head) and camera-modulated, token-major (N, S, 256), which IS `feat_flatten` of the reference.
 """
 import fnmatch
+import functools
 import math
 import os
 
@@ -104,6 +105,16 @@ class _Lin:
 
     def __call__(self, x, act=None, res=None, out=None, out_dtype=torch.float32):
         return ops.linear(x, self.pc, act=act, res=res, out=out, out_dtype=out_dtype)
+
+
+def _with_tile_tables(fn):
+    """Entry points that issue (or capture) convolutions run under the engine's own tile tables: ops.use_tile_tables is thread-local and
+    restores the previous selection on exit, so engines with different settings -- and stand-alone ops -- can share a process."""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        with ops.use_tile_tables(self.bf16_tile_table()):
+            return fn(self, *args, **kwargs)
+    return wrapped
 
 
 class Far3DEngine:
@@ -358,12 +369,6 @@ class Far3DEngine:
             return self.tile_table
         return "tuning_mi355x_tput.json" if (self.pipeline and self.use_graph) else "tuning_mi355x.json"
 
-    def _select_tile_tables(self):
-        """Point the conv wrappers at this engine's tile tables (module state of far3d_amd.ops, consulted when a launch is issued or
-        captured): every entry point that issues convolutions calls this first, so engines with different settings can share a process."""
-        ops.BF16_TILE_TABLE = self.bf16_tile_table()
-        ops.PAIR_TILE_TABLE = ops.BF16_TILE_TABLE.replace("tuning_mi355x", "tuning_mi355x_pair")
-
     def check_proposal_overflow(self):
         """Fixed-capacity threshold mode: raise if the latest frame had more proposals than rows (or a camera filled its selection
         capacity).  Synchronises; call it when the outputs are read, not between pipelined frames."""
@@ -392,12 +397,12 @@ class Far3DEngine:
         return b
 
     # ------------------------------------------------------------------------------------------ a2: backbone
+    @_with_tile_tables
     def backbone(self, img, keep_stage2=True):
         """img (N,3,H,W) f32 NCHW on device -> [stage2..stage5] dense NHWC maps (pair mode: 2C stored bf16 channels each).
         keep_stage2=False (the detector's own frames): nothing but the stage-3 pooling reads the stage-2 map, so its last eSE writes
         the pooled map only and the first entry of the result is None (the stand-alone VoVNet module returns all four maps)."""
         act, spec, cs, pair = self.prec["act"], self.spec, self.cs, self.pair
-        self._select_tile_tables()
         N = img.shape[0]
         Lb = spec["layer_per_block"]
         # eSE workspace (per-workgroup partial channel sums + gates): stream-ordered, so one buffer serves every block
@@ -485,9 +490,9 @@ class Far3DEngine:
         return outs
 
     # ------------------------------------------------------------------------------------------ a3 + MLN: FPN
+    @_with_tile_tables
     def fpn(self, feats, mln_scale, mln_shift):
         """Returns (raw levels [NHWC act; pair mode: 512 stored channels], feat_flatten (N,S,256) value dtype, level_hw, level_start)."""
-        self._select_tile_tables()
         act, val = self.prec["act"], self.prec["value"]
         ins = feats[1:]
         N = ins[0].shape[0]
@@ -509,10 +514,10 @@ class Far3DEngine:
         return raw, tokens, hw, starts
 
     # ------------------------------------------------------------------------------------------ a4: 2D head + depth
+    @_with_tile_tables
     def roi_head(self, raw, centers2d=None):
         """YOLOX towers + depth head on the raw FPN maps.  centers2d: optional list that receives the (N,h,w,2) centre-offset maps
         (a loss input the inference path never reads; the stand-alone YOLOXHeadCustom.forward returns them like the reference)."""
-        self._select_tile_tables()
         cls, reg = [], []
         for l, x in enumerate(raw):
             lv = self.roi[l]
@@ -732,10 +737,10 @@ class Far3DEngine:
         return outs
 
     # ------------------------------------------------------------------------------------------ one frame
+    @_with_tile_tables
     def camera_stage(self, img, dd, cam_ids, pad_hw, block_rows=None):
         """Everything that is independent per camera: backbone, FPN (+MLN), 2D head, depth, proposal
         selection and adaptive-query construction.  img (n,3,H,W) on device for the contiguous camera block `cam_ids`."""
-        self._select_tile_tables()
         cfg = self.cfg
         n = img.shape[0]
         cam_ids = list(cam_ids)
@@ -795,11 +800,11 @@ class Far3DEngine:
         return dict(ref2d=ref2d, ctx=ctx, box2d=box2d, score2d=score2d, sel_idx=sel_idx, sel_cnt=sel_cnt, depth_logit=depth_logit, peak_weight=wgt,
                     m_dev=m_dev, overflow=ovf)
 
+    @_with_tile_tables
     def head_stage(self, tokens, ref2d, ctx, M, dd, img_metas, hw, starts, pad_hw, m_dev=None, qshard=None):
         """The cross-camera part: streaming memory, query construction, 6-layer decoder, heads, decode (a6-a12).
         M: adaptive-query ROWS.  m_dev (int32 device scalar; fixed-capacity threshold mode): only the first m_dev of them are
         queries, rows [nq + m_dev, nq + M) are the masked hole (their inputs are zero-filled by proposal_gather)."""
-        self._select_tile_tables()
         cfg = self.cfg
         E = cfg["embed_dims"]
         lidar2img = dd["lidar2img"][0]
@@ -996,6 +1001,7 @@ class Far3DEngine:
         TQ[:nq].copy_(self.tgt_fixed); QP[:nq].copy_(self.qpos_fixed); RF[:nq].copy_(self.ref_fixed)
 
     @torch.no_grad()
+    @_with_tile_tables
     def forward_frame(self, data, img_metas):
         """data: the reference's per-frame dict (img (1,N,3,H,W), lidar2img, intrinsics, extrinsics, ego_pose(_inv),
         timestamp); tensors may live on the host (they are uploaded) or already on the device.  With `use_graph` the
@@ -1004,7 +1010,6 @@ class Far3DEngine:
         Outputs live in engine-owned buffers that the next frame overwrites: clone what must outlive it."""
         pad_hw = tuple(img_metas[0]["pad_shape"][0][:2])
         steady = img_metas[0]["scene_token"] == self.prev_scene and self._mem_valid
-        self._select_tile_tables()
         if self.pipeline and self.use_graph and self.static_adaptive_rows() is not None:
             self._par = self._fidx % max(2, int(self.pipeline_sets))
             self._fidx += 1

@@ -3,7 +3,9 @@
 Every function launches on torch's *current* HIP stream of the tensors' device (so torch.cuda
 events / graphs see the kernels) and never synchronises.
 """
+import contextlib
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -210,8 +212,42 @@ ACT = {None: 0, "none": 0, "relu": 1, "swish": 2}
 _TUNING = {}
 
 
-BF16_TILE_TABLE = "tuning_mi355x.json"      # the bf16 table conv2d_nhwc / linear consult (an engine may point it at the throughput-tuned one)
-PAIR_TILE_TABLE = "tuning_mi355x_pair.json"  # the same for pair-stored activations (the bf16x3 engine mode)
+# Tile tables conv2d_nhwc / linear consult when the caller passes tile = 0.  The two names below are the PROCESS DEFAULTS (what a
+# stand-alone op or a plugin module gets); an engine selects its own tables for the duration of its entry points with
+# use_tile_tables(), which is thread-local and restores the previous selection on exit -- an engine that ran earlier, or one driven
+# from another thread, never changes what somebody else's launches look up (the tables used to be re-assigned module globals).
+BF16_TILE_TABLE = "tuning_mi355x.json"
+PAIR_TILE_TABLE = "tuning_mi355x_pair.json"   # pair-stored activations (the bf16x3 engine mode)
+_PAIR_TABLE_OF = {"tuning_mi355x.json": "tuning_mi355x_pair.json", "tuning_mi355x_tput.json": "tuning_mi355x_pair_tput.json"}
+_TABLE_SEL = threading.local()
+
+
+def pair_table_for(bf16_table):
+    """The pair-storage tile table that goes with a bf16 one: the shipped pairs by name, `<stem>_pair.json` beside a custom table when
+    that file exists, else the default pair table -- never the bf16 table itself."""
+    if bf16_table in _PAIR_TABLE_OF:
+        return _PAIR_TABLE_OF[bf16_table]
+    import os
+    cand = bf16_table[:-5] + "_pair.json" if bf16_table.endswith(".json") else bf16_table + "_pair"
+    if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", cand)):
+        return cand
+    return "tuning_mi355x_pair.json"
+
+
+def tile_tables():
+    """(bf16 table, pair table) in force for this thread."""
+    return getattr(_TABLE_SEL, "cur", None) or (BF16_TILE_TABLE, PAIR_TILE_TABLE)
+
+
+@contextlib.contextmanager
+def use_tile_tables(bf16_table, pair_table=None):
+    """Select the tile tables for the launches issued (or captured into a graph) inside the block, for this thread only."""
+    prev = getattr(_TABLE_SEL, "cur", None)
+    _TABLE_SEL.cur = (bf16_table, pair_table or pair_table_for(bf16_table))
+    try:
+        yield
+    finally:
+        _TABLE_SEL.cur = prev
 
 
 def _tuned_tile(Cout, Cin, k, stride, npix, table=None):
@@ -219,7 +255,7 @@ def _tuned_tile(Cout, Cin, k, stride, npix, table=None):
     Shapes that were not swept (e.g. fewer cameras per rank in camera-sharded mode) borrow the entry of the same layer
     geometry with the closest pixel count.  table: tuning_mi355x.json (bf16) or tuning_mi355x_bf16x3.json (split mode)."""
     if table is None:
-        table = BF16_TILE_TABLE
+        table = tile_tables()[0]
     tab = _TUNING.get(table)
     if tab is None:
         import json
@@ -307,7 +343,7 @@ def _pair_tile(pc, Cin, npix, tile):
     library default), mapped to a hi-planes-only kernel when the layer is assigned a single bf16 product (pc.terms == 1)."""
     fast = pc.stride == 1 and ((pc.KH == 3 and pc.pad == 1) or (pc.KH == 1 and pc.pad == 0))
     if tile == 0:
-        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, PAIR_TILE_TABLE)
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, tile_tables()[1])
     if pc.terms == 1 and fast and (tile == 0 or 150 <= tile < 200):
         tile = _HI_ONLY_TILE.get(tile, 260 if pc.KH == 3 else 279)
     return tile

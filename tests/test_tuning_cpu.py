@@ -75,3 +75,37 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
         allowed = ids["igemm"] | ({t for t in ids["pipe3"] if t < 300} if (k == 3 and stride == 1) else ids["gemm"] if (k == 1 and stride == 1) else
                                   {t for t in ids["pipe3"] if t >= 330} if (k == 3 and stride == 2) else set())
         assert tile in allowed and not 200 <= tile < 300, "tile %d is not a split-product tile for layer %s" % (tile, key)
+
+
+def test_tile_table_selection_is_scoped_and_thread_local():
+    """ops.use_tile_tables: an engine's tables hold for the block only (nested selections restore each other), another thread keeps the
+    process defaults meanwhile, and a custom bf16 table never becomes the pair table (the tables were re-assigned module
+    globals, and the pair name was derived with str.replace)."""
+    import threading
+    from far3d_amd import ops
+    base = ops.tile_tables()
+    assert base == ("tuning_mi355x.json", "tuning_mi355x_pair.json")
+    seen = {}
+
+    def other():
+        seen["other"] = ops.tile_tables()
+    with ops.use_tile_tables("tuning_mi355x_tput.json"):
+        assert ops.tile_tables() == ("tuning_mi355x_tput.json", "tuning_mi355x_pair_tput.json")
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        with ops.use_tile_tables("my_custom_table.json"):
+            assert ops.tile_tables() == ("my_custom_table.json", "tuning_mi355x_pair.json")
+        assert ops.tile_tables()[0] == "tuning_mi355x_tput.json"
+        # the lookup follows the selection: stage-2 concat layer, latency table vs throughput table
+        assert ops._tuned_tile(256, 768, 1, 1, 268800) == ops._tuned_tile(256, 768, 1, 1, 268800, "tuning_mi355x_tput.json")
+    assert seen["other"] == base and ops.tile_tables() == base
+    assert ops._tuned_tile(256, 768, 1, 1, 268800) == ops._tuned_tile(256, 768, 1, 1, 268800, "tuning_mi355x.json")
+
+
+def test_engine_entry_points_run_under_the_engines_tables():
+    import inspect
+    from far3d_amd import engine
+    for name in ("backbone", "fpn", "roi_head", "camera_stage", "head_stage", "forward_frame"):
+        fn = getattr(engine.Far3DEngine, name)
+        assert hasattr(fn, "__wrapped__") and "use_tile_tables" in inspect.getsource(engine._with_tile_tables), name

@@ -59,7 +59,7 @@ def run(k):
     dev = "cuda:0"
     out = {}
     if os.environ.get("FAR3D_ABL_TABLE"):
-        ops.BF16_TILE_TABLE = os.environ["FAR3D_ABL_TABLE"]
+        ops.BF16_TILE_TABLE = os.environ["FAR3D_ABL_TABLE"]      # the process default (no engine selection is active here)
     for name, N, H, W, Cin, Cout, ks, tile in LAYERS:
         x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
         pc = ops.PackedConv(torch.randn(Cout, Cin, ks, ks) * 0.05, torch.randn(Cout), stride=1, pad=ks // 2, dtype=torch.bfloat16, device=dev)
