@@ -149,7 +149,7 @@ def agg_traffic(fp32_rows=False):
     return None, None
 
 
-def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk"):
+def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk", latency_runner=True):
     """Build an engine of `precision`, run the parity frames, the warm-up, the timed region (K frames between two syncs), the
     reference's sync-per-frame protocol and (optionally) the per-kernel roofline timings.  Returns a dict of raw figures."""
     from far3d_amd import engine, ops, synth, weights
@@ -237,9 +237,10 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         step_i += 1
     per_frame.sort()
 
-    # ---- opt-in: the same per-frame protocol with the frame's cameras split into groups that run side by side (far3d_amd.latency)
+    # ---- the same per-frame protocol with the frame's cameras split into groups that run side by side (far3d_amd.latency; --latency-groups 0 skips it)
     lat_groups = None
-    if args.latency_groups > 1 and world == 1 and not sharded and proposals == "topk":
+    if latency_runner and args.latency_groups > 1 and world == 1 and not sharded and proposals == "topk" and not args.eager and \
+            precision in ("bf16", "fp32"):      # the modes tests/test_latency_gpu.py covers
         from far3d_amd.latency import CameraGroupFrame
         sync()
         was = eng.pipeline
@@ -406,8 +407,9 @@ def main():
                     help="bf16 conv tile table: tuned for a launch alone, or under the pipeline's 3-stream concurrency (auto: by mode; A/B)")
     ap.add_argument("--cam-streams", type=int, default=3, help="streams the camera stages of consecutive frames alternate between (A/B)")
     ap.add_argument("--cam-priority", type=int, default=-1, help="HIP stream priority of the camera-stage streams in pipeline mode (-1 = high, 0 = default; A/B)")
-    ap.add_argument("--latency-groups", type=int, default=0, help="single GPU, opt-in: also time the sync-per-frame protocol with the frame's "
-                    "cameras split into this many groups on parallel streams (far3d_amd.latency; reported as protocol.sync_per_frame_groups)")
+    ap.add_argument("--latency-groups", type=int, default=2, help="single GPU: also time the sync-per-frame protocol with the frame's cameras "
+                    "split into this many groups on parallel streams (far3d_amd.latency; reported as protocol.sync_per_frame_groups beside the "
+                    "plain engine's protocol.sync_per_frame; 0 = skip)")
     ap.add_argument("--no-fused-rows", dest="fused_rows", action="store_false", help="A/B: run the row-local parts of the decoder layers and the "
                     "cls / reg branches as separate GEMM / LayerNorm launches instead of the row-resident chains (engine.fused_rows, the default "
                     "since round 5; bf16 decoder only)")
@@ -460,7 +462,7 @@ def main():
     # exact-fp32 decoder) -- same workload, same protocol, fewer timed frames -- and reports it as the `in_tolerance` block.
     res_tol = None
     if world == 1 and args.precision == "bf16" and not args.no_in_tolerance and not args.eager and args.proposals == "topk":
-        res_tol = measure(args, "bf16x3", max(50, args.steps // 2), args.warmup, world, rank, dev, sharded, dist, kernel_timings=True)
+        res_tol = measure(args, "bf16x3", max(50, args.steps // 2), args.warmup, world, rank, dev, sharded, dist, kernel_timings=True, latency_runner=False)
 
     if rank == 0:
         dt, dev_ms, per_frame, A, N, S, C, cfg = (res[k] for k in ("dt", "dev_ms", "per_frame", "A", "N", "S", "C", "cfg"))
