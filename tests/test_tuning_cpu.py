@@ -109,3 +109,23 @@ def test_engine_entry_points_run_under_the_engines_tables():
     for name in ("backbone", "fpn", "roi_head", "camera_stage", "head_stage", "forward_frame"):
         fn = getattr(engine.Far3DEngine, name)
         assert hasattr(fn, "__wrapped__") and "use_tile_tables" in inspect.getsource(engine._with_tile_tables), name
+
+
+def test_serial_load_scan_counts_drained_loads():
+    """tools/scan_serial_loads.py: a load followed by `s_waitcnt vmcnt(0)` before the next load counts, loads issued back to back before one
+    wait do not, LDS-DMA loads are not looked at."""
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_serial_loads as ssl
+    serial = "\n".join("\tglobal_load_dword v%d, v[2:3], off\n\ts_waitcnt vmcnt(0)\n\tv_add_u32 v9, v9, v%d" % (i, i) for i in range(6))
+    batched = "\n".join("\tglobal_load_dword v%d, v[2:3], off" % i for i in range(6)) + "\n\ts_waitcnt vmcnt(0)"
+    dma = "\n".join("\tbuffer_load_dword v1, s[4:7], 0 offen lds\n\ts_waitcnt vmcnt(0)" for _ in range(6))
+    txt = ""
+    for name, body in (("_Z6serialv", serial), ("_Z7batchedv", batched), ("_Z3dmav", dma)):
+        txt += "%s:                                ; @%s\n%s\n\ts_endpgm\n" % (name, name, body)
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write(txt)
+    rows = ssl.scan(f.name)
+    os.unlink(f.name)
+    assert [(r[1], r[2], r[3]) for r in rows] == [("_Z6serialv", 6, 6)]
