@@ -11,9 +11,13 @@ N > 1 (default --mode sharded): the cameras of the SAME sample are sharded acros
 of the value maps; --mode replicas: one independent scene stream per GPU (BASELINE configs[4]; weak scaling, no collective).
 Prints ONE JSON line on rank 0.
 
-Timing protocol (reference tools/analysis_tools/benchmark.py:84-111): `value` is K frames issued back to
-back between two device syncs (the contract of this file); `protocol.sync_per_frame` repeats the reference's own protocol --
-synchronise before and after EVERY frame, wall clock per frame -- and reports mean and p50 next to it.
+Headline (`value`, `dtype`, `ms_per_step`): the engine that MEETS the north-star logit tolerance (bf16x3: every
+conv product as three bf16 MFMAs on pair-stored activations, exact-fp32 decoder; `parity.meets_tolerance` true) under the REFERENCE's
+timing protocol (tools/analysis_tools/benchmark.py:84-111): K frames, a device sync (and a barrier for N > 1) before
+and after EVERY frame, between the barrier + sync that bracket the timed region -- `value` = K / that time.  Side blocks of the same
+run: `protocol.pipelined` (the same engine, K frames issued back to back with the frame pipeline on: throughput of a stream),
+`protocol.sync_per_frame_groups` (the frame's cameras as two groups on parallel streams), and `fast_mode` (the bf16 engine -- BASELINE
+configs[1]'s dtype, 40x outside the tolerance -- under both protocols; `--no-fast-mode` skips it).
 """
 import argparse
 import json
@@ -93,6 +97,7 @@ def parity_block(precision, eng_frames, orc_frames):
         pos = {k: j for j, k in enumerate(want_sel)}
         nq = 644
         rows_g, rows_w = list(range(nq)), list(range(nq))
+        disc_g, disc_w = [], []
         common = discrete = 0
         for j, k in enumerate(got["sel"]):
             if k in pos:
@@ -104,26 +109,35 @@ def parity_block(precision, eng_frames, orc_frames):
                     jw = pos[k]
                     if (got["ref"][j] - o["ref"][jw]).abs().max().item() > 1e-3 or (got["score2d"][j].item() > 0) != (o["score2d"][jw].item() > 0):
                         discrete += 1
+                        disc_g.append(nq + j); disc_w.append(nq + jw)
                         continue
                 rows_g.append(nq + j); rows_w.append(nq + pos[k])
         A = got["logits"].shape[2]
         M = len(want_sel)
         rows_g += list(range(nq + len(got["sel"]), A)); rows_w += list(range(nq + M, A))
         d = (got["logits"][:, 0, rows_g] - o["logits"][:, 0, rows_w]).abs()
+        d_disc = (got["logits"][:, 0, disc_g] - o["logits"][:, 0, disc_w]).abs().max().item() if disc_g else 0.0
         qs = torch.quantile(d.flatten()[::2].double(), torch.tensor([0.5, 0.99], dtype=torch.float64))
         par.append(dict(frame=fi, logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(), logit_p50_abs=qs[0].item(), logit_p99_abs=qs[1].item(),
                         last_layer_logit_max_abs=d[-1].max().item(), proposals_in_common=common, proposals=M,
                         rows_compared=len(rows_g), rows_excluded=(A - len(rows_g)), rows_excluded_same_peak_other_bin_or_peak_test=discrete,
+                        logit_max_abs_incl_same_peak_rows=max(d.max().item(), d_disc),
                         rows_excluded_what="adaptive-query rows whose 2D peak (camera, cell) the other side did not select, or selected with another "
                                            "depth bin / peak-test outcome: different queries, not compared",
                         engine_path=got["path"]))
+    # rows left out as "a different query on the two sides" must stay a handful: a regression of the depth decode / un-projection /
+    # peak test that moves MANY reference points would otherwise be filtered out of the comparison and pass
+    cap = max(4, 644 // 100)
+    excluded_ok = all(p["rows_excluded_same_peak_other_bin_or_peak_test"] <= cap for p in par)
     # Frame 0 is the clean comparison.  From frame 1 on the two sides also differ through the streaming memory: which 256 queries
     # are kept is a discrete top-k on scores ~1e-4 apart, so any rounding difference (let alone bf16) changes the memory contents
     # and the frames stop being the same computation (tests/test_engine_full_gpu.py quantifies this with an fp64 oracle).
     return dict(precision=precision, tolerance_north_star=1e-3, checker="oracle (fp32 CPU port of the reference path), same seeded weights/inputs",
                 logit_max_abs=par[0]["logit_max_abs"], logit_mean_abs=par[0]["logit_mean_abs"],
                 # every frame this block reports must be inside the bar, not only the first
-                meets_tolerance=bool(all(p["logit_max_abs"] < 1e-3 for p in par)), meets_tolerance_frame0=bool(par[0]["logit_max_abs"] < 1e-3),
+                meets_tolerance=bool(excluded_ok and all(p["logit_max_abs"] < 1e-3 for p in par)),
+                meets_tolerance_frame0=bool(excluded_ok and par[0]["logit_max_abs"] < 1e-3),
+                excluded_rows_cap=cap, excluded_rows_within_cap=bool(excluded_ok),
                 headline_frame=0, frames=par,
                 see="tests/test_engine_full_gpu.py (per-stage budget, fp64 yardstick), DESIGN.md section 4")
 
@@ -150,8 +164,10 @@ def agg_traffic(fp32_rows=False):
 
 
 def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk", latency_runner=True):
-    """Build an engine of `precision`, run the parity frames, the warm-up, the timed region (K frames between two syncs), the
-    reference's sync-per-frame protocol and (optionally) the per-kernel roofline timings.  Returns a dict of raw figures."""
+    """Build an engine of `precision` and run, in this order: the parity frames; region A -- the reference's protocol, K frames with a
+    device sync (+ barrier) around every one, on the engine in its single-frame configuration (one hipGraph per frame, no frame
+    overlap, tiles tuned for launches alone); region B -- K frames back to back with the frame pipeline on; the camera-group latency
+    runner; the per-kernel roofline timings.  Returns a dict of raw figures."""
     from far3d_amd import engine, ops, synth, weights
     from far3d_amd import dist as fdist
     # proposals: "topk" = 92 best peaks per camera (static, SURVEY 8(d): 644 adaptive queries); "threshold" = the reference's rule
@@ -170,23 +186,27 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     for fi in range(4):   # a few distinct frames (ego motion on), resident in HBM before the timed region
         frames.append(synth.make_frame(7, (640, 960), seed=0 if not (world > 1 and not sharded) else rank, frame_index=fi, device=dev,
                                        ego_motion=True))
-    # N > 1 sharded: per-rank hipGraphs for the per-camera stages and the replicated head, collectives eager in between
-    # the tile table is settled BEFORE the sharded runner is built: ShardedFrame picks the throughput-tuned table for its pipelined
-    # frames when none was asked for, and `auto` must not undo that afterwards
-    eng.tile_table = {"auto": None, "latency": "tuning_mi355x.json", "tput": "tuning_mi355x_tput.json"}[args.tile_table]
+    table = {"auto": None, "latency": "tuning_mi355x.json", "tput": "tuning_mi355x_tput.json"}[args.tile_table]
     eng.pipeline_sets = args.pipeline_sets
     eng.cam_streams = args.cam_streams
-    runner = fdist.ShardedFrame(eng, use_graph=not args.eager, pipeline=not args.no_pipeline) if sharded else eng
-    eng.use_graph = (not sharded) and not args.eager   # whole steady-state frame as ONE hipGraph (no host launch gaps)
-    # frames of one stream are software-pipelined: the per-camera stages of frame i+1 overlap the head of frame i (engine.py)
-    eng.pipeline = eng.use_graph and not args.no_pipeline
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- the first two frames of the sequence are kept for the parity check (frame 0: eager; frame 1: first graph replay)
+    # ---------------------------------------------------------------- region A: the reference's protocol (sync around every frame)
+    # single-frame configuration: the whole steady-state frame as ONE hipGraph (per rank: camera graph, exchange, head graph), no frame
+    # overlap, tiles tuned for a launch running alone
+    eng.tile_table = table if table is not None else "tuning_mi355x.json"
+    eng.pipeline = False
+    if sharded:
+        runner = fdist.ShardedFrame(eng, use_graph=not args.eager, pipeline=False)
+        runner.record_stage_times = True
+    else:
+        runner = eng
+        eng.use_graph = not args.eager
+    # the first two frames of the sequence are kept for the parity check (frame 0: eager; frame 1: first graph replay)
     eng_frames = []
     for fi in range(2):
         o = runner.forward_frame(*frames[fi])
@@ -198,9 +218,49 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
                                score2d=o["bbox2d_scores"].float().reshape(-1)[:len(sel)].cpu().clone() if "bbox2d_scores" in o else None,
                                path="eager (first frame of the scene)" if fi == 0 or args.eager else "hipGraph replay"))
     step_i = 2
+    for _ in range(max(1, warmup)):
+        runner.forward_frame(*frames[step_i % len(frames)])
+        step_i += 1
+    if sharded:
+        runner.stage_times.clear()
+    sync()
+    per_frame = []
+    t0 = time.perf_counter()
+    for k in range(steps):
+        t1 = time.perf_counter()
+        out = runner.forward_frame(*frames[step_i % len(frames)])
+        sync()
+        per_frame.append((time.perf_counter() - t1) * 1e3)
+        step_i += 1
+    dt_sync = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_sync], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_sync = t.item()
+    per_frame.sort()
+    stage_ms = None
+    if sharded:       # where a rank's frame goes (DESIGN.md section 7's table): mean over the timed frames, gathered from every rank
+        mine = runner.mean_stage_times()
+        allr = [None] * world
+        dist.all_gather_object(allr, dict(rank=rank, cameras=len(runner.cams), **mine))
+        stage_ms = allr
+    A = out["all_cls_scores"].shape[2]
+    N, S, C = out["feat_flatten"].shape
+    lg = out["all_cls_scores"]          # fixed-capacity proposal mode: the rows without a query carry -inf logits by construction
+    assert not torch.isnan(lg).any() and not (lg == float("inf")).any(), "non-finite logits"
+
+    # ---------------------------------------------------------------- region B: frames back to back, frame pipeline on
+    # frames of one stream are software-pipelined: the per-camera stages of the next frames overlap the head of frame i (engine.py);
+    # tiles tuned under that concurrency unless a table was asked for
+    pipe = not args.no_pipeline and not args.eager
+    eng.tile_table = table
+    if sharded:
+        runner = fdist.ShardedFrame(eng, use_graph=not args.eager, pipeline=pipe)
+    else:
+        eng.pipeline = pipe
     # every buffer set of the frame pipeline captures its hipGraphs on its first steady frame (a device sync each): keep that out
     # of the timed region whatever --warmup says
-    for _ in range(eng.pipeline_sets + 1 if (eng.pipeline or (sharded and not args.no_pipeline)) else 1):
+    for _ in range(eng.pipeline_sets + 1 if pipe else 1):
         runner.forward_frame(*frames[step_i % len(frames)])
         step_i += 1
     for _ in range(warmup):
@@ -221,48 +281,42 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    A = out["all_cls_scores"].shape[2]
-    N, S, C = out["feat_flatten"].shape
-    lg = out["all_cls_scores"]          # fixed-capacity proposal mode: the rows without a query carry -inf logits by construction
-    assert not torch.isnan(lg).any() and not (lg == float("inf")).any(), "non-finite logits"
+    pipeline_on = bool(runner.pipeline)
+    frames_in_flight = int(eng.pipeline_sets) if pipeline_on else 1
+    camera_streams = len(runner._pipe["s_cams"]) if (pipeline_on and getattr(runner, "_pipe", None)) else 1
+    tile_table_pipelined = eng.bf16_tile_table()
+    sync()
 
-    # ---- the reference's own protocol: sync before and after every frame (tools/analysis_tools/benchmark.py:84-111)
-    per_frame = []
-    for _ in range(min(steps, 50)):
-        sync()
-        t1 = time.perf_counter()
-        runner.forward_frame(*frames[step_i % len(frames)])
-        sync()
-        per_frame.append((time.perf_counter() - t1) * 1e3)
-        step_i += 1
-    per_frame.sort()
-
-    # ---- the same per-frame protocol with the frame's cameras split into groups that run side by side (far3d_amd.latency; --latency-groups 0 skips it)
+    # ---- the reference's protocol again with the frame's cameras split into groups that run side by side (far3d_amd.latency; --latency-groups 0 skips it)
     lat_groups = None
-    if latency_runner and args.latency_groups > 1 and world == 1 and not sharded and proposals == "topk" and not args.eager and \
-            precision in ("bf16", "fp32"):      # the modes tests/test_latency_gpu.py covers
+    if latency_runner and args.latency_groups > 1 and world == 1 and not sharded and proposals == "topk" and not args.eager:
         from far3d_amd.latency import CameraGroupFrame
         sync()
-        was = eng.pipeline
-        eng.pipeline = False
-        lat = CameraGroupFrame(eng, groups=args.latency_groups, use_graph=not args.eager)
-        for _ in range(4):                                   # one eager frame (buffers), the captures, two replays
-            lat.forward_frame(*frames[step_i % len(frames)])
-            step_i += 1
-        pf = []
-        for _ in range(min(steps, 50)):
-            sync()
-            t1 = time.perf_counter()
-            out_l = lat.forward_frame(*frames[step_i % len(frames)])
-            sync()
-            pf.append((time.perf_counter() - t1) * 1e3)
-            step_i += 1
-        pf.sort()
-        assert not torch.isnan(out_l["all_cls_scores"]).any()
-        lat_groups = {"groups": [list(b) for b in lat.blocks], "frames": len(pf), "mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2],
-                      "what": "sync before and after every frame; the frame's per-camera stages as camera groups on parallel streams "
-                              "(far3d_amd.latency.CameraGroupFrame), head after all groups"}
-        eng.pipeline = was
+        was, was_table = eng.pipeline, eng.tile_table
+        try:
+            eng.pipeline, eng.tile_table = False, (table if table is not None else "tuning_mi355x.json")
+            lat = CameraGroupFrame(eng, groups=args.latency_groups, use_graph=not args.eager)
+            for _ in range(4):                                   # one eager frame (buffers), the captures, two replays
+                lat.forward_frame(*frames[step_i % len(frames)])
+                step_i += 1
+            pf = []
+            for _ in range(min(steps, 50)):
+                sync()
+                t1 = time.perf_counter()
+                out_l = lat.forward_frame(*frames[step_i % len(frames)])
+                sync()
+                pf.append((time.perf_counter() - t1) * 1e3)
+                step_i += 1
+            pf.sort()
+            assert not torch.isnan(out_l["all_cls_scores"]).any()
+            lat_groups = {"groups": [list(b) for b in lat.blocks], "frames": len(pf), "mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2],
+                          "samples_per_s_mean": 1e3 * len(pf) / sum(pf),
+                          "what": "sync before and after every frame; the frame's per-camera stages as camera groups on parallel streams "
+                                  "(far3d_amd.latency.CameraGroupFrame), head after all groups"}
+        except Exception as e:   # noqa: BLE001  (a side block must never cost the headline)
+            lat_groups = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+            torch.cuda.synchronize(dev)
+        eng.pipeline, eng.tile_table = was, was_table
 
     # Kernel durations for the rooflines: HIP events (on the launch stream) around hipGraph replays that contain ONLY
     # that kernel, fed with this run's live tensors (last decoder layer's operands / the staged images) -- a launch-gap-free
@@ -294,21 +348,21 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
             agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
                                                                 num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
                                                                 variant=args.agg_variant, tables=tab_, split=getattr(eng, "last_agg_split", None)), 24)]
-        # the backbone ALONE: launches one after the other, so with the tile table tuned for that regime (what a non-pipelined engine
-        # uses; the pipelined frames above run the table tuned under their 3-stream concurrency, engine.tile_table)
+        # the backbone ALONE, exactly the launch sequence of the frame (keep_stage2=False: the stage-2 map is consumed by the pooling
+        # pass only): launches one after the other, so with the tile table tuned for that regime
         keep_table, eng.tile_table = eng.tile_table, "tuning_mi355x.json"
-        bb_ms = [device_time(lambda: eng.backbone(img_local), 2)] if img_local.shape[0] > 0 else []
+        bb_ms = [device_time(lambda: eng.backbone(img_local, keep_stage2=False), 2)] if img_local.shape[0] > 0 else []
         eng.tile_table = keep_table
     except Exception as e:   # noqa: BLE001
         timing_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
     n_adapt = int(out["num_adaptive_dev"].item()) if out.get("num_adaptive_dev") is not None else int(out["num_adaptive"])
     overflow = bool(int(out["proposal_overflow"].item())) if out.get("proposal_overflow") is not None else False
-    res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dev_ms=dev_ms, per_frame=per_frame, lat_groups=lat_groups, A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms,
-               timing_error=timing_error, prec=dict(eng.prec), pipeline=bool(runner.pipeline), cfg=cfg, tile_table=eng.bf16_tile_table(),
+    res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dt_sync=dt_sync, dev_ms=dev_ms, per_frame=per_frame, lat_groups=lat_groups,
+               A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms, stage_ms=stage_ms,
+               timing_error=timing_error, prec=dict(eng.prec), pipeline=pipeline_on, cfg=cfg, tile_table=tile_table_pipelined,
                ncam_local=len(runner.cams) if sharded else 7, agg_split_extra=int(getattr(eng, "agg_split_extra", 0)),
                # what the runner actually did (read back, not assumed): frames in flight and camera streams of its pipeline
-               frames_in_flight=int(eng.pipeline_sets) if runner.pipeline else 1,
-               camera_streams=len(runner._pipe["s_cams"]) if (runner.pipeline and getattr(runner, "_pipe", None)) else 1)
+               frames_in_flight=frames_in_flight, camera_streams=camera_streams)
     del eng, runner, frames, out
     torch.cuda.empty_cache()
     return res
@@ -389,10 +443,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act", "bf16_fp32dec", "bf16_fp32val"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act", "bf16_fp32dec", "bf16_fp32val"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-in-tolerance", action="store_true", help="skip the second, in-tolerance (bf16x3) engine of the default run")
+    ap.add_argument("--no-fast-mode", "--no-in-tolerance", dest="fast_mode", action="store_false",
+                    help="skip the second engine of the default run (the bf16 `fast_mode` block); --no-in-tolerance is the flag's old name")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="single GPU: do not overlap the camera stages of frame i+1 with the head of frame i")
     ap.add_argument("--agg-variant", type=int, default=0, help="far3d_aggregate_forward kernel variant (A/B timing)")
@@ -409,12 +464,12 @@ def main():
     ap.add_argument("--cam-priority", type=int, default=-1, help="HIP stream priority of the camera-stage streams in pipeline mode (-1 = high, 0 = default; A/B)")
     ap.add_argument("--latency-groups", type=int, default=2, help="single GPU: also time the sync-per-frame protocol with the frame's cameras "
                     "split into this many groups on parallel streams (far3d_amd.latency; reported as protocol.sync_per_frame_groups beside the "
-                    "plain engine's protocol.sync_per_frame; 0 = skip)")
+                    "plain engine's protocol.sync_per_frame = `value`; 0 = skip)")
     ap.add_argument("--no-fused-rows", dest="fused_rows", action="store_false", help="A/B: run the row-local parts of the decoder layers and the "
                     "cls / reg branches as separate GEMM / LayerNorm launches instead of the row-resident chains (engine.fused_rows, the default "
                     "since round 5; bf16 decoder only)")
     ap.add_argument("--fused-rows", dest="fused_rows", action="store_true", help="(default) kept so that round 4's command lines still parse")
-    ap.set_defaults(fused_rows=True)
+    ap.set_defaults(fused_rows=True, fast_mode=True)
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="N ranks on fewer than N GPUs (test rig only): ranks share devices and exchange over gloo; the line says so and "
                          "is not a scaling measurement")
@@ -457,30 +512,44 @@ def main():
     sharded = world > 1 and args.mode == "sharded"
 
     res = measure(args, args.precision, args.steps, args.warmup, world, rank, dev, sharded, dist, proposals=args.proposals)
-    # The headline precision is what BASELINE configs[1] names (bf16) and misses the north-star logit tolerance; the same run
-    # therefore also times the fastest assignment that MEETS it (bf16x3: pair-stored activations, 3 bf16 MFMAs per conv product,
-    # exact-fp32 decoder) -- same workload, same protocol, fewer timed frames -- and reports it as the `in_tolerance` block.
-    res_tol = None
-    if world == 1 and args.precision == "bf16" and not args.no_in_tolerance and not args.eager and args.proposals == "topk":
-        res_tol = measure(args, "bf16x3", max(50, args.steps // 2), args.warmup, world, rank, dev, sharded, dist, kernel_timings=True, latency_runner=False)
+    # The headline engine is the one that MEETS the north-star logit tolerance (bf16x3).  The same run also times the bf16 engine --
+    # BASELINE configs[1]'s dtype, ~40x outside the tolerance -- same workload, same two protocols, and reports it as `fast_mode`.
+    res_fast = None
+    if world == 1 and args.precision == "bf16x3" and args.fast_mode and not args.eager and args.proposals == "topk":
+        res_fast = measure(args, "bf16", args.steps, args.warmup, world, rank, dev, sharded, dist, kernel_timings=True)
 
     if rank == 0:
+        def rates(r):
+            pf = r["per_frame"]
+            return {"pipelined": {"frames": r["steps"], "mean_ms": r["dt"] / r["steps"] * 1e3, "samples_per_s": r["steps"] * rep / r["dt"],
+                                  "p50_ms_device_events": r["dev_ms"][len(r["dev_ms"]) // 2], "p50_samples_per_s": 1e3 / r["dev_ms"][len(r["dev_ms"]) // 2],
+                                  "what": "frames issued back to back, ONE sync at each end: the throughput of a stream of frames (not `value`)",
+                                  "frame_overlap": r["pipeline"], "frames_in_flight": r["frames_in_flight"], "camera_streams": r["camera_streams"],
+                                  "tile_table": r["tile_table"],
+                                  "frame_overlap_what": "the per-camera stages of the next frames (one frame per camera stream, high priority) run "
+                                                        "concurrently while the head of frame i is in flight (one buffer set per frame in flight, head "
+                                                        "graphs ordered on one stream: results identical to the unpipelined engine)"},
+                    "sync_per_frame": {"frames": len(pf), "mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2],
+                                       "samples_per_s_mean": 1e3 * len(pf) / sum(pf),
+                                       "what": "reference protocol (tools/analysis_tools/benchmark.py:84-111): device sync before and after every frame "
+                                               "-> `value`; one hipGraph per frame, no frame overlap"}}
         dt, dev_ms, per_frame, A, N, S, C, cfg = (res[k] for k in ("dt", "dev_ms", "per_frame", "A", "N", "S", "C", "cfg"))
-        samples = args.steps * (world if (world > 1 and not sharded) else 1)
-        # the committed PMC passes measured the bf16-row kernel: no traffic figure for the fp32-row modes
+        rep = world if (world > 1 and not sharded) else 1        # replicas: every rank ran its own stream of frames
+        samples = args.steps * rep
+        dt_sync = res["dt_sync"]
+        # the committed PMC passes measured the bf16-row kernel: the fp32-row modes carry their own passes or nothing
         traffic, traffic_src = agg_traffic(fp32_rows=res["prec"]["value"] != torch.bfloat16)
-        sync_rate = 1e3 * len(per_frame) / sum(per_frame)
         line = {
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
-            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak",
+            "value": samples / dt_sync, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_sync / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak",
+            "value_protocol": "sync_per_frame (the reference's: a device sync" + (" + barrier" if world > 1 else "") + " around every one of the K frames)",
             # read back from the process group, not from the flag: how many ranks actually took part, and over which backend
             "rccl_ranks": dist.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0),
             "ranks": dist.get_world_size() if world > 1 else 1, "backend": backend or "none (single process)",
             "visible_gpus": ndev, "shared_gpu": shared_gpu,
-            "vs_baseline": (samples / dt) / 6.4 if world == 1 else None,   # 6.4 samples/s (hardware not stated)
-            # the reference's figure was taken with a device sync around every frame (benchmark.py:84-111): the like-for-like ratio
-            "vs_baseline_sync_per_frame": sync_rate / 6.4 if world == 1 else None,
+            # 6.4 samples/s (hardware not stated), taken with a device sync around every frame like `value`
+            "vs_baseline": (samples / dt_sync) / 6.4 if world == 1 else None,
             "dtype": args.precision if args.precision in ("fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act") else "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: 7 cameras 3x640x960, VoV-99, A=%d queries (644 learned + 644 adaptive + 256 "
                                     "propagated), 2312 self-attn keys, 6 decoder layers, streaming memory on, ego motion on" % A) if args.proposals == "topk" else
@@ -492,19 +561,7 @@ def main():
                                                                        "%d independent scene streams (replicas, no collective)" % world),
                        "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res["prec"].items()},
                        "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)", "commit": build_commit()},
-            "protocol": {"pipelined": {"frames": args.steps, "mean_ms": dt / args.steps * 1e3, "p50_ms_device_events": dev_ms[len(dev_ms) // 2],
-                                       "what": "frames issued back to back, one sync at each end (this file's contract -> `value`)",
-                                       "frame_overlap": res["pipeline"],
-                                       "p50_samples_per_s": 1e3 / dev_ms[len(dev_ms) // 2],
-                                       "frames_in_flight": res["frames_in_flight"], "camera_streams": res["camera_streams"],
-                                       "tile_table": res["tile_table"],
-                                       "frame_overlap_what": "the per-camera stages of the next frames (one frame per camera stream, high priority) run "
-                                                             "concurrently while the head of frame i is in flight (one buffer set per frame in flight, head "
-                                                             "graphs ordered on one stream: results identical to the unpipelined engine); "
-                                                             "--pipeline-sets 2 = camera || head only (round 3)"},
-                         "sync_per_frame": {"frames": len(per_frame), "mean_ms": sum(per_frame) / len(per_frame), "p50_ms": per_frame[len(per_frame) // 2],
-                                            "samples_per_s_mean": sync_rate,
-                                            "what": "reference protocol (tools/analysis_tools/benchmark.py:84-111): device sync before and after every frame"}},
+            "protocol": rates(res),
             "roofline": agg_roofline(args, res, traffic, traffic_src),
             "roofline_backbone": backbone_roofline(res),
         }
@@ -512,6 +569,9 @@ def main():
             line["kernel_timing_error"] = res["timing_error"]
         if res.get("lat_groups"):
             line["protocol"]["sync_per_frame_groups"] = res["lat_groups"]
+        if res.get("stage_ms"):
+            # per rank: where a (sync-per-frame) frame goes -- per-camera stages, the exchange, the replicated head
+            line["per_rank_stage_ms"] = res["stage_ms"]
 
         def finite(o):           # strict JSON: no NaN / Infinity (a missing kernel timing becomes null)
             if isinstance(o, dict):
@@ -525,21 +585,22 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.proposals == "topk":
             line["cpu_baseline"], orc = oracle_frames(2)
             line["parity"] = parity_block(args.precision, res["eng_frames"], orc)
-        if res_tol is not None:
-            pf = res_tol["per_frame"]
-            blk = {"dtype": "bf16x3", "what": "the fastest precision assignment that meets the north-star logit tolerance (1e-3): conv-stage "
-                                              "activations pair-stored ([hi|lo] bf16, 16 significant bits), every conv product = 3 bf16 MFMAs "
-                                              "with fp32 accumulation, fp32 value maps, exact-fp32 decoder / FarHead GEMMs; same workload, "
-                                              "same timing protocol as `value`",
-                   "value": res_tol["steps"] / res_tol["dt"], "unit": "samples/s", "steps": res_tol["steps"],
-                   "ms_per_step": res_tol["dt"] / res_tol["steps"] * 1e3, "vs_baseline": res_tol["steps"] / res_tol["dt"] / 6.4,
-                   "sync_per_frame": {"mean_ms": sum(pf) / len(pf), "p50_ms": pf[len(pf) // 2], "samples_per_s_mean": 1e3 * len(pf) / sum(pf)},
-                   "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res_tol["prec"].items()},
-                   "roofline": agg_roofline(args, res_tol, *agg_traffic(fp32_rows=True)), "roofline_backbone": backbone_roofline(res_tol)}
+            line["meets_tolerance"] = line["parity"]["meets_tolerance"]
+        if res_fast is not None:
+            r = rates(res_fast)
+            blk = {"dtype": "bf16", "what": "BASELINE configs[1]'s dtype: bf16 activations / weights / value maps / decoder GEMM operands, ONE bf16 "
+                                            "MFMA per product.  ~40x outside the north-star logit tolerance (parity below): reported beside the "
+                                            "headline, never as `value`",
+                   "value": r["sync_per_frame"]["samples_per_s_mean"], "unit": "samples/s", "ms_per_step": r["sync_per_frame"]["mean_ms"],
+                   "value_protocol": "sync_per_frame", "steps": res_fast["steps"], "protocol": r,
+                   "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res_fast["prec"].items()},
+                   "roofline": agg_roofline(args, res_fast, *agg_traffic(fp32_rows=False)), "roofline_backbone": backbone_roofline(res_fast)}
+            if res_fast.get("lat_groups"):
+                blk["protocol"]["sync_per_frame_groups"] = res_fast["lat_groups"]
             if orc is not None:
-                blk["parity"] = parity_block("bf16x3", res_tol["eng_frames"], orc)
+                blk["parity"] = parity_block("bf16", res_fast["eng_frames"], orc)
                 blk["meets_tolerance"] = blk["parity"]["meets_tolerance"]
-            line["in_tolerance"] = blk
+            line["fast_mode"] = blk
         print(json.dumps(finite(line)))
     if world > 1:
         dist.destroy_process_group()

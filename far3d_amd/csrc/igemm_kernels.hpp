@@ -113,6 +113,13 @@ __device__ __forceinline__ void pix_split(long p, int HoWo, int& n, int& rem) {
   rem = (int)(u - (unsigned)n * (unsigned)HoWo);
 }
 
+// Bytes of the packed weight rows a BM-row tile at row m0 may touch: the packed matrix holds ceil(Cout / 128) * 128 rows (ops.PackedConv),
+// so a 256-row tile whose second half lies past them must not describe it -- rows beyond the descriptor read as zeros.
+__device__ __forceinline__ long w_tile_bytes(int BM, int m0, int Cout, int Ktot) {
+  const int rows = ((Cout + 127) / 128) * 128 - m0;
+  return (long)(rows < BM ? (rows > 0 ? rows : 0) : BM) * Ktot * 2;
+}
+
 template <typename TC> struct Cfg;
 template <> struct Cfg<bf16_t> { static constexpr int E = 8, ROWB = 80, KSUB = 2; };
 template <> struct Cfg<float> { static constexpr int E = 4, ROWB = 144, KSUB = 4; };
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_pipe_kernel(IgemmParam
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const bf16_t*>(P.x) + (long)n * P.x_img_stride), 0, (int)(img_bytes < 0x7fffffffL ? img_bytes : 0x7fffffffL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)w_tile_bytes(BM, m0, P.Cout, Ktot), 0x00020000);
   unsigned pvoff[GPL], wvoff[GWL];
   int pdst[GPL], wdst[GWL];
 #pragma unroll
@@ -1291,7 +1298,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)(x_bytes < 0x7fffffffL ? x_bytes : 0x7fffffffL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)w_tile_bytes(BM, m0, P.Cout, Ktot), 0x00020000);
   unsigned avoff[AW], bvoff[BW];
 #pragma unroll
   for (int i = 0; i < AW; ++i) {
@@ -1522,7 +1529,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_wide_kernel(IgemmParam
   const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)(x_bytes < 0x7fffffffL ? x_bytes : 0x7fffffffL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)((long)BM * Ktot * 2), 0x00020000);
+      (void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot), 0, (int)w_tile_bytes(BM, m0, P.Cout, Ktot), 0x00020000);
   unsigned avoff[AW], bvoff[BW], avoff_h[AW], bvoff_h[BW];       // _h: the half step (upper four slots out of range)
 #pragma unroll
   for (int i = 0; i < AW; ++i) {
@@ -1755,7 +1762,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_split_kernel(IgemmPara
   const bool is_a = wv < NWA;                                    // wave-uniform role: weight pieces / activation pieces
   const int dw = is_a ? wv : wv - NWA, nr = is_a ? NWA : NWB, npw = is_a ? APW : BPW;
   const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
-  const long w_bytes = (long)BM * Ktot * 2;
+  const long w_bytes = w_tile_bytes(BM, m0, P.Cout, Ktot);
   const void* base = is_a ? (const void*)(reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot) : P.x;
   const long nbytes = is_a ? w_bytes : x_bytes;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nbytes < 0x7fffffffL ? nbytes : 0x7fffffffL), 0x00020000);

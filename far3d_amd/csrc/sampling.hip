@@ -1434,10 +1434,15 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
         const unsigned long long* other = reinterpret_cast<const unsigned long long*>(prm.split_part + ((long)a * 2 + (1 - part)) * 256 + c);
         __hip_atomic_store(mine, (unsigned long long)__float_as_uint(s0) | ((unsigned long long)__float_as_uint(s1) << 32), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // Publish order (MI355X guide, inter-workgroup visibility): the partials above are `sc1` write-through stores
+        // (relaxed agent-scope atomic stores of 8 bytes), so no L2 write-back is needed -- but the ticket must not become visible
+        // before EVERY wave's stores have left the CU: each wave drains its own vmcnt (inline asm: the compiler cannot drop it),
+        // then the barrier, then thread 0 draws the ticket.  A workgroup-scope fence orders nothing another CU can observe.  The
+        // merger reads the sibling's partials with `sc1` loads (they bypass its L1), valid because the producer stored `sc1`.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* tk = reinterpret_cast<int*>(stat_s + 12);
-        if (t == 0) *tk = atomicAdd(prm.split_tick + a, 1);
+        if (t == 0) *tk = __hip_atomic_fetch_add(prm.split_tick + a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*tk == 0) return;                        // first to arrive: the sibling finishes the row
         const unsigned long long o = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

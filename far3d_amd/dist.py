@@ -206,6 +206,27 @@ class ShardedFrame:
         self._scene = None
         self._fidx = 0
         self._pipe = None
+        # record_stage_times (unpipelined frames only; bench.py --gpus N): device events around the three parts of a rank's frame --
+        # per-camera stages, exchange, replicated head -- so that a scaling line can be read against DESIGN.md section 7's table
+        self.record_stage_times = False
+        self.stage_times = []        # per frame: [event start, after the camera stages, after the exchange, after the head]
+
+    def mean_stage_times(self):
+        """Mean ms per part over the recorded frames (synchronises)."""
+        if not self.stage_times:
+            return dict(frames=0, camera_stage_ms=None, exchange_ms=None, head_ms=None)
+        torch.cuda.synchronize(self.eng.dev)
+        n = len(self.stage_times)
+        cam = sum(e[0].elapsed_time(e[1]) for e in self.stage_times) / n
+        exc = sum(e[1].elapsed_time(e[2]) for e in self.stage_times) / n
+        head = sum(e[2].elapsed_time(e[3]) for e in self.stage_times) / n
+        return dict(frames=n, camera_stage_ms=cam, exchange_ms=exc, head_ms=head)
+
+    def _mark(self, evs):
+        if evs is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.eng.dev))
+            evs.append(e)
 
     # ------------------------------------------------------------------------------------------ buffers
     def _gather_bufs(self, p, tok, rec):
@@ -371,6 +392,8 @@ class ShardedFrame:
         eng._ready = None
         dd = eng._stage_inputs(data)      # every rank keeps the (small) calibration inputs; images are sliced per rank
         self._drop_stale_graphs(p, dd)
+        evs = [] if (self.record_stage_times and steady and p in self._g_head) else None      # replayed frames only (a capture is not a frame)
+        self._mark(evs)
         # ---- per-camera stages: eager, or one hipGraph per rank in steady state
         if steady and self.cams:
             if p not in self._g_cam:
@@ -379,14 +402,19 @@ class ShardedFrame:
             st = self._st[p]
         else:
             st = self._camera_part(dd, pad_hw)
+        self._mark(evs)
         for w in self._exchange(p, st):
             w.wait()
+        self._mark(evs)
         # ---- replicated head on the gathered buffers: eager on the first frame of a scene (memory reset), else a hipGraph
         if not steady:
             return self._head(p, dd, img_metas, st["hw"], st["starts"], pad_hw)
         if p not in self._g_head:
             self._g_head[p], self._head_out[p] = self._capture_head(lambda: self._head(p, dd, img_metas, st["hw"], st["starts"], pad_hw))
         self._g_head[p].replay()
+        self._mark(evs)
+        if evs is not None:
+            self.stage_times.append(evs)
         eng._overflow = self._head_out[p].get("proposal_overflow")
         return self._head_out[p]
 

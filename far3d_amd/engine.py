@@ -435,6 +435,7 @@ class Far3DEngine:
         outs = []
         stage_in = None   # dense input of the stage (stem3 output is written straight into the first concat buffer)
         pooled_by_ese = False      # the previous stage's last eSE launch already wrote this stage's pooled input
+        next_cat = None            # ... into this tensor (the next stage's first concat buffer)
         for si, blocks in enumerate(self.bb["stages"]):
             sc, oc = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
             if si > 0:
@@ -444,10 +445,18 @@ class Far3DEngine:
                     H -= 1
                 if (W - 1) * 2 >= Wp:
                     W -= 1
-            cat = self._buf(("cat", si, 0), (N, H, W, (in_ch + Lb * sc) * cs), act)
+            # this stage's first concat buffer: the SAME tensor the previous stage's last eSE pass pooled into (fetched once there and
+            # handed over: a second _buf lookup with a drifted shape would silently allocate another buffer)
+            want_shape = (N, H, W, (in_ch + Lb * sc) * cs)
+            if next_cat is not None:
+                assert tuple(next_cat.shape) == want_shape, (tuple(next_cat.shape), want_shape)
+                cat, next_cat = next_cat, None
+            else:
+                cat = self._buf(("cat", si, 0), want_shape, act)
             if si == 0:
                 ops.conv2d_nhwc(x, self.bb["stem3"], out=cat[..., :in_ch * cs], act="relu")
             elif not pooled_by_ese:
+                assert stage_in is not None, "the previous stage's map was skipped (keep_stage2=False) but its eSE pass did not pool it"
                 ops.maxpool3x3s2_nhwc(stage_in, out=cat[..., :in_ch * cs], pair=pair)
             pooled_by_ese = False
             cur_in = in_ch
@@ -467,7 +476,8 @@ class Far3DEngine:
                 if will_fuse and last and si + 1 < len(self.bb["stages"]):   # the next stage's input slice: MaxPool2d(3, 2, ceil) of this output
                     Hn, Wn = ops.maxpool_out_hw(H, W)
                     nsc = spec["stage_conv_ch"][si + 1]
-                    pooled = self._buf(("cat", si + 1, 0), (N, Hn, Wn, (oc + Lb * nsc) * cs), act)[..., :oc * cs]
+                    next_cat = self._buf(("cat", si + 1, 0), (N, Hn, Wn, (oc + Lb * nsc) * cs), act)
+                    pooled = next_cat[..., :oc * cs]
                 skip_out = pooled is not None and si == 0 and not keep_stage2     # nothing but the pooling reads the stage-2 map
                 if last:
                     out = None if skip_out else self._buf(("stage", si), (N, H, W, oc * cs), act)

@@ -429,16 +429,25 @@ class Far3DOracle:
         return dict(boxes_3d=b, scores_3d=scores, labels_3d=labels)
 
     # ------------------------------------------------------------------ a1: one frame (detectors/far3d.py:64-99,244-277)
-    def simple_test(self, data, img_metas, forced_valid=None, forced_topk=None, forced_depth=None):
+    def simple_test(self, data, img_metas, forced_valid=None, forced_topk=None, forced_depth=None, camera_cache=None):
         """forced_*: hooks of the test rigs (tests/test_engine_full_gpu.py) that make the oracle adopt the device's choice where a
         discrete decision sits on a near-tie: forced_valid (2D peak selection), forced_topk (memory top-k), forced_depth
-        (callable(pred_depth (BN,D,H,W), depth_idx (BN,H,W,1)) -> depth_idx: the per-cell depth-bin argmax)."""
+        (callable(pred_depth (BN,D,H,W), depth_idx (BN,H,W,1)) -> depth_idx: the per-cell depth-bin argmax).
+        camera_cache: optional (dict, key) of a test rig that runs the SAME frame through several oracles of the same weights and
+        dtype (decisions adopted or not): the per-camera stages (backbone, FPN, 2D head: 90 % of a frame's CPU time) depend on the
+        images only, not on the streaming state or on any decision, so their outputs are computed once per key and re-used."""
         img = data["img"]
         B, N = img.shape[:2]
         assert B == 1
         pad_hw = img_metas[0]["pad_shape"][0][:2]
-        feats = self.fpn(self.backbone(img.reshape(B * N, *img.shape[2:])))
-        outs_roi = self.roi_head(feats)
+        hit = camera_cache[0].get(camera_cache[1]) if camera_cache is not None else None
+        if hit is not None:
+            feats, outs_roi = list(hit[0]), dict(hit[1])
+        else:
+            feats = self.fpn(self.backbone(img.reshape(B * N, *img.shape[2:])))
+            outs_roi = self.roi_head(feats)
+            if camera_cache is not None:
+                camera_cache[0][camera_cache[1]] = (list(feats), dict(outs_roi))
         if callable(forced_valid):
             forced_valid = forced_valid(self.get_bboxes(outs_roi))
         outs_roi.update(self.get_bboxes(outs_roi, forced_valid))

@@ -1,4 +1,4 @@
-"""CPU, 2 processes, gloo: the camera-shard / all-gather / un-pad logic of far3d_amd.dist (no compute kernels run)."""
+"""CPU, 2 and 8 processes, gloo: the camera-shard / all-gather / un-pad logic of far3d_amd.dist (no compute kernels run)."""
 import os
 import socket
 
@@ -49,19 +49,48 @@ def _worker(rank, world, port, q):
         w.wait()
     ok = ok and torch.equal(d_tok[:num_cams], full_tok) and d_cnt[:, 0].tolist() == [r + 2 for r in range(world)]
     ok = ok and all(bool((d_blk[4 * r:4 * r + 4] == r + 1).all()) for r in range(world))
+    # what far3d_compact_rows (HIP, ops.compact_rows) does with the gathered blocks in ShardedFrame._head: the first cnt[r] rows of every
+    # rank's block, in rank order -- rank order IS camera order (contiguous camera blocks per rank), so the packed rows are the
+    # reference's camera-major proposal order; an idle rank (no camera: 8 ranks, 7 cameras) contributes a zero count and no row.
+    # Here each rank's block carries its cameras' proposals tagged (camera, index); counts differ per camera.
+    ncam_props = [c % 3 + 1 for c in range(num_cams)]                            # proposals per camera
+    rows = [(c, j) for c in mine for j in range(ncam_props[c])]
+    cap = per * 3
+    blk2 = torch.full((cap, 2), -9.0)
+    if rows:
+        blk2[:len(rows)] = torch.tensor(rows, dtype=torch.float32)
+    cnt2 = torch.tensor([[len(rows), 0]], dtype=torch.int32)
+    g_blk, g_cnt = torch.empty((world * cap, 2)), torch.empty((world, 2), dtype=torch.int32)
+    for w in fdist.gather_many([(blk2, g_blk), (cnt2, g_cnt)]):
+        w.wait()
+    packed = torch.cat([g_blk.view(world, cap, 2)[r, :int(g_cnt[r, 0])] for r in range(world)])
+    want = torch.tensor([(c, j) for c in range(num_cams) for j in range(ncam_props[c])], dtype=torch.float32)
+    ok = ok and torch.equal(packed, want) and int(g_cnt[:, 0].sum()) == sum(ncam_props)
+    if world == 8:
+        ok = ok and (len(mine) == 0) == (rank == 7) and int(g_cnt[7, 0]) == 0
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_camera_major_two_ranks_gloo():
+def _run_world(world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_gather_camera_major_two_ranks_gloo():
+    _run_world(2)
+
+
+def test_gather_eight_ranks_seven_cameras_one_idle_rank_gloo():
+    """BASELINE configs[2]'s layout: 8 ranks, 7 cameras -- rank 7 owns only a padding slot, contributes padding to the value maps, a
+    zero count to the fixed-capacity records, and the packed proposal rows still come out in the reference's camera-major order."""
+    _run_world(8)

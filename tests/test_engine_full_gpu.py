@@ -23,10 +23,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 K = 92
 FRAMES = 3
+FRAMES_QUEUE = 5      # frames of the un-adopted witness: the 1024-slot memory queue (4 x 256, far3d.py:80-82) is full after frame 3 and
+                      # frame 4 drops live entries (farhead.py:467-471) -- BASELINE configs[4]'s "4-frame memory queue"
+# The per-camera stages of the oracle (backbone, FPN, 2D head: ~90 % of a frame's CPU time) do not depend on the streaming state or on
+# any adopted decision: computed once per (frame, dtype) for the whole module and re-used by every oracle run of these weights
+# (the suite's wall time is mostly full-size oracle frames).
+_CAMERA_CACHE = {}
 
 
-def _frames(device="cpu"):
-    return [synth.make_frame(7, (640, 960), seed=0, frame_index=fi, device=device, ego_motion=True) for fi in range(FRAMES)]
+def _frames(device="cpu", n=FRAMES):
+    return [synth.make_frame(7, (640, 960), seed=0, frame_index=fi, device=device, ego_motion=True) for fi in range(n)]
 
 
 LEVEL_HW = [(80, 120), (40, 60), (20, 30), (10, 15)]      # 640x960 at strides 8, 16, 32, 64
@@ -125,14 +131,20 @@ def _resolve_depth_ties(depth_logit_dev, tag, tol=1e-3):
     return pick
 
 
-def _run_engine(sd, precision):
-    """3 streaming frames through the engine; everything the comparisons need, on the host."""
+def _run_engine(sd, precision, frames=FRAMES, light=False):
+    """`frames` streaming frames through the engine; everything the comparisons need, on the host (light: logits and decisions only)."""
     eng = _engine(sd, precision)
     got = []
-    for data, metas in _frames():
+    for data, metas in _frames(n=frames):
+        live = int((eng.mem["emb"][0].abs().sum(-1) > 0).sum().item()) if eng._mem_valid else 0     # live memory slots the frame starts from
         o = eng.forward_frame(data, metas)
         cnt = o["sel_cnt"].cpu().numpy()
-        got.append(dict(sel=[(n, int(i)) for n in range(7) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()],
+        if light:
+            got.append(dict(sel=[(n, int(i)) for n in range(7) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()], memory_live=live,
+                            memory_topk=o["memory_topk"].cpu().clone(), depth_logit=o["depth_logit"].float().cpu().clone(),
+                            score2d=o["bbox2d_scores"].float().cpu().clone(), all_cls_scores=o["all_cls_scores"].cpu().clone()))
+            continue
+        got.append(dict(sel=[(n, int(i)) for n in range(7) for i in o["sel_idx"][n, :cnt[n]].cpu().numpy()], memory_live=live,
                         memory_topk=o["memory_topk"].cpu().clone(), depth_logit=o["depth_logit"].float().cpu().clone(),
                         ref=o["reference_points"].float().cpu().clone(), bbox2d=o["bbox2d"].float().cpu().clone(),
                         score2d=o["bbox2d_scores"].float().cpu().clone(),
@@ -147,7 +159,7 @@ def _run_engine(sd, precision):
 
 def _run_oracle(sd, got, with_f64, tie_tol=2e-5):
     """The oracle on the same frames, adopting the device's near-tie decisions (checked to BE near-ties: 2D scores within a
-    relative `tie_tol`, the rounding-noise level of the mode under test)."""
+    relative `tie_tol`, the rounding-noise level of the mode under test).  As many frames as `got` holds."""
     from oracle import far3d_oracle
     keep = lambda o: dict(logits=o["all_cls_scores"].clone(), boxes=o["all_bbox_preds"].clone(), outs_dec=o["outs_dec"].clone(),
                           feat_flatten=o["feat_flatten"].clone(), fpn=[f.clone() for f in o["feat_levels"]],
@@ -157,15 +169,17 @@ def _run_oracle(sd, got, with_f64, tie_tol=2e-5):
     o64 = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K), dtype=torch.float64) if with_f64 else None
     outs = []
     with torch.no_grad():
-        for fi, (data, metas) in enumerate(_frames()):
+        for fi, (data, metas) in enumerate(_frames(n=len(got))):
             w = keep(orc.simple_test(data, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d" % fi, tie_tol, got[fi]["score2d"]),
                                      forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d" % fi),
-                                     forced_depth=_resolve_depth_ties(got[fi]["depth_logit"], "frame %d" % fi, max(1e-4, 20 * tie_tol))))
+                                     forced_depth=_resolve_depth_ties(got[fi]["depth_logit"], "frame %d" % fi, max(1e-4, 20 * tie_tol)),
+                                     camera_cache=(_CAMERA_CACHE, (fi, "f32"))))
             if with_f64:
                 d64 = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
                 w["f64"] = keep(o64.simple_test(d64, metas, forced_valid=_resolve_topk_ties(got[fi]["sel"], "frame %d (fp64)" % fi, tie_tol, got[fi]["score2d"]),
                                                 forced_topk=_resolve_memory_ties(got[fi]["memory_topk"], "frame %d (fp64)" % fi),
-                                                forced_depth=_resolve_depth_ties(got[fi]["depth_logit"], "frame %d (fp64)" % fi, max(1e-4, 20 * tie_tol))))
+                                                forced_depth=_resolve_depth_ties(got[fi]["depth_logit"], "frame %d (fp64)" % fi, max(1e-4, 20 * tie_tol)),
+                                                camera_cache=(_CAMERA_CACHE, (fi, "f64"))))
             outs.append(w)
     return outs
 
@@ -433,52 +447,88 @@ def _row_ids(sel, prev_ids, prev_topk, A, nq=644):
     return ids + [("P", prev_ids[int(r)]) for r in prev_topk[:n_prop].tolist()]
 
 
-def test_bf16x3_streaming_parity_without_adopting_any_device_decision(hip_lib):
-    """The un-adopted witness: the in-tolerance engine (bf16x3) on 3 streaming frames at the benchmarked size
-    against the oracle run with NO forced_* hooks -- the oracle takes every discrete decision (K-th 2D peak, 3x3 peak test, depth-bin
-    argmax, memory top-256) by itself; a recording pass-through only notes its memory selection.  Rows are matched by IDENTITY, not by
-    position: learned queries by index, adaptive queries by (camera, cell) of their 2D peak (what bench.py's parity block does,
-    yolox_head.py:429-458), propagated queries by the identity of the previous frame's row they came from (farhead.py:488-491,
-    736-766).  Asserted per frame: >= 642 of the 644 adaptive queries in common, every logit of every matched row < 1e-3, and the
-    rows left out (different queries on the two sides) counted, printed and bounded."""
+def _unadopted_oracle(sd, dtype, frames):
+    """The oracle on `frames` streaming frames with NO forced_* hook: it takes every discrete decision (K-th 2D peak, 3x3 peak test,
+    depth-bin argmax, memory top-256) by itself; a recording pass-through only notes its memory selection."""
     from oracle import far3d_oracle
+    orc = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K), dtype=dtype)
+    tag = "f64" if dtype == torch.float64 else "f32"
+    out = []
+    with torch.no_grad():
+        for fi, (data, metas) in enumerate(_frames(n=frames)):
+            if dtype == torch.float64:
+                data = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
+            rec = []
+            o = orc.simple_test(data, metas, forced_topk=lambda score, own: (rec.append(own.clone()), own)[1],      # adopts nothing
+                                camera_cache=(_CAMERA_CACHE, (fi, tag)))
+            out.append(dict(sel=[(int(n), int(i)) for n, i, _ in o["roi"]["valid_indices"].nonzero().numpy()],
+                            memory_topk=rec[0].flatten().clone(), all_cls_scores=o["all_cls_scores"].clone()))
+    return out
+
+
+def _identity_matched(a, b, tag):
+    """Two runs of the same frames (each a list of dicts with sel, memory_topk, all_cls_scores) compared on the query rows that are
+    the SAME query on both sides: learned queries by index, adaptive queries by (camera, cell) of their 2D peak (what bench.py's parity
+    block does, yolox_head.py:429-458), propagated queries by the identity of the previous frame's row they came from
+    (farhead.py:488-491, 736-766).  Returns the per-frame report."""
+    report, ids_a, ids_b, topk_a, topk_b = [], None, None, None, None
+    for fi, (ga, gb) in enumerate(zip(a, b)):
+        A = ga["all_cls_scores"].shape[2]
+        assert gb["all_cls_scores"].shape[2] == A
+        ids_a = _row_ids(ga["sel"], ids_a, topk_a, A)
+        ids_b = _row_ids(gb["sel"], ids_b, topk_b, A)
+        topk_a, topk_b = ga["memory_topk"].flatten(), gb["memory_topk"].flatten()
+        pos = {k: j for j, k in enumerate(ids_b)}
+        assert len(pos) == len(ids_b), "%s: row identities are not unique" % tag
+        ra = [j for j, k in enumerate(ids_a) if k in pos]
+        rb = [pos[ids_a[j]] for j in ra]
+        common = sum(1 for j in ra if ids_a[j][0] == "A")
+        d = (ga["all_cls_scores"][:, 0][:, ra].double() - gb["all_cls_scores"][:, 0][:, rb].double()).abs()
+        rep = dict(pair=tag, frame=fi, adaptive_in_common=common, adaptive=len(gb["sel"]), rows_compared=len(ra), rows_excluded=A - len(ra),
+                   excluded_adaptive=len(ga["sel"]) - common, excluded_propagated=(A - len(ra)) - (len(ga["sel"]) - common),
+                   memory_topk_in_common=len(set(topk_a.tolist()) & set(topk_b.tolist())),
+                   logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(), **{"logit_" + k: v for k, v in _pct(d).items() if k != "max"})
+        report.append(rep)
+    return report
+
+
+def test_streaming_parity_without_adopting_any_device_decision(hip_lib):
+    """The un-adopted witness: the in-tolerance engine (bf16x3) AND the exact-fp32 engine on 5 streaming
+    frames at the benchmarked size -- the 1024-slot memory queue is full after frame 3 and overflows at frame 4 (BASELINE configs[4]'s
+    "4-frame memory queue", farhead.py:453-508) -- against the oracle run with NO forced_* hooks: the oracle takes every discrete
+    decision by itself.  Rows are matched by IDENTITY, not by position (_identity_matched).
+
+    The yardstick: what the REFERENCE ARITHMETIC itself does over the same five un-adopted frames when only its rounding changes --
+    the oracle in fp32 against the oracle in fp64, both taking their own decisions, matched the same way.  Where one side's K-th-place
+    or top-256 near-tie falls the other way, the differing query is excluded but stays a self-attention key of every other query of
+    its frame and feeds the memory rows of the following ones: the two runs compute slightly different things from then on, whatever
+    the arithmetic.  Asserted per frame, for both engines: >= 640 of the 644 adaptive queries in common, 99.9 % of the matched logits
+    inside 1e-3, and the worst matched logit <= max(1e-3, 2 x the yardstick's worst of that frame) -- no hard-coded allowance."""
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     sd = weights.init_state_dict(weights.detector_spec("V-99-eSE"), seed=0)
-    got = _run_engine(sd, "bf16x3")
-    orc = far3d_oracle.Far3DOracle(sd, far3d_oracle.default_cfg(proposal_topk=K))
-    report, ids_g, ids_w, topk_g, topk_w = [], None, None, None, None
-    with torch.no_grad():
-        for fi, (data, metas) in enumerate(_frames()):
-            rec = []
-            o = orc.simple_test(data, metas, forced_topk=lambda score, own: (rec.append(own.clone()), own)[1])   # adopts nothing
-            sel_w = [(int(n), int(i)) for n, i, _ in o["roi"]["valid_indices"].nonzero().numpy()]
-            A = o["all_cls_scores"].shape[2]
-            g = got[fi]
-            ids_g = _row_ids(g["sel"], ids_g, topk_g, A)
-            ids_w = _row_ids(sel_w, ids_w, topk_w, A)
-            topk_g, topk_w = g["memory_topk"].flatten(), rec[0].flatten()
-            pos = {k: j for j, k in enumerate(ids_w)}
-            assert len(pos) == len(ids_w), "oracle row identities are not unique"
-            rg = [j for j, k in enumerate(ids_g) if k in pos]
-            rw = [pos[ids_g[j]] for j in rg]
-            common = sum(1 for j in rg if ids_g[j][0] == "A")
-            d = (g["all_cls_scores"][:, 0][:, rg] - o["all_cls_scores"][:, 0][:, rw]).abs()
-            rep = dict(frame=fi, adaptive_in_common=common, adaptive=len(sel_w), rows_compared=len(rg), rows_excluded=A - len(rg),
-                       excluded_adaptive=len(g["sel"]) - common, excluded_propagated=(A - len(rg)) - (len(g["sel"]) - common),
-                       memory_topk_in_common=len(set(topk_g.tolist()) & set(topk_w.tolist())),
-                       logit_max_abs=d.max().item(), logit_mean_abs=d.mean().item(), **{"logit_" + k: v for k, v in _pct(d).items() if k != "max"})
-            report.append(rep)
-            print("\nbf16x3 vs the oracle, nothing adopted, frame %d: %s" % (fi, json.dumps(rep)))
+    n = FRAMES_QUEUE
+    got = {p: _run_engine(sd, p, frames=n, light=True) for p in ("bf16x3", "fp32")}
+    for p, g in got.items():
+        live = [f["memory_live"] for f in g]
+        assert live[4] == 1024 and live[3] == 768, "%s: the memory queue does not fill (live slots at frame start: %s)" % (p, live)
+    o32 = _unadopted_oracle(sd, torch.float32, n)
+    o64 = _unadopted_oracle(sd, torch.float64, n)
+    yard = _identity_matched(o32, o64, "oracle fp32 vs oracle fp64, nothing adopted")
+    reports = {"yardstick": yard}
+    for p in ("bf16x3", "fp32"):
+        reports[p] = _identity_matched(got[p], o32, "%s engine vs oracle fp32, nothing adopted" % p)
+        reports[p + "_vs_oracle64"] = _identity_matched(got[p], o64, "%s engine vs oracle fp64, nothing adopted" % p)
+    for k, rep in reports.items():
+        for r in rep:
+            print("\n%s: %s" % (k, json.dumps(r)))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_full_bf16x3_unadopted.json"), "w") as f:
-        json.dump(report, f, indent=1)
-    for rep in report:
-        assert rep["adaptive_in_common"] >= 642, rep
-        assert rep["rows_excluded"] <= 8, rep          # different queries on the two sides: <= 2 adaptive + the rows propagated from them / memory near-ties
-        # Measured (profiles/r5/parity_full_bf16x3_unadopted.json): 6.3e-05 / 3.3e-04 / 1.7e-03.  Frames 0-1 are inside the bar outright.
-        # Frame 1 has ONE adaptive query the two sides chose differently (a K-th-place near-tie; excluded above) -- but that query is a
-        # self-attention key of every other query of frame 1, so the 256 memory rows frame 2 starts from already differ in the 4th digit
-        # on the two sides: frame 2 compares two slightly different computations.  99.9 % of its logits stay inside 1e-3 and the worst one
-        # within 2.5x the bar; the rig that ADOPTS the near-tie decisions (test above) holds every logit of frame 2 inside 1e-3.
-        assert rep["logit_p999"] < 1e-3, rep
-        assert rep["logit_max_abs"] < (1e-3 if rep["frame"] < 2 else 2.5e-3), rep
+    with open(os.path.join(ROOT, "gpurun_out", "parity_full_unadopted.json"), "w") as f:
+        json.dump(reports, f, indent=1)
+    for p in ("bf16x3", "fp32"):
+        for rep, y in zip(reports[p], yard):
+            assert rep["adaptive_in_common"] >= 640, rep
+            assert rep["rows_excluded"] <= 16 + 8 * rep["frame"], rep       # different queries on the two sides and the rows propagated from them
+            assert rep["logit_p999"] < 1e-3, rep
+            bar = max(1e-3, 2 * y["logit_max_abs"])
+            assert rep["logit_max_abs"] <= bar, "%s frame %d: worst matched logit %.3e > max(1e-3, 2 x yardstick %.3e)" % (
+                p, rep["frame"], rep["logit_max_abs"], y["logit_max_abs"])

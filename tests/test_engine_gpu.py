@@ -36,12 +36,19 @@ def _golden_engine(precision, name="far3d_small_seq", **over):
 LOOSE = {}
 
 
-@pytest.mark.parametrize("name", ["far3d_small_seq", "far3d_c1_seq"])
+@pytest.mark.parametrize("name", ["far3d_small_seq", "far3d_c1_seq", "far3d_overflow_seq"])
 def test_engine_fp32_matches_reference_golden_sequence(hip_lib, name):
+    """far3d_overflow_seq: 7 frames of one scene, memory_len = 3 x num_propagated, 16 entries pushed per frame --
+    the queue is full after frame 2, so frames 3-6 run the truncation of pre_update_memory (farhead.py:467-471) on LIVE entries and
+    carry timestamps / poses three frames old; every frame is held to the 1e-3 bar against the REFERENCE's own outputs."""
     eng, z, rc = _golden_engine("fp32", name)
     for fi in range(rc["frames"]):
         loose = LOOSE.get((name, fi), 1.0)
         data, metas = synth.recipe_frame(rc, fi)
+        if name == "far3d_overflow_seq" and fi >= 3:
+            # the queue the frame starts from is full of live entries (none of the zero rows a scene start leaves): what the
+            # post-update of this frame pushes drops the oldest topk_proposals of them
+            assert int((eng.mem["emb"][0].abs().sum(-1) > 0).sum().item()) == rc["memory_len"], "frame %d: the memory queue is not full" % fi
         o = eng.forward_frame(data, metas)
         # 2D proposals: same peaks, same order
         want_idx = z["f%d_valid_idx" % fi]          # rows (camera, flat index, 0)

@@ -40,10 +40,11 @@ def test_schema_matches_reference_manifest():
     assert "img_backbone.stem.stem_1/conv.weight" in spec   # '/'-containing names are kept
 
 
-@pytest.mark.parametrize("name", ["far3d_small_seq", "far3d_c1_seq"])
+@pytest.mark.parametrize("name", ["far3d_small_seq", "far3d_c1_seq", "far3d_overflow_seq"])
 def test_oracle_reproduces_reference_golden_sequence(name):
     """far3d_small_seq: 2 cameras, 4 frames with ego motion and a scene change at frame 2; far3d_c1_seq: the single-camera
-    256x256 case of BASELINE.json configs[0].  Both were produced by the reference's own files (tools/gen_golden.py)."""
+    256x256 case of BASELINE.json configs[0]; far3d_overflow_seq: 7 frames of one scene into a 48-slot memory queue (16 pushed per
+    frame: it overflows from frame 3 on, farhead.py:467-471).  All were produced by the reference's own files (tools/gen_golden.py)."""
     z, rc = load_small(name)
     orc, _ = small_oracle(rc)
     with torch.no_grad():
