@@ -1,0 +1,43 @@
+// Instantiations of the persistent wave-specialised 3x3 convolution (conv_ws.hpp).  Tile ids of far3d_conv2d_nhwc:
+//   400-419  pair-stored activations, split products (x_dt = FAR3D_DT_BF16_PAIR): the in-tolerance engine's backbone / FPN / 2D head
+//   420-439  plain bf16
+// Epilogue: bias + activation + pair / bf16 store only (no residual, no second output, no channel sums): far3d_conv2d_nhwc refuses
+// the tile for a layer that needs more.
+#include "conv_ws.hpp"
+
+#ifdef FAR3D_PROFILING
+std::atomic<int> g_ws_ablate{0};
+extern "C" int far3d_conv_ws_set_ablate(int mask) { g_ws_ablate.store(mask); return 0; }     // probes only (see conv_ws.hpp)
+#endif
+
+int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
+  switch (tile) {
+    // (consumer grid WGM x WGN, tiles per consumer WM x WN, producers, pair, double-buffered fragments)
+    case 400: return launch_conv3x3_ws<2, 4, 2, 2, 4, true, true>(P, st);    // 128 ch x 8 rows: 8 consumers of 64 ch x 2 rows + 4 producers
+    case 401: return launch_conv3x3_ws<1, 8, 2, 1, 4, true, true>(P, st);    // 64 ch x 8 rows: 8 consumers of 64 ch x 1 row (Cout 64)
+    case 402: return launch_conv3x3_ws<1, 8, 5, 1, 4, true, false>(P, st);   // 160 ch x 8 rows: 8 consumers of 160 ch x 1 row (stage 3)
+    case 403: return launch_conv3x3_ws<2, 4, 3, 1, 4, true, true>(P, st);    // 192 ch x 4 rows: 8 consumers of 96 ch x 1 row (stage 4)
+    case 404: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true>(P, st);    // 64 ch x 4 rows: 4 consumers of 32 ch x 2 rows + 2 producers (2 per CU)
+    case 405: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true>(P, st);    // 128 ch x 4 rows: 8 consumers of 64 ch x 1 row
+    case 406: return launch_conv3x3_ws<2, 4, 1, 2, 4, true, true>(P, st);    // 64 ch x 8 rows: 8 consumers of 32 ch x 2 rows
+    case 407: return launch_conv3x3_ws<1, 4, 5, 1, 2, true, false>(P, st);   // 160 ch x 4 rows: 4 consumers of 160 ch x 1 row + 2 producers
+    case 408: return launch_conv3x3_ws<1, 4, 3, 1, 2, true, true>(P, st);    // 96 ch x 4 rows: 4 consumers + 2 producers (2 per CU)
+    case 409: return launch_conv3x3_ws<2, 4, 2, 2, 2, true, true>(P, st);    // 400 with 2 producers
+    // deeper weight rings (the producers run NSW - 1 steps ahead)
+    case 410: return launch_conv3x3_ws<2, 4, 2, 2, 4, true, true, 4>(P, st);   // 400 with 4 stages (154 KB)
+    case 411: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 6>(P, st);   // 405 (128 ch x 4 rows) with 6 stages
+    case 412: return launch_conv3x3_ws<2, 4, 1, 2, 4, true, true, 8>(P, st);   // 406 (64 ch x 8 rows) with 8 stages
+    case 413: return launch_conv3x3_ws<1, 8, 2, 1, 4, true, true, 8>(P, st);   // 401 (64 ch x 8 rows, Cout 64) with 8 stages
+    case 414: return launch_conv3x3_ws<1, 4, 5, 1, 2, true, false, 5>(P, st);  // 407 (160 ch x 4 rows) with 5 stages
+    case 415: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 6>(P, st);   // 404 (64 ch x 4 rows, 2 per CU) with 6 stages
+    case 416: return launch_conv3x3_ws<2, 4, 3, 1, 4, true, true, 4>(P, st);   // 403 (192 ch x 4 rows) with 4 stages
+    case 417: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 4>(P, st);   // 405 with 4 stages
+    case 420: return launch_conv3x3_ws<2, 4, 2, 2, 4, false, true>(P, st);   // plain bf16: 128 ch x 8 rows
+    case 421: return launch_conv3x3_ws<1, 8, 2, 1, 4, false, true>(P, st);   // plain bf16: 64 ch x 8 rows
+    case 422: return launch_conv3x3_ws<1, 8, 5, 1, 4, false, true>(P, st);   // plain bf16: 160 ch x 8 rows
+    case 423: return launch_conv3x3_ws<2, 4, 3, 1, 4, false, true>(P, st);   // plain bf16: 192 ch x 4 rows
+    default: break;
+  }
+  far3d_set_error("far3d_conv2d_nhwc: unknown wave-specialised tile %d", tile);
+  return FAR3D_ERR_ARG;
+}

@@ -4,6 +4,7 @@
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
+int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 3x3, tiles 400-439)
 
 #ifdef FAR3D_PROFILING
 // tools/conv_phase_times.py: where the per-workgroup stamps of the pipelined conv / GEMM kernels go (8 x uint64 per workgroup)
@@ -67,6 +68,19 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
                                    : ((tile >= 70 && tile <= 89) || (tile >= 110 && tile <= 117) || (tile >= 120 && tile <= 129) || (tile >= 140 && tile <= 145));
     FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && gemm_tile && (pair_in || (x_dt == FAR3D_DT_BF16 && Cin % 32 == 0 && P.x_vec)),
                     "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-117, 120-129, 140-145; pair: 170-181, 279, 280); got k=%d tile=%d", KH, tile);
+  }
+  if (tile >= 400 && tile < 440) {     // persistent wave-specialised 3x3 kernel: a refusal is an error of the call, never a silent fallback
+    const bool pair_tile = tile < 420;
+    FAR3D_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && !res && !y2 && !chan_sums && Cin % 32 == 0 && Cout % 32 == 0 &&
+                    pair_tile == pair_in && (pair_in ? pair_out : (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && y_dt == FAR3D_DT_BF16)) &&
+                    aligned(x, 16) && aligned(y, 16) && ldx % 8 == 0 && ldy % 8 == 0 && x_img_stride % 8 == 0 && y_img_stride % 8 == 0 &&
+                    (long)N * H * W < (1L << 31) - 4096,
+                    "far3d_conv2d_nhwc: tile %d (wave-specialised 3x3) needs a 3x3 / stride 1 / pad 1 layer, Cin and Cout multiples of 32, %s in and out, "
+                    "16-byte aligned rows and no residual / second output / channel sums", tile, pair_tile ? "pair-stored" : "bf16");
+    const int rc = far3d_conv_ws_launch(P, tile, st);
+    if (rc != FAR3D_OK) return rc;
+    FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
+    return FAR3D_OK;
   }
   if (pair_in) {
     FAR3D_CHECK_ARG(aligned(x, 16) && ldx % 8 == 0 && x_img_stride % 8 == 0 && (!pair_out || (aligned(y, 8) && ldy % 4 == 0 && y_img_stride % 4 == 0)),

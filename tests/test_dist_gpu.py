@@ -37,6 +37,9 @@ def _worker(rank, world, port, q, use_graph, frames, pipeline=False, capacity=No
     from far3d_amd import synth
     from far3d_amd import dist as fdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # `world` processes build an engine each (90 M parameters initialised and packed on the host): without a cap every one of them
+    # spawns a thread per core and the builds slow each other down (a 4-rank case took 149 s, profiles/r6)
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         eng, rc = _build(capacity=capacity)
@@ -238,6 +241,9 @@ def _qs_worker(rank, world, port, q, use_graph, pipeline, capacity, frames, prec
     from far3d_amd import synth
     from far3d_amd import dist as fdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # `world` processes build an engine each (90 M parameters initialised and packed on the host): without a cap every one of them
+    # spawns a thread per core and the builds slow each other down (a 4-rank case took 149 s, profiles/r6)
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         eng, rc = _build(precision=precision, capacity=capacity)

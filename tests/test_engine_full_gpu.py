@@ -498,12 +498,17 @@ def test_streaming_parity_without_adopting_any_device_decision(hip_lib):
     "4-frame memory queue", farhead.py:453-508) -- against the oracle run with NO forced_* hooks: the oracle takes every discrete
     decision by itself.  Rows are matched by IDENTITY, not by position (_identity_matched).
 
-    The yardstick: what the REFERENCE ARITHMETIC itself does over the same five un-adopted frames when only its rounding changes --
-    the oracle in fp32 against the oracle in fp64, both taking their own decisions, matched the same way.  Where one side's K-th-place
-    or top-256 near-tie falls the other way, the differing query is excluded but stays a self-attention key of every other query of
-    its frame and feeds the memory rows of the following ones: the two runs compute slightly different things from then on, whatever
-    the arithmetic.  Asserted per frame, for both engines: >= 640 of the 644 adaptive queries in common, 99.9 % of the matched logits
-    inside 1e-3, and the worst matched logit <= max(1e-3, 2 x the yardstick's worst of that frame) -- no hard-coded allowance."""
+    Two yardsticks say what the REFERENCE ARITHMETIC itself does over the same five frames, matched the same way:
+      Y1  rounding: the oracle in fp32 against the oracle in fp64, both taking their own decisions;
+      Y2  one near-tie decision falling the other way: the fp32 oracle taking its own decisions against the SAME fp32 oracle made to
+          adopt the engine's decisions where they differ -- each such difference checked to BE a near-tie (K-th-place 2D scores within
+          a relative 5e-4, top-256 cut within 1e-2, depth-bin probabilities within 1e-2: _resolve_*_ties).  Same arithmetic on both
+          sides, so Y2 is purely what a flipped near-tie costs: the differing query is excluded from the comparison but stays a
+          self-attention key of every other query of its frame and feeds the memory rows of the following ones -- the two runs
+          compute slightly different things from then on, whatever the arithmetic.
+    Asserted per frame, for both engines: >= 640 of the 644 adaptive queries in common, 99.9 % of the matched logits inside 1e-3, the
+    worst matched logit <= max(1e-3, 2 x max(Y1, Y2) of that frame) -- no hard-coded allowance -- and, against the oracle that adopts
+    the engine's near-tie decisions, EVERY logit of all five frames inside 1e-3 (the in-bar statement, now with the queue overflowing)."""
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     sd = weights.init_state_dict(weights.detector_spec("V-99-eSE"), seed=0)
     n = FRAMES_QUEUE
@@ -513,11 +518,17 @@ def test_streaming_parity_without_adopting_any_device_decision(hip_lib):
         assert live[4] == 1024 and live[3] == 768, "%s: the memory queue does not fill (live slots at frame start: %s)" % (p, live)
     o32 = _unadopted_oracle(sd, torch.float32, n)
     o64 = _unadopted_oracle(sd, torch.float64, n)
-    yard = _identity_matched(o32, o64, "oracle fp32 vs oracle fp64, nothing adopted")
-    reports = {"yardstick": yard}
-    for p in ("bf16x3", "fp32"):
+    yard = _identity_matched(o32, o64, "Y1: oracle fp32 vs oracle fp64, nothing adopted")
+    reports = {"yardstick_rounding": yard}
+    for p, tol in (("bf16x3", 5e-4), ("fp32", 2e-5)):
         reports[p] = _identity_matched(got[p], o32, "%s engine vs oracle fp32, nothing adopted" % p)
         reports[p + "_vs_oracle64"] = _identity_matched(got[p], o64, "%s engine vs oracle fp64, nothing adopted" % p)
+        # the fp32 oracle adopting this engine's near-tie decisions (camera stages from the cache: heads only)
+        ad = _run_oracle(sd, got[p], with_f64=False, tie_tol=tol)
+        o32a = [dict(sel=[(int(a), int(b)) for a, b, _ in w["valid"].nonzero().numpy()], memory_topk=got[p][fi]["memory_topk"].flatten(),
+                     all_cls_scores=w["logits"]) for fi, w in enumerate(ad)]
+        reports[p + "_yardstick_flipped_near_ties"] = _identity_matched(o32a, o32, "Y2: oracle fp32 adopting the %s engine's near-tie decisions vs oracle fp32 on its own" % p)
+        reports[p + "_vs_oracle_adopting"] = _identity_matched(got[p], o32a, "%s engine vs oracle fp32 adopting its near-tie decisions" % p)
     for k, rep in reports.items():
         for r in rep:
             print("\n%s: %s" % (k, json.dumps(r)))
@@ -525,10 +536,12 @@ def test_streaming_parity_without_adopting_any_device_decision(hip_lib):
     with open(os.path.join(ROOT, "gpurun_out", "parity_full_unadopted.json"), "w") as f:
         json.dump(reports, f, indent=1)
     for p in ("bf16x3", "fp32"):
-        for rep, y in zip(reports[p], yard):
+        for rep, y1, y2, ra in zip(reports[p], yard, reports[p + "_yardstick_flipped_near_ties"], reports[p + "_vs_oracle_adopting"]):
             assert rep["adaptive_in_common"] >= 640, rep
             assert rep["rows_excluded"] <= 16 + 8 * rep["frame"], rep       # different queries on the two sides and the rows propagated from them
             assert rep["logit_p999"] < 1e-3, rep
-            bar = max(1e-3, 2 * y["logit_max_abs"])
-            assert rep["logit_max_abs"] <= bar, "%s frame %d: worst matched logit %.3e > max(1e-3, 2 x yardstick %.3e)" % (
-                p, rep["frame"], rep["logit_max_abs"], y["logit_max_abs"])
+            y = max(y1["logit_max_abs"], y2["logit_max_abs"])
+            assert rep["logit_max_abs"] <= max(1e-3, 2 * y), "%s frame %d: worst matched logit %.3e > max(1e-3, 2 x yardstick %.3e (Y1 %.3e, Y2 %.3e))" % (
+                p, rep["frame"], rep["logit_max_abs"], y, y1["logit_max_abs"], y2["logit_max_abs"])
+            # with the near-tie decisions adopted the two sides hold the same queries: every row, the bar itself
+            assert ra["rows_excluded"] == 0 and ra["logit_max_abs"] < 1e-3, ra

@@ -63,6 +63,50 @@ def test_pair_conv3x3_split_products(hip_lib, tile):
         assert (y32.cpu().permute(0, 3, 1, 2).double() - want).abs().max().item() < bound
 
 
+TILES_WS = [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413, 414, 415, 416, 417]
+
+
+@pytest.mark.parametrize("tile", TILES_WS)
+def test_pair_conv3x3_wave_specialised_persistent_kernel(hip_lib, tile):
+    """The persistent wave-specialised 3x3 kernel (csrc/conv_ws.hpp: producer waves issue every LDS-DMA, consumer waves only read LDS and
+    run MFMAs, a workgroup walks several tiles as one stream of steps, register epilogue with v_permlane32_swap 16-byte stores): ragged
+    sizes (W % 32, H % TH, Cout % BM incl. a channel tile past the packed weight rows), channel slices of wider buffers on both sides,
+    more tiles than workgroups' first round (the persistent loop and its cross-tile prefetch), Cin of one chunk and of many.  Checked
+    against float64 AND bit for bit against the shipped tile 163 (same products, same order)."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(tile)
+    for (N, Cin, Cout, H, W, act) in ((2, 64, 224, 13, 45, "relu"), (1, 96, 160, 20, 30, "relu"), (3, 32, 64, 9, 70, None), (7, 128, 128, 160, 240, "swish"),
+                                      (2, 160, 192, 40, 60, "relu")):
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        pc = ops.PackedConv(w, b, stride=1, pad=1, dtype=torch.float32, device=DEV, compute="bf16x3")
+        xin = torch.full((N, H, W, 2 * (Cin + 64)), 3.0, dtype=torch.bfloat16, device=DEV)
+        xin[..., 64:64 + 2 * Cin] = ops.pair_from_float(x.permute(0, 2, 3, 1)).to(DEV)     # logical channels [32, 32 + Cin)
+        bufs = []
+        for tl in (tile, 163):
+            buf = torch.full((N, H, W, 2 * (Cout + 64)), 7.0, dtype=torch.bfloat16, device=DEV)
+            ops.conv2d_nhwc(xin[..., 64:64 + 2 * Cin], pc, out=buf[..., 128:128 + 2 * Cout], act=act, tile=tl)
+            bufs.append(buf)
+        buf = bufs[0]
+        assert (buf[..., :128] == 7.0).all() and (buf[..., 128 + 2 * Cout:] == 7.0).all()
+        assert torch.equal(bufs[0], bufs[1]), "tile %d differs from tile 163 on %s (max %.3e)" % (
+            tile, (N, Cin, Cout, H, W), (ops.pair_to_float(bufs[0][..., 128:128 + 2 * Cout].contiguous()) -
+                                         ops.pair_to_float(bufs[1][..., 128:128 + 2 * Cout].contiguous())).abs().max().item())
+        if N * H * W <= 4096:
+            want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+            want = want.relu() if act == "relu" else (want * torch.sigmoid(want) if act == "swish" else want)
+            got = ops.pair_to_float(buf[..., 128:128 + 2 * Cout].contiguous()).cpu().permute(0, 3, 1, 2)
+            bound, bf16_level = _bound(Cin * 9, x, w)
+            err = (got.double() - want).abs().max().item()
+            assert err < bound + want.abs().max().item() * 2.0 ** -16, (tile, err, bound)
+    # what the kernel does not do is an error of the call, never a silent fallback: f32 output, residual
+    x = ops.pair_from_float(torch.randn(1, 8, 32, 32)).to(DEV)
+    pc = ops.PackedConv(torch.randn(32, 32, 3, 3), None, stride=1, pad=1, dtype=torch.float32, device=DEV, compute="bf16x3")
+    with pytest.raises(Exception):
+        ops.conv2d_nhwc(x, pc, out=torch.empty(1, 8, 32, 32, device=DEV), tile=tile)
+
+
 @pytest.mark.parametrize("tile", TILES_1X1)
 def test_pair_conv1x1_split_products(hip_lib, tile):
     """1x1 GEMM over K = 160 / 1056 / 32 logical channels (odd and single step counts), ragged pixel / channel tiles."""
