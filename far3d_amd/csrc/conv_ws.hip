@@ -1,6 +1,7 @@
 // Instantiations of the persistent wave-specialised 3x3 convolution (conv_ws.hpp).  Tile ids of far3d_conv2d_nhwc:
 //   400-419  pair-stored activations, split products (x_dt = FAR3D_DT_BF16_PAIR): the in-tolerance engine's backbone / FPN / 2D head
 //   420-439  plain bf16
+//   440-459  pair-stored, step hand-over through LDS counters instead of a barrier
 // Epilogue: bias + activation + pair / bf16 store only (no residual, no second output, no channel sums): far3d_conv2d_nhwc refuses
 // the tile for a layer that needs more.
 #include "conv_ws.hpp"
@@ -32,6 +33,12 @@ int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
     case 415: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 6>(P, st);   // 404 (64 ch x 4 rows, 2 per CU) with 6 stages
     case 416: return launch_conv3x3_ws<2, 4, 3, 1, 4, true, true, 4>(P, st);   // 403 (192 ch x 4 rows) with 4 stages
     case 417: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 4>(P, st);   // 405 with 4 stages
+    // hand-over through LDS counters instead of a workgroup barrier per step (FLAGS): consumer waves run free of each other.  Measured
+    // SLOWER than the barrier form (profiles/r6/ws_ab_pair.txt: s2.c1 281 us against 212, s4.c1 59 against 38): the polls cost more than
+    // the lockstep they remove.  Kept as tested tiles for the record.
+    case 440: return launch_conv3x3_ws<2, 4, 2, 2, 4, true, true, 3, true>(P, st);   // 400
+    case 444: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 3, true>(P, st);   // 404 (64 ch x 4 rows, 2 per CU)
+    case 445: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 6, true>(P, st);   // 411 (128 ch x 4 rows, 6 stages)
     case 420: return launch_conv3x3_ws<2, 4, 2, 2, 4, false, true>(P, st);   // plain bf16: 128 ch x 8 rows
     case 421: return launch_conv3x3_ws<1, 8, 2, 1, 4, false, true>(P, st);   // plain bf16: 64 ch x 8 rows
     case 422: return launch_conv3x3_ws<1, 8, 5, 1, 4, false, true>(P, st);   // plain bf16: 160 ch x 8 rows

@@ -64,7 +64,7 @@ extern std::atomic<int> g_ws_ablate;
 // id, 1 s_memtime at entry, 2 first step's operands landed (consumer wave 0 past the first barrier), 3 s_memtime at the end of consumer
 // wave 0, 4 tiles processed, 5 steps, 6 / 7 s_memrealtime (100 MHz) at entry / end, 8 cycles consumer wave 0 spent between arriving at a
 // step's barrier and leaving it, 9 cycles it spent in the steps' bodies (fragment reads + MFMA issue), 10 cycles in the epilogues.
-template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3>
+template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false>
 __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(IgemmParams P, int tiles_x, int tiles_y, int n_mt, int n_items, int ablate) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NWC = WGM * WGN;                      // consumer waves
@@ -78,8 +78,23 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
   constexpr int GA = BM / 16, WST = BM * 64, WSTAGE = PLD * WST;
   constexpr int PBASE = NSW * WSTAGE, PBUF = PLD * PATCH_B;
   constexpr int RB = WN + 2;
-  static_assert(PBASE + 2 * PBUF <= 163840, "LDS budget");
+  // FLAGS: the step hand-over through LDS counters instead of a workgroup barrier.  The barrier forces all consumer waves into lockstep
+  // -- every step ends with the matrix pipes of the whole CU drained, 345 of 2120 cycles per step in the round-6 stamps -- although no
+  // consumer ever needs another consumer: a consumer needs the producers' data (prod_done[p] = steps whose pieces of producer p have
+  // landed), a producer needs the consumers' releases (cons_done[i] = steps whose fragment reads of consumer i have returned).  Both
+  // are monotonic counters in LDS, written by one lane of their owner, polled by the other side (a read ahead of time, s_sleep in the
+  // rare wait); every wait is bounded and a wave that gives up stops waiting for good (garbage out, never a hang).
+  constexpr int FLAGB = PBASE + 2 * PBUF;               // [16] prod_done, [16] cons_done (u32)
+  static_assert(FLAGB + (FLAGS ? 128 : 0) <= 163840, "LDS budget");
+  static_assert(!FLAGS || (NP <= 4 && NWC <= 8), "flag words: one b128 read per 4 counters");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  [[maybe_unused]] volatile unsigned* const flg = reinterpret_cast<volatile unsigned*>(smem + FLAGB);
+  if constexpr (FLAGS) {
+    if (threadIdx.x < 32) flg[threadIdx.x] = 0u;
+    __syncthreads();
+  }
+  [[maybe_unused]] bool gave_up = false;
+  constexpr int SPIN_LIMIT = 1 << 18;
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nchunks = P.cin_pad / 32;
   const int spt = 9 * nchunks;                                                   // steps per tile
@@ -203,10 +218,33 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
       ahead = ahead > NSW - 2 ? NSW - 2 : ahead;
       const int cnt = ahead * nw + __builtin_popcount(phist & ((1u << (NSW - 1)) - 1u)) * np;
       if (ablate & 1) wait_vmcnt<0>(); else wait_vmcnt_dyn(cnt);
+      if constexpr (FLAGS) {
+        if (lane == 0) flg[pw] = (unsigned)(S + 1);      // this wave's pieces of steps <= S (and of S's patch) are in LDS
+        // stage (S - 1) % NSW and, at a chunk boundary, the previous chunk's patch buffer are free once EVERY consumer has released step S - 1
+        if (S > 0 && !(ablate & 8)) {
+          for (int spins = 0; !gave_up; ++spins) {
+            const u32x4_t c0 = *reinterpret_cast<volatile u32x4_t*>(smem + FLAGB + 64);
+            u32x4_t c1 = c0;
+            if constexpr (NWC > 4) c1 = *reinterpret_cast<volatile u32x4_t*>(smem + FLAGB + 80);
+            unsigned m = c0.x;
+            if constexpr (NWC > 1) m = min(m, c0.y);
+            if constexpr (NWC > 2) m = min(m, c0.z);
+            if constexpr (NWC > 3) m = min(m, c0.w);
+            if constexpr (NWC > 4) m = min(m, c1.x);
+            if constexpr (NWC > 5) m = min(m, c1.y);
+            if constexpr (NWC > 6) m = min(m, c1.z);
+            if constexpr (NWC > 7) m = min(m, c1.w);
+            if (__builtin_amdgcn_readfirstlane(m) >= (unsigned)S) break;
+            if (spins > SPIN_LIMIT) gave_up = true;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      } else {
 #ifdef FAR3D_PROFILING
-      if (!(ablate & 8))
+        if (!(ablate & 8))
 #endif
-      __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      }
       asm volatile("" ::: "memory");
       if (w_left > 0) next_w();                          // W(S+NSW-1) into the stage step S-1 has just released
       phist <<= 1;
@@ -275,6 +313,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
 
   int G = 0;                                             // global chunk ordinal of this workgroup (patch buffer = G & 1)
   int soff = 0;                                          // ring stage of the current step, in bytes
+  [[maybe_unused]] int Sg = 0;                           // FLAGS: global step ordinal
+  [[maybe_unused]] u32x4_t pfl = {0u, 0u, 0u, 0u};       // FLAGS: the producers' counters as last read
 #ifdef FAR3D_PROFILING
   unsigned long long pf_ta = 0, pf_tb = 0, pf_wait = 0, pf_body = 0, pf_epi = 0;
   const bool pf_on = P.prof != nullptr && wv == 0;
@@ -307,10 +347,29 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
           pf_ta = now;
         }
 #endif
+        if constexpr (FLAGS) {
+          // every fragment read of steps < S has returned: release them; then wait for the producers' pieces of step S (the counters
+          // were read ahead, in the middle of the previous step: the common case takes no LDS round trip here)
+          if (lane == 0) flg[16 + wv] = (unsigned)Sg;
+          if (!(ablate & 8)) {
+            for (int spins = 0; !gave_up; ++spins) {
+              unsigned m = pfl.x;
+              if constexpr (NP > 1) m = min(m, pfl.y);
+              if constexpr (NP > 2) m = min(m, pfl.z);
+              if constexpr (NP > 3) m = min(m, pfl.w);
+              if (__builtin_amdgcn_readfirstlane(m) >= (unsigned)(Sg + 1)) break;
+              if (spins > SPIN_LIMIT) gave_up = true;
+              __builtin_amdgcn_s_sleep(1);
+              pfl = *reinterpret_cast<volatile u32x4_t*>(smem + FLAGB);
+            }
+          }
+          ++Sg;
+        } else {
 #ifdef FAR3D_PROFILING
-        if (!(ablate & 8))
+          if (!(ablate & 8))
 #endif
-        __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_barrier();
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #ifdef FAR3D_PROFILING
@@ -324,6 +383,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
           if (tap > 0 || c > 0) mma_set(1);              // Y = (S - 1, k-half 1): its latency-free MFMAs cover X's LDS round trip
           __builtin_amdgcn_sched_barrier(0);
           load_a(1, stage, 1);                           // Y's weight fragments; X has landed by now, the counter never holds two full sets
+          if constexpr (FLAGS) pfl = *reinterpret_cast<volatile u32x4_t*>(smem + FLAGB);      // the producers' counters, for the next step's check
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (PAIR) {
             mma_term(0, 0);
@@ -345,6 +405,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
           mma_set(0);
           __builtin_amdgcn_sched_barrier(0);
           load_set(0, stage, tap, 1);
+          if constexpr (FLAGS) pfl = *reinterpret_cast<volatile u32x4_t*>(smem + FLAGB);
           __builtin_amdgcn_sched_barrier(0);
           mma_set(0);
           __builtin_amdgcn_sched_barrier(0);
@@ -449,11 +510,11 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
 #endif
 }
 
-template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3>
+template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false>
 static int launch_conv3x3_ws(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PLD = PAIR ? 2 : 1;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
-  constexpr size_t lds = (size_t)NSW * PLD * BM * 64 + (size_t)2 * PLD * PG * 1024;
+  constexpr size_t lds = (size_t)NSW * PLD * BM * 64 + (size_t)2 * PLD * PG * 1024 + (FLAGS ? 128 : 0);
   static_assert(lds <= 163840, "LDS budget");
   const int tiles_x = (P.Wo + 31) / 32, tiles_y = (P.Ho + TH - 1) / TH, n_mt = (P.Cout + BM - 1) / BM;
   const int n_items = P.N * tiles_x * tiles_y * n_mt;
@@ -469,8 +530,8 @@ static int launch_conv3x3_ws(const IgemmParams& P, hipStream_t st) {
   const int grid = n_items < cus * wg_per_cu ? n_items : cus * wg_per_cu;
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds > 65536)
-    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
-  hipLaunchKernelGGL((conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW>), dim3((unsigned)grid), dim3(64 * (WGM * WGN + NP)), lds, st, P, tiles_x, tiles_y, n_mt,
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW, FLAGS>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
+  hipLaunchKernelGGL((conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW, FLAGS>), dim3((unsigned)grid), dim3(64 * (WGM * WGN + NP)), lds, st, P, tiles_x, tiles_y, n_mt,
                      n_items, FAR3D_WS_ABLATE_ARG);
   return 0;
 }

@@ -4,7 +4,7 @@
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
-int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 3x3, tiles 400-439)
+int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 3x3, tiles 400-459)
 
 #ifdef FAR3D_PROFILING
 // tools/conv_phase_times.py: where the per-workgroup stamps of the pipelined conv / GEMM kernels go (8 x uint64 per workgroup)
@@ -69,8 +69,8 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && gemm_tile && (pair_in || (x_dt == FAR3D_DT_BF16 && Cin % 32 == 0 && P.x_vec)),
                     "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-117, 120-129, 140-145; pair: 170-181, 279, 280); got k=%d tile=%d", KH, tile);
   }
-  if (tile >= 400 && tile < 440) {     // persistent wave-specialised 3x3 kernel: a refusal is an error of the call, never a silent fallback
-    const bool pair_tile = tile < 420;
+  if (tile >= 400 && tile < 460) {     // persistent wave-specialised 3x3 kernel: a refusal is an error of the call, never a silent fallback
+    const bool pair_tile = tile < 420 || tile >= 440;
     FAR3D_CHECK_ARG(KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && !res && !y2 && !chan_sums && Cin % 32 == 0 && Cout % 32 == 0 &&
                     pair_tile == pair_in && (pair_in ? pair_out : (x_dt == FAR3D_DT_BF16 && w_dt == FAR3D_DT_BF16 && y_dt == FAR3D_DT_BF16)) &&
                     aligned(x, 16) && aligned(y, 16) && ldx % 8 == 0 && ldy % 8 == 0 && x_img_stride % 8 == 0 && y_img_stride % 8 == 0 &&

@@ -250,10 +250,16 @@ def use_tile_tables(bf16_table, pair_table=None):
         _TABLE_SEL.cur = prev
 
 
-def _tuned_tile(Cout, Cin, k, stride, npix, table=None):
+WS_TILES = range(400, 460)      # persistent wave-specialised 3x3 kernel (csrc/conv_ws.hpp): bias + activation + pair / bf16 store only
+
+
+def _tuned_tile(Cout, Cin, k, stride, npix, table=None, ws_ok=False):
     """Workgroup tile measured fastest on MI355X for this conv shape (tools/tune_conv.py); 0 = kernel heuristic.
     Shapes that were not swept (e.g. fewer cameras per rank in camera-sharded mode) borrow the entry of the same layer
-    geometry with the closest pixel count.  table: tuning_mi355x.json (bf16) or tuning_mi355x_bf16x3.json (split mode)."""
+    geometry with the closest pixel count.  table: tuning_mi355x.json (bf16) or tuning_mi355x_bf16x3.json (split mode).
+    An entry may be a pair [ws tile, other tile]: the wave-specialised kernel where the call allows it (ws_ok: no residual, second
+    output or channel sums, same storage in and out), else the fastest of the general kernels -- an explicit choice per call, the
+    library itself never substitutes a kernel."""
     if table is None:
         table = tile_tables()[0]
     tab = _TUNING.get(table)
@@ -265,11 +271,14 @@ def _tuned_tile(Cout, Cin, k, stride, npix, table=None):
         tab = _TUNING[table] = {}
         for key, tile in raw.items():
             co, ci, kk, st, npx = (int(v) for v in key.split(","))
-            tab.setdefault((co, ci, kk, st), []).append((npx, int(tile)))
+            tab.setdefault((co, ci, kk, st), []).append((npx, tuple(int(t) for t in tile) if isinstance(tile, (list, tuple)) else int(tile)))
     cands = tab.get((Cout, Cin, k, stride))
     if not cands:
         return 0
-    return min(cands, key=lambda c: abs(c[0] - npix))[1]
+    tile = min(cands, key=lambda c: abs(c[0] - npix))[1]
+    if isinstance(tile, tuple):
+        return tile[0] if ws_ok else tile[1]
+    return tile
 
 
 class PackedConv:
@@ -338,12 +347,12 @@ def _is_pair_input(x, pc):
 _HI_ONLY_TILE = {160: 260, 165: 265, 152: 252, 179: 279, 180: 280}
 
 
-def _pair_tile(pc, Cin, npix, tile):
+def _pair_tile(pc, Cin, npix, tile, ws_ok=False):
     """Tile id for a pair-stored input: the measured split-product tile (far3d_amd/data/tuning_mi355x_pair.json, ids 150+, 0 = the
     library default), mapped to a hi-planes-only kernel when the layer is assigned a single bf16 product (pc.terms == 1)."""
     fast = pc.stride == 1 and ((pc.KH == 3 and pc.pad == 1) or (pc.KH == 1 and pc.pad == 0))
     if tile == 0:
-        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, tile_tables()[1])
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, npix, tile_tables()[1], ws_ok=ws_ok and pc.terms != 1)
     if pc.terms == 1 and fast and (tile == 0 or 150 <= tile < 200):
         tile = _HI_ONLY_TILE.get(tile, 260 if pc.KH == 3 else 279)
     return tile
@@ -395,10 +404,14 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
         if y2_scale.numel() != N * pc.Cout or y2_shift.numel() != N * pc.Cout or tuple(y2.shape) != (N, Ho, Wo, pc.Cout):
             raise ValueError("conv2d_nhwc: y2/scale/shift shapes inconsistent")
         y2p, y2dt, sp, hp = _ptr(y2), _dt(y2), _ptr(y2_scale), _ptr(y2_shift)
+    # what the wave-specialised 3x3 kernel covers (anything else takes the table's general tile)
+    ws_ok = (res is None and y2 is None and sums is None and pc.KH == 3 and pc.KW == 3 and pc.stride == 1 and pc.pad == 1 and
+             Cin % 32 == 0 and pc.Cout % 32 == 0 and out.dtype == torch.bfloat16 and ldx % 8 == 0 and ldy % 8 == 0 and
+             x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and xs % 8 == 0 and ys % 8 == 0)
     if pair_in:
-        tile = _pair_tile(pc, Cin, N * H * W, tile)
+        tile = _pair_tile(pc, Cin, N * H * W, tile, ws_ok)
     elif tile == 0 and x.dtype == torch.bfloat16:
-        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W)
+        tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W, ws_ok=ws_ok)
     elif tile == 0 and pc.w_code == DT_F32_BF16X3:
         tile = _tuned_tile(pc.Cout, Cin, pc.KH, pc.stride, N * H * W, "tuning_mi355x_bf16x3.json")
     _lib.check(lib.far3d_conv2d_nhwc(

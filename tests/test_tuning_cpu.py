@@ -66,14 +66,22 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
     ids = {"igemm": set(), "pipe3": set(), "gemm": set()}
     for m in re.finditer(r"case (\d+): (?:rc = |return )?(launch_[a-z0-9_]+)<", src):
         ids[{"launch_igemm": "igemm", "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm"}[m.group(2)]].add(int(m.group(1)))
+    ws_src = open(os.path.join(ROOT, "far3d_amd", "csrc", "conv_ws.hip")).read()
+    ws_pair = {int(m.group(1)) for m in re.finditer(r"case (\d+): return launch_conv3x3_ws<[^>]*, true, (?:true|false)(?:, \d+(?:, true)?)?>", ws_src)}
     table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))
-    assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5}
+    assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5} and ws_pair and all(400 <= t < 460 for t in ws_pair)
     assert set(table) == set(json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json"))))
+    from far3d_amd import ops
     for key, tile in table.items():
         cout, cin, k, stride, npix = (int(v) for v in key.split(","))
         assert cin % 32 == 0, key
         allowed = ids["igemm"] | ({t for t in ids["pipe3"] if t < 300} if (k == 3 and stride == 1) else ids["gemm"] if (k == 1 and stride == 1) else
                                   {t for t in ids["pipe3"] if t >= 330} if (k == 3 and stride == 2) else set())
+        if isinstance(tile, list):
+            # [wave-specialised tile (csrc/conv_ws.hip, plain 3x3 layers only), the general tile every other call of the layer shape takes]
+            ws, tile = tile
+            assert k == 3 and stride == 1 and cout % 32 == 0 and ws in ws_pair and ws in ops.WS_TILES, (key, ws)
+            assert ops._tuned_tile(cout, cin, k, stride, npix, name, ws_ok=True) == ws and ops._tuned_tile(cout, cin, k, stride, npix, name) == tile
         assert tile in allowed and not 200 <= tile < 300, "tile %d is not a split-product tile for layer %s" % (tile, key)
 
 

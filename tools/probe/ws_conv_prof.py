@@ -11,8 +11,8 @@ from far3d_amd import lib as flib
 flib.LIB_PATH = os.path.join(os.path.dirname(flib.LIB_PATH), "libfar3d_hip_prof.so")
 from far3d_amd import ops
 
-LAYERS = [("stem2", 7, 320, 480, 64, 64, (401, 413)), ("s2.c1", 7, 160, 240, 128, 128, (400, 410, 405, 406)),
-          ("s3.c1", 7, 80, 120, 160, 160, (407, 414)), ("s4.c1", 7, 40, 60, 192, 192, (403, 404)), ("c512.l0", 7, 80, 120, 256, 512, (400,))]
+LAYERS = [("stem2", 7, 320, 480, 64, 64, (401, 413)), ("s2.c1", 7, 160, 240, 128, 128, (400, 440, 445)),
+          ("s3.c1", 7, 80, 120, 160, 160, (407, 414)), ("s4.c1", 7, 40, 60, 192, 192, (403, 449, 444)), ("c512.l0", 7, 80, 120, 256, 512, (400,))]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 lib = flib.load()
 setp = lib.far3d_prof_set_conv_timestamps
@@ -26,7 +26,7 @@ for name, N, H, W, Cin, Cout, tiles in LAYERS:
     pc = ops.PackedConv(torch.randn(Cout, Cin, 3, 3) * 0.05, torch.randn(Cout), stride=1, pad=1, dtype=torch.float32, device=dev, compute="bf16x3")
     y = torch.empty(N, H, W, 2 * Cout, device=dev, dtype=torch.bfloat16)
     for tile in tiles:
-        for mask in (0, 1, 5, 13, 9):
+        for mask in (0, 1):
             abl(ctypes.c_int(mask))
             ts = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
             for _ in range(3):

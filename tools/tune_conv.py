@@ -118,7 +118,9 @@ def main():
         if x3:
             tiles = (0, 1, 2, 3, 4, 5)
         if pair:
-            tiles = (0, 150, 152, 154, 155, 157, 160, 161, 162, 163, 164, 165, 166, 167, 168, 191, 192, 193, 197) if (k == 3 and stride == 1) else \
+            tiles = (0, 150, 152, 154, 155, 157, 160, 161, 162, 163, 164, 165, 166, 167, 168, 191, 192, 193, 197) + \
+                    ((400, 401, 403, 404, 405, 406, 410, 411, 412, 413, 416, 417) if Cout % 32 == 0 and not os.environ.get("NO_WS") else ()) \
+                if (k == 3 and stride == 1) else \
                     ((0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181) if (k == 1 and stride == 1) else
                      (0, 1, 2, 3, 4, 5, 330, 331) if (k == 3 and stride == 2) else (0, 1, 2, 3, 4, 5))
         if k == 3 and stride == 1 and os.environ.get("EXTRA_TILES"):
@@ -144,6 +146,11 @@ def main():
             res[0] = float("nan")
         best = min((t, tl) for tl, t in res.items() if tl != 0)
         table[key] = best[1]
+        if best[1] in ops.WS_TILES:
+            # the persistent wave-specialised kernel covers plain layers only: the entry carries the fastest general tile beside it, and the
+            # ws tile is taken only where it wins by more than the run-to-run noise (3 %)
+            other = min((t, tl) for tl, t in res.items() if tl != 0 and tl not in ops.WS_TILES)
+            table[key] = [best[1], other[1]] if best[0] < 0.97 * other[0] else other[1]
         print("%-10s %-24s auto %7.1f us | " % (name, key, res[0] * 1e6) + " ".join("t%d %4.0f" % (tl, res[tl] * 1e6) for tl in tiles if tl) +
               " | best t%d %6.1f us %6.1f TF/s" % (best[1], best[0] * 1e6, fl / best[0] / 1e12), flush=True)
     name = "tuning_mi355x_pair" if pair else ("tuning_mi355x_bf16x3" if x3 else "tuning_mi355x")
