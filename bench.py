@@ -149,7 +149,7 @@ def agg_traffic(fp32_rows=False):
     Counters cannot be read from inside this process; the file carries the kernel name and the commit it was taken at, and a figure
     for another kernel is not reported."""
     name = "aggregate_pmc_fp32rows.json" if fp32_rows else "aggregate_pmc.json"
-    for rnd in ("r5", "r4"):
+    for rnd in ("r6", "r5", "r4"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         try:
             with open(p) as f:
@@ -161,6 +161,52 @@ def agg_traffic(fp32_rows=False):
         except Exception:   # noqa: BLE001
             continue
     return None, None
+
+
+def agg_traffic_live(fp32_rows, timeout_s=150):
+    """HBM bytes per launch of the aggregation kernel measured BY THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+    passes, --kernel-trace only -- the guide's HBM section) over tools/probe/run_agg_once.py, which launches the kernel eight times on
+    benchmark-size operands (tests/cases.config2_aggregate_case: 7 cameras, 12750 tokens, A = 1544; value rows in this mode's dtype).
+    FETCH_SIZE x2 on gfx950 (the counter tallies 128-byte requests at 64 bytes), WRITE_SIZE as reported.  Returns (bytes, source) or
+    (None, reason): no rocprofv3 on PATH, a pass that fails or times out -- the caller then falls back to the committed in-frame figure."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself being profiled (no nested profiler runs)"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="far3d_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", N_LAUNCH="8")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "probe", "run_agg_once.py"), "--camsort"] + (["--fp32"] if fp32_rows else [])
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s pass timed out after %d s" % (ctr, timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+            got = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if AGG_KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        got.append(float(row["Counter_Value"]))
+            if len(got) < 4:
+                return None, "rocprofv3 --pmc %s pass: %d launches of %s in the counter file" % (ctr, len(got), AGG_KERNEL)
+            got = got[2:]                                  # the first launches fill the caches
+            vals[ctr] = sum(got) / len(got)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    by = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
+    return by, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, x2 fetch correction of gfx950) over launches "
+                "3-8 of tools/probe/run_agg_once.py on benchmark-size operands, %s value rows; FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB" %
+                ("fp32" if fp32_rows else "bf16", vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
 
 
 def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk", latency_runner=True):
@@ -368,7 +414,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     return res
 
 
-def agg_roofline(args, res, traffic=None, traffic_src=None):
+def agg_roofline(args, res, traffic=None, traffic_src=None, live=False, committed=None, committed_src=None):
     """roofline block of the aggregation kernel: SURVEY.md 8(d)'s algorithmic bytes of one launch (all queries x all cameras of one
     decoder layer, value rows in the mode's value dtype) over the launch time measured live in this run."""
     cfg = res["cfg"]
@@ -379,7 +425,8 @@ def agg_roofline(args, res, traffic=None, traffic_src=None):
             else "aggregate_v%d_kernel (A/B variant %d)" % (3 if args.agg_variant == 3 else 7, args.agg_variant),
             "bound": "hbm", "achieved": by / agg_t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": by / agg_t / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-            "traffic_measured_in_this_run": False if traffic is not None else None,
+            "traffic_measured_in_this_run": bool(live) if traffic is not None else None,
+            "traffic_in_frame_committed": committed, "traffic_in_frame_committed_source": committed_src,
             "value_row_bytes": 256 * evb, "algorithmic_bytes_per_launch": by,
             "avg_launch_us": agg_t * 1e6, "timing": "HIP events around a hipGraph of 24 launches x 3 replays, live frame operands"}
 
@@ -446,6 +493,8 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act", "bf16_fp32dec", "bf16_fp32val"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc passes (two short sub-runs); the "
+                    "committed in-frame figure of the evidence set is reported instead")
     ap.add_argument("--no-fast-mode", "--no-in-tolerance", dest="fast_mode", action="store_false",
                     help="skip the second engine of the default run (the bf16 `fast_mode` block); --no-in-tolerance is the flag's old name")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
@@ -537,8 +586,17 @@ def main():
         rep = world if (world > 1 and not sharded) else 1        # replicas: every rank ran its own stream of frames
         samples = args.steps * rep
         dt_sync = res["dt_sync"]
-        # the committed PMC passes measured the bf16-row kernel: the fp32-row modes carry their own passes or nothing
-        traffic, traffic_src = agg_traffic(fp32_rows=res["prec"]["value"] != torch.bfloat16)
+        # HBM traffic of the dominant kernel: measured by this run when rocprofv3 is there (isolated launches on benchmark-size operands),
+        # with the committed IN-FRAME figure of the evidence set beside it; without rocprofv3 the committed figure alone, labelled
+        fp32_rows = res["prec"]["value"] != torch.bfloat16
+        committed, committed_src = agg_traffic(fp32_rows=fp32_rows)
+        traffic, traffic_src, live = committed, committed_src, False
+        if world == 1 and not args.no_pmc:
+            tl, src = agg_traffic_live(fp32_rows)
+            if tl is not None:
+                traffic, traffic_src, live = tl, src, True
+            else:
+                traffic_src = "%s; live measurement unavailable: %s" % (committed_src, src)
         line = {
             "metric": "samples/sec (7-cam frame) end-to-end @ VoV-99 640x960",
             "value": samples / dt_sync, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -562,7 +620,7 @@ def main():
                        "precision_assignment": {k: str(v).replace("torch.", "") for k, v in res["prec"].items()},
                        "weights": "seeded random (far3d_amd.weights.init_state_dict, seed 0)", "commit": build_commit()},
             "protocol": rates(res),
-            "roofline": agg_roofline(args, res, traffic, traffic_src),
+            "roofline": agg_roofline(args, res, traffic, traffic_src, live, committed, committed_src),
             "roofline_backbone": backbone_roofline(res),
         }
         if res["timing_error"]:

@@ -75,6 +75,14 @@ def main():
             cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)      # cu_id, sh_id, se_id, xcc
             tt = t[:, 1:6].astype(np.int64)
             real = t[:, 6].astype(np.int64)
+            # a kernel that does not take one of the stamps leaves the slot zero (tile 145 has no "first fill" hook: round 5's report
+            # printed the difference to the zero as a negative phase): an unset stamp takes the previous stamp's value, its phase reads
+            # 0 and is said to be unset; a stamp that runs backwards is an error of the hooks, not something to print
+            unset = [int(k) for k in range(1, 5) if (tt[:, k] == 0).all()]
+            for k in range(1, 5):
+                z = tt[:, k] == 0
+                tt[z, k] = tt[z, k - 1]
+            assert (np.diff(tt, axis=1) >= 0).all(), "%s tile %d: phase stamps run backwards" % (name, tile)
             os.makedirs(os.path.join(ROOT, "gpurun_out", "conv_phases"), exist_ok=True)
             np.savez_compressed(os.path.join(ROOT, "gpurun_out", "conv_phases", "%s_t%d.npz" % (name, tile)), stamps=t)
             # s_memtime is a per-XCD counter: clock rate, spans and overlaps are evaluated per CU and then combined
@@ -100,14 +108,23 @@ def main():
                         busy2 += when - last
                     alive += d
                     last = when
+            if not rates:
+                # one round of workgroups, one per CU: no two entry stamps on a CU.  s_memtime is a per-XCD counter, so the workgroups of one
+                # XCD give the rate as well (their entries are spread over the dispatch time of the grid)
+                for xc in np.unique(xcc):
+                    m = xcc == xc
+                    dr = real[m].max() - real[m].min()
+                    if dr > 20:
+                        rates.append(100.0 * (tt[m, 0].max() - tt[m, 0].min()) / dr)
             mhz = float(np.median(rates)) if rates else float("nan")
             us = (lambda ticks: ticks / mhz) if rates else (lambda ticks: float("nan"))
             tot = float(np.sum(spans))
             print("%-7s tile %3d: %5d workgroups on %3d CUs (max %d per CU) | s_memtime %5.0f MHz | per-CU span median %6.1f us (%d ticks) | median per "
                   "workgroup [ticks]: set-up %5.0f  first fill %5.0f  K loop %6.0f  epilogue %5.0f  life %6.0f (p10 %.0f p90 %.0f) = %.2f us | "
-                  "a CU has >=1 workgroup alive %4.1f %% of its span, >=2 alive %4.1f %%" %
+                  "a CU has >=1 workgroup alive %4.1f %% of its span, >=2 alive %4.1f %%%s" %
                   (name, tile, len(t), len(cus), max(nper), mhz, us(med(spans)), med(spans), med(ph[:, 0]), med(ph[:, 1]), med(ph[:, 2]), med(ph[:, 3]),
-                   med(life), np.percentile(life, 10), np.percentile(life, 90), us(med(life)), 100.0 * busy1 / tot, 100.0 * busy2 / tot), flush=True)
+                   med(life), np.percentile(life, 10), np.percentile(life, 90), us(med(life)), 100.0 * busy1 / tot, 100.0 * busy2 / tot,
+                   " | stamps this kernel does not take (phase reads 0): %s" % [("set-up", "first fill", "K loop", "epilogue")[k - 1] for k in unset] if unset else ""), flush=True)
 
 
 if __name__ == "__main__":

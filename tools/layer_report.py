@@ -31,17 +31,30 @@ for l in range(4):
 p = N*80*120
 layers += [("depth.c0", p, 256, 2304), ("depth.c1", p, 256, 2304), ("depth.cls", p, 51, 256)]
 rows = list(csv.DictReader(open(sys.argv[1])))
+# rocprofv3 writes the trace in completion-record order, not in launch order: two neighbouring launches can come out swapped (round 5's
+# report paired s4.b3.c4 with the concat GEMM's launch and printed 2 460.9 TF/s for the layer after it).  The layers of a frame run on
+# ONE stream, so their start times are their order.
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+PEAK_TF = {"bf16": 2500.0, "x3": 2500.0 / 3}
 # a frame starts with the stem: far3d_stem_im2col (+ a GEMM) in the fp32 / pair modes, stem_conv_kernel (the fused stem_1, itself layer 0) in bf16
 idx = max(i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"] or "stem_conv_kernel" in r["Kernel_Name"])
-ig = [r for r in rows[idx:] if "igemm" in r["Kernel_Name"] or "conv3x3_p" in r["Kernel_Name"] or "gemm1x1" in r["Kernel_Name"] or "stem_conv_kernel" in r["Kernel_Name"]][:len(layers)]
+ig = [r for r in rows[idx:] if "igemm" in r["Kernel_Name"] or "conv3x3_" in r["Kernel_Name"] or "gemm1x1" in r["Kernel_Name"] or "stem_conv_kernel" in r["Kernel_Name"]][:len(layers)]
+assert len(ig) == len(layers), "the trace's last frame holds %d conv launches, the model has %d layers" % (len(ig), len(layers))
 tot_t = tot_f = 0
 agg = {}
 for (name, npix, cout, K), r in zip(layers, ig):
     t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     fl = 2.0 * npix * cout * K
+    # sanity of the pairing: a 3x3 layer runs on a 3x3 / generic kernel, never on the 1x1 GEMM kernel, and the other way round; no
+    # layer can exceed the matrix peak of its arithmetic (three MFMAs per product in the pair / split modes)
+    kn = r["Kernel_Name"]
+    is3 = K % 9 == 0 and not name.endswith((".cat", "clsh", "regh", ".cls")) and not name.startswith("fpn.lat")
+    assert not (is3 and "gemm1x1" in kn) and not (not is3 and "conv3x3_" in kn), "layer %s (K=%d) paired with launch %s" % (name, K, kn[:60])
+    peak = PEAK_TF["x3"] if ("true" in kn.split("<")[-1] or "pair_t" in kn or "split_t" in kn) else PEAK_TF["bf16"]
+    assert t > 0 and fl / t / 1e12 <= peak, "layer %s: %.1f TF/s exceeds the %.0f TF/s peak (%s, %.1f us)" % (name, fl / t / 1e12, peak, kn[:60], t * 1e6)
     var = "S(fused stem)" if "stem_conv_kernel" in r["Kernel_Name"] else \
         ("P" if "conv3x3" in r["Kernel_Name"] else "G" if "gemm1x1" in r["Kernel_Name"] else "D" if "dma" in r["Kernel_Name"] else "R") + r["Kernel_Name"].split("<")[1].split(">")[0].replace("unsigned short", "bf16").replace(" ", "")
-    blocks = int(r["Grid_Size_X"]) // 256 * int(r["Grid_Size_Y"])
+    blocks = int(r["Grid_Size_X"]) // max(1, int(r.get("Workgroup_Size_X", 256) or 256)) * int(r["Grid_Size_Y"])
     key = name.split(".")[0]
     a = agg.setdefault(key, [0.0, 0.0]); a[0] += t; a[1] += fl
     tot_t += t; tot_f += fl
