@@ -39,6 +39,15 @@ int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
     case 440: return launch_conv3x3_ws<2, 4, 2, 2, 4, true, true, 3, true>(P, st);   // 400
     case 444: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 3, true>(P, st);   // 404 (64 ch x 4 rows, 2 per CU)
     case 445: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 6, true>(P, st);   // 411 (128 ch x 4 rows, 6 stages)
+    // one barrier per KERNEL ROW (3 taps) instead of per tap, ring of 2 or 3 rows (GRP = 3)
+    case 450: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 6, false, 3>(P, st);   // 128 ch x 4 rows, ring of 2 rows (149 KB)
+    case 451: return launch_conv3x3_ws<2, 4, 1, 2, 4, true, true, 6, false, 3>(P, st);   // 64 ch x 8 rows, ring of 2 rows
+    case 452: return launch_conv3x3_ws<2, 4, 1, 2, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 8 rows, ring of 3 rows (160 KB)
+    case 453: return launch_conv3x3_ws<1, 8, 2, 1, 4, true, true, 6, false, 3>(P, st);   // 64 ch x 8 rows (Cout 64), ring of 2 rows
+    case 454: return launch_conv3x3_ws<1, 8, 2, 1, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 8 rows (Cout 64), ring of 3 rows
+    case 457: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 6, false, 3>(P, st);   // 64 ch x 4 rows, 4 consumers + 2 producers
+    case 458: return launch_conv3x3_ws<1, 4, 3, 1, 2, true, true, 6, false, 3>(P, st);   // 96 ch x 4 rows, 4 consumers + 2 producers
+    case 459: return launch_conv3x3_ws<2, 4, 1, 1, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 4 rows, 8 consumers of 32 ch x 1 row, ring of 3 rows
     case 420: return launch_conv3x3_ws<2, 4, 2, 2, 4, false, true>(P, st);   // plain bf16: 128 ch x 8 rows
     case 421: return launch_conv3x3_ws<1, 8, 2, 1, 4, false, true>(P, st);   // plain bf16: 64 ch x 8 rows
     case 422: return launch_conv3x3_ws<1, 8, 5, 1, 4, false, true>(P, st);   // plain bf16: 160 ch x 8 rows

@@ -64,7 +64,7 @@ extern std::atomic<int> g_ws_ablate;
 // id, 1 s_memtime at entry, 2 first step's operands landed (consumer wave 0 past the first barrier), 3 s_memtime at the end of consumer
 // wave 0, 4 tiles processed, 5 steps, 6 / 7 s_memrealtime (100 MHz) at entry / end, 8 cycles consumer wave 0 spent between arriving at a
 // step's barrier and leaving it, 9 cycles it spent in the steps' bodies (fragment reads + MFMA issue), 10 cycles in the epilogues.
-template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false>
+template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false, int GRP = 1>
 __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(IgemmParams P, int tiles_x, int tiles_y, int n_mt, int n_items, int ablate) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NWC = WGM * WGN;                      // consumer waves
@@ -72,6 +72,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
   // with 3 stages the persistent kernel only TIED the shipped one -- a step took 1.18 us against 0.73 us of MFMA work: two steps
   // (32 KB) in flight per CU do not cover the LDS-DMA round trip under load.)
   static_assert(NSW >= 3, "ring depth");
+  // GRP: taps per hand-over (1, or 3 = one kernel row).  The per-step stamps of round 6 put the hand-over itself -- every wave of the
+  // workgroup drained at a barrier, restart -- at ~345 cycles, against 770 (64 channels x 4 rows per consumer pair) to 1 540 cycles
+  // of MFMA work per tap: with one barrier per kernel row that price is paid a third as often.  The ring then holds NSW / GRP groups
+  // of GRP taps and the producers run NSW / GRP - 1 groups ahead.
+  static_assert(GRP == 1 || (GRP == 3 && (NSW == 6 || NSW == 9) && !FLAGS), "one barrier per tap, or per kernel row with a ring of 2 or 3 rows");
+  constexpr int NG = NSW / GRP;                       // groups in the ring
   constexpr int PLD = PAIR ? 2 : 1;                   // 64-byte planes per 32-channel chunk (pair storage: hi, lo)
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PW = 34, PH = TH + 2, PPIX = PW * PH;
   constexpr int PG = (PPIX + 15) / 16, PATCH_B = PG * 1024;
@@ -204,19 +210,21 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
       gp_buf ^= 1;
       if (++gp_chunk == nchunks) { gp_chunk = 0; ++gp_tile; if (p_left > 0) set_p_tile(gp_tile); }
     };
-    // prologue: P(0), W(0) .. W(NSW-2)  (the patch first: what stays in flight at the first barrier are the later weight steps only)
+    // prologue: P(0), then the weights of the first NG - 1 groups  (the patch first: what stays in flight at the first barrier are later groups only)
     next_p();
 #pragma unroll
-    for (int i = 0; i < NSW - 1; ++i)
+    for (int i = 0; i < (NG - 1) * GRP; ++i)
       if (w_left > 0) next_w();
-    int tap = 0;                                         // tap of step S
-    unsigned phist = 0;                                  // bit d: a patch was issued in iteration S - 1 - d
-    for (int S = 0; S < total_steps; ++S) {
-      // pieces issued after W(S), which may stay in flight: W(S+1) .. W(S+NSW-2), and the patches issued in iterations S-NSW+1 (there
-      // after W(S)) .. S-1
-      int ahead = total_steps - 1 - S;
-      ahead = ahead > NSW - 2 ? NSW - 2 : ahead;
-      const int cnt = ahead * nw + __builtin_popcount(phist & ((1u << (NSW - 1)) - 1u)) * np;
+    const int total_groups = total_steps / GRP, gpc = 9 / GRP;      // groups per chunk
+    int gic = 0;                                         // group of the chunk (0: the chunk starts here)
+    unsigned phist = 0;                                  // bit d: a patch was issued in iteration g - 1 - d
+    for (int g = 0; g < total_groups; ++g) {
+      // pieces issued after the last tap of group g, which may stay in flight: the weights of groups g+1 .. g+NG-2, and the patches issued
+      // in iterations g-NG+1 (there after group g's weights) .. g-1
+      int ahead = total_groups - 1 - g;
+      ahead = ahead > NG - 2 ? NG - 2 : ahead;
+      const int cnt = ahead * GRP * nw + __builtin_popcount(phist & ((1u << (NG - 1)) - 1u)) * np;
+      const int S = g * GRP;
       if (ablate & 1) wait_vmcnt<0>(); else wait_vmcnt_dyn(cnt);
       if constexpr (FLAGS) {
         if (lane == 0) flg[pw] = (unsigned)(S + 1);      // this wave's pieces of steps <= S (and of S's patch) are in LDS
@@ -246,10 +254,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
         __builtin_amdgcn_s_barrier();
       }
       asm volatile("" ::: "memory");
-      if (w_left > 0) next_w();                          // W(S+NSW-1) into the stage step S-1 has just released
+#pragma unroll
+      for (int i = 0; i < GRP; ++i)
+        if (w_left > 0) next_w();                        // group g+NG-1 into the stages group g-1 has just released
       phist <<= 1;
-      if (tap == 0 && p_left > 0) { next_p(); phist |= 1u; }      // P(chunk+1) into the buffer the previous chunk has released
-      tap = tap == 8 ? 0 : tap + 1;
+      if (gic == 0 && p_left > 0) { next_p(); phist |= 1u; }      // P(chunk+1) into the buffer the previous chunk has released
+      gic = gic == gpc - 1 ? 0 : gic + 1;
     }
     return;
   }
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
         // every fragment read of the previous step has returned (the producers overwrite its stage / patch after this barrier)
         // (the BUILTIN, not inline asm: hipcc's wait-count pass then knows that nothing is outstanding at the top of a step and emits
         // counted lgkmcnt waits inside it; behind an opaque asm wait it re-waits lgkmcnt(0) before the first MFMA)
+        if (tap % GRP == 0) {                            // hand-over points: the first tap of a group (compile-time after unrolling)
         __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0), vmcnt / expcnt untouched
 #ifdef FAR3D_PROFILING
         if (pf_on) {                                     // stamps are read here, where the wave waits for lgkmcnt(0) anyway
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
         if (pf_on) pf_tb = __builtin_amdgcn_s_memtime();
         if (tap == 0 && c == 0 && k == 0 && P.prof && t == 0) P.prof[(long)blockIdx.x * 16 + 2] = (unsigned long long)__builtin_amdgcn_s_memtime();
 #endif
+        }
         if (ablate & 2) { soff = soff == (NSW - 1) * WSTAGE ? 0 : soff + WSTAGE; continue; }      // timing-only: barriers alone
         if constexpr (DBUF) {
           load_set(0, stage, tap, 0);                    // X <- (S, k-half 0): 2 PLD (WM + WN) reads
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
 #endif
 }
 
-template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false>
+template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false, int GRP = 1>
 static int launch_conv3x3_ws(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, TH = WGN * WN, PLD = PAIR ? 2 : 1;
   constexpr int PG = (34 * (TH + 2) + 15) / 16;
@@ -530,8 +542,8 @@ static int launch_conv3x3_ws(const IgemmParams& P, hipStream_t st) {
   const int grid = n_items < cus * wg_per_cu ? n_items : cus * wg_per_cu;
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds > 65536)
-    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW, FLAGS>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
-  hipLaunchKernelGGL((conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW, FLAGS>), dim3((unsigned)grid), dim3(64 * (WGM * WGN + NP)), lds, st, P, tiles_x, tiles_y, n_mt,
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW, FLAGS, GRP>), (int)lds, lds_ok, "far3d_conv2d_nhwc")) return rc;
+  hipLaunchKernelGGL((conv3x3_ws_kernel<WGM, WGN, WM, WN, NP, PAIR, DBUF, NSW, FLAGS, GRP>), dim3((unsigned)grid), dim3(64 * (WGM * WGN + NP)), lds, st, P, tiles_x, tiles_y, n_mt,
                      n_items, FAR3D_WS_ABLATE_ARG);
   return 0;
 }

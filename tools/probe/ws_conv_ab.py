@@ -15,16 +15,16 @@ dev = "cuda:0"
 pair = MODE == "pair"
 # name, N, H, W, Cin, Cout, shipped tile(s), ws tiles
 LAYERS = [
-    ("stem2", 7, 320, 480, 64, 64, (163,), (413, 441)),
-    ("s2.c1", 7, 160, 240, 128, 128, (163,), (400, 440, 448, 411, 445, 412, 446)),
-    ("s3.c0", 7, 80, 120, 256, 160, (165,), (414, 447, 442)),
-    ("s3.c1", 7, 80, 120, 160, 160, (152,), (414, 447, 442)),
-    ("s3.c0b", 7, 80, 120, 512, 160, (192,), (414, 447, 442)),
-    ("s4.c1", 7, 40, 60, 192, 192, (163,), (403, 449, 443, 404, 444)),
-    ("s4.c0", 7, 40, 60, 768, 192, (160,), (403, 449, 443, 404, 444)),
-    ("c256.l0", 7, 80, 120, 256, 256, (163,), (400, 440, 445)),
-    ("c512.l0", 7, 80, 120, 256, 512, (163,), (400, 440, 445)),
-    ("c256.l1", 7, 40, 60, 256, 256, (163,), (400, 440, 445, 444)),
+    ("stem2", 7, 320, 480, 64, 64, (163,), (406, 413, 453, 454, 451)),
+    ("s2.c1", 7, 160, 240, 128, 128, (163,), (400, 406, 411, 450, 451, 452)),
+    ("s3.c0", 7, 80, 120, 256, 160, (165,), (414, 451, 458)),
+    ("s3.c1", 7, 80, 120, 160, 160, (152,), (414, 451, 458)),
+    ("s3.c0b", 7, 80, 120, 512, 160, (192,), (414, 451, 458)),
+    ("s4.c1", 7, 40, 60, 192, 192, (163,), (403, 404, 457, 458, 459, 451)),
+    ("s4.c0", 7, 40, 60, 768, 192, (160,), (403, 404, 457, 458, 459, 451)),
+    ("c256.l0", 7, 80, 120, 256, 256, (163,), (400, 406, 450, 451, 452)),
+    ("c512.l0", 7, 80, 120, 256, 512, (163,), (400, 450, 451, 452)),
+    ("c256.l1", 7, 40, 60, 256, 256, (163,), (400, 410, 450, 451, 457, 459)),
 ] if pair else [
     ("stem2", 7, 320, 480, 64, 64, (63,), (421,)),
     ("s2.c1", 7, 160, 240, 128, 128, (60,), (420,)),
