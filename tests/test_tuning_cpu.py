@@ -67,7 +67,8 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
     for m in re.finditer(r"case (\d+): (?:rc = |return )?(launch_[a-z0-9_]+)<", src):
         ids[{"launch_igemm": "igemm", "launch_conv3x3_pipe": "pipe3", "launch_gemm1x1_pipe": "gemm"}[m.group(2)]].add(int(m.group(1)))
     ws_src = open(os.path.join(ROOT, "far3d_amd", "csrc", "conv_ws.hip")).read()
-    ws_pair = {int(m.group(1)) for m in re.finditer(r"case (\d+): return launch_conv3x3_ws<[^>]*, true, (?:true|false)(?:, \d+(?:, true)?)?>", ws_src)}
+    # launch_conv3x3_ws<WGM, WGN, WM, WN, NP, PAIR, ...>: the tiles whose sixth template argument says pair storage
+    ws_pair = {int(m.group(1)) for m in re.finditer(r"case (\d+): return launch_conv3x3_ws<([^>]*)>", ws_src) if m.group(2).split(",")[5].strip() == "true"}
     table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))
     assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5} and ws_pair and all(400 <= t < 460 for t in ws_pair)
     assert set(table) == set(json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json"))))
