@@ -286,8 +286,20 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
   // key parts per workgroup (2 waves each): fp32 2, bf16 4 (an 8-part bf16 instantiation was measured in round 4 -- 27.4 vs 28 us,
   // profiles/r4/attn_parts8.txt: the per-tile MFMA -> exp -> MFMA chain is what a wave waits on -- and removed)
   if (dtype == FAR3D_DT_F32) {
-    hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
-                       Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
+    // fp32 (the in-tolerance engine's decoder): 4 key parts since round 6 -- 9 instead of 18 serial 64-key tiles per wave and 1 600 instead
+    // of 800 waves on the chip's 1 024 SIMDs; the four fp32 K / V tile pairs (72 KB) are dynamic LDS.  FAR3D_ATTN_F32_PARTS=2 (read
+    // once) keeps the round-5 form for A/B.
+    static const int parts = [] { const char* e = getenv("FAR3D_ATTN_F32_PARTS"); return e && atoi(e) == 2 ? 2 : 4; }();
+    if (parts == 4) {
+      constexpr int lds = 4 * (ATT_KT * ACfg<float>::KROW + ATT_KT * ACfg<float>::VROW);
+      static std::atomic<unsigned long long> lds_ok{0};
+      if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<float, 4>), lds, lds_ok, "far3d_attention_forward")) return rc;
+      hipLaunchKernelGGL((attn_fwd_kernel<float, 4>), grid, dim3(512), lds, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
+                         Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
+    } else {
+      hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
+                         Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
+    }
   } else {
     hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        out, out_dt, Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);

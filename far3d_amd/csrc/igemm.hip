@@ -4,6 +4,7 @@
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
+int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st);     // igemm_pair.hip (exact fp32 on the pipelined kernel, tiles 482-486)
 int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 3x3, tiles 400-459)
 
 #ifdef FAR3D_PROFILING
@@ -103,6 +104,20 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     // exact-fp32 kernel, profiles/r5/fp32_rows_gemm.txt); the 8-wave 128 x 128 tile only when even that one fills the chip 8 times over
     const int t = tile ? tile : ((((Npix + 127) / 128) * ((Cout + 127) / 128) >= 2048) ? 479 : 480);
     const int rc = far3d_conv_f32rows_launch(Q, t, st);
+    if (rc != FAR3D_OK) return rc;
+    FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
+    return FAR3D_OK;
+  }
+  // fp32 rows x fp32 weights, 1x1, explicit tiles 482-486: EXACT fp32 MFMA on the pipelined LDS-DMA kernel (far3d_amd.ops.linear picks them
+  // for the decoder-sized GEMMs; tile 0 keeps the register-staged kernel, which takes every shape)
+  if (tile >= 482 && tile <= 486) {
+    FAR3D_CHECK_ARG(x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cin % 32 == 0 && !chan_sums &&
+                    aligned(x, 16) && ldx % 4 == 0 && x_img_stride % 4 == 0 && ((long)(N - 1) * x_img_stride + (long)Ho * Wo * ldx) * 4 < 0x7fffffffL,
+                    "far3d_conv2d_nhwc: tile %d (exact fp32 on the pipelined kernel) needs fp32 rows and fp32 weights, a 1x1 / stride 1 layer, Cin %% 32 == 0 "
+                    "and 16-byte aligned rows", tile);
+    IgemmParams Q = P;
+    Q.ldx = 2 * ldx; Q.x_img_stride = 2 * x_img_stride;
+    const int rc = far3d_conv_f32x_launch(Q, tile, st);
     if (rc != FAR3D_OK) return rc;
     FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
     return FAR3D_OK;

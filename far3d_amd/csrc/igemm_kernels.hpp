@@ -1261,6 +1261,47 @@ __device__ __forceinline__ void gemm_step_split_f32b(const unsigned char* smem, 
   }
 }
 
+// EXACT fp32 on the pipelined kernel (F32X, round 6: the in-tolerance engine's decoder / FarHead GEMMs ran on the register-staged
+// exact-fp32 kernel at 12-19 us a launch, three times their MFMA time -- no LDS-DMA ring, every K step a global-load round trip).  fp32
+// rows on BOTH sides: 32 floats = 128 bytes = the DMA pattern of the pair kernel (sub-tile 0: floats 0-15, sub-tile 1: floats 16-31 of a
+// 32-channel block).  A lane feeds v_mfma_f32_32x32x2_f32 with ONE float per operand and MFMA: lane (row, hi) reads logical chunks 2 hi
+// and 2 hi + 1 (4 floats each) of its row in a sub-tile, on the weight side and on the activation side alike, and the eight MFMAs of a
+// sub-tile pair element e of chunk c of the two half-waves -- a permutation of K, the same on both operands.  Exact products, fp32
+// accumulation: only the summation order differs from the staged kernel.
+template <int WM, int WN, int SOFF, int BM, int SUBB>
+__device__ __forceinline__ void gemm_step_exact_f32(const unsigned char* smem, const int (&aaddr)[2][WM], const int (&baddr)[2][WN],
+                                                    f32x16_t (&acc)[WM][WN]) {
+  u32x4_t ax[2][2][WM], bx[2][2][WN];       // [register buffer = sub-tile][chunk c][tile]
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) ax[0][c][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + aaddr[c][i]);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bx[0][c][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + baddr[c][j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    if (kk == 0) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) ax[1][c][i] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + SUBB + aaddr[c][i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bx[1][c][j] = *reinterpret_cast<const u32x4_t*>(smem + SOFF + BM * 64 + SUBB + baddr[c][j]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma<float>(acc[i][j], ax[kk][c][i], bx[kk][c][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // NT / PAIR as in conv3x3_pipe_kernel: pair-stored activations + pre-split weights; NT = 3 split products, NT = 1 hi planes only.
 // NS: LDS ring depth in 64-channel steps.  NS = 2: the step that follows the one being computed is in flight (each barrier waits
 // for vmcnt(0)).  NS >= 3: NS - 1 steps are in flight and a barrier waits for the OLDEST one only (counted vmcnt: the LDS-DMAs of a
@@ -1268,7 +1309,8 @@ __device__ __forceinline__ void gemm_step_split_f32b(const unsigned char* smem, 
 // decoder (4..16 steps) that is most of the K loop issued up front.
 
 // F32B: the activations are fp32 rows handed over as if pair-stored (the caller doubles ldx / x_img_stride: same bytes), weights pre-split.
-template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false>
+// F32X: fp32 rows on both sides, exact fp32 MFMA (gemm_step_exact_f32); instantiated with NT = 3, PAIR = true, F32B = true for the byte geometry.
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false, bool F32X = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WGM * WGN;
@@ -1289,6 +1331,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   const long Npix = (long)P.N * HoWo;
   static_assert(NT == 1 || (NT == 3 && PAIR), "split products need pair-stored operands");
   static_assert(!F32B || (NT == 3 && PAIR), "fp32 activation rows: split products, weights pre-split");
+  static_assert(!F32X || F32B, "exact fp32: the fp32-row geometry");
   constexpr int PLS = PAIR ? 2 : 1;
   constexpr int KSTR = (PAIR && NT == 1) ? 128 : 64;      // bytes along K between the sub-tiles this kernel consumes
   const int Ktot = P.cin_pad * PLS;
@@ -1349,8 +1392,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int r = (wm * WM + i) * 32 + l31;
-    aaddr[0][i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
-    aaddr[1][i] = aaddr[0][i] ^ 32;
+    if constexpr (F32X) {     // fp32 weight rows: [c] = logical chunk 2 * hi + c, like the activation side
+      aaddr[0][i] = r * 64 + (((2 * hi) ^ ((r >> 2) & 3)) << 4);
+      aaddr[1][i] = aaddr[0][i] ^ 16;
+    } else {
+      aaddr[0][i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+      aaddr[1][i] = aaddr[0][i] ^ 32;
+    }
   }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -1369,7 +1417,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   constexpr int UNIT = AW + BW;                 // LDS-DMA instructions of one 32-channel sub-tile, per wave
   static_assert(NS >= 2 && NS <= 4, "ring depth");
   static_assert(NS == 2 || (A_EXACT && B_EXACT), "counted vmcnt needs the same number of DMA instructions in every wave");
-  static_assert(NS == 2 || NT == 1, "deep rings: plain bf16 products only");
+  static_assert(NS == 2 || NT == 1 || F32X, "deep rings: plain bf16 products, or the exact fp32 mode (always whole 32-channel blocks: no half step)");
   const int nsteps = nfull + tail;              // step s < nfull: two sub-tiles; step nfull (if tail): one
 #pragma unroll
   for (int s = 0; s < D; ++s) {
@@ -1400,7 +1448,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
     if ((S) + D < nfull) issue((S) + D, (((STG) + D) % NS) * STAGE, 2);                                      \
     else if ((S) + D < nsteps) issue((S) + D, (((STG) + D) % NS) * STAGE, 1);                                \
     }                                                                                                        \
-    if constexpr (F32B) gemm_step_split_f32b<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);       \
+    if constexpr (F32X) gemm_step_exact_f32<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);        \
+    else if constexpr (F32B) gemm_step_split_f32b<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);  \
     else if constexpr (NT == 3) gemm_step_split<WM, WN, (STG) * STAGE, BM, SUB>(smem, aaddr, baddr, acc);    \
     else gemm_step_pipelined<WM, WN, (STG) * STAGE, BM, SUB, 4>(smem, aaddr, baddr, acc);                    \
   }
@@ -1449,7 +1498,7 @@ static bool gemm_sums_ok(const IgemmParams& P, size_t lds_sums) {
   return true;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false>
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false, bool F32X = false>
 static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
@@ -1461,10 +1510,10 @@ static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return FAR3D_ERR_ARG;
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds_sums > 65536)
-    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B>),
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X>),
                                        (int)(lds_sums <= 163840 ? lds_sums : lds0), lds_ok, "far3d_conv2d_nhwc")) return rc;
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
-  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
+  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
   return 0;
 }
 

@@ -103,3 +103,18 @@ int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st) {
   far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for fp32 activation rows with split weights (479-481)", tile);
   return FAR3D_ERR_ARG;
 }
+
+// fp32 activation rows x fp32 weight rows, EXACT fp32 MFMA on the pipelined GEMM kernel (F32X; 1x1 / stride 1, Cin % 32 == 0; P.ldx and
+// P.x_img_stride doubled by the caller: the kernel counts bf16-sized units).  Tile ids 482-486.
+int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st) {
+  switch (tile) {
+    case 482: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 2, true, true>(P, st);   // 64 x 64, 4 waves, 2 stages
+    case 483: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 4, true, true>(P, st);   // 64 x 64, 4 waves, 4 stages (3 steps in flight)
+    case 484: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true, 3, true, true>(P, st);   // 128 x 128, 8 waves, 3 stages
+    case 485: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true, 2, true, true>(P, st);   // 128 x 128, 16 waves, 2 stages
+    case 486: return launch_gemm1x1_pipe<2, 4, 1, 1, 3, true, 2, true, true>(P, st);   // 64 x 128, 8 waves, 2 stages
+    default: break;
+  }
+  far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for exact-fp32 rows on the pipelined kernel (482-486)", tile);
+  return FAR3D_ERR_ARG;
+}

@@ -423,6 +423,9 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
     return out
 
 
+# linear(): tile for fp32 rows x fp32 weights (exact fp32 MFMA on the pipelined GEMM kernel, far3d_hip.h tiles 482-486); 0 = the
+# register-staged kernel of rounds 1-5.  483 = 64 x 64, 4 stages (tools/probe/f32x_gemm_ab.py, profiles/r6/f32x_gemm_ab.txt)
+F32X_LINEAR_TILE = 483
 SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
 # GEMM tiles that exist AND leave LDS for the channel-sum scratch (114 / 115 fill the 160 KB with their ring; 118 / 119 are no kernels)
 _GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | {279, 280}
@@ -468,6 +471,10 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
     if tile == 0 and x.dtype == torch.bfloat16 and pc.w.dtype == torch.bfloat16 and x.shape[1] % 32 == 0 and \
             _tuned_tile(pc.Cout, x.shape[1], 1, 1, M) == 0:
         tile = 80     # untuned small GEMM: 64x64 pipelined tile (the winner on every decoder-sized shape of the table)
+    if tile == 0 and F32X_LINEAR_TILE and x.dtype == torch.float32 and pc.w.dtype == torch.float32 and pc.w_code == DT_F32 and \
+            x.shape[1] % 32 == 0 and M >= 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and M * x.stride(0) * 4 < 2 ** 31 - 1:
+        # exact fp32 on the LDS-DMA pipelined kernel (round 6): the decoder-sized GEMMs of the fp32 / in-tolerance engines
+        tile = F32X_LINEAR_TILE
     conv2d_nhwc(xv, pc, out=ov, act=act, res=rv, tile=tile)
     return out
 

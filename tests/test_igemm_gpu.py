@@ -283,6 +283,36 @@ def test_fp32_rows_on_the_pipelined_gemm_kernel(hip_lib, tile, shape, epilogue):
     assert err < bound, (err, bound)
 
 
+@pytest.mark.parametrize("tile", [482, 483, 484, 485, 486])
+@pytest.mark.parametrize("shape", [(1544, 256, 256), (333, 96, 200), (2568, 1024, 256), (70, 32, 40), (1544, 512, 455)])
+@pytest.mark.parametrize("epilogue", ["plain", "relu_residual_strided"])
+def test_exact_fp32_on_the_pipelined_gemm_kernel(hip_lib, tile, shape, epilogue):
+    """fp32 rows x fp32 weights on the LDS-DMA pipelined GEMM kernel with the EXACT fp32 MFMA (tiles 482-486, round 6: the decoder /
+    FarHead GEMMs of the in-tolerance and fp32 engines).  Exact products, fp32 accumulation: fp32 rounding noise against float64, and
+    within that noise of the register-staged exact kernel (tile 0) -- only the summation order differs.  Ragged M / N, K of one to 32
+    steps, strided rows, residual + activation through the generic epilogue; asymmetric operands (a transposed fragment would show)."""
+    from far3d_amd import ops
+    M, Kd, Co = shape
+    g = torch.Generator().manual_seed(M + Kd + Co + tile)
+    xs = torch.randn(M, Kd + 8, generator=g)
+    x = xs[:, 4:4 + Kd]                               # row stride Kd + 8, 16-byte aligned start
+    w = torch.randn(Co, Kd, generator=g) * 0.1 * torch.linspace(0.5, 1.5, Kd)[None]
+    b = torch.randn(Co, generator=g)
+    pc = ops.PackedConv(w, b, dtype=torch.float32, device=DEV)
+    xd = xs.to(DEV)[:, 4:4 + Kd]
+    want = F.linear(x.double(), w.double(), b.double())
+    if epilogue == "plain":
+        got, old = ops.linear(xd, pc, tile=tile).cpu(), ops.linear(xd, pc, tile=3).cpu()
+    else:
+        res = torch.randn(M, Co, generator=g)
+        want = want.relu() + res.double()
+        got, old = ops.linear(xd, pc, act="relu", res=res.to(DEV), tile=tile).cpu(), ops.linear(xd, pc, act="relu", res=res.to(DEV), tile=3).cpu()
+    scale = (x.abs().mean() * w.abs().mean()).item()
+    bound = 8 * 2.0 ** -24 * Kd ** 0.5 * max(1.0, want.abs().max().item()) + 4 * 2.0 ** -24 * Kd * scale
+    assert (got.double() - want).abs().max().item() < bound, ((got.double() - want).abs().max().item(), bound)
+    assert (got - old).abs().max().item() < bound
+
+
 def test_split_mode_rejects_bf16_operands(hip_lib):
     from far3d_amd import lib, ops
     with pytest.raises(ValueError):
