@@ -424,8 +424,9 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
 
 
 # linear(): tile for fp32 rows x fp32 weights (exact fp32 MFMA on the pipelined GEMM kernel, far3d_hip.h tiles 482-486); 0 = the
-# register-staged kernel of rounds 1-5.  483 = 64 x 64, 4 stages (tools/probe/f32x_gemm_ab.py, profiles/r6/f32x_gemm_ab.txt)
-F32X_LINEAR_TILE = 483
+# register-staged kernel of rounds 1-5.  482 = 64 x 64, 2 stages: the fastest of 482-486 on every decoder shape (tools/probe/f32x_gemm_ab.py,
+# profiles/r6/f32x_gemm_ab.txt)
+F32X_LINEAR_TILE = 482
 SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
 # GEMM tiles that exist AND leave LDS for the channel-sum scratch (114 / 115 fill the 160 KB with their ring; 118 / 119 are no kernels)
 _GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | {279, 280}
