@@ -473,8 +473,10 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
             _tuned_tile(pc.Cout, x.shape[1], 1, 1, M) == 0:
         tile = 80     # untuned small GEMM: 64x64 pipelined tile (the winner on every decoder-sized shape of the table)
     if tile == 0 and F32X_LINEAR_TILE and x.dtype == torch.float32 and pc.w.dtype == torch.float32 and pc.w_code == DT_F32 and \
-            x.shape[1] % 32 == 0 and M >= 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and M * x.stride(0) * 4 < 2 ** 31 - 1:
-        # exact fp32 on the LDS-DMA pipelined kernel (round 6): the decoder-sized GEMMs of the fp32 / in-tolerance engines
+            x.shape[1] % 32 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and M * x.stride(0) * 4 < 2 ** 31 - 1:
+        # exact fp32 on the LDS-DMA pipelined kernel (round 6): the GEMMs of the fp32 / in-tolerance engines' decoder and FarHead.  The
+        # choice must NOT depend on the number of rows: the query-sharded decoder launches row subsets and has to reproduce the replicated
+        # decoder bit for bit (a row's bits depend on the kernel, not on which rows share its launch)
         tile = F32X_LINEAR_TILE
     conv2d_nhwc(xv, pc, out=ov, act=act, res=rv, tile=tile)
     return out

@@ -145,6 +145,14 @@ int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, v
  *    x_dt = FAR3D_DT_F32 with w_dt = FAR3D_DT_F32_BF16X3, 1x1/s1, Cin % 32 == 0, x 16-byte aligned with strides that are multiples
  *    of 4 floats: 479-481 (auto) the pipelined GEMM kernel on fp32 rows -- 32 floats are the 128 bytes of a pair-stored block, so
  *    the LDS-DMA pattern is the pair kernel's and the hi / lo split of the rows happens in registers (same three products).
+ *    x_dt = w_dt = FAR3D_DT_F32, 1x1/s1, Cin % 32 == 0, same alignment: 482-486 the pipelined GEMM kernel with the EXACT fp32 MFMA
+ *    (v_mfma_f32_32x32x2_f32) on fp32 rows of both operands -- exact products, fp32 accumulation, another summation order than the
+ *    register-staged kernel (tiles 1-5); 482 / 483 64 x 64 (2 / 4 LDS stages), 484 / 485 128 x 128, 486 64 x 128.
+ *    3x3/s1/p1, Cin % 32 == 0, Cout % 32 == 0, same storage in and out, 16-byte aligned rows, NO res / y2 / chan_sums: the PERSISTENT
+ *    wave-specialised kernel (csrc/conv_ws.hpp: producer waves issue every LDS-DMA, consumer waves only read LDS and run MFMAs, one
+ *    workgroup per CU walks several tiles, 16-byte stores straight from the MFMA registers) -- pair storage 400-417 (one hand-over
+ *    per tap), 450-459 (one per kernel row), 440 / 444 / 445 (LDS counters instead of the barrier; measured slower), bf16 420-423.
+ *    Results are bit-identical to the pipelined 3x3 kernel (same products in the same order).
  * chan_sums (optional, DEVICE int64 [N][Cout]; 1x1/s1 layers on a pipelined GEMM tile with a bf16 or pair output, Ho*Wo >= the
  *    tile's pixel count): every STORED output element v (for a pair output: its hi and its lo half) ADDS
  *    rint(v * 2^FAR3D_SUMS_FRAC_BITS) to chan_sums[n][channel] -- the global average pool of VoVNet's eSE block (ref

@@ -1,16 +1,20 @@
-"""CPU: the committed evidence under profiles/r5/ is internally consistent with the bench contract -- the JSON lines carry every
-field the contract names, the roofline block is arithmetic on its own fields, the kernel it names is the one in the committed
-rocprofv3 stats and in the PMC file, and the live HIP-event timing agrees with the profiler's average for that kernel."""
+"""CPU: the committed evidence under profiles/r6/ is internally consistent with the bench contract -- the JSON lines carry every
+field the contract names, the headline IS the engine that meets the tolerance under the reference's sync-per-frame protocol, the roofline
+block is arithmetic on its own fields, the kernel it names is the one in the committed rocprofv3 stats and in the PMC files, the live
+HIP-event timing agrees with the profiler's average for that kernel, and the reports hold no impossible figure (a layer above the matrix
+peak, a negative phase) -- VERDICT r5 items 1c and 7."""
 import csv
 import json
 import os
+import re
+import subprocess
 
 import pytest
 
 from tests.conftest import ROOT
 
-P = os.path.join(ROOT, "profiles", "r5")
-LINES = ["bench.json", "bench_fp32.json", "bench_bf16x3.json"]
+P = os.path.join(ROOT, "profiles", "r6")
+LINES = ["bench.json", "bench_fp32.json", "bench_bf16.json"]
 
 
 def _load(name):
@@ -21,11 +25,16 @@ def _load(name):
 def test_bench_line_follows_the_contract(name):
     d = _load(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline"):
+              "data", "config", "roofline", "value_protocol"):
         assert k in d, k
     assert d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["data"] == "synthetic"
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6                       # value = 1 / time per frame at N = 1
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["commit"]
+    # `value` is the reference's protocol: K frames with a device sync around every one (tools/analysis_tools/benchmark.py:84-111)
+    assert d["value_protocol"].startswith("sync_per_frame")
+    sp = d["protocol"]["sync_per_frame"]
+    assert sp["frames"] == d["steps"] and abs(sp["mean_ms"] - d["ms_per_step"]) < 0.02 * d["ms_per_step"]
+    assert d["protocol"]["pipelined"]["samples_per_s"] >= 0.98 * d["value"]             # frames back to back are never slower
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -33,65 +42,106 @@ def test_bench_line_follows_the_contract(name):
     assert abs(r["achieved"] * 1e9 - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6)) < 1e-3 * r["achieved"] * 1e9
     rb = d["roofline_backbone"]
     assert rb["bound"] == "mfma" and abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9
-    assert d["dtype"] == {"bench.json": "bf16", "bench_fp32.json": "fp32", "bench_bf16x3.json": "bf16x3"}[name]
+    assert d["dtype"] == {"bench.json": "bf16x3", "bench_fp32.json": "fp32", "bench_bf16.json": "bf16"}[name]
 
 
-def test_headline_line_has_cpu_baseline_and_parity():
+def test_headline_is_the_in_tolerance_engine_with_cpu_baseline_and_parity():
     d = _load("bench.json")
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < 1.0
+    # the headline engine is inside the north-star tolerance on EVERY frame the parity block reports, with the excluded rows capped
     p = d["parity"]
-    assert p["tolerance_north_star"] == 1e-3 and p["meets_tolerance"] is False and p["logit_max_abs"] > 1e-3   # bf16: measured, not met
-    # the SAME driver-style run also times an engine that is inside the tolerance on EVERY frame it reports
-    t = d["in_tolerance"]
-    assert t["dtype"] == "bf16x3" and t["meets_tolerance"] is True and all(f["logit_max_abs"] < 1e-3 for f in t["parity"]["frames"])
-    assert len(t["parity"]["frames"]) >= 2 and t["steps"] >= 50
-    assert t["unit"] == "samples/s" and abs(t["value"] * t["ms_per_step"] / 1e3 - 1.0) < 1e-6
-    assert t["value"] >= 75.0, "the in-tolerance engine fell below the round's 75 samples/s bar: %.1f" % t["value"]
-    rb = t["roofline_backbone"]
-    assert rb["bound"] == "mfma" and abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9 and abs(rb["peak"] - 2500.0 / 3) < 1e-6
-    ra = t["roofline"]                       # the aggregation kernel on fp32 rows, timed in the same run
-    assert ra["bound"] == "hbm" and ra["value_row_bytes"] == 1024 and abs(ra["frac"] - ra["achieved"] / ra["peak"]) < 1e-9
-    assert ra["algorithmic_bytes_per_launch"] == 112081600 and d["roofline"]["algorithmic_bytes_per_launch"] == 66385600
-    # the like-for-like ratio against the reference's sync-per-frame protocol is printed next to vs_baseline
-    assert abs(d["vs_baseline_sync_per_frame"] - d["protocol"]["sync_per_frame"]["samples_per_s_mean"] / 6.4) < 1e-9
+    assert d["dtype"] == "bf16x3" and d["meets_tolerance"] is True and p["meets_tolerance"] is True and p["tolerance_north_star"] == 1e-3
+    assert len(p["frames"]) >= 2 and all(f["logit_max_abs"] < 1e-3 for f in p["frames"])
+    assert p["excluded_rows_within_cap"] is True and all(f["rows_excluded_same_peak_other_bin_or_peak_test"] <= p["excluded_rows_cap"] for f in p["frames"])
+    assert d["value"] >= 60.0, "the in-tolerance engine under the sync-per-frame protocol fell below 60 samples/s: %.1f" % d["value"]
+    assert abs(d["vs_baseline"] - d["value"] / 6.4) < 1e-9
+    rb = d["roofline_backbone"]
+    assert rb["bound"] == "mfma" and abs(rb["peak"] - 2500.0 / 3) < 1e-6            # three MFMAs per useful product
+    ra = d["roofline"]                       # the aggregation kernel on fp32 rows, timed in the same run
+    assert ra["bound"] == "hbm" and ra["value_row_bytes"] == 1024 and ra["algorithmic_bytes_per_launch"] == 112081600
+    assert ra["frac"] >= 0.60, "the headline engine's sampling kernel fell below 0.60 of the HBM peak: %.3f" % ra["frac"]
+    # the bf16 engine rides beside it, labelled as what it is
+    f = d["fast_mode"]
+    assert f["dtype"] == "bf16" and f["meets_tolerance"] is False and f["parity"]["logit_max_abs"] > 1e-3 and f["value_protocol"] == "sync_per_frame"
+    assert f["roofline"]["algorithmic_bytes_per_launch"] == 66385600 and f["value"] > d["value"]
+    assert abs(f["value"] * f["ms_per_step"] / 1e3 - 1.0) < 1e-6
     # the ranks that took part are read back from the process group
     assert d["ranks"] == 1 and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
-    # the full-size rig holds the in-tolerance engine to the bar on every streaming frame
+    # the full-size rig holds the in-tolerance engine to the bar on every streaming frame with the near-tie decisions adopted
     full = _load("parity_full_bf16x3.json")
     assert len(full) == 3 and all(r["logit_abs_err_vs_oracle32"]["max"] < 1e-3 for r in full)
+
+
+def test_unadopted_witness_covers_a_full_memory_queue_and_both_yardsticks():
+    u = _load("parity_full_unadopted.json")
+    for k in ("yardstick_rounding", "bf16x3", "fp32", "bf16x3_yardstick_flipped_near_ties", "fp32_yardstick_flipped_near_ties",
+              "bf16x3_vs_oracle_adopting", "fp32_vs_oracle_adopting"):
+        assert k in u and len(u[k]) == 5, k
+    for p in ("bf16x3", "fp32"):
+        for rep, y1, y2, ra in zip(u[p], u["yardstick_rounding"], u[p + "_yardstick_flipped_near_ties"], u[p + "_vs_oracle_adopting"]):
+            assert rep["adaptive_in_common"] >= 640 and rep["logit_p999"] < 1e-3
+            assert rep["logit_max_abs"] <= max(1e-3, 2 * max(y1["logit_max_abs"], y2["logit_max_abs"]))      # no constant allowance
+            assert ra["rows_excluded"] == 0 and ra["logit_max_abs"] < 1e-3
 
 
 def test_roofline_kernel_matches_the_committed_profiles():
     d = _load("bench.json")
     kernel = d["roofline"]["kernel"].split(" ")[0]
     assert kernel == "aggregate_v8_kernel"
-    pmc = _load("aggregate_pmc.json")
-    assert pmc["kernel"] == kernel
-    # the traffic figure is a committed constant of the PMC passes (separate runs), labelled as such when the line carries it
-    assert d["roofline"]["traffic"] is None or (d["roofline"]["traffic_measured_in_this_run"] is False and
-                                                abs(d["roofline"]["traffic"] - pmc["hbm_bytes_per_launch"]) / pmc["hbm_bytes_per_launch"] < 0.02)
-    assert 0.3 * d["roofline"]["algorithmic_bytes_per_launch"] < pmc["hbm_bytes_per_launch"] < 1.2 * d["roofline"]["algorithmic_bytes_per_launch"]
-    rows = [r for r in csv.DictReader(open(os.path.join(P, "bench_kernel_stats.csv"))) if kernel in r["Name"]]
-    assert len(rows) == 1, [r["Name"][:40] for r in rows]
+    px = _load("aggregate_pmc_fp32rows.json")          # in-frame passes on the headline engine's fp32 rows
+    pmc = _load("aggregate_pmc.json")                  # in-frame passes on bf16 rows (fast_mode)
+    assert px["kernel"] == kernel and pmc["kernel"] == kernel and px["hbm_bytes_per_launch"] > pmc["hbm_bytes_per_launch"]
+    r = d["roofline"]
+    # the traffic figure is measured by the run (isolated launches) or, without rocprofv3, the committed in-frame figure -- labelled either way
+    assert r["traffic"] is not None and r["traffic_measured_in_this_run"] in (True, False)
+    if r["traffic_measured_in_this_run"]:
+        assert "measured by this run" in r["traffic_source"] and 0.2 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.2 * r["algorithmic_bytes_per_launch"]
+    else:
+        assert abs(r["traffic"] - px["hbm_bytes_per_launch"]) / px["hbm_bytes_per_launch"] < 0.02
+    assert 0.3 * r["algorithmic_bytes_per_launch"] < px["hbm_bytes_per_launch"] < 1.2 * r["algorithmic_bytes_per_launch"]
+    rows = [x for x in csv.DictReader(open(os.path.join(P, "bench_kernel_stats.csv"))) if kernel in x["Name"]]
+    assert len(rows) == 1, [x["Name"][:40] for x in rows]
     avg_us = float(rows[0]["AverageNs"]) * 1e-3
-    live_us = d["roofline"]["avg_launch_us"]
+    live_us = r["avg_launch_us"]
     # the profiler's in-frame average (frames one at a time) and the live back-to-back timing of the same launches agree within 12 %
-    # (the two files come from two GPU calls = two boxes of the pool, which differ by 3-5 % themselves)
+    # (the two files come from two GPU calls = possibly two boxes of the pool)
     assert abs(avg_us - live_us) / live_us < 0.12, (avg_us, live_us)
-    # round-4 bar of VERDICT r3 item 1: <= 18 us in frame, >= 0.46 of the HBM peak in the bench line
-    assert live_us <= 18.0 and d["roofline"]["frac"] >= 0.46
-    # the fp32-row modes time the same kernel on 1-KiB rows and do not borrow the bf16 traffic figure: they carry the PMC passes taken on
-    # fp32 rows (round 5, aggregate_pmc_fp32rows.json) or nothing
-    px = _load("aggregate_pmc_fp32rows.json")
-    assert px["kernel"] == kernel and px["hbm_bytes_per_launch"] > pmc["hbm_bytes_per_launch"]
-    for name in ("bench_fp32.json", "bench_bf16x3.json"):
-        r = _load(name)["roofline"]
-        assert r["traffic"] is None or ("fp32rows" in r["traffic_source"] and r["traffic_measured_in_this_run"] is False)
-    tr = d["in_tolerance"]["roofline"]
-    assert tr["traffic"] is None or "fp32rows" in tr["traffic_source"]
+    # the PMC files were taken on a tree whose sampling kernel is the one the line timed: their commit is not older than the last commit
+    # that touched csrc/sampling.hip (skipped where git cannot answer, e.g. a source snapshot)
+    try:
+        last = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%H", "--", "far3d_amd/csrc/sampling.hip"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:   # noqa: BLE001
+        last = ""
+    for j in (px, pmc):
+        c = j.get("commit", "").split("+")[0]
+        if last and c and c != "?":
+            ok = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", last, c], capture_output=True, timeout=10).returncode
+            assert ok == 0, "PMC file taken at %s, before the last change of csrc/sampling.hip (%s)" % (c, last[:7])
+
+
+def test_reports_hold_no_impossible_figure():
+    """round 5's layer report paired two launches with the wrong layers (2 460.9 TF/s) and its phase report printed a
+    negative stamp difference."""
+    for name, peak in (("conv_layers.txt", 2500.0 / 3), ("conv_layers_bf16.txt", 2500.0)):
+        n = 0
+        for ln in open(os.path.join(P, name)):
+            m = re.search(r"([0-9.]+) us +([0-9.]+) TF/s", ln)
+            if m and "npix=" in ln:
+                n += 1
+                assert float(m.group(2)) <= peak, "%s: %s" % (name, ln.strip())
+                is3 = " P" in ln[40:60] or " R" in ln[40:60]
+                assert not (ln.split()[0].endswith(".cat") and " P" in ln[40:64]), "a concat layer paired with a 3x3 launch: %s" % ln.strip()
+        assert n >= 100, "%s: %d layer rows" % (name, n)
+    txt = open(os.path.join(P, "conv_phase_times.txt")).read()
+    assert "tile" in txt and not re.search(r"(set-up|first fill|K loop|epilogue) +-\d", txt) and "nan MHz" not in txt
+    ws = open(os.path.join(P, "ws_conv_phase_times.txt")).read()
+    assert "cycles / step" in ws and not re.search(r"= barrier wait -|body -", ws)
+    # every wave-specialised tile of the A/B is bit-identical to the shipped kernel (the probe prints DIFF otherwise)
+    ab = open(os.path.join(P, "ws_ab_pair.txt")).read()
+    assert "t163" in ab and "t45" in ab and "DIFF" not in ab
 
 
 def test_threshold_mode_and_stage_time_evidence():
@@ -105,20 +155,19 @@ def test_threshold_mode_and_stage_time_evidence():
     # three frames in flight: one camera per rank costs less than 1.5 ms per frame, seven cameras gain > 15 %
     assert st["camera_stages_1cam_3streams_ms_per_frame"] < 1.5
     assert st["camera_stages_7cam_3streams_ms_per_frame"] < 0.85 * st["camera_stages_7cam_ms"]
-    # the frame pipeline's A/B: the default protocol against round 3's (2 buffer sets, equal priorities) on the same tree
-    assert _load("bench.json")["value"] > 1.15 * _load("bench_pipeline_r3.json")["value"]
-    assert _load("bench.json")["protocol"]["pipelined"]["frames_in_flight"] == 4
 
 
 def test_gpu_suite_and_smoke_logs_are_green():
     txt = open(os.path.join(P, "pytest_gpu.txt")).read()
     assert " passed" in txt and "failed" not in txt and "error" not in txt.lower()
+    m = re.search(r"in ([0-9.]+)s", txt)
+    assert m and float(m.group(1)) < 900.0, "the GPU suite must stay well inside the driver's 1200 s limit (VERDICT r5 weak #11)"
     assert "smoke ok" in open(os.path.join(P, "smoke.txt")).read()
 
 
 def test_design_is_rendered_from_the_evidence():
-    """DESIGN.md is DESIGN.tmpl.md with every measured number filled from profiles/r5/ -- or, where a placeholder says r4/, from that round's set -- (tools/fill_design.py): a figure that is
-    not in the committed evidence cannot be quoted, and a stale one fails here (DESIGN.md:260 carried a round-2 number)."""
+    """DESIGN.md is DESIGN.tmpl.md with every measured number filled from profiles/ (tools/fill_design.py; a placeholder names its round,
+    r6 by default): a figure that is not in the committed evidence cannot be quoted, and a stale one fails here."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fill_design", os.path.join(ROOT, "tools", "fill_design.py"))
     fd = importlib.util.module_from_spec(spec)
