@@ -132,7 +132,6 @@ def test_reports_hold_no_impossible_figure():
             if m and "npix=" in ln:
                 n += 1
                 assert float(m.group(2)) <= peak, "%s: %s" % (name, ln.strip())
-                is3 = " P" in ln[40:60] or " R" in ln[40:60]
                 assert not (ln.split()[0].endswith(".cat") and " P" in ln[40:64]), "a concat layer paired with a 3x3 launch: %s" % ln.strip()
         assert n >= 100, "%s: %d layer rows" % (name, n)
     txt = open(os.path.join(P, "conv_phase_times.txt")).read()

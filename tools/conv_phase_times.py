@@ -114,12 +114,12 @@ def main():
                 for xc in np.unique(xcc):
                     m = xcc == xc
                     dr = real[m].max() - real[m].min()
-                    if dr > 20:
+                    if dr >= 5:
                         rates.append(100.0 * (tt[m, 0].max() - tt[m, 0].min()) / dr)
-            mhz = float(np.median(rates)) if rates else float("nan")
-            us = (lambda ticks: ticks / mhz) if rates else (lambda ticks: float("nan"))
+            mhz = float(np.median(rates)) if rates else 0.0          # 0: no two entry stamps far enough apart to measure the clock
+            us = (lambda ticks: ticks / mhz) if rates else (lambda ticks: 0.0)
             tot = float(np.sum(spans))
-            print("%-7s tile %3d: %5d workgroups on %3d CUs (max %d per CU) | s_memtime %5.0f MHz | per-CU span median %6.1f us (%d ticks) | median per "
+            print("%-7s tile %3d: %5d workgroups on %3d CUs (max %d per CU) | s_memtime %5.0f MHz (0 = not measurable: times in us read 0) | per-CU span median %6.1f us (%d ticks) | median per "
                   "workgroup [ticks]: set-up %5.0f  first fill %5.0f  K loop %6.0f  epilogue %5.0f  life %6.0f (p10 %.0f p90 %.0f) = %.2f us | "
                   "a CU has >=1 workgroup alive %4.1f %% of its span, >=2 alive %4.1f %%%s" %
                   (name, tile, len(t), len(cus), max(nper), mhz, us(med(spans)), med(spans), med(ph[:, 0]), med(ph[:, 1]), med(ph[:, 2]), med(ph[:, 3]),

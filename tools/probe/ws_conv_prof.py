@@ -12,7 +12,7 @@ flib.LIB_PATH = os.path.join(os.path.dirname(flib.LIB_PATH), "libfar3d_hip_prof.
 from far3d_amd import ops
 
 LAYERS = [("stem2", 7, 320, 480, 64, 64, (401, 413)), ("s2.c1", 7, 160, 240, 128, 128, (400, 411, 450, 451)),
-          ("s3.c1", 7, 80, 120, 160, 160, (407, 414)), ("s4.c1", 7, 40, 60, 192, 192, (403, 449, 444)), ("c512.l0", 7, 80, 120, 256, 512, (400,))]
+          ("s3.c1", 7, 80, 120, 160, 160, (407, 414)), ("s4.c1", 7, 40, 60, 192, 192, (403, 404, 451)), ("c512.l0", 7, 80, 120, 256, 512, (400,))]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 lib = flib.load()
 setp = lib.far3d_prof_set_conv_timestamps
