@@ -266,6 +266,191 @@ __global__ __launch_bounds__(128 * NS) void attn_fwd_kernel(const T* __restrict_
   }
 }
 
+// fp32, round 6: the key loop WITHOUT LDS and without barriers.  The staged kernel above walks its 64-key tiles in lockstep (two workgroup
+// barriers per tile: every wave of a SIMD is in its MFMA phase, then every wave in its exp phase), so the exact-fp32 MFMA pipe -- the
+// bound of this kernel: 3.7 GFLOP at 256 FLOP / cycle / CU -- idles half the time.  Here a wave owns (32 queries, one part of the keys)
+// and feeds the MFMAs from registers it loads itself: the A operand of S^T = K Q^T is lane (key, hi)'s 16 bytes of its key row, the A
+// operand of O^T += V^T P^T one float of a value row per lane (128 contiguous bytes per half-wave) -- both are plain coalesced global
+// loads of L2-resident rows (a head's K and V are 590 KB; workgroup id % heads = head, so with 8 heads an XCD's L2 holds ONE head).  The
+// next 32-key tile's 20 loads are in flight under the current tile's 32 MFMAs; waves run free of each other until the merge of the key
+// parts (one barrier).  Same arithmetic as the staged kernel per 32-key tile: exact products, fp32 accumulation, online softmax.
+template <int QB, int NS, int QW = 1>     // QB query blocks per workgroup, NS key parts (waves = QB * NS); a wave owns QW x 32 queries
+__global__ __launch_bounds__(64 * QB * NS) void attn_f32_direct_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                      const float* __restrict__ V, void* __restrict__ O, int out_dt, int Aq,
+                                                                      int Nk, int heads, int ldq, int ldk, int ldv, int ldo, float scale,
+                                                                      const int* __restrict__ hole_count, int hole_start, int hole_end) {
+  // QW = 2: one set of K / V fragments feeds two independent MFMA chains (queries l31 and 32 + l31 of the block): half the loads per
+  // product and a second chain to issue while the first one's result is on its way
+  __shared__ float mb[(NS - 1) * QB * QW * 18 * 64];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
+  const int part = wv / QB, qb = wv % QB;
+  const int head = blockIdx.x % heads, qblk = blockIdx.x / heads;
+  const int q0 = (qblk * QB + qb) * 32 * QW + l31;          // this lane's query of chain w: q0 + 32 w
+  const int ntiles = (Nk + 31) >> 5;                       // 32-key tiles
+  const int ptiles = (ntiles + NS - 1) / NS;
+  const int t0 = part * ptiles, t1 = min(ntiles, t0 + ptiles);
+  const int hole_lo = hole_count ? hole_start + min(max(*hole_count, 0), hole_end - hole_start) : hole_end;
+  u32x4_t qf[QW][4];
+#pragma unroll
+  for (int w = 0; w < QW; ++w)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[w][kk] = u32x4_t{0u, 0u, 0u, 0u};
+      if (q0 + 32 * w < Aq) {
+        const float4 v = *reinterpret_cast<const float4*>(Q + (long)(q0 + 32 * w) * ldq + head * ATT_D + kk * 8 + hi * 4);
+        qf[w][kk] = u32x4_t{__float_as_uint(v.x * scale), __float_as_uint(v.y * scale), __float_as_uint(v.z * scale), __float_as_uint(v.w * scale)};
+      }
+    }
+  const float* Kh = K + head * ATT_D + hi * 4;
+  const float* Vh = V + head * ATT_D + l31;
+  u32x4_t kf[2][4];
+  float vf[2][16];
+  auto gload = [&](int tile, u32x4_t (&kd)[4], float (&vd)[16]) __attribute__((always_inline)) {
+    const int k0 = tile * 32;
+    const float* kr = Kh + (long)min(k0 + l31, Nk - 1) * ldk;           // rows past Nk: a valid row, masked below
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kd[kk] = *reinterpret_cast<const u32x4_t*>(kr + kk * 8);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vd[r] = Vh[(long)min(k0 + (r & 3) + 8 * (r >> 2) + 4 * hi, Nk - 1) * ldv];
+  };
+  f32x16_t o[QW];
+  float m_run[QW], l_run[QW];
+#pragma unroll
+  for (int w = 0; w < QW; ++w) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[w][r] = 0.f;
+    m_run[w] = -INFINITY; l_run[w] = 0.f;
+  }
+  auto compute = [&](int tile, const u32x4_t (&kd)[4], const float (&vd)[16]) __attribute__((always_inline)) {
+    if (tile * 32 >= hole_lo && (tile + 1) * 32 <= hole_end) return;      // wave-uniform: a tile inside the hole
+    f32x16_t s[QW];
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[w][r] = 0.f;
+    // exact-fp32 MFMAs of the chains interleaved: consecutive instructions do not wait for each other's accumulator
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float ka[4] = {__uint_as_float(kd[kk].x), __uint_as_float(kd[kk].y), __uint_as_float(kd[kk].z), __uint_as_float(kd[kk].w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int w = 0; w < QW; ++w) {
+          const float qe = __uint_as_float(e == 0 ? qf[w][kk].x : e == 1 ? qf[w][kk].y : e == 2 ? qf[w][kk].z : qf[w][kk].w);
+          s[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qe, s[w], 0, 0, 0);
+        }
+    }
+    const int kbase = tile * 32 + 4 * hi;
+    const bool ragged = (tile + 1) * 32 > Nk || ((tile + 1) * 32 > hole_lo && tile * 32 < hole_end);     // wave-uniform: only a ragged tile is masked
+    // e^(s - m) as the hardware's 2^x of one fma (1 ulp, the accuracy of expf without its ~18 instructions: per 32-key tile the exp phase
+    // was as long as the 32 exact-fp32 MFMAs, profiles/r6/attn_f32_ab.txt)
+    constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + (r & 3) + 8 * (r >> 2);
+          s[w][r] = (key < Nk && !(key >= hole_lo && key < hole_end)) ? s[w][r] : -INFINITY;
+        }
+      }
+      float mloc = fmaxf(fmaxf(fmaxf(s[w][0], s[w][1]), fmaxf(s[w][2], s[w][3])), fmaxf(fmaxf(s[w][4], s[w][5]), fmaxf(s[w][6], s[w][7])));
+      mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(s[w][8], s[w][9]), fmaxf(s[w][10], s[w][11])), fmaxf(fmaxf(s[w][12], s[w][13]), fmaxf(s[w][14], s[w][15]))));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float m_new = fmaxf(m_run[w], mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float mneg = -m_use * LOG2E;
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[w], LOG2E, mneg));      // m_run = -inf -> 0
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[w][r], LOG2E, mneg));
+        s[w][r] = p;
+        psum += p;
+      }
+      l_run[w] = l_run[w] * alpha + psum;
+      m_run[w] = m_new;
+      if (__ballot(alpha != 1.f)) {                                                // the running maximum moved for some query of the wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[w][r] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int w = 0; w < QW; ++w) o[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(vd[r], s[w][r], o[w], 0, 0, 0);
+  };
+  if (t0 < t1) {
+    gload(t0, kf[0], vf[0]);
+    for (int tile = t0; tile < t1; tile += 2) {
+      if (tile + 1 < t1) gload(tile + 1, kf[1], vf[1]);
+      compute(tile, kf[0], vf[0]);
+      if (tile + 1 >= t1) break;
+      if (tile + 2 < t1) gload(tile + 2, kf[0], vf[0]);
+      compute(tile + 1, kf[1], vf[1]);
+    }
+  }
+  // ---- merge the key parts in part order (as the staged kernel)
+  float l_tot[QW];
+#pragma unroll
+  for (int w = 0; w < QW; ++w) l_tot[w] = l_run[w] + __shfl_xor(l_run[w], 32);
+  if (part >= 1) {
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+      float* dst = mb + (((part - 1) * QB + qb) * QW + w) * 18 * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = o[w][r];
+      dst[16 * 64] = m_run[w];
+      dst[17 * 64] = l_tot[w];
+    }
+  }
+  __syncthreads();
+  if (part != 0) return;
+#pragma unroll
+  for (int w = 0; w < QW; ++w) {
+    const int q = q0 + 32 * w;
+    if (q >= Aq) continue;
+    float m = m_run[w];
+#pragma unroll
+    for (int p = 1; p < NS; ++p) m = fmaxf(m, mb[(((p - 1) * QB + qb) * QW + w) * 18 * 64 + lane + 16 * 64]);
+    const float mu = (m == -INFINITY) ? 0.f : m;
+    float ap[NS];
+    ap[0] = expf(m_run[w] - mu);
+    float den = l_tot[w] * ap[0];
+#pragma unroll
+    for (int p = 1; p < NS; ++p) {
+      const float* src = mb + (((p - 1) * QB + qb) * QW + w) * 18 * 64 + lane;
+      ap[p] = expf(src[16 * 64] - mu);
+      den += src[17 * 64] * ap[p];
+    }
+    const float inv = 1.f / den;
+    const long off = (long)q * ldo + head * ATT_D + 4 * hi;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float acc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = o[w][4 * qd + e] * ap[0];
+#pragma unroll
+      for (int p = 1; p < NS; ++p) {
+        const float* src = mb + (((p - 1) * QB + qb) * QW + w) * 18 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += src[(4 * qd + e) * 64] * ap[p];
+      }
+      const float4 r = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+      if (out_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off + 8 * qd) = r;
+      else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(O) + off + 8 * qd) = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+    }
+  }
+}
+
+template <int QB, int NS, int QW = 1>
+static void launch_attn_f32_direct(const float* q, const float* k, const float* v, void* out, int out_dt, int Aq, int Nk, int heads, int ldq,
+                                   int ldk, int ldv, int ldo, float scale, const int* hole_count, int hole_start, int hole_end, hipStream_t st) {
+  const int nqb = (Aq + 32 * QB * QW - 1) / (32 * QB * QW);
+  hipLaunchKernelGGL((attn_f32_direct_kernel<QB, NS, QW>), dim3(nqb * heads), dim3(64 * QB * NS), 0, st, q, k, v, out, out_dt, Aq, Nk, heads, ldq,
+                     ldk, ldv, ldo, scale, hole_count, hole_start, hole_end);
+}
+
 extern "C" int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq,
                                        int Nk, int heads, int head_dim, int ldq, int ldk, int ldv, int ldo,
                                        float scale, const int32_t* hole_count, int hole_start, int hole_end, void* stream) {
@@ -286,17 +471,28 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
   // key parts per workgroup (2 waves each): fp32 2, bf16 4 (an 8-part bf16 instantiation was measured in round 4 -- 27.4 vs 28 us,
   // profiles/r4/attn_parts8.txt: the per-tile MFMA -> exp -> MFMA chain is what a wave waits on -- and removed)
   if (dtype == FAR3D_DT_F32) {
-    // fp32 (the in-tolerance engine's decoder): 4 key parts since round 6 -- 9 instead of 18 serial 64-key tiles per wave and 1 600 instead
-    // of 800 waves on the chip's 1 024 SIMDs; the four fp32 K / V tile pairs (72 KB) are dynamic LDS.  FAR3D_ATTN_F32_PARTS=2 (read
-    // once) keeps the round-5 form for A/B.
-    static const int parts = [] { const char* e = getenv("FAR3D_ATTN_F32_PARTS"); return e && atoi(e) == 2 ? 2 : 4; }();
-    if (parts == 4) {
+    // fp32 (the in-tolerance engine's decoder): the register-fed kernel (attn_f32_direct_kernel) since round 6; the staged kernel with 4
+    // key parts (its four fp32 K / V tile pairs, 72 KB, are dynamic LDS) or 2 (round 5) stays selectable for A/B.
+    static const int parts = [] { const char* e = getenv("FAR3D_ATTN_F32_PARTS"); return e ? atoi(e) : 0; }();
+    // FAR3D_ATTN_F32_PARTS (read once; A/B): 10 * QB + NS picks a register-fed instantiation, 2 / 4 the staged kernel of rounds 5 / 6
+    const float* qf_ = (const float*)q; const float* kf_ = (const float*)k; const float* vf_ = (const float*)v;
+#define FAR3D_ATTN_DIRECT(QB_, NS_, QW_) launch_attn_f32_direct<QB_, NS_, QW_>(qf_, kf_, vf_, out, out_dt, Aq, Nk, heads, ldq, ldk, ldv, ldo, scale, \
+                                                                              (const int*)hole_count, hole_start, hole_end, st)
+    // measured at 1544 x 2312 x 8 heads (profiles/r6/attn_f32_ab.txt): staged 4 parts 80 us; register-fed with expf 75; with the one-fma
+    // exp2 62-63 in every shape tried (2 x 4, 1 x 4, 1 x 8 with 64 queries per wave) -- the exact-fp32 MFMA runs at the VECTOR fp32 rate
+    // (MI355X guide) and shares its time with the softmax's VALU work; 200-392 workgroups on 256 CUs leave a quarter of the chip idle
+    if (parts == 0 || parts == 24) FAR3D_ATTN_DIRECT(2, 4, 1);
+    else if (parts == 14) FAR3D_ATTN_DIRECT(1, 4, 1);
+    else if (parts == 118) FAR3D_ATTN_DIRECT(1, 8, 2);      // 64 queries per wave
+#undef FAR3D_ATTN_DIRECT
+    else if (parts == 4) {
       constexpr int lds = 4 * (ATT_KT * ACfg<float>::KROW + ATT_KT * ACfg<float>::VROW);
       static std::atomic<unsigned long long> lds_ok{0};
       if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<float, 4>), lds, lds_ok, "far3d_attention_forward")) return rc;
       hipLaunchKernelGGL((attn_fwd_kernel<float, 4>), grid, dim3(512), lds, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                          Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
     } else {
+      FAR3D_CHECK_ARG(parts == 2, "far3d_attention_forward: FAR3D_ATTN_F32_PARTS=%d names no fp32 instantiation", parts);
       hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                          Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
     }

@@ -4,7 +4,7 @@
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
-int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st);     // igemm_pair.hip (exact fp32 on the pipelined kernel, tiles 482-486)
+int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st);     // igemm_pair.hip (exact fp32 on the pipelined kernel, tiles 482-494)
 int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 3x3, tiles 400-459)
 
 #ifdef FAR3D_PROFILING
@@ -108,9 +108,9 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
     return FAR3D_OK;
   }
-  // fp32 rows x fp32 weights, 1x1, explicit tiles 482-486: EXACT fp32 MFMA on the pipelined LDS-DMA kernel (far3d_amd.ops.linear picks them
+  // fp32 rows x fp32 weights, 1x1, explicit tiles 482-494: EXACT fp32 MFMA on the pipelined LDS-DMA kernel (far3d_amd.ops.linear picks them
   // for the decoder-sized GEMMs; tile 0 keeps the register-staged kernel, which takes every shape)
-  if (tile >= 482 && tile <= 486) {
+  if (tile >= 482 && tile <= 494) {
     FAR3D_CHECK_ARG(x_dt == FAR3D_DT_F32 && w_dt == FAR3D_DT_F32 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cin % 32 == 0 && !chan_sums &&
                     aligned(x, 16) && ldx % 4 == 0 && x_img_stride % 4 == 0 && ((long)(N - 1) * x_img_stride + (long)Ho * Wo * ldx) * 4 < 0x7fffffffL,
                     "far3d_conv2d_nhwc: tile %d (exact fp32 on the pipelined kernel) needs fp32 rows and fp32 weights, a 1x1 / stride 1 layer, Cin %% 32 == 0 "

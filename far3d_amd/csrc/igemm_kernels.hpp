@@ -1310,17 +1310,26 @@ __device__ __forceinline__ void gemm_step_exact_f32(const unsigned char* smem, c
 
 // F32B: the activations are fp32 rows handed over as if pair-stored (the caller doubles ldx / x_img_stride: same bytes), weights pre-split.
 // F32X: fp32 rows on both sides, exact fp32 MFMA (gemm_step_exact_f32); instantiated with NT = 3, PAIR = true, F32B = true for the byte geometry.
-template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false, bool F32X = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {
+// KS (round 6, F32X only): K groups INSIDE the workgroup.  The exact-fp32 MFMA runs a 32 x 32 tile through 32 floats of K in 1 024 cycles, so
+// a wave that owns a tile over K = 1 024 is a 33 k-cycle serial chain (16 us) however idle the chip is -- and the decoder's GEMMs (1 544
+// rows) hand out 100-400 tiles to 1 024 SIMDs.  With KS > 1 the workgroup has KS x WGM x WGN waves: group kg takes the K steps kg, kg + KS,
+// ... of the SAME output tile through its own LDS ring (the groups share nothing but the workgroup barriers), the groups' partial tiles are
+// added in group order through LDS and group 0 runs the epilogue.  Which K steps a group takes depends on K and KS alone: a row's bits do
+// not depend on the number of rows in the launch (the query-sharded decoder reproduces the replicated one).
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false, bool F32X = false, int KS = 1>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void gemm1x1_pipe_kernel(IgemmParams P, int npt, int nct) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NW = WGM * WGN;
+  constexpr int NW = WGM * WGN;                                 // waves of one K group
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   constexpr int GA = BM / 16, GB = BP / 16;                     // 1 KB DMA pieces per 32-channel sub-tile
   constexpr int AW = (GA + NW - 1) / NW, BW = (GB + NW - 1) / NW;
   constexpr bool A_EXACT = GA % NW == 0, B_EXACT = GB % NW == 0;
   constexpr int SUB = (BM + BP) * 64, STAGE = 2 * SUB;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  static_assert(KS == 1 || F32X, "K groups: the exact fp32 mode only");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_all[];
+  const int t = threadIdx.x, lane = t & 63, wv_all = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kg = KS > 1 ? wv_all / NW : 0, wv = KS > 1 ? wv_all % NW : wv_all;
+  unsigned char* const smem = smem_all + kg * (NS * STAGE);     // this group's ring
   const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
   // XCD-aware numbering: id % 8 = XCD; inside an XCD channel tiles are consecutive for a fixed pixel tile
   const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
@@ -1365,7 +1374,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
 #pragma unroll
     for (int sidx = 0; sidx < 2; ++sidx) {
       if (sidx >= nsubs) break;
-      const int kb = (2 * step + sidx) * KSTR;               // bytes along K
+      const int kb = (2 * (step * KS + kg) + sidx) * KSTR;   // bytes along K (step: the group's own step count)
 #pragma unroll
       for (int i = 0; i < AW; ++i) {
         const int g = wv + NW * i;
@@ -1412,7 +1421,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
     }
   }
   // sub-tiles of 64 bytes along K: NT 1: one per 32 channels, a step takes two; NT 3: the hi and lo plane of one 32-channel block
-  const int nsub = NT == 3 ? P.cin_pad / 16 : P.cin_pad / 32, nfull = nsub >> 1, tail = nsub & 1;   // full steps + an optional half one
+  const int nsub = NT == 3 ? P.cin_pad / 16 : P.cin_pad / 32;
+  const int nfull_all = nsub >> 1, tail = KS > 1 ? 0 : (nsub & 1);   // full steps + an optional half one (F32X: whole blocks only)
+  const int nfull = KS > 1 ? (nfull_all - kg + KS - 1) / KS : nfull_all;      // this group's steps
   constexpr int D = NS - 1;                     // steps in flight ahead of the one being computed
   constexpr int UNIT = AW + BW;                 // LDS-DMA instructions of one 32-channel sub-tile, per wave
   static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -1471,8 +1482,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_pipe_kernel(IgemmParam
   }
 #undef FAR3D_GEMM_STEP
 #undef FAR3D_GEMM_SYNC
+  if constexpr (KS > 1) {
+    // every wave passes the same number of barriers (the groups' step counts differ by at most one), then the rings are dead: partial
+    // tiles of groups 1 .. KS-1 -> LDS [group][wave][tile register][lane], group 0 adds them in group order and stores
+    if (nfull < (nfull_all + KS - 1) / KS) __builtin_amdgcn_s_barrier();
+    __syncthreads();
+    constexpr int PART = WM * WN * 16 * 64;
+    float* red = reinterpret_cast<float*>(smem_all);
+    if (kg > 0) {
+      float* dst = red + ((kg - 1) * NW + wv) * PART + lane;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((i * WN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float* src = red + ((g - 1) * NW + wv) * PART + lane;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * WN + j) * 16 + r) * 64];
+    }
+  }
   if constexpr (FAR3D_ABLATE & 1) { ablate_epilogue<WM, WN>(P, acc); return; }
-  if (P.y_rows16) {
+  if (KS == 1 && P.y_rows16) {
     constexpr int RING = NS * 2 * (BM + BP) * 64, OUTB = BP * (BM * (PAIR ? 4 : 2) + 16);
     int ep_n0, ep_r0;
     pix_split((long)p0, HoWo, ep_n0, ep_r0);
@@ -1498,22 +1538,28 @@ static bool gemm_sums_ok(const IgemmParams& P, size_t lds_sums) {
   return true;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false, bool F32X = false>
+template <int WGM, int WGN, int WM, int WN, int NT = 1, bool PAIR = false, int NS = 2, bool F32B = false, bool F32X = false, int KS = 1>
 static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
   const long Npix = (long)P.N * P.Ho * P.Wo;
   const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
-  constexpr size_t lds_ring = (size_t)NS * 2 * (BM + BP) * 64, lds_out = (size_t)BP * (BM * (PAIR ? 4 : 2) + 16);
+  constexpr size_t lds_part = (size_t)(KS - 1) * WGM * WGN * WM * WN * 4096;      // K groups: the partial tiles of groups 1 .. KS-1
+  constexpr size_t lds_ring = (size_t)KS * NS * 2 * (BM + BP) * 64 > lds_part ? (size_t)KS * NS * 2 * (BM + BP) * 64 : lds_part;
+  constexpr size_t lds_out = KS > 1 ? 0 : (size_t)BP * (BM * (PAIR ? 4 : 2) + 16);
   static_assert(lds_ring <= 163840, "LDS budget");
+  static_assert(64 * WGM * WGN * KS <= 1024, "workgroup size");
   constexpr size_t lds0 = lds_ring > lds_out ? lds_ring : lds_out, lds_sums = lds0 + 2 * BM * sizeof(long long);
+  if constexpr (KS > 1) {
+    if (P.chan_sums) { far3d_set_error("far3d_conv2d_nhwc: the K-group tiles of the exact-fp32 GEMM take no channel sums"); return FAR3D_ERR_ARG; }
+  }
   const size_t lds = P.chan_sums ? lds_sums : lds0;
   if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return FAR3D_ERR_ARG;
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds_sums > 65536)
-    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X>),
+    if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X, KS>),
                                        (int)(lds_sums <= 163840 ? lds_sums : lds0), lds_ok, "far3d_conv2d_nhwc")) return rc;
   const unsigned blocks = (unsigned)((npt + 7) / 8 * 8) * (unsigned)nct;
-  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X>), dim3(blocks), dim3(64 * WGM * WGN), lds, st, P, npt, nct);
+  hipLaunchKernelGGL((gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X, KS>), dim3(blocks), dim3(64 * WGM * WGN * KS), lds, st, P, npt, nct);
   return 0;
 }
 

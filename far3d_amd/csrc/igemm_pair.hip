@@ -105,7 +105,7 @@ int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st) {
 }
 
 // fp32 activation rows x fp32 weight rows, EXACT fp32 MFMA on the pipelined GEMM kernel (F32X; 1x1 / stride 1, Cin % 32 == 0; P.ldx and
-// P.x_img_stride doubled by the caller: the kernel counts bf16-sized units).  Tile ids 482-486.
+// P.x_img_stride doubled by the caller: the kernel counts bf16-sized units).  Tile ids 482-494.
 int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st) {
   switch (tile) {
     case 482: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 2, true, true>(P, st);   // 64 x 64, 4 waves, 2 stages
@@ -113,8 +113,17 @@ int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st) {
     case 484: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true, 3, true, true>(P, st);   // 128 x 128, 8 waves, 3 stages
     case 485: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true, 2, true, true>(P, st);   // 128 x 128, 16 waves, 2 stages
     case 486: return launch_gemm1x1_pipe<2, 4, 1, 1, 3, true, 2, true, true>(P, st);   // 64 x 128, 8 waves, 2 stages
+    // K groups inside the workgroup (igemm_kernels.hpp, KS): (channels x rows) tile, waves = groups x waves per group
+    case 487: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 2, true, true, 2>(P, st);   // 64 x 64, 2 groups x 4 waves
+    case 488: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 2, true, true, 4>(P, st);   // 64 x 64, 4 groups x 4 waves
+    case 489: return launch_gemm1x1_pipe<1, 2, 1, 1, 3, true, 2, true, true, 4>(P, st);   // 32 x 64, 4 groups x 2 waves
+    case 490: return launch_gemm1x1_pipe<2, 1, 1, 1, 3, true, 2, true, true, 4>(P, st);   // 64 x 32, 4 groups x 2 waves
+    case 491: return launch_gemm1x1_pipe<1, 1, 1, 1, 3, true, 2, true, true, 4>(P, st);   // 32 x 32, 4 groups x 1 wave
+    case 492: return launch_gemm1x1_pipe<1, 1, 1, 1, 3, true, 2, true, true, 8>(P, st);   // 32 x 32, 8 groups x 1 wave
+    case 493: return launch_gemm1x1_pipe<1, 2, 1, 1, 3, true, 2, true, true, 2>(P, st);   // 32 x 64, 2 groups x 2 waves
+    case 494: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true, 3, true, true, 2>(P, st);   // 64 x 64, 2 groups x 4 waves, 3 stages
     default: break;
   }
-  far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for exact-fp32 rows on the pipelined kernel (482-486)", tile);
+  far3d_set_error("far3d_conv2d_nhwc: tile %d is not available for exact-fp32 rows on the pipelined kernel (482-494)", tile);
   return FAR3D_ERR_ARG;
 }

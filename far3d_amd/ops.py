@@ -423,10 +423,23 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
     return out
 
 
-# linear(): tile for fp32 rows x fp32 weights (exact fp32 MFMA on the pipelined GEMM kernel, far3d_hip.h tiles 482-486); 0 = the
-# register-staged kernel of rounds 1-5.  482 = 64 x 64, 2 stages: the fastest of 482-486 on every decoder shape (tools/probe/f32x_gemm_ab.py,
-# profiles/r6/f32x_gemm_ab.txt)
+# linear(): tile for fp32 rows x fp32 weights (exact fp32 MFMA on the pipelined GEMM kernel, far3d_hip.h tiles 482-494); 0 = the
+# register-staged kernel of rounds 1-5.  482 = 64 x 64, 2 stages: the fastest of 482-486 on every decoder shape; 487-494 split K between
+# wave groups INSIDE the workgroup (a 32 x 32 tile over K = 1 024 is a 16 us serial MFMA chain however idle the chip is): 493 (32 x 64, 2
+# groups) wins the K <= 512 shapes of up to 768 columns, 489 (32 x 64, 4 groups) the K = 1 024 one, 482 stays for >= 1 024 columns where
+# the tiles already fill the chip (tools/probe/f32x_gemm_ab.py, profiles/r6/f32x_gemm_ab.txt).
 F32X_LINEAR_TILE = 482
+
+
+def f32x_linear_tile(cout, K):
+    """The exact-fp32 tile of linear() for a (cout, K) weight.  A function of the WEIGHT's shape only, never of the number of rows: the
+    tile fixes the order in which a row's products are added, and the query-sharded decoder (row subsets) reproduces the replicated one
+    bit for bit."""
+    if not F32X_LINEAR_TILE:
+        return 0
+    if K >= 1024:
+        return 489
+    return F32X_LINEAR_TILE if cout >= 1024 else 493
 SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
 # GEMM tiles that exist AND leave LDS for the channel-sum scratch (114 / 115 fill the 160 KB with their ring; 118 / 119 are no kernels)
 _GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | {279, 280}
@@ -477,7 +490,7 @@ def linear(x, pc, act=None, res=None, out=None, out_dtype=torch.float32, tile=0)
         # exact fp32 on the LDS-DMA pipelined kernel (round 6): the GEMMs of the fp32 / in-tolerance engines' decoder and FarHead.  The
         # choice must NOT depend on the number of rows: the query-sharded decoder launches row subsets and has to reproduce the replicated
         # decoder bit for bit (a row's bits depend on the kernel, not on which rows share its launch)
-        tile = F32X_LINEAR_TILE
+        tile = f32x_linear_tile(pc.Cout, x.shape[1])
     conv2d_nhwc(xv, pc, out=ov, act=act, res=rv, tile=tile)
     return out
 

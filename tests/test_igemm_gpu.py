@@ -283,12 +283,13 @@ def test_fp32_rows_on_the_pipelined_gemm_kernel(hip_lib, tile, shape, epilogue):
     assert err < bound, (err, bound)
 
 
-@pytest.mark.parametrize("tile", [482, 483, 484, 485, 486])
+@pytest.mark.parametrize("tile", [482, 483, 484, 485, 486, 487, 488, 489, 490, 491, 492, 493, 494])
 @pytest.mark.parametrize("shape", [(1544, 256, 256), (333, 96, 200), (2568, 1024, 256), (70, 32, 40), (1544, 512, 455)])
 @pytest.mark.parametrize("epilogue", ["plain", "relu_residual_strided"])
 def test_exact_fp32_on_the_pipelined_gemm_kernel(hip_lib, tile, shape, epilogue):
     """fp32 rows x fp32 weights on the LDS-DMA pipelined GEMM kernel with the EXACT fp32 MFMA (tiles 482-486, round 6: the decoder /
-    FarHead GEMMs of the in-tolerance and fp32 engines).  Exact products, fp32 accumulation: fp32 rounding noise against float64, and
+    FarHead GEMMs of the in-tolerance and fp32 engines; 487-494: K groups inside the workgroup, partial tiles added in group order -- K of
+    one step leaves groups without work, K of three steps uneven ones).  Exact products, fp32 accumulation: fp32 rounding noise against float64, and
     within that noise of the register-staged exact kernel (tile 0) -- only the summation order differs.  Ragged M / N, K of one to 32
     steps, strided rows, residual + activation through the generic epilogue; asymmetric operands (a transposed fragment would show)."""
     from far3d_amd import ops
@@ -311,6 +312,10 @@ def test_exact_fp32_on_the_pipelined_gemm_kernel(hip_lib, tile, shape, epilogue)
     bound = 8 * 2.0 ** -24 * Kd ** 0.5 * max(1.0, want.abs().max().item()) + 4 * 2.0 ** -24 * Kd * scale
     assert (got.double() - want).abs().max().item() < bound, ((got.double() - want).abs().max().item(), bound)
     assert (got - old).abs().max().item() < bound
+    if epilogue == "plain" and M > 200:
+        # a row's bits depend on the tile and on K, not on which rows share the launch (the query-sharded decoder launches row subsets)
+        sub = ops.linear(xd[37:37 + 130], pc, tile=tile).cpu()
+        assert torch.equal(sub, got[37:37 + 130])
 
 
 def test_split_mode_rejects_bf16_operands(hip_lib):

@@ -1,4 +1,4 @@
-"""A/B of the exact-fp32 pipelined GEMM tiles (482-486) against the register-staged exact kernel (tile 3 / auto) and the split-product
+"""A/B of the exact-fp32 pipelined GEMM tiles (482-486; 487-494 = K groups inside the workgroup) against the register-staged exact kernel (tile 3 / auto) and the split-product
 fp32-row tiles (479-481, bf16x3 arithmetic) on the decoder's GEMM shapes; and of the fp32 attention core with 2 / 4 key parts
 (FAR3D_ATTN_F32_PARTS, read once per process: run twice)."""
 import os, sys
@@ -34,7 +34,7 @@ for name, M, K, N in SHAPES:
     pcs = ops.PackedConv(w, b, dtype=torch.float32, device=dev, compute="bf16x3")
     out = torch.empty(M, N, device=dev)
     line = "%-9s M=%5d K=%4d N=%4d |" % (name, M, K, N)
-    for tile in (3, 1, 482, 483, 484, 485, 486):
+    for tile in (3, 482, 486, 487, 488, 489, 490, 491, 492, 493, 494):
         line += " t%d %5.1f us |" % (tile, timeit(lambda: ops.linear(x, pc, out=out, tile=tile)))
     line += " split(bf16x3) t480 %5.1f us |" % timeit(lambda: ops.linear(x, pcs, out=out, tile=480))
     print(line, flush=True)
