@@ -12,7 +12,7 @@
 // bf16 MFMA A-fragment is ONE ds_read_b128); the next tile's global loads are in flight during the MFMAs.
 // T = bf16: v_mfma_f32_32x32x16_bf16.  T = float: exact-fp32 v_mfma_f32_32x32x2_f32 (parity mode).
 #include "common.hpp"
-#include <stdlib.h>
+#include <atomic>
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
@@ -451,6 +451,13 @@ static void launch_attn_f32_direct(const float* q, const float* k, const float* 
                      ldk, ldv, ldo, scale, hole_count, hole_start, hole_end);
 }
 
+// A/B switch of the fp32 instantiation (far3d_attention_f32_variant; tools/probe/attn_f32_ab.py): 0 = default
+static std::atomic<int> g_attn_f32_variant{0};
+extern "C" int far3d_attention_f32_variant(int variant) {
+  if (variant < 0) return g_attn_f32_variant.load(std::memory_order_relaxed);
+  return g_attn_f32_variant.exchange(variant, std::memory_order_relaxed);
+}
+
 extern "C" int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq,
                                        int Nk, int heads, int head_dim, int ldq, int ldk, int ldv, int ldo,
                                        float scale, const int32_t* hole_count, int hole_start, int hole_end, void* stream) {
@@ -473,8 +480,9 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
   if (dtype == FAR3D_DT_F32) {
     // fp32 (the in-tolerance engine's decoder): the register-fed kernel (attn_f32_direct_kernel) since round 6; the staged kernel with 4
     // key parts (its four fp32 K / V tile pairs, 72 KB, are dynamic LDS) or 2 (round 5) stays selectable for A/B.
-    static const int parts = [] { const char* e = getenv("FAR3D_ATTN_F32_PARTS"); return e ? atoi(e) : 0; }();
-    // FAR3D_ATTN_F32_PARTS (read once; A/B): 10 * QB + NS picks a register-fed instantiation, 2 / 4 the staged kernel of rounds 5 / 6
+    // far3d_attention_f32_variant (A/B): 0 the default; 10 * QB + NS (+ 100: 64 queries per wave) a register-fed instantiation; 2 / 4 the
+    // staged kernel with that many key parts (round 5 / earlier in round 6)
+    const int parts = g_attn_f32_variant.load(std::memory_order_relaxed);
     const float* qf_ = (const float*)q; const float* kf_ = (const float*)k; const float* vf_ = (const float*)v;
 #define FAR3D_ATTN_DIRECT(QB_, NS_, QW_) launch_attn_f32_direct<QB_, NS_, QW_>(qf_, kf_, vf_, out, out_dt, Aq, Nk, heads, ldq, ldk, ldv, ldo, scale, \
                                                                               (const int*)hole_count, hole_start, hole_end, st)
@@ -492,7 +500,7 @@ extern "C" int far3d_attention_forward(const void* q, const void* k, const void*
       hipLaunchKernelGGL((attn_fwd_kernel<float, 4>), grid, dim3(512), lds, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                          Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
     } else {
-      FAR3D_CHECK_ARG(parts == 2, "far3d_attention_forward: FAR3D_ATTN_F32_PARTS=%d names no fp32 instantiation", parts);
+      FAR3D_CHECK_ARG(parts == 2, "far3d_attention_forward: far3d_attention_f32_variant(%d) names no fp32 instantiation", parts);
       hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, out, out_dt,
                          Aq, Nk, ldq, ldk, ldv, ldo, scale, (const int*)hole_count, hole_start, hole_end);
     }

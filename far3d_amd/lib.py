@@ -36,6 +36,7 @@ SIGNATURES = {
                           [c_long] + [c_int] * 5 + [_p, c_int, c_int, c_long, c_int, c_int] +
                           [_p, c_int, c_int, c_long, _p, _p, _p, c_int, _p]),
     "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p, c_int] + [c_int] * 8 + [c_float, _p, c_int, c_int, _p]),
+    "far3d_attention_f32_variant": (c_int, [c_int]),
     "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, c_int, _p]),
     "far3d_rowchain_attn_out": (c_int, [_p, c_int, _p, c_int, _p, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_int, _p, c_int,
                                         c_int, c_float, _p]),

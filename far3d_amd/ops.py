@@ -647,6 +647,11 @@ def rowchain_branches(h, rb, cls_out, reg_out, eps=1e-5):
 # --------------------------------------------------------------------------------------------------
 # attention / normalisation / pooling
 # --------------------------------------------------------------------------------------------------
+def attention_f32_variant(variant=-1):
+    """A/B switch of the fp32 attention instantiation (include/far3d_hip.h); returns the previous value, -1 only reads."""
+    return _lib.load().far3d_attention_f32_variant(int(variant))
+
+
 def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32, hole=None):
     """softmax(q k^T / sqrt(d)) v per head.  q (Aq,E), k/v (Nk,E) f32|bf16 with unit inner stride; out (Aq,E) f32.
     hole: keys [start + count, end) are masked (see _hole)."""

@@ -145,9 +145,12 @@ int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, v
  *    x_dt = FAR3D_DT_F32 with w_dt = FAR3D_DT_F32_BF16X3, 1x1/s1, Cin % 32 == 0, x 16-byte aligned with strides that are multiples
  *    of 4 floats: 479-481 (auto) the pipelined GEMM kernel on fp32 rows -- 32 floats are the 128 bytes of a pair-stored block, so
  *    the LDS-DMA pattern is the pair kernel's and the hi / lo split of the rows happens in registers (same three products).
- *    x_dt = w_dt = FAR3D_DT_F32, 1x1/s1, Cin % 32 == 0, same alignment: 482-486 the pipelined GEMM kernel with the EXACT fp32 MFMA
+ *    x_dt = w_dt = FAR3D_DT_F32, 1x1/s1, Cin % 32 == 0, same alignment: 482-494 the pipelined GEMM kernel with the EXACT fp32 MFMA
  *    (v_mfma_f32_32x32x2_f32) on fp32 rows of both operands -- exact products, fp32 accumulation, another summation order than the
- *    register-staged kernel (tiles 1-5); 482 / 483 64 x 64 (2 / 4 LDS stages), 484 / 485 128 x 128, 486 64 x 128.
+ *    register-staged kernel (tiles 1-5); 482 / 483 64 x 64 (2 / 4 LDS stages), 484 / 485 128 x 128, 486 64 x 128; 487-494 split K
+ *    between 2-8 wave groups INSIDE the workgroup (each group its own LDS ring, partial tiles added in group order through LDS):
+ *    487 / 488 / 494 64 x 64 (2 / 4 / 2 groups), 489 / 493 32 x 64 (4 / 2), 490 64 x 32 (4), 491 / 492 32 x 32 (4 / 8).  The bits
+ *    of an output row depend on the tile and on Cin only, never on the number of rows in the call.
  *    3x3/s1/p1, Cin % 32 == 0, Cout % 32 == 0, same storage in and out, 16-byte aligned rows, NO res / y2 / chan_sums: the PERSISTENT
  *    wave-specialised kernel (csrc/conv_ws.hpp: producer waves issue every LDS-DMA, consumer waves only read LDS and run MFMAs, one
  *    workgroup per CU walks several tiles, 16-byte stores straight from the MFMA registers) -- pair storage 400-417 (one hand-over
@@ -172,7 +175,7 @@ int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const fl
  *   (ref cfg projects/configs/far3d.py:112-116; call site models/utils/detr3d_transformer.py:385-394; in-tree
  *   statement of the wrapper models/utils/petr_transformer.py:286-326).  The in/out projections are
  *   far3d_conv2d_nhwc calls.
- * q (Aq, heads*32), k/v (Nk, heads*32) of `dtype` (F32 -> exact fp32 MFMA, BF16 -> bf16 MFMA), row strides
+ * q (Aq, heads*32), k/v (Nk, heads*32) of `dtype` (F32 -> exact fp32 MFMA fed from registers, BF16 -> bf16 MFMA), row strides
  * ldq/ldk/ldv elements; out (Aq, heads*32) of dtype out_dt (f32 | bf16), row stride ldo.  head_dim must be 32.
  * The one mask of the inference path -- the "query hole" of the fixed-capacity proposal mode (see FAR3D "hole" below): with
  * hole_count != NULL (DEVICE int32) the keys [hole_start + *hole_count, hole_end) are excluded from every softmax; their K / V
@@ -180,6 +183,12 @@ int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_dt, const fl
 int far3d_attention_forward(const void* q, const void* k, const void* v, int dtype, void* out, int out_dt, int Aq, int Nk,
                             int heads, int head_dim, int ldq, int ldk, int ldv, int ldo, float scale,
                             const int32_t* hole_count, int hole_start, int hole_end, void* stream);
+
+/* A/B switch for the fp32 instantiation far3d_attention_forward launches (process-wide; tools/probe/attn_f32_ab.py): 0 = the default
+ * (register-fed kernel, 64-query workgroups x 4 key parts), 14 / 118 other shapes of it, 4 / 2 the LDS-staged kernel of earlier rounds.
+ * Returns the previous value; variant < 0 only reads.  Every variant computes the same products in fp32 (the summation order and
+ * the exp differ at the last bit). */
+int far3d_attention_f32_variant(int variant);
 
 /* y = act(LayerNorm_C(x) * gamma + beta); optional y2 = y + add (next GEMM's "query + query_pos").
  * Replaces nn.LayerNorm at ref models/utils/detr3d_transformer.py:304-307,398-400,506-512 and

@@ -23,14 +23,20 @@ def _mha_core(q, k, v, H):
     return (p @ vh).transpose(0, 1).reshape(Aq, E)
 
 
+@pytest.mark.parametrize("variant", [0, 14, 118, 4, 2])      # 0: the default (register-fed kernel); 14 / 118 its other shapes; 4 / 2 the LDS-staged kernel
 @pytest.mark.parametrize("Aq,Nk", [(37, 50), (128, 64), (300, 333), (1544, 2312)])
-def test_attention_fp32_exact_mode(hip_lib, Aq, Nk):
+def test_attention_fp32_exact_mode(hip_lib, Aq, Nk, variant):
     from far3d_amd import ops
     g = torch.Generator().manual_seed(Aq)
     q, k, v = (torch.randn(n, 256, generator=g) for n in (Aq, Nk, Nk))
     q = q * 2.0   # make the softmax peaky enough to exercise the running-max rescale
     want = _mha_core(q, k, v, 8)
-    got = ops.attention_forward(q.to(DEV), k.to(DEV), v.to(DEV)).cpu()
+    prev = ops.attention_f32_variant(variant)
+    try:
+        got = ops.attention_forward(q.to(DEV), k.to(DEV), v.to(DEV)).cpu()
+    finally:
+        ops.attention_f32_variant(prev)
+    assert ops.attention_f32_variant() == prev
     assert (got - want).abs().max().item() < 2e-5
 
 

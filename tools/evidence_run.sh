@@ -25,7 +25,7 @@ timeout 400 python tools/probe/ws_conv_ab.py pair 5 > $O/ws_ab_pair.txt 2>&1
 [ -f far3d_amd/libfar3d_hip_prof.so ] && timeout 200 python tools/conv_phase_times.py 2>/dev/null | grep tile > $O/conv_phase_times.txt
 # the exact-fp32 decoder of the in-tolerance engine: GEMM tiles (482-494: K groups inside the workgroup) and the fp32 attention kernels
 timeout 250 python tools/probe/f32x_gemm_ab.py 2>/dev/null | grep -v amdgpu.ids > $O/f32x_gemm_ab.txt
-bash tools/probe/attn_f32_ab.sh 2>/dev/null | grep -v amdgpu.ids > $O/attn_f32_ab.txt
+timeout 200 python tools/probe/attn_f32_ab.py 2>/dev/null | grep -v amdgpu.ids > $O/attn_f32_ab.txt
 timeout 200 python tools/topk_phase_times.py --shipped 2>/dev/null | grep -v amdgpu.ids > $O/topk_phase_times_final.txt
 cd /tmp && export TMPDIR=/tmp
 # the per-kernel statistics come from frames that run ONE AT A TIME (sync-per-frame region + --no-pipeline for the back-to-back region): with

@@ -1,6 +1,5 @@
 """A/B of the exact-fp32 pipelined GEMM tiles (482-486; 487-494 = K groups inside the workgroup) against the register-staged exact kernel (tile 3 / auto) and the split-product
-fp32-row tiles (479-481, bf16x3 arithmetic) on the decoder's GEMM shapes; and of the fp32 attention core with 2 / 4 key parts
-(FAR3D_ATTN_F32_PARTS, read once per process: run twice)."""
+fp32-row tiles (479-481, bf16x3 arithmetic) on the decoder's GEMM shapes (the fp32 attention core: tools/probe/attn_f32_ab.py)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -38,7 +37,3 @@ for name, M, K, N in SHAPES:
         line += " t%d %5.1f us |" % (tile, timeit(lambda: ops.linear(x, pc, out=out, tile=tile)))
     line += " split(bf16x3) t480 %5.1f us |" % timeit(lambda: ops.linear(x, pcs, out=out, tile=480))
     print(line, flush=True)
-q = torch.randn(1544, 256, device=dev); k = torch.randn(2312, 256, device=dev); v = torch.randn(2312, 256, device=dev)
-o = torch.empty(1544, 256, device=dev)
-print("attention fp32, 1544 x 2312 x 8 heads, FAR3D_ATTN_F32_PARTS=%s: %.1f us" %
-      (os.environ.get("FAR3D_ATTN_F32_PARTS", "4 (default)"), timeit(lambda: ops.attention_forward(q, k, v, num_heads=8, out=o))), flush=True)
