@@ -45,6 +45,8 @@ int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
     case 452: return launch_conv3x3_ws<2, 4, 1, 2, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 8 rows, ring of 3 rows (160 KB)
     case 453: return launch_conv3x3_ws<1, 8, 2, 1, 4, true, true, 6, false, 3>(P, st);   // 64 ch x 8 rows (Cout 64), ring of 2 rows
     case 454: return launch_conv3x3_ws<1, 8, 2, 1, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 8 rows (Cout 64), ring of 3 rows
+    case 455: return launch_conv3x3_ws<1, 7, 2, 1, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 7 rows: stage 4's 40 rows = 6 x 7 -> 252 items on 256 CUs
+    case 456: return launch_conv3x3_ws<2, 7, 1, 1, 2, true, true, 9, false, 3>(P, st);   // 64 ch x 7 rows, 14 consumers of 32 ch x 1 row + 2 producers
     case 457: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 6, false, 3>(P, st);   // 64 ch x 4 rows, 4 consumers + 2 producers
     case 458: return launch_conv3x3_ws<1, 4, 3, 1, 2, true, true, 6, false, 3>(P, st);   // 96 ch x 4 rows, 4 consumers + 2 producers
     case 459: return launch_conv3x3_ws<2, 4, 1, 1, 4, true, true, 9, false, 3>(P, st);   // 64 ch x 4 rows, 8 consumers of 32 ch x 1 row, ring of 3 rows

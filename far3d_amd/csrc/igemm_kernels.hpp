@@ -326,7 +326,9 @@ __device__ __forceinline__ void epilogue_rows16(const IgemmParams& P, unsigned c
                                                 int wm, int wn, int l31, int hi, PixFn pix_off, long sums_p0 = -1, int lsum_off = 0) {
   constexpr int EB = PO ? 4 : 2;                       // bytes per logical channel of a staged row
   constexpr int RS = BM * EB + 16, CPP = BM * EB / 16, NT = 64 * NW;
-  constexpr bool SUMS_OK = NT % CPP == 0;              // a thread keeps one 16-byte chunk column over its pixels (every GEMM tile)
+  // a thread keeps one 16-byte chunk column over its pixels, and the lanes of a wave that share a column are a power-of-two stride apart
+  // (every GEMM tile that takes sums; launch_gemm1x1_pipe refuses the others)
+  constexpr bool SUMS_OK = NT % CPP == 0 && (CPP & (CPP - 1)) == 0 && CPP <= 64;
   const bool do_sums = SUMS_OK && P.chan_sums != nullptr && sums_p0 >= 0;     // workgroup-uniform
   long long* lsum = reinterpret_cast<long long*>(smem + lsum_off);
   if (do_sums)
@@ -1554,6 +1556,13 @@ static int launch_gemm1x1_pipe(const IgemmParams& P, hipStream_t st) {
   }
   const size_t lds = P.chan_sums ? lds_sums : lds0;
   if (P.chan_sums && !gemm_sums_ok<BM, BP, 64 * WGM * WGN>(P, lds_sums)) return FAR3D_ERR_ARG;
+  {
+    constexpr int CPP = BM * (PAIR ? 4 : 2) / 16;        // 16-byte chunks of a staged output row (epilogue_rows16)
+    if (P.chan_sums && !((64 * WGM * WGN) % CPP == 0 && (CPP & (CPP - 1)) == 0 && CPP <= 64)) {
+      far3d_set_error("far3d_conv2d_nhwc: this tile's %d-channel rows do not take channel sums (power-of-two channel tiles only)", BM);
+      return FAR3D_ERR_ARG;
+    }
+  }
   static std::atomic<unsigned long long> lds_ok{0};
   if constexpr (lds_sums > 65536)
     if (const int rc = far3d_allow_lds(reinterpret_cast<const void*>(&gemm1x1_pipe_kernel<WGM, WGN, WM, WN, NT, PAIR, NS, F32B, F32X, KS>),

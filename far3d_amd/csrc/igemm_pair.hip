@@ -44,6 +44,14 @@ int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
       case 179: return launch_gemm1x1_pipe<4, 2, 1, 2, 3, true>(P, st);   // 128 x 128, 8 waves (1x2 tiles per wave)
       case 180: return launch_gemm1x1_pipe<2, 2, 1, 1, 3, true>(P, st);   // 64 x 64, 4 waves
       case 181: return launch_gemm1x1_pipe<4, 4, 1, 1, 3, true>(P, st);   // 128 x 128, 16 waves
+      // round 6: pixel tiles of 160 / 96 for the maps a 128-pixel grid leaves half empty (stage 5's 4 200 pixels x 1 024 channels are 264
+      // workgroups of 128 x 128 = 1.03 per CU; 128 x 160 is 216 -- one round: 64 -> 58 us; FPN lateral 1: 33 -> 29 us).  192-channel tiles
+      // for stage 4 (792 workgroups = 3.09 per CU) were measured too and are SLOWER than 128 x 128 (142-168 against 116-135 us,
+      // profiles/r6/tune_pair_fill_tiles.log): two co-resident workgroups per CU already even that grid out.
+      case 185: return launch_gemm1x1_pipe<2, 5, 2, 1, 3, true>(P, st);   // 128 x 160, 10 waves
+      case 186: return launch_gemm1x1_pipe<4, 1, 1, 5, 3, true>(P, st);   // 128 x 160, 4 waves of 32 ch x 160 px
+      case 187: return launch_gemm1x1_pipe<2, 3, 1, 1, 3, true>(P, st);   // 64 x 96, 6 waves
+      case 188: return launch_gemm1x1_pipe<1, 3, 2, 1, 3, true>(P, st);   // 64 x 96, 3 waves
       case 279: return launch_gemm1x1_pipe<4, 2, 1, 2, 1, true>(P, st);   // hi only: 128 x 128, 8 waves
       case 280: return launch_gemm1x1_pipe<2, 2, 1, 1, 1, true>(P, st);   // hi only: 64 x 64, 4 waves
       default: break;
@@ -67,6 +75,10 @@ int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st) {
       case 166: return launch_conv3x3_pipe<4, 4, 1, 1, 2, 1, 3, true>(P, st);   // 128 x 4 rows, 16 waves
       case 167: return launch_conv3x3_pipe<4, 2, 1, 1, 2, 1, 3, true>(P, st);   // 128 x 2 rows, 8 waves
       case 168: return launch_conv3x3_pipe<2, 4, 2, 1, 2, 1, 3, true>(P, st);   // 128 x 4 rows, 8 waves of 64 ch x 1 row
+      // 7 rows: stage 4's 40-row maps are 6 x 7 (252 workgroups of 64 channels on 256 CUs) instead of 5 x 8 (210)
+      case 169: return launch_conv3x3_pipe<2, 7, 1, 1, 2, 1, 3, true>(P, st);   // 64 x 7 rows, 14 waves
+      case 190: return launch_conv3x3_pipe<1, 7, 1, 1, 2, 1, 3, true>(P, st);   // 32 x 7 rows, 7 waves
+      case 198: return launch_conv3x3_pipe<1, 7, 2, 1, 2, 1, 3, true>(P, st);   // 64 x 7 rows, 7 waves of 64 ch x 1 row
       // 3-deep weight ring
       case 191: return launch_conv3x3_pipe<2, 4, 1, 1, 3, 1, 3, true>(P, st);   // 64 x 4 rows, 8 waves
       case 192: return launch_conv3x3_pipe<1, 8, 1, 1, 3, 1, 3, true>(P, st);   // 32 x 8 rows, 8 waves

@@ -442,7 +442,7 @@ def f32x_linear_tile(cout, K):
     return F32X_LINEAR_TILE if cout >= 1024 else 493
 SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
 # GEMM tiles that exist AND leave LDS for the channel-sum scratch (114 / 115 fill the 160 KB with their ring; 118 / 119 are no kernels)
-_GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | {279, 280}
+_GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | set(range(185, 189)) | {279, 280}
 _GEMM_TILE_PIXELS = 512  # no GEMM tile holds more pixels
 
 

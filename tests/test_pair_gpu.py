@@ -13,8 +13,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-TILES_3X3 = [0, 150, 152, 153, 154, 155, 157, 159, 160, 161, 162, 163, 164, 165, 166, 167, 168, 191, 192, 193, 197, 1, 3, 5]
-TILES_1X1 = [0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181, 2, 4]
+TILES_3X3 = [0, 150, 152, 153, 154, 155, 157, 159, 160, 161, 162, 163, 164, 165, 166, 167, 168, 169, 190, 198, 191, 192, 193, 197, 1, 3, 5]
+TILES_1X1 = [0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181, 185, 186, 187, 188, 2, 4]
 
 
 def _bound(K, x, w):
@@ -63,7 +63,7 @@ def test_pair_conv3x3_split_products(hip_lib, tile):
         assert (y32.cpu().permute(0, 3, 1, 2).double() - want).abs().max().item() < bound
 
 
-TILES_WS = [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413, 414, 415, 416, 417, 440, 444, 445, 450, 451, 452, 453, 454, 457, 458, 459]
+TILES_WS = [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413, 414, 415, 416, 417, 440, 444, 445, 450, 451, 452, 453, 454, 455, 456, 457, 458, 459]
 
 
 @pytest.mark.parametrize("tile", TILES_WS)

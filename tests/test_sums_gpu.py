@@ -40,7 +40,7 @@ def test_bf16_gemm_tiles_accumulate_exact_channel_sums(hip_lib, tile):
         assert torch.equal(sums.cpu(), 2 * _expected(y, Cout, False))
 
 
-@pytest.mark.parametrize("tile", [0, 170, 173, 179, 180, 181])
+@pytest.mark.parametrize("tile", [0, 170, 173, 179, 180, 181, 185, 186, 187, 188])
 def test_pair_gemm_tiles_accumulate_exact_channel_sums(hip_lib, tile):
     from far3d_amd import ops
     g = torch.Generator().manual_seed(300 + tile)
