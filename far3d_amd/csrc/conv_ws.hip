@@ -59,3 +59,29 @@ int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
   far3d_set_error("far3d_conv2d_nhwc: unknown wave-specialised tile %d", tile);
   return FAR3D_ERR_ARG;
 }
+
+// The wave-specialised persistent 1x1 GEMM on pair-stored maps (gemm1x1_ws_kernel), tile ids 460-479:
+// (consumer grid WGM x WGN, tiles per consumer WM x WN, producers, ring stages, steps per hand-over)
+int far3d_gemm_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
+  switch (tile) {
+    case 460: return launch_gemm1x1_ws<4, 2, 1, 2, 4, 4, 1>(P, st);   // 128 x 128: 8 consumers of 32 ch x 64 px + 4 producers, 4 stages (128 KB)
+    case 461: return launch_gemm1x1_ws<4, 2, 1, 2, 4, 4, 2>(P, st);   // 460 with a hand-over every 2 steps
+    case 462: return launch_gemm1x1_ws<2, 4, 2, 1, 4, 4, 2>(P, st);   // 128 x 128: 8 consumers of 64 ch x 32 px
+    case 463: return launch_gemm1x1_ws<2, 2, 2, 2, 4, 4, 2>(P, st);   // 128 x 128: 4 consumers of 64 x 64 + 4 producers
+    case 464: return launch_gemm1x1_ws<4, 2, 2, 2, 4, 3, 1>(P, st);   // 256 x 128: 8 consumers of 64 x 64, 3 stages of 48 KB
+    case 465: return launch_gemm1x1_ws<4, 2, 1, 2, 2, 4, 2>(P, st);   // 461 with 2 producers
+    case 466: return launch_gemm1x1_ws<2, 2, 1, 2, 4, 6, 3>(P, st);   // 64 x 128: 4 consumers of 32 ch x 64 px, 6 stages of 24 KB, hand-over every 3
+    case 467: return launch_gemm1x1_ws<2, 4, 1, 1, 4, 6, 2>(P, st);   // 64 x 128: 8 consumers of 32 x 32, 6 stages
+    case 468: return launch_gemm1x1_ws<2, 2, 1, 2, 2, 3, 1>(P, st);   // 64 x 128: 4 consumers + 2 producers, 3 stages (72 KB: 2 per CU)
+    case 469: return launch_gemm1x1_ws<4, 2, 1, 2, 4, 2, 1>(P, st);   // 460 with 2 stages (64 KB: 2 per CU)
+    case 470: return launch_gemm1x1_ws<2, 4, 2, 2, 4, 3, 1>(P, st);   // 128 x 256: 8 consumers of 64 x 64, 3 stages of 48 KB
+    case 471: return launch_gemm1x1_ws<2, 2, 4, 2, 4, 3, 1>(P, st);   // 256 x 128: 4 consumers of 128 ch x 64 px
+    case 473: return launch_gemm1x1_ws<4, 2, 2, 2, 2, 3, 1>(P, st);   // 464 with 2 producers
+    case 474: return launch_gemm1x1_ws<3, 2, 2, 2, 4, 3, 1>(P, st);   // 192 x 128: 6 consumers of 64 x 64, 3 stages of 40 KB
+    case 475: return launch_gemm1x1_ws<2, 2, 2, 2, 4, 4, 1>(P, st);   // 463 with a hand-over per step
+    case 476: return launch_gemm1x1_ws<2, 4, 2, 2, 2, 3, 1>(P, st);   // 470 with 2 producers
+    default: break;
+  }
+  far3d_set_error("far3d_conv2d_nhwc: unknown wave-specialised GEMM tile %d", tile);
+  return FAR3D_ERR_ARG;
+}

@@ -25,6 +25,7 @@
 // per k-half), so results are bit-identical to it (tests/test_igemm_gpu.py).
 #pragma once
 #include "igemm_kernels.hpp"
+#include <type_traits>
 
 // A buffer descriptor whose four words are PROVABLY wave-uniform (v_readfirstlane of the pointer halves and the size): hipcc otherwise keeps
 // a descriptor that lives across loop iterations in VGPRs and wraps every `buffer_load ... lds` that uses it in a waterfall loop
@@ -520,6 +521,462 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void conv3x3_ws_kernel(Igemm
   }
 #endif
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same division of labour for the 1x1 / stride 1 layers on pair-stored maps (the OSA concat GEMMs and the FPN laterals: 3.3 ms of the
+// in-tolerance frame at 260-330 useful TFLOP/s against the 3x3 layers' 395).  A GEMM has no patch to re-use: EVERY 32-channel step
+// brings (BM + BP) x 128 bytes through LDS-DMA, 32 pieces for a 128 x 128 tile, and in gemm1x1_pipe_kernel each of the 8 waves pays
+// the issue cost of its 4 pieces (100-185 cycles apiece among MFMAs and fragment reads, MI355X guide) on top of its 384 cycles of MFMA
+// work per step, then meets the others at a barrier.  Here NP producer waves issue all of them -- weights and activation rows into one
+// ring of NSW stages, GRP steps per hand-over -- and the consumers do what the 3x3 consumers do: fragments from LDS (two register sets,
+// skewed across the hand-over), MFMAs, a register epilogue with 16-byte stores.  The workgroup is persistent over (pixel tile, channel
+// tile) items in the XCD-aware order of gemm1x1_pipe_kernel; its steps form ONE stream across tiles (a hand-over group may straddle two
+// tiles).  Products and their order are those of gemm_step_split: bit-identical results.
+// Channel sums (P.chan_sums: the eSE pooling of the concat layers, fixed point as in epilogue_rows16 -- rint(v * 2^FRAC_BITS) of every
+// STORED hi and lo value, integer addition, so the result is bit-identical to every other tile's): a consumer sums its quantised values
+// over its WN sub-tiles per lane, over the 32 pixels of the half-wave on the VALU (four DPP row rotations + v_permlane16_swap; 32 bits
+// while every |v| < 64, else two 16-bit limbs), and lanes 0 / 32 add the wave's 16 WM channel sums into a per-workgroup LDS array
+// lsum[tile parity][image slot][BM] (64-bit LDS atomics).  Every consumer runs a tile's epilogue between the SAME two hand-over barriers and drains its LDS counter before a
+// barrier, so lsum[T & 1] is complete once the barrier that follows tile T's last step has passed: right behind it every consumer wave
+// flushes ITS slice of the array (one global atomic per non-zero (image, channel)) and zeroes it, long before tile T + 2 adds to it again
+// (a tile is >= 2 hand-over groups).  The producers stay out of it: an atomic in their vector-memory queue would break the counted
+// vmcnt their ring rests on.  No residual or second output: far3d_conv2d_nhwc refuses the tile for a call that needs them.
+template <int WGM, int WGN, int WM, int WN, int NP, int NSW, int GRP, bool SUMS>
+__global__ __launch_bounds__(64 * (WGM * WGN + NP)) void gemm1x1_ws_kernel(IgemmParams P, int npt, int nct, int ablate) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NWC = WGM * WGN;
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr int GA = BM / 16, GB = BP / 16, SLOTS = GA + GB;      // 1 KB DMA pieces per 64-byte plane of a step
+  static_assert(SLOTS % NP == 0, "every producer issues the same number of pieces per step (counted vmcnt)");
+  constexpr int SPW = SLOTS / NP;                                 // slots per producer wave and step; a slot = the hi and the lo piece
+  constexpr int SUB = (BM + BP) * 64, STAGE = 2 * SUB;            // a stage: [hi plane: A rows | B rows][lo plane: the same]
+  static_assert(NSW % GRP == 0 && NSW / GRP >= 2, "ring = at least two hand-over groups");
+  constexpr int NG = NSW / GRP;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int SUMB = NSW * STAGE;                               // lsum[2 tile parities][2 image slots][BM] int64 behind the ring
+  static_assert(SUMB + 4 * BM * 8 <= 163840, "LDS budget");
+  [[maybe_unused]] long long* const lsum = reinterpret_cast<long long*>(smem + SUMB);
+  constexpr bool do_sums = SUMS;                                  // a second instantiation: the sums cost ~25 VGPRs the plain kernel keeps
+  if (do_sums) {
+    for (int i = threadIdx.x; i < 4 * BM; i += 64 * (NWC + NP)) lsum[i] = 0;
+    __syncthreads();
+  }
+  const int HoWo = P.Ho * P.Wo;
+  const long Npix = (long)P.N * HoWo;
+  const int nsteps = P.cin_pad / 32;                              // steps per tile (pair storage: one 32-channel block = 2 planes)
+  const int Ktot = P.cin_pad * 2;
+  // items of this workgroup: L = blockIdx.x + k * gridDim.x (gridDim.x % 8 == 0), xcd = L & 7, slot = L >> 3, channel tile = slot % nct,
+  // pixel tile = (slot / nct) * 8 + xcd; the valid ones (pixel tile < npt) are the first my_items of the sequence
+  const int xcd = (int)blockIdx.x & 7, slot0 = (int)blockIdx.x >> 3, dslot = (int)gridDim.x >> 3;
+  const int vslots = ((npt - xcd + 7) >> 3) * nct;                // slots with a valid pixel tile on this XCD
+  const int my_items = vslots > slot0 ? (vslots - slot0 + dslot - 1) / dslot : 0;
+  const int total_steps = my_items * nsteps;
+  const int total_groups = (total_steps + GRP - 1) / GRP;
+  auto decode = [&](int k, int& p0, int& m0) __attribute__((always_inline)) {
+    const int slot = slot0 + k * dslot;
+    const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+    p0 = __builtin_amdgcn_readfirstlane(pt * BP); m0 = __builtin_amdgcn_readfirstlane(ct * BM);
+  };
+
+  if (wv >= NWC) {
+    // ============================================================ PRODUCER
+    const int pw = wv - NWC;
+    const int rg = lane >> 2, pc = lane & 3;
+    const int lc = pc ^ ((rg >> 2) & 3);
+    constexpr unsigned OOB = 0x80000000u;
+    const long x_bytes = ((long)(P.N - 1) * P.x_img_stride + (long)HoWo * P.ldx) * 2;
+    unsigned voff[SPW];                                // per-lane source byte offsets of this wave's slots (weights: constant; pixels: per tile)
+    int sdst[SPW];                                     // slot's byte offset inside a plane of a stage
+    bool isw[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int q = pw + NP * i;                       // compile-time after unrolling? pw is wave-uniform: the branches below are scalar
+      isw[i] = q < GA;
+      const int g = isw[i] ? q : q - GA;
+      sdst[i] = (isw[i] ? 0 : BM * 64) + g * 1024;
+      voff[i] = isw[i] ? (unsigned)(((g * 16 + rg) * Ktot + lc * 8) * 2) : 0u;
+    }
+    const bf16_t* w_base = nullptr;
+    long w_bytes = 0;
+    int cur_tile = 0, cur_step = 0, cur_stage = 0, left = total_steps;
+    auto set_tile = [&](int k) __attribute__((always_inline)) {
+      int p0, m0;
+      decode(k, p0, m0);
+      w_base = reinterpret_cast<const bf16_t*>(P.w) + (long)m0 * Ktot;
+      w_bytes = w_tile_bytes(BM, m0, P.Cout, Ktot);
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        if (!isw[i]) {
+          const int g = pw + NP * i - GA;
+          const long p = (long)p0 + g * 16 + rg;
+          if (p < Npix) {
+            int n, rem;
+            pix_split(p, HoWo, n, rem);
+            voff[i] = (unsigned)(((long)n * P.x_img_stride + (long)rem * P.ldx + lc * 8) * 2);
+          } else {
+            voff[i] = OOB;
+          }
+        }
+      }
+    };
+    auto next = [&]() __attribute__((always_inline)) {            // issue the cursor's step into the cursor's stage, advance
+      if (!(ablate & 1)) {
+        const __amdgpu_buffer_rsrc_t rs_w = uniform_rsrc(w_base, w_bytes);
+        const __amdgpu_buffer_rsrc_t rs_x = uniform_rsrc(P.x, x_bytes);
+        const int sbase = __builtin_amdgcn_readfirstlane(cur_stage * STAGE);
+        const int kb = __builtin_amdgcn_readfirstlane(cur_step * 128);
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            if (isw[i])
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + sbase + pl * SUB + sdst[i]), 16, voff[i], kb + pl * 64, 0, 0);
+            else
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(smem + sbase + pl * SUB + sdst[i]), 16, voff[i], kb + pl * 64, 0, 0);
+          }
+        }
+      }
+      --left;
+      cur_stage = cur_stage == NSW - 1 ? 0 : cur_stage + 1;
+      if (++cur_step == nsteps) { cur_step = 0; ++cur_tile; if (left > 0) set_tile(cur_tile); }
+    };
+    if (my_items > 0) set_tile(0);
+#pragma unroll
+    for (int i = 0; i < (NG - 1) * GRP; ++i)
+      if (left > 0) next();
+    for (int g = 0; g < total_groups; ++g) {
+      // steps issued after the last step of group g (they may stay in flight): those of groups g+1 .. g+NG-2
+      int later = total_steps - (g + 1) * GRP;
+      later = later < 0 ? 0 : (later > (NG - 2) * GRP ? (NG - 2) * GRP : later);
+      if (ablate & 1) wait_vmcnt<0>(); else wait_vmcnt_dyn(later * SPW * 2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < GRP; ++i)
+        if (left > 0) next();                            // group g+NG-1 into the stages group g-1 has just released
+    }
+    if (do_sums) __builtin_amdgcn_s_barrier();           // the consumers' matching barrier follows their last epilogue (they flush the last sums)
+    return;
+  }
+
+  // ============================================================== CONSUMER
+  const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+  int aaddr[WM], baddr[WN];                              // k-half 0, hi plane, stage 0; k-half 1 = ^ 32; lo plane = + SUB
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    aaddr[i] = r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int r = (wn * WN + j) * 32 + l31;
+    baddr[j] = BM * 64 + r * 64 + ((hi ^ ((r >> 2) & 3)) << 4);
+  }
+  f32x16_t acc[WM][WN];
+  u32x4_t fa[2][2][WM], fb[2][2][WN];                    // [set X / Y][plane][tile]
+  auto load_a = [&](int set, int soff, int kk) __attribute__((always_inline)) {
+    const int x32 = kk * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[set][pl][i] = *reinterpret_cast<const u32x4_t*>(smem + pl * SUB + ((aaddr[i] ^ x32) + soff));
+  };
+  auto load_b = [&](int set, int soff, int kk) __attribute__((always_inline)) {
+    const int x32 = kk * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[set][pl][j] = *reinterpret_cast<const u32x4_t*>(smem + pl * SUB + ((baddr[j] ^ x32) + soff));
+  };
+  auto mma_term = [&](int set, int term) __attribute__((always_inline)) {      // 0: lo * hi', 1: hi * lo', 2: hi * hi' (gemm_step_split's order)
+    const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) mma<bf16_t>(acc[i][j], fa[set][pa][i], fb[set][pb][j]);
+  };
+  int soff = 0, gs = 0;                                  // ring stage of the current step (bytes); step ordinal inside the hand-over group
+  [[maybe_unused]] int flush_tile = 0, gcount = 0;       // sums: next tile to flush; hand-over barriers passed
+  auto flush = [&](int T) __attribute__((always_inline)) {      // this wave's slice of lsum[T & 1] -> P.chan_sums, zeroed
+    int fp0, fm0;
+    decode(T, fp0, fm0);
+    const int fcam0 = (int)((long)fp0 / P.sums_hw);
+    long long* src = lsum + (T & 1) * 2 * BM;
+    for (int i = wv * 64 + lane; i < 2 * BM; i += 64 * NWC) {
+      const int sl = i / BM, chn = i - sl * BM, cam = fcam0 + sl;
+      const long long v = src[i];
+      if (v != 0) {
+        src[i] = 0;
+        if (cam < P.N && fm0 + chn < P.Cout)
+          atomicAdd(reinterpret_cast<unsigned long long*>(P.chan_sums + (long)cam * P.Cout + fm0 + chn), (unsigned long long)v);
+      }
+    }
+  };
+  for (int k = 0; k < my_items; ++k) {
+    int p0, m0;
+    decode(k, p0, m0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < nsteps; ++s) {
+      const int stage = soff;
+      if (gs == 0) {                                     // hand-over: every fragment read of the previous group has returned
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (do_sums) {
+          // this was the barrier of group gcount: the tiles whose last step lies in an earlier group have their sums complete
+          while (flush_tile < k && ((flush_tile + 1) * nsteps - 1) / GRP < gcount) { flush(flush_tile); ++flush_tile; }
+          ++gcount;
+        }
+      }
+      gs = gs == GRP - 1 ? 0 : gs + 1;
+      if (ablate & 2) { soff = soff == (NSW - 1) * STAGE ? 0 : soff + STAGE; continue; }
+      load_a(0, stage, 0); load_b(0, stage, 0);          // X <- (s, k-half 0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s > 0) { mma_term(1, 0); mma_term(1, 1); mma_term(1, 2); }      // Y = (s - 1, k-half 1)
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(1, stage, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_term(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(1, stage, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_term(0, 1);
+      mma_term(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      soff = soff == (NSW - 1) * STAGE ? 0 : soff + STAGE;
+    }
+    if (!(ablate & 2)) { mma_term(1, 0); mma_term(1, 1); mma_term(1, 2); }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- register epilogue (the 3x3 kernel's): bias / activation / hi-lo split, v_permlane32_swap pairs the half-waves' 8-byte pieces
+    {
+      unsigned char* yb = reinterpret_cast<unsigned char*>(P.y);
+      // channel sums: the tile's pixels lie in at most two images (sums_hw >= BP, checked at launch)
+      const int cam0 = do_sums ? (int)((long)p0 / P.sums_hw) : 0;
+      const long bnd = (long)(cam0 + 1) * P.sums_hw;
+      const bool two = do_sums && (long)p0 + BP > bnd;       // workgroup-uniform: the tile spans an image boundary
+      long pix_b[WN];
+      bool okj[WN], secj[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const long p = (long)p0 + (wn * WN + j) * 32 + l31;
+        okj[j] = p < Npix;
+        secj[j] = p >= bnd;                                  // this lane's pixel belongs to image cam0 + 1
+        pix_b[j] = 0;
+        if (okj[j]) {
+          int n, rem;
+          pix_split(p, HoWo, n, rem);
+          pix_b[j] = ((long)n * P.y_img_stride + (long)rem * P.ldy) * 2;
+        }
+      }
+      // the stored hi / lo words of quad q of tile (i, j): channels cb + 8 q + 4 hi .. + 3 at this lane's pixel
+      auto stored = [&](int i, int j, int q, int cb, uint2& h, uint2& l) __attribute__((always_inline)) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + cb + 8 * q + 4 * hi);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (P.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (P.act == ACT_SWISH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.f / (1.f + expf(-v[e])));
+        }
+        split4f(v[0], v[1], v[2], v[3], h, l);
+      };
+      // this lane's quantised values of quad q: qs[4 q + e] += rint(hi * 2^F) + rint(lo * 2^F)   (epilogue_rows16's sums_add8, per element)
+      auto quantise = [&](const uint2& h, const uint2& l, int q, int (&qs)[16], float& mx) __attribute__((always_inline)) {
+        const unsigned w4[4] = {h.x, h.y, l.x, l.y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float h0 = __uint_as_float(w4[e] << 16), h1 = __uint_as_float(w4[e] & 0xffff0000u);
+          const float l0 = __uint_as_float(w4[2 + e] << 16), l1 = __uint_as_float(w4[2 + e] & 0xffff0000u);
+          mx = fmaxf(mx, fmaxf(fabsf(h0), fabsf(h1)));
+          qs[4 * q + 2 * e] += __float2int_rn(h0 * (float)(1 << FAR3D_SUMS_FRAC_BITS)) + __float2int_rn(l0 * (float)(1 << FAR3D_SUMS_FRAC_BITS));
+          qs[4 * q + 2 * e + 1] += __float2int_rn(h1 * (float)(1 << FAR3D_SUMS_FRAC_BITS)) + __float2int_rn(l1 * (float)(1 << FAR3D_SUMS_FRAC_BITS));
+        }
+      };
+      // the half-wave's 32 pixels added up on the VALU -- four DPP row rotations, then v_permlane16_swap pairs the two 16-lane rows of the
+      // half -- lanes 0 / 32 -> lsum[tile parity][slot][channel] (64-bit LDS atomics)
+      auto half_sum = [&](int x) __attribute__((always_inline)) -> int {
+        x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);      // row_ror:8
+        x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, true);      // row_ror:4
+        x += __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, true);      // row_ror:2
+        x += __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, true);      // row_ror:1
+        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+        const u2_t r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        const unsigned rx = r.x, ry = r.y;
+        return (int)(rx + ry);
+      };
+      auto reduce_add = [&](const int (&qs)[16], float mx, int sl, int cb) __attribute__((always_inline)) {
+        // a |v| >= 64 could overflow the 32-bit sum over the half-wave (2 WN values of < 2^24 per lane, 32 lanes): then two 16-bit limbs
+        // -- wave-uniform, practically never taken (epilogue_rows16's sums_add8_wide is the same escape).  |v| >= 2^12 saturates the
+        // 32-bit quantisation itself: the caller re-quantises such a tile in 64 bits (quantise_wide)
+        const bool wide = WN > 2 || __any(mx >= (float)(1 << (24 - FAR3D_SUMS_FRAC_BITS)));
+        long long* dst = lsum + ((k & 1) * 2 + sl) * BM + (cb - m0) + 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          long long tot;
+          if (!wide) {
+            tot = (long long)half_sum(qs[r]);
+          } else {
+            const int lo16 = qs[r] & 0xffff, hi16 = qs[r] >> 16;      // qs = hi16 * 65536 + lo16, lo16 in [0, 65535]: limb sums cannot overflow
+            tot = (long long)half_sum(hi16) * 65536ll + (long long)half_sum(lo16);
+          }
+          if (l31 == 0 && tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(dst + 8 * (r >> 2) + (r & 3)), (unsigned long long)tot);
+        }
+      };
+      // one 32-channel block of the wave's tile (an explicit instantiation per block: left to `#pragma unroll` the body is too large for
+      // the unroller, and a dynamic index into the accumulators would put them into scratch memory)
+      auto channel_block = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const int cb = m0 + (wm * WM + i) * 32;              // first channel of this 32-channel block
+        if (cb >= P.Cout) return;                            // wave-uniform (Cout % 32 == 0)
+        int qs[16];
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qs[r] = 0;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            uint2 h[2], l[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              stored(i, j, 2 * qp + u, cb, h[u], l[u]);
+              if (do_sums && okj[j] && !secj[j]) quantise(h[u], l[u], 2 * qp + u, qs, mx);
+            }
+            // lower lanes: [own quad 2qp | upper's quad 2qp]; upper lanes: [lower's quad 2qp+1 | own quad 2qp+1]
+            u32x4_t oh, ol;
+            {
+              const auto sx = __builtin_amdgcn_permlane32_swap(h[0].x, h[1].x, false, false);
+              const auto sy = __builtin_amdgcn_permlane32_swap(h[0].y, h[1].y, false, false);
+              oh = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+            }
+            {
+              const auto sx = __builtin_amdgcn_permlane32_swap(l[0].x, l[1].x, false, false);
+              const auto sy = __builtin_amdgcn_permlane32_swap(l[0].y, l[1].y, false, false);
+              ol = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+            }
+            if (okj[j]) {
+              unsigned char* d = yb + pix_b[j] + (long)(cb >> 5) * 128 + (2 * qp + hi) * 16;
+              *reinterpret_cast<u32x4_t*>(d) = oh;
+              *reinterpret_cast<u32x4_t*>(d + 64) = ol;
+            }
+          }
+        }
+        if constexpr (do_sums) {
+          // |v| >= 2^11: a lane's 32-bit sum of 2 WN quantised values could overflow (and from 2^13 the 32-bit quantisation saturates):
+          // such a tile is summed again from the accumulators in 64 bits, element by element (any finite magnitude; never taken in practice)
+          auto exact_add = [&](int sl) __attribute__((always_inline)) {
+            long long* dst = lsum + ((k & 1) * 2 + sl) * BM + (cb - m0) + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              long long x[4] = {0, 0, 0, 0};
+#pragma unroll
+              for (int j = 0; j < WN; ++j) {
+                uint2 h, l;
+                stored(i, j, q, cb, h, l);
+                if (okj[j] && secj[j] == (sl == 1)) {
+                  const unsigned w4[4] = {h.x, h.y, l.x, l.y};
+#pragma unroll
+                  for (int e = 0; e < 2; ++e) {
+                    const float h0 = __uint_as_float(w4[e] << 16), h1 = __uint_as_float(w4[e] & 0xffff0000u);
+                    const float l0 = __uint_as_float(w4[2 + e] << 16), l1 = __uint_as_float(w4[2 + e] & 0xffff0000u);
+                    x[2 * e] += __double2ll_rn((double)h0 * (double)(1 << FAR3D_SUMS_FRAC_BITS)) + __double2ll_rn((double)l0 * (double)(1 << FAR3D_SUMS_FRAC_BITS));
+                    x[2 * e + 1] += __double2ll_rn((double)h1 * (double)(1 << FAR3D_SUMS_FRAC_BITS)) + __double2ll_rn((double)l1 * (double)(1 << FAR3D_SUMS_FRAC_BITS));
+                  }
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {                  // four 16-bit limbs (the top one signed): limb sums over 32 lanes cannot overflow
+                const long long v = x[e];
+                const long long tot = (long long)half_sum((int)(v & 0xffff)) + ((long long)half_sum((int)((v >> 16) & 0xffff)) << 16) +
+                                      ((long long)half_sum((int)((v >> 32) & 0xffff)) << 32) + ((long long)half_sum((int)(v >> 48)) << 48);
+                if (l31 == 0 && tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(dst + 8 * q + e), (unsigned long long)tot);
+              }
+            }
+          };
+          const bool huge = __any(mx >= 2048.f);               // wave-uniform
+          if (huge) exact_add(0); else reduce_add(qs, mx, 0, cb);
+          if (two) {                                         // the pixels of image cam0 + 1: their values once more from the accumulators (a few tiles per launch)
+            float mx1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qs[r] = 0;
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                uint2 h, l;
+                stored(i, j, q, cb, h, l);
+                if (okj[j] && secj[j]) quantise(h, l, q, qs, mx1);
+              }
+            if (__any(mx1 >= 2048.f)) exact_add(1); else reduce_add(qs, mx1, 1, cb);
+          }
+        }
+      };
+      static_assert(WM <= 4, "channel blocks per consumer");
+      channel_block(std::integral_constant<int, 0>{});
+      if constexpr (WM > 1) channel_block(std::integral_constant<int, 1>{});
+      if constexpr (WM > 2) channel_block(std::integral_constant<int, 2>{});
+      if constexpr (WM > 3) channel_block(std::integral_constant<int, 3>{});
+    }
+  }
+  if constexpr (do_sums) {                               // the producers' matching barrier: the last tiles' sums are complete behind it
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    while (flush_tile < my_items) { flush(flush_tile); ++flush_tile; }
+  }
+#endif
+}
+
+template <int WGM, int WGN, int WM, int WN, int NP, int NSW, int GRP>
+static int launch_gemm1x1_ws(const IgemmParams& P, hipStream_t st) {
+  constexpr int BM = 32 * WGM * WM, BP = 32 * WGN * WN;
+  constexpr size_t lds = (size_t)NSW * 2 * (BM + BP) * 64 + 4 * BM * 8;      // ring + lsum[2][2][BM]
+  static_assert(lds <= 163840, "LDS budget");
+  const long Npix = (long)P.N * P.Ho * P.Wo;
+  const int npt = (int)((Npix + BP - 1) / BP), nct = (P.Cout + BM - 1) / BM;
+  static std::atomic<unsigned long long> lds_ok_s{0};
+  static std::atomic<int> n_cu{0};
+  int cus = n_cu.load(std::memory_order_relaxed);
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    n_cu.store(cus, std::memory_order_relaxed);
+  }
+  constexpr int wg_per_cu = lds <= 81920 && 64 * (WGM * WGN + NP) <= 1024 ? 2 : 1;
+  const long items = (long)((npt + 7) / 8 * 8) * nct;
+  long grid = (long)cus * wg_per_cu;
+  grid = (grid + 7) / 8 * 8;
+  if (items < grid) grid = items;                       // items is a multiple of 8
+  static std::atomic<unsigned long long> lds_ok{0};
+  if constexpr (lds > 65536)
+    if (const int rc = far3d_allow_lds(P.chan_sums ? reinterpret_cast<const void*>(&gemm1x1_ws_kernel<WGM, WGN, WM, WN, NP, NSW, GRP, true>)
+                                                   : reinterpret_cast<const void*>(&gemm1x1_ws_kernel<WGM, WGN, WM, WN, NP, NSW, GRP, false>),
+                                       (int)lds, P.chan_sums ? lds_ok_s : lds_ok, "far3d_conv2d_nhwc")) return rc;
+  if (P.chan_sums) {
+    if (P.sums_hw < BP || P.cin_pad / 32 < 2 * GRP) {
+      far3d_set_error("far3d_conv2d_nhwc: channel sums on this wave-specialised GEMM tile need Ho*Wo (%d) >= %d pixels and Cin >= %d", P.sums_hw, BP, 64 * GRP);
+      return FAR3D_ERR_ARG;
+    }
+    hipLaunchKernelGGL((gemm1x1_ws_kernel<WGM, WGN, WM, WN, NP, NSW, GRP, true>), dim3((unsigned)grid), dim3(64 * (WGM * WGN + NP)), lds, st, P, npt, nct, FAR3D_WS_ABLATE_ARG);
+  } else {
+    hipLaunchKernelGGL((gemm1x1_ws_kernel<WGM, WGN, WM, WN, NP, NSW, GRP, false>), dim3((unsigned)grid), dim3(64 * (WGM * WGN + NP)), lds, st, P, npt, nct, FAR3D_WS_ABLATE_ARG);
+  }
+  return 0;
 }
 
 template <int WGM, int WGN, int WM, int WN, int NP, bool PAIR, bool DBUF, int NSW = 3, bool FLAGS = false, int GRP = 1>

@@ -250,7 +250,7 @@ def use_tile_tables(bf16_table, pair_table=None):
         _TABLE_SEL.cur = prev
 
 
-WS_TILES = range(400, 460)      # persistent wave-specialised 3x3 kernel (csrc/conv_ws.hpp): bias + activation + pair / bf16 store only
+WS_TILES = range(400, 480)      # persistent wave-specialised kernels (csrc/conv_ws.hpp; 400-459 3x3, 460-479 1x1 GEMM on pair maps): bias + activation + pair / bf16 store only
 
 
 def _tuned_tile(Cout, Cin, k, stride, npix, table=None, ws_ok=False):
@@ -404,8 +404,10 @@ def conv2d_nhwc(x, pc, out=None, act=None, out_dtype=None, res=None, y2=None, y2
         if y2_scale.numel() != N * pc.Cout or y2_shift.numel() != N * pc.Cout or tuple(y2.shape) != (N, Ho, Wo, pc.Cout):
             raise ValueError("conv2d_nhwc: y2/scale/shift shapes inconsistent")
         y2p, y2dt, sp, hp = _ptr(y2), _dt(y2), _ptr(y2_scale), _ptr(y2_shift)
-    # what the wave-specialised 3x3 kernel covers (anything else takes the table's general tile)
-    ws_ok = (res is None and y2 is None and sums is None and pc.KH == 3 and pc.KW == 3 and pc.stride == 1 and pc.pad == 1 and
+    # what the wave-specialised kernels cover (anything else takes the table's general tile)
+    ws_ok = (res is None and y2 is None and pc.stride == 1 and
+             ((pc.KH == 3 and pc.KW == 3 and pc.pad == 1 and sums is None) or
+              (pc.KH == 1 and pc.KW == 1 and pc.pad == 0 and pair_in and (sums is None or (Ho * Wo >= 256 and Cin >= 192)))) and
              Cin % 32 == 0 and pc.Cout % 32 == 0 and out.dtype == torch.bfloat16 and ldx % 8 == 0 and ldy % 8 == 0 and
              x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and xs % 8 == 0 and ys % 8 == 0)
     if pair_in:
@@ -442,7 +444,7 @@ def f32x_linear_tile(cout, K):
     return F32X_LINEAR_TILE if cout >= 1024 else 493
 SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
 # GEMM tiles that exist AND leave LDS for the channel-sum scratch (114 / 115 fill the 160 KB with their ring; 118 / 119 are no kernels)
-_GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | set(range(185, 189)) | {279, 280}
+_GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | set(range(185, 189)) | {279, 280} | set(range(460, 480))
 _GEMM_TILE_PIXELS = 512  # no GEMM tile holds more pixels
 
 

@@ -126,6 +126,60 @@ def test_pair_conv1x1_split_products(hip_lib, tile):
         assert (y32.double() - want).abs().max().item() < bound, tile
 
 
+TILES_WS_GEMM = [460, 461, 462, 463, 464, 465, 466, 467, 468, 469, 470, 471, 473, 474, 475, 476]
+
+
+@pytest.mark.parametrize("tile", TILES_WS_GEMM)
+def test_pair_gemm_wave_specialised_persistent_kernel(hip_lib, tile):
+    """The persistent wave-specialised 1x1 GEMM (csrc/conv_ws.hpp gemm1x1_ws_kernel): producer waves stream weights AND activation rows
+    through one LDS ring, a workgroup walks (pixel tile, channel tile) items as one stream of steps whose hand-over groups straddle tiles
+    (odd step counts), pixel tiles that span two images, ragged pixel / channel tiles, more items than the grid's first round, channel
+    slices of wider buffers.  Bit for bit the shipped tile 179 (same products, same order) and within the split-product bound of float64."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(tile)
+    for (N, Cin, Cout, H, W, act) in ((2, 160, 96, 7, 19, "relu"), (2, 1056, 512, 5, 9, "relu"), (3, 32, 64, 23, 31, None), (7, 768, 256, 40, 60, "relu"),
+                                      (2, 96, 288, 150, 161, "swish"), (3, 224, 160, 17, 23, "relu"), (5, 192, 64, 16, 16, None)):
+        x = torch.randn(N, Cin, H, W, generator=g)
+        if Cout == 64:
+            x[:, :, :3] *= 40.0                     # stored values beyond 64: the 64-bit escape of the channel sums
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        pc = ops.PackedConv(w, b, dtype=torch.float32, device=DEV, compute="bf16x3")
+        xin = torch.full((N, H, W, 2 * (Cin + 64)), 3.0, dtype=torch.bfloat16, device=DEV)
+        xin[..., 64:64 + 2 * Cin] = ops.pair_from_float(x.permute(0, 2, 3, 1)).to(DEV)
+        # channel sums (the eSE pooling fused into the concat layers): maps of at least one 256-pixel tile, K of at least six steps
+        with_sums = H * W >= 256 and Cin >= 192
+        bufs, sums = [], []
+        for tl in (tile, 179):
+            buf = torch.full((N, H, W, 2 * (Cout + 64)), 7.0, dtype=torch.bfloat16, device=DEV)
+            sm = torch.zeros(N, Cout, dtype=torch.int64, device=DEV) if with_sums else None
+            ops.conv2d_nhwc(xin[..., 64:64 + 2 * Cin], pc, out=buf[..., 128:128 + 2 * Cout], act=act, tile=tl, sums=sm)
+            if with_sums:
+                ops.conv2d_nhwc(xin[..., 64:64 + 2 * Cin], pc, out=buf[..., 128:128 + 2 * Cout], act=act, tile=tl, sums=sm)      # sums accumulate
+            bufs.append(buf)
+            sums.append(sm)
+        if with_sums:
+            assert sums[0].abs().sum().item() > 0 and torch.equal(sums[0], sums[1]), "tile %d: channel sums differ from tile 179 on %s (%d entries)" % (
+                tile, (N, Cin, Cout, H, W), (sums[0] != sums[1]).sum().item())
+        assert (bufs[0][..., :128] == 7.0).all() and (bufs[0][..., 128 + 2 * Cout:] == 7.0).all()
+        assert torch.equal(bufs[0], bufs[1]), "tile %d differs from tile 179 on %s (max %.3e)" % (
+            tile, (N, Cin, Cout, H, W), (ops.pair_to_float(bufs[0][..., 128:128 + 2 * Cout].contiguous()) -
+                                         ops.pair_to_float(bufs[1][..., 128:128 + 2 * Cout].contiguous())).abs().max().item())
+        if N * H * W <= 4096:
+            want = F.conv2d(x.double(), w.double(), b.double())
+            want = want.relu() if act == "relu" else (want * torch.sigmoid(want) if act == "swish" else want)
+            got = ops.pair_to_float(bufs[0][..., 128:128 + 2 * Cout].contiguous()).cpu().permute(0, 3, 1, 2)
+            bound, _ = _bound(Cin, x, w)
+            assert (got.double() - want).abs().max().item() < bound + want.abs().max().item() * 2.0 ** -16, tile
+    # what the kernel does not do is an error of the call: f32 output, channel sums
+    x = ops.pair_from_float(torch.randn(1, 8, 32, 32)).to(DEV)
+    pc = ops.PackedConv(torch.randn(32, 32, 1, 1), None, dtype=torch.float32, device=DEV, compute="bf16x3")
+    with pytest.raises(Exception):
+        ops.conv2d_nhwc(x, pc, out=torch.empty(1, 8, 32, 32, device=DEV), tile=tile)
+    with pytest.raises(Exception):       # a map smaller than the pixel tile takes no channel sums
+        ops.conv2d_nhwc(x[:, :4, :4], pc, tile=tile, sums=torch.zeros(1, 32, dtype=torch.int64, device=DEV))
+
+
 def test_pair_conv_small_cout_f32_heads_and_swish(hip_lib):
     """The 2D head's last 1x1 convs: Cout = 26 / 5 / 51 (f32 outputs, padded weight rows); Swish towers with pair output."""
     from far3d_amd import ops

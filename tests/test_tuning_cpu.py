@@ -69,8 +69,10 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
     ws_src = open(os.path.join(ROOT, "far3d_amd", "csrc", "conv_ws.hip")).read()
     # launch_conv3x3_ws<WGM, WGN, WM, WN, NP, PAIR, ...>: the tiles whose sixth template argument says pair storage
     ws_pair = {int(m.group(1)) for m in re.finditer(r"case (\d+): return launch_conv3x3_ws<([^>]*)>", ws_src) if m.group(2).split(",")[5].strip() == "true"}
+    ws_gemm = {int(m.group(1)) for m in re.finditer(r"case (\d+): return launch_gemm1x1_ws<", ws_src)}      # persistent 1x1 GEMM (pair storage only)
     table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))
     assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5} and ws_pair and all(400 <= t < 460 for t in ws_pair)
+    assert ws_gemm and all(460 <= t < 480 for t in ws_gemm)
     assert set(table) == set(json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json"))))
     from far3d_amd import ops
     for key, tile in table.items():
@@ -79,9 +81,9 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
         allowed = ids["igemm"] | ({t for t in ids["pipe3"] if t < 300} if (k == 3 and stride == 1) else ids["gemm"] if (k == 1 and stride == 1) else
                                   {t for t in ids["pipe3"] if t >= 330} if (k == 3 and stride == 2) else set())
         if isinstance(tile, list):
-            # [wave-specialised tile (csrc/conv_ws.hip, plain 3x3 layers only), the general tile every other call of the layer shape takes]
+            # [wave-specialised tile (csrc/conv_ws.hip: 3x3 layers without residual / sums, 1x1 layers on pair maps), the general tile every other call of the layer shape takes]
             ws, tile = tile
-            assert k == 3 and stride == 1 and cout % 32 == 0 and ws in ws_pair and ws in ops.WS_TILES, (key, ws)
+            assert stride == 1 and cout % 32 == 0 and ws in ops.WS_TILES and ((k == 3 and ws in ws_pair) or (k == 1 and ws in ws_gemm)), (key, ws)
             assert ops._tuned_tile(cout, cin, k, stride, npix, name, ws_ok=True) == ws and ops._tuned_tile(cout, cin, k, stride, npix, name) == tile
         assert tile in allowed and not 200 <= tile < 300, "tile %d is not a split-product tile for layer %s" % (tile, key)
 
