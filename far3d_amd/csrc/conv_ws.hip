@@ -33,6 +33,8 @@ int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
     case 415: return launch_conv3x3_ws<2, 2, 1, 2, 2, true, true, 6>(P, st);   // 404 (64 ch x 4 rows, 2 per CU) with 6 stages
     case 416: return launch_conv3x3_ws<2, 4, 3, 1, 4, true, true, 4>(P, st);   // 403 (192 ch x 4 rows) with 4 stages
     case 417: return launch_conv3x3_ws<2, 4, 2, 1, 4, true, true, 4>(P, st);   // 405 with 4 stages
+    case 418: return launch_conv3x3_ws<4, 2, 2, 2, 4, true, true, 3>(P, st);   // 256 ch x 4 rows: 8 consumers of 64 ch x 2 rows (148 KB)
+    case 419: return launch_conv3x3_ws<4, 2, 2, 1, 4, true, true, 3>(P, st);   // 256 ch x 2 rows: 8 consumers of 64 ch x 1 row
     // hand-over through LDS counters instead of a workgroup barrier per step (FLAGS): consumer waves run free of each other.  Measured
     // SLOWER than the barrier form (profiles/r6/ws_ab_pair.txt: s2.c1 281 us against 212, s4.c1 59 against 38): the polls cost more than
     // the lockstep they remove.  Kept as tested tiles for the record.

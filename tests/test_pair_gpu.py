@@ -63,7 +63,7 @@ def test_pair_conv3x3_split_products(hip_lib, tile):
         assert (y32.cpu().permute(0, 3, 1, 2).double() - want).abs().max().item() < bound
 
 
-TILES_WS = [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413, 414, 415, 416, 417, 440, 444, 445, 450, 451, 452, 453, 454, 455, 456, 457, 458, 459]
+TILES_WS = [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413, 414, 415, 416, 417, 418, 419, 440, 444, 445, 450, 451, 452, 453, 454, 455, 456, 457, 458, 459]
 
 
 @pytest.mark.parametrize("tile", TILES_WS)

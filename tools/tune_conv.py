@@ -119,7 +119,7 @@ def main():
             tiles = (0, 1, 2, 3, 4, 5)
         if pair:
             tiles = (0, 150, 152, 154, 155, 157, 160, 161, 162, 163, 164, 165, 166, 167, 168, 169, 190, 198, 191, 192, 193, 197) + \
-                    ((400, 401, 403, 404, 405, 406, 410, 411, 412, 413, 416, 417, 450, 451, 452, 453, 454, 455, 456, 457, 459) if Cout % 32 == 0 and not os.environ.get("NO_WS") else ()) \
+                    ((400, 401, 403, 404, 405, 406, 410, 411, 412, 413, 416, 417, 418, 419, 450, 451, 452, 453, 454, 455, 456, 457, 459) if Cout % 32 == 0 and not os.environ.get("NO_WS") else ()) \
                 if (k == 3 and stride == 1) else \
                     ((0, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181, 185, 186, 187, 188) + ((460, 461, 462, 463, 464, 465, 466, 467, 468, 469, 470, 471, 473, 474, 475, 476) if Cout % 32 == 0 and not os.environ.get("NO_WS") else ()) if (k == 1 and stride == 1) else
                      (0, 1, 2, 3, 4, 5, 330, 331) if (k == 3 and stride == 2) else (0, 1, 2, 3, 4, 5))
