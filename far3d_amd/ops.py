@@ -275,9 +275,11 @@ def _tuned_tile(Cout, Cin, k, stride, npix, table=None, ws_ok=False):
     cands = tab.get((Cout, Cin, k, stride))
     if not cands:
         return 0
-    tile = min(cands, key=lambda c: abs(c[0] - npix))[1]
+    npx, tile = min(cands, key=lambda c: abs(c[0] - npix))
     if isinstance(tile, tuple):
-        return tile[0] if ws_ok else tile[1]
+        # a persistent tile was measured at ITS pixel count (its grid is one workgroup per CU walking npix / tile items): a borrowed entry
+        # (camera-sharded ranks see 1/2 .. 1/7 of the pixels) keeps the general tile
+        return tile[0] if (ws_ok and 4 * abs(npx - npix) <= npx) else tile[1]
     return tile
 
 

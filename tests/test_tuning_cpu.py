@@ -88,6 +88,19 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
         assert tile in allowed and not 200 <= tile < 300, "tile %d is not a split-product tile for layer %s" % (tile, key)
 
 
+def test_persistent_tiles_are_not_borrowed_across_pixel_counts():
+    """A [ws tile, general tile] entry hands out its persistent tile only near the pixel count it was measured at: a camera-sharded rank
+    (1 of 7 cameras) borrows the entry of the 7-camera layer and must get the general tile."""
+    from far3d_amd import ops
+    name = "tuning_mi355x_pair.json"
+    ws, gen = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))["256,768,1,1,268800"]
+    assert ws in ops.WS_TILES and gen not in ops.WS_TILES
+    assert ops._tuned_tile(256, 768, 1, 1, 268800, name, ws_ok=True) == ws and ops._tuned_tile(256, 768, 1, 1, 268800, name) == gen
+    assert ops._tuned_tile(256, 768, 1, 1, 230400, name, ws_ok=True) == ws          # 6 of 7 cameras: within a quarter
+    for npix in (38400, 76800, 153600):                                             # 1, 2, 4 cameras per rank
+        assert ops._tuned_tile(256, 768, 1, 1, npix, name, ws_ok=True) in (gen, 185), npix      # (185: the layer's own 16 800-pixel entry)
+
+
 def test_tile_table_selection_is_scoped_and_thread_local():
     """ops.use_tile_tables: an engine's tables hold for the block only (nested selections restore each other), another thread keeps the
     process defaults meanwhile, and a custom bf16 table never becomes the pair table (the tables were re-assigned module
