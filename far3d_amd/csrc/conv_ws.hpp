@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NP)) void gemm1x1_ws_kernel(Igemm
     bool isw[SPW];
 #pragma unroll
     for (int i = 0; i < SPW; ++i) {
-      const int q = pw + NP * i;                       // compile-time after unrolling? pw is wave-uniform: the branches below are scalar
+      const int q = pw + NP * i;                       // pw is wave-uniform: the weight / activation branches below are scalar
       isw[i] = q < GA;
       const int g = isw[i] ? q : q - GA;
       sdst[i] = (isw[i] ? 0 : BM * 64) + g * 1024;

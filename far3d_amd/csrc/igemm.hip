@@ -87,9 +87,9 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   if (tile >= 460 && tile < 480) {     // persistent wave-specialised 1x1 GEMM on pair-stored maps: a refusal is an error of the call
     FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && !res && !y2 && Cin % 32 == 0 && Cout % 32 == 0 && pair_in && pair_out &&
                     aligned(x, 16) && aligned(y, 16) && ldx % 8 == 0 && ldy % 8 == 0 && x_img_stride % 8 == 0 && y_img_stride % 8 == 0 &&
-                    (long)N * H * W < (1L << 31) - 4096,
+                    (long)N * H * W < (1L << 31) - 4096 && ((long)(N - 1) * x_img_stride + (long)H * W * ldx) * 2 < 0x7fffffffL,
                     "far3d_conv2d_nhwc: tile %d (wave-specialised GEMM) needs a 1x1 / stride 1 layer on pair-stored maps, Cin and Cout multiples of 32, "
-                    "16-byte aligned rows and no residual / second output", tile);
+                    "16-byte aligned rows, an input map below 2 GB and no residual / second output", tile);
     const int rc = far3d_gemm_ws_launch(P, tile, st);
     if (rc != FAR3D_OK) return rc;
     FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");

@@ -136,8 +136,8 @@ int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, v
  *    kernel size / stride); 50-67, 90-97, 100-103 pipelined 3x3/s1/p1 kernel (channels x rows of 32 pixels, 4/8/16 waves, 2- or 3-deep
  *    weight ring, one kernel row or -- 100-103 -- all 9 taps per barrier step); 70-81 pipelined 1x1/s1 GEMM kernel.
  *    x_dt = FAR3D_DT_BF16_PAIR (w_dt must be FAR3D_DT_F32_BF16X3; y_dt pair or f32; res_dt any): 1-5 register-staged kernel (any
- *    kernel size / stride); 150-168, 191-197 the pipelined 3x3 shapes 50-68 / 91-97 with split products; 170-181 the pipelined 1x1
- *    shapes; 252, 260, 265, 279, 280: the hi halves only (ONE bf16 product per term: a single-bf16 layer inside a pair-stored
+ *    kernel size / stride); 150-168, 191-197 the pipelined 3x3 shapes 50-68 / 91-97 with split products (169 / 190 / 198: 7-row
+ *    forms); 170-181 the pipelined 1x1 shapes (185 / 186 128 x 160, 187 / 188 64 x 96 for the small maps); 252, 260, 265, 279, 280: the hi halves only (ONE bf16 product per term: a single-bf16 layer inside a pair-stored
  *    network).  An id the layer cannot use is an error, not a silent fallback.
  *    bf16, 1x1/s1 only: 82-89 the GEMM tiles with 3- / 4-deep LDS rings, 110-117 256 x 256 (and other large) tiles, 120-129 the
  *    GEMM with full-line LDS-DMA pieces (8 rows x 128 bytes per piece instead of 16 x 64), 140-145 split weight / activation rings;
@@ -153,9 +153,13 @@ int far3d_agg_tables(const float* Vc, float* tables, int layers, int N, int J, v
  *    of an output row depend on the tile and on Cin only, never on the number of rows in the call.
  *    3x3/s1/p1, Cin % 32 == 0, Cout % 32 == 0, same storage in and out, 16-byte aligned rows, NO res / y2 / chan_sums: the PERSISTENT
  *    wave-specialised kernel (csrc/conv_ws.hpp: producer waves issue every LDS-DMA, consumer waves only read LDS and run MFMAs, one
- *    workgroup per CU walks several tiles, 16-byte stores straight from the MFMA registers) -- pair storage 400-417 (one hand-over
+ *    workgroup per CU walks several tiles, 16-byte stores straight from the MFMA registers) -- pair storage 400-419 (one hand-over
  *    per tap), 450-459 (one per kernel row), 440 / 444 / 445 (LDS counters instead of the barrier; measured slower), bf16 420-423.
  *    Results are bit-identical to the pipelined 3x3 kernel (same products in the same order).
+ *    1x1/s1 on pair-stored maps (x and y pair storage, Cin % 32 == 0, Cout % 32 == 0, 16-byte aligned rows, input below 2 GB, NO res /
+ *    y2): 460-476 the persistent wave-specialised GEMM (gemm1x1_ws_kernel: the producers stream weights AND activation rows through one
+ *    LDS ring; 460-463, 465, 469 128 x 128, 464 / 471 / 473 256 x 128, 470 / 476 128 x 256, 474 192 x 128, 466-468 64 x 128), bit-identical to
+ *    the pipelined GEMM; chan_sums allowed when Ho*Wo >= the tile's pixels and Cin >= 64 x the tile's steps per hand-over.
  * chan_sums (optional, DEVICE int64 [N][Cout]; 1x1/s1 layers on a pipelined GEMM tile with a bf16 or pair output, Ho*Wo >= the
  *    tile's pixel count): every STORED output element v (for a pair output: its hi and its lo half) ADDS
  *    rint(v * 2^FAR3D_SUMS_FRAC_BITS) to chan_sums[n][channel] -- the global average pool of VoVNet's eSE block (ref
