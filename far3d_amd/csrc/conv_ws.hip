@@ -62,7 +62,7 @@ int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
   return FAR3D_ERR_ARG;
 }
 
-// The wave-specialised persistent 1x1 GEMM on pair-stored maps (gemm1x1_ws_kernel), tile ids 460-479:
+// The wave-specialised persistent 1x1 GEMM on pair-stored maps (gemm1x1_ws_kernel), tile ids 460-477:
 // (consumer grid WGM x WGN, tiles per consumer WM x WN, producers, ring stages, steps per hand-over)
 int far3d_gemm_ws_launch(const IgemmParams& P, int tile, hipStream_t st) {
   switch (tile) {

@@ -4,7 +4,7 @@
 
 int far3d_conv_pair_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
 int far3d_conv_f32rows_launch(const IgemmParams& P, int tile, hipStream_t st);   // igemm_pair.hip
-int far3d_gemm_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 1x1 GEMM, tiles 460-479)
+int far3d_gemm_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 1x1 GEMM, tiles 460-477)
 int far3d_conv_f32x_launch(const IgemmParams& P, int tile, hipStream_t st);     // igemm_pair.hip (exact fp32 on the pipelined kernel, tiles 482-494)
 int far3d_conv_ws_launch(const IgemmParams& P, int tile, hipStream_t st);        // conv_ws.hip (persistent wave-specialised 3x3, tiles 400-459)
 
@@ -66,10 +66,10 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
   P.y_rows16 = (y_dt == FAR3D_DT_BF16 || pair_out) && !res && !y2 && aligned(y, 16) && (ldy % 8 == 0) && (y_img_stride % 8 == 0) && (Cout % 8 == 0);
   hipStream_t st = (hipStream_t)stream;
   if (chan_sums) {       // only the pipelined GEMM kernels accumulate them; anything else is an error, not a silent fallback
-    const bool gemm_tile = pair_in ? (tile == 0 || (tile >= 170 && tile <= 181) || (tile >= 185 && tile <= 188) || tile == 279 || tile == 280 || (tile >= 460 && tile < 480))
+    const bool gemm_tile = pair_in ? (tile == 0 || (tile >= 170 && tile <= 181) || (tile >= 185 && tile <= 188) || tile == 279 || tile == 280 || (tile >= 460 && tile < 478))
                                    : ((tile >= 70 && tile <= 89) || (tile >= 110 && tile <= 117) || (tile >= 120 && tile <= 129) || (tile >= 140 && tile <= 145));
     FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && gemm_tile && (pair_in || (x_dt == FAR3D_DT_BF16 && Cin % 32 == 0 && P.x_vec)),
-                    "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-117, 120-129, 140-145; pair: 170-181, 185-188, 279, 280, 460-479); got k=%d tile=%d", KH, tile);
+                    "far3d_conv2d_nhwc: channel sums need a 1x1 / stride 1 layer on a pipelined GEMM tile (bf16: 70-89, 110-117, 120-129, 140-145; pair: 170-181, 185-188, 279, 280, 460-477); got k=%d tile=%d", KH, tile);
   }
   if (tile >= 400 && tile < 460) {     // persistent wave-specialised 3x3 kernel: a refusal is an error of the call, never a silent fallback
     const bool pair_tile = tile < 420 || tile >= 440;
@@ -84,7 +84,7 @@ extern "C" int far3d_conv2d_nhwc(const void* x, int x_dt, const void* w, int w_d
     FAR3D_CHECK_LAUNCH("far3d_conv2d_nhwc");
     return FAR3D_OK;
   }
-  if (tile >= 460 && tile < 480) {     // persistent wave-specialised 1x1 GEMM on pair-stored maps: a refusal is an error of the call
+  if (tile >= 460 && tile < 478) {     // persistent wave-specialised 1x1 GEMM on pair-stored maps: a refusal is an error of the call
     FAR3D_CHECK_ARG(KH == 1 && KW == 1 && stride == 1 && pad == 0 && !res && !y2 && Cin % 32 == 0 && Cout % 32 == 0 && pair_in && pair_out &&
                     aligned(x, 16) && aligned(y, 16) && ldx % 8 == 0 && ldy % 8 == 0 && x_img_stride % 8 == 0 && y_img_stride % 8 == 0 &&
                     (long)N * H * W < (1L << 31) - 4096 && ((long)(N - 1) * x_img_stride + (long)H * W * ldx) * 2 < 0x7fffffffL,

@@ -250,7 +250,7 @@ def use_tile_tables(bf16_table, pair_table=None):
         _TABLE_SEL.cur = prev
 
 
-WS_TILES = range(400, 480)      # persistent wave-specialised kernels (csrc/conv_ws.hpp; 400-459 3x3, 460-479 1x1 GEMM on pair maps): bias + activation + pair / bf16 store only
+WS_TILES = range(400, 478)      # persistent wave-specialised kernels (csrc/conv_ws.hpp; 400-459 3x3, 460-477 1x1 GEMM on pair maps; 479-481 are fp32-row GEMM tiles): bias + activation + pair / bf16 store only
 
 
 def _tuned_tile(Cout, Cin, k, stride, npix, table=None, ws_ok=False):
@@ -446,7 +446,7 @@ def f32x_linear_tile(cout, K):
     return F32X_LINEAR_TILE if cout >= 1024 else 493
 SUMS_FRAC_BITS = 18      # FAR3D_SUMS_FRAC_BITS in include/far3d_hip.h
 # GEMM tiles that exist AND leave LDS for the channel-sum scratch (114 / 115 fill the 160 KB with their ring; 118 / 119 are no kernels)
-_GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | set(range(185, 189)) | {279, 280} | set(range(460, 480))
+_GEMM_TILES = set(range(70, 90)) | {110, 111, 112, 113, 116, 117} | set(range(120, 130)) | set(range(140, 146)) | set(range(170, 182)) | set(range(185, 189)) | {279, 280} | set(range(460, 478))
 _GEMM_TILE_PIXELS = 512  # no GEMM tile holds more pixels
 
 

@@ -72,7 +72,7 @@ def test_pair_tuning_table_names_only_implemented_tiles(name):
     ws_gemm = {int(m.group(1)) for m in re.finditer(r"case (\d+): return launch_gemm1x1_ws<", ws_src)}      # persistent 1x1 GEMM (pair storage only)
     table = json.load(open(os.path.join(ROOT, "far3d_amd", "data", name)))
     assert table and ids["pipe3"] and ids["gemm"] and ids["igemm"] == {1, 2, 3, 4, 5} and ws_pair and all(400 <= t < 460 for t in ws_pair)
-    assert ws_gemm and all(460 <= t < 480 for t in ws_gemm)
+    assert ws_gemm and all(460 <= t < 478 for t in ws_gemm)
     assert set(table) == set(json.load(open(os.path.join(ROOT, "far3d_amd", "data", "tuning_mi355x_pair.json"))))
     from far3d_amd import ops
     for key, tile in table.items():
