@@ -1047,19 +1047,28 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   float* wt_s = wt_all + wv * CAPT * 8;
 
   AGG_TS(0);
-  // ---- loads that do not depend on the query: table rows (mV, EV) and the projection matrices of this lane's two cameras
+  // ---- loads that do not depend on the query: table rows (mV, EV) and the projection matrices of this lane's two cameras.  Round 6: each
+  // wave loads what ITS half of the specialised front end reads -- wave 0 (projection, dealing) the matrices, the reference point and the
+  // key-point offsets, wave 1 (softmax statistics) the table rows and the query's logits; before, both waves loaded everything: 26 KB
+  // of vector-memory requests per workgroup, of which 13 KB were never read, in the one phase where all 3 088 waves of the launch load at
+  // once.  No branch: the ADDRESSES are selected per wave (scalar selects) and the same six loads are issued by both waves -- values
+  // loaded inside a branch and used behind the join are waited for (and copied) inside the branch, which serialises the round trips.
+  // A slot the wave does not need reads tab[0] in every lane: one cache line.
   const float4 NEG4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), Z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* T4 = reinterpret_cast<const float4*>(tab);
   // (every load is unconditional with a clamped index and the selection happens on registers: a load under a lane condition is
   // split into dword loads behind exec-mask branches, and a load inside a branch is waited for inside it)
   const bool v0 = lane < n4, v1 = lane + 64 < n4;
   const int i0 = min(lane, n4 - 1), i1 = min(lane + 64, n4 - 1);
-  float4 mv0 = T4[i0], mv1 = T4[i1];
-  const float4 es0 = T4[n4 + i0], es1 = T4[n4 + i1];
   const int r = lane >> 4, p = lane & 15;
+  const bool w0 = wv == 0;                                    // wave-uniform
   const float4* mA = reinterpret_cast<const float4*>(l2i + min(r, N - 1) * 16);
   const float4* mB = reinterpret_cast<const float4*>(l2i + min(r + 4, N - 1) * 16);
-  const float4 mA0 = mA[0], mA1 = mA[1], mA2 = mA[2], mB0 = mB[0], mB1 = mB[1], mB2 = mB[2];
+  const float4 ld0 = *(w0 ? mA : T4 + i0), ld1 = *(w0 ? mA + 1 : T4 + i1), ld2 = *(w0 ? mA + 2 : T4 + n4 + i0);
+  const float4 ld3 = *(w0 ? mB : T4 + n4 + i1), ld4 = *(w0 ? mB + 1 : T4), ld5 = *(w0 ? mB + 2 : T4);
+  const float4 mA0 = ld0, mA1 = ld1, mA2 = ld2, mB0 = ld3, mB1 = ld4, mB2 = ld5;        // wave 0's reading of the six slots
+  float4 mv0 = ld0, mv1 = ld1;                                                          // wave 1's
+  const float4 es0 = ld2, es1 = ld3;
   int a = perm ? perm[a0] : a0;
   bool split = false;
   if constexpr (SPLIT) {
@@ -1077,12 +1086,13 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     a &= AGG_ROW_MASK;
   }
   const int part = sibling ? 1 : 0;
-  // ---- query-dependent loads, issued together: reference point, this lane's key-point offset, the query part of the logits
+  // ---- query-dependent loads, issued together: reference point and this lane's key-point offset (read by wave 0), the query part of
+  // the logits (wave 1; wave 0 receives e^U from wave 1 through LDS below, its two slots read tab[0])
   const float rf0 = ref[a * 3], rf1 = ref[a * 3 + 1], rf2 = ref[a * 3 + 2];
   const float* op_ = offs + (long)a * prm.ldO + min(p, P - 1) * 3;
   const float of0 = op_[0], of1 = op_[1], of2 = op_[2];
   const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
-  float4 eu0 = U4[i0], eu1 = U4[i1];
+  float4 eu0 = *(w0 ? T4 : U4 + i0), eu1 = *(w0 ? T4 : U4 + i1);
   if (!v0) mv0 = NEG4;         // lanes past the row: logit -inf -> weight 0 (register selects)
   if (!v1) mv1 = NEG4;
   AGG_TS(8);
