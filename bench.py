@@ -209,7 +209,8 @@ def agg_traffic_live(fp32_rows, timeout_s=150):
                 ("fp32" if fp32_rows else "bf16", vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
 
 
-def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk", latency_runner=True):
+def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, kernel_timings=True, proposals="topk", latency_runner=True,
+            two_streams=False):
     """Build an engine of `precision` and run, in this order: the parity frames; region A -- the reference's protocol, K frames with a
     device sync (+ barrier) around every one, on the engine in its single-frame configuration (one hipGraph per frame, no frame
     overlap, tiles tuned for launches alone); region B -- K frames back to back with the frame pipeline on; the camera-group latency
@@ -227,6 +228,14 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         eng.agg_split_extra = args.agg_split
     eng.cam_priority = args.cam_priority
     eng.fused_rows = args.fused_rows        # row-resident decoder chains (bf16 decoder only; csrc/rowchain.hip); --no-fused-rows for A/B
+    eng2 = None
+    if two_streams and world == 1 and not sharded and proposals == "topk" and not args.eager and not args.no_pipeline:
+        # a SECOND scene stream on the same device (configs[4]'s batch of independent streams, ref tools/test.py:229-234):
+        # its own engine = its own buffers, memory queue, streams and hipGraphs, the same weights
+        eng2 = engine.Far3DEngine(sd, cfg, device=dev, precision=precision)
+        eng2.agg_variant, eng2.cam_priority, eng2.fused_rows = eng.agg_variant, args.cam_priority, args.fused_rows
+        if args.agg_split is not None:
+            eng2.agg_split_extra = args.agg_split
     del sd
     frames = []
     for fi in range(4):   # a few distinct frames (ego motion on), resident in HBM before the timed region
@@ -333,6 +342,41 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     tile_table_pipelined = eng.bf16_tile_table()
     sync()
 
+    # ---- two independent scene streams interleaved on the one device (frames of stream A and stream B alternate; each stream is the
+    # frame pipeline of region B with its own buffers and memory queue).  Reported BESIDE the single-stream figures, never instead.
+    two = None
+    if eng2 is not None and pipeline_on:
+        try:
+            eng2.pipeline_sets, eng2.cam_streams, eng2.tile_table, eng2.pipeline, eng2.use_graph = eng.pipeline_sets, eng.cam_streams, table, True, True
+            frames_b = [(d, [dict(m, scene_token="bench-stream-b") for m in metas]) for d, metas in frames]
+            sb = 0
+            for _ in range(eng2.pipeline_sets + 3 + warmup):          # scene start (eager), the captures of every buffer set, warm-up
+                eng2.forward_frame(*frames_b[sb % len(frames_b)])
+                sb += 1
+            sync()
+            half = max(1, steps // 2)
+            t0 = time.perf_counter()
+            for k in range(half):
+                oa = eng.forward_frame(*frames[step_i % len(frames)])
+                ob = eng2.forward_frame(*frames_b[sb % len(frames_b)])
+                step_i += 1
+                sb += 1
+            eng.wait_outputs()
+            eng2.wait_outputs()
+            sync()
+            dt2 = time.perf_counter() - t0
+            assert not torch.isnan(oa["all_cls_scores"]).any() and not torch.isnan(ob["all_cls_scores"]).any()
+            two = {"streams": 2, "frames": 2 * half, "samples_per_s": 2 * half / dt2, "ms_per_frame": dt2 / (2 * half) * 1e3,
+                   "single_stream_pipelined_samples_per_s": steps / dt,
+                   "what": "two independent scene streams (two engines: own buffers, memory queues, streams, hipGraphs; same weights), "
+                           "their frames enqueued alternately, each stream with the frame pipeline of protocol.pipelined"}
+        except Exception as e:   # noqa: BLE001  (a side block must never cost the headline)
+            two = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+            torch.cuda.synchronize(dev)
+    if eng2 is not None:
+        del eng2
+        torch.cuda.empty_cache()
+
     # ---- the reference's protocol again with the frame's cameras split into groups that run side by side (far3d_amd.latency; --latency-groups 0 skips it)
     lat_groups = None
     if latency_runner and args.latency_groups > 1 and world == 1 and not sharded and proposals == "topk" and not args.eager:
@@ -404,6 +448,7 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
     n_adapt = int(out["num_adaptive_dev"].item()) if out.get("num_adaptive_dev") is not None else int(out["num_adaptive"])
     overflow = bool(int(out["proposal_overflow"].item())) if out.get("proposal_overflow") is not None else False
     res = dict(n_adaptive=n_adapt, proposal_overflow=overflow, steps=steps, dt=dt, dt_sync=dt_sync, dev_ms=dev_ms, per_frame=per_frame, lat_groups=lat_groups,
+               two_streams=two,
                A=A, N=N, S=S, C=C, eng_frames=eng_frames, agg_ms=agg_ms, bb_ms=bb_ms, stage_ms=stage_ms,
                timing_error=timing_error, prec=dict(eng.prec), pipeline=pipeline_on, cfg=cfg, tile_table=tile_table_pipelined,
                ncam_local=len(runner.cams) if sharded else 7, agg_split_extra=int(getattr(eng, "agg_split_extra", 0)),
@@ -493,6 +538,8 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "fp32", "bf16x3", "bf16x3_all", "bf16x3_2d1", "bf16x3_f32act", "bf16_fp32dec", "bf16_fp32val"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"], help="N>1: shard one sample's cameras, or one scene stream per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-streams", dest="two_streams", action="store_false",
+                    help="single GPU: skip protocol.two_streams_pipelined (a second engine = a second, independent scene stream interleaved with the first)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc passes (two short sub-runs); the "
                     "committed in-frame figure of the evidence set is reported instead")
     ap.add_argument("--no-fast-mode", "--no-in-tolerance", dest="fast_mode", action="store_false",
@@ -560,7 +607,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     sharded = world > 1 and args.mode == "sharded"
 
-    res = measure(args, args.precision, args.steps, args.warmup, world, rank, dev, sharded, dist, proposals=args.proposals)
+    res = measure(args, args.precision, args.steps, args.warmup, world, rank, dev, sharded, dist, proposals=args.proposals,
+                  two_streams=args.two_streams and world == 1)
     # The headline engine is the one that MEETS the north-star logit tolerance (bf16x3).  The same run also times the bf16 engine --
     # BASELINE configs[1]'s dtype, ~40x outside the tolerance -- same workload, same two protocols, and reports it as `fast_mode`.
     res_fast = None
@@ -627,6 +675,8 @@ def main():
             line["kernel_timing_error"] = res["timing_error"]
         if res.get("lat_groups"):
             line["protocol"]["sync_per_frame_groups"] = res["lat_groups"]
+        if res.get("two_streams"):
+            line["protocol"]["two_streams_pipelined"] = res["two_streams"]
         if res.get("stage_ms"):
             # per rank: where a (sync-per-frame) frame goes -- per-camera stages, the exchange, the replicated head
             line["per_rank_stage_ms"] = res["stage_ms"]

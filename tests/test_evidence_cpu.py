@@ -68,6 +68,9 @@ def test_headline_is_the_in_tolerance_engine_with_cpu_baseline_and_parity():
     assert f["dtype"] == "bf16" and f["meets_tolerance"] is False and f["parity"]["logit_max_abs"] > 1e-3 and f["value_protocol"] == "sync_per_frame"
     assert f["roofline"]["algorithmic_bytes_per_launch"] == 66385600 and f["value"] > d["value"]
     assert abs(f["value"] * f["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    # a second, independent scene stream interleaved on the same device rides beside the single-stream figures
+    tw = d["protocol"]["two_streams_pipelined"]
+    assert tw["streams"] == 2 and tw["frames"] >= 20 and tw["samples_per_s"] > 0.8 * d["protocol"]["pipelined"]["samples_per_s"]
     # the ranks that took part are read back from the process group
     assert d["ranks"] == 1 and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
     # the full-size rig holds the in-tolerance engine to the bar on every streaming frame with the near-tie decisions adopted

@@ -11,8 +11,8 @@ if [ "${TESTS:-1}" = "1" ]; then
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $O/smoke.txt
 fi
 timeout 900 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-300 $O/bench.json
-timeout 600 python bench.py --precision fp32 --steps 20 --no-cpu-baseline --no-pmc 2>$O/bench_fp32.err | tail -1 > $O/bench_fp32.json; cut -c1-200 $O/bench_fp32.json
-timeout 600 python bench.py --precision bf16 --steps 50 --no-cpu-baseline --no-pmc 2>$O/bench_bf16.err | tail -1 > $O/bench_bf16.json; cut -c1-200 $O/bench_bf16.json
+timeout 600 python bench.py --precision fp32 --steps 20 --no-cpu-baseline --no-pmc --no-two-streams 2>$O/bench_fp32.err | tail -1 > $O/bench_fp32.json; cut -c1-200 $O/bench_fp32.json
+timeout 600 python bench.py --precision bf16 --steps 50 --no-cpu-baseline --no-pmc --no-two-streams 2>$O/bench_bf16.err | tail -1 > $O/bench_bf16.json; cut -c1-200 $O/bench_bf16.json
 timeout 600 python bench.py --proposals threshold --capacity 4096 --steps 30 --no-cpu-baseline --no-pmc 2>$O/bench_thr.err | tail -1 > $O/bench_threshold.json; cut -c1-200 $O/bench_threshold.json
 timeout 300 python tools/stage_times.py bf16 > $O/stage_times_bf16.txt 2>&1; tail -16 $O/stage_times_bf16.txt
 timeout 300 python tools/stage_times.py bf16x3 > $O/stage_times_bf16x3.txt 2>&1
