@@ -433,11 +433,11 @@ def measure(args, precision, steps, warmup, world, rank, dev, sharded, dist, ker
         img_in = eng._ins[0]["img"]
         img_local = img_in if not sharded else img_in[runner.cams[0]:runner.cams[-1] + 1] if runner.cams else img_in[:0]
         if kernel_timings:
-            tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_, tab_ = eng.last_agg
+            tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, pad_, perm_, tab_, qbase_ = eng.last_agg
             agg_out = torch.empty(ref_.shape[0], 256, device=dev, dtype=eng.prec["dec"])
             agg_ms = [device_time(lambda: ops.aggregate_forward(tokens, ref_, offs_, l2i_, U_, Vc_, hw_, st_, cfg["pc_range"], pad_,
                                                                 num_groups=cfg["num_groups"], perm=perm_, out=agg_out,
-                                                                variant=args.agg_variant, tables=tab_, split=getattr(eng, "last_agg_split", None)), 24)]
+                                                                variant=args.agg_variant, tables=tab_, split=getattr(eng, "last_agg_split", None), qbase=qbase_), 24)]
         # the backbone ALONE, exactly the launch sequence of the frame (keep_stage2=False: the stage-2 map is consumed by the pooling
         # pass only): launches one after the other, so with the tile table tuned for that regime
         keep_table, eng.tile_table = eng.tile_table, "tuning_mi355x.json"

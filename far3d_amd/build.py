@@ -27,12 +27,12 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs) if hs else 0.0
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(src, objdir=None, extra=()):
+    obj = os.path.join(objdir or OBJ, src[:-4] + ".o")
     sp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _newest_header()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -78,5 +78,29 @@ def build(force=False, verbose=True):
     return LIB
 
 
+PROF_LIB = os.path.join(HERE, "libfar3d_hip_prof.so")
+
+
+def build_profiling(verbose=True):
+    """libfar3d_hip_prof.so: the same sources with -DFAR3D_PROFILING (s_memtime stamps at phase boundaries; tools/ only, never the
+    product library).  Objects cached per source under csrc/_obj_prof, compiled in parallel like build()."""
+    objdir = os.path.join(CSRC, "_obj_prof")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda f: _compile(f, objdir, ("-DFAR3D_PROFILING",)), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(PROF_LIB) or os.path.getmtime(PROF_LIB) < max(os.path.getmtime(o) for o in objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROF_LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[far3d_amd.build] linked", PROF_LIB)
+    return PROF_LIB
+
+
 if __name__ == "__main__":
+    if "--profiling" in sys.argv:
+        build_profiling()
+        sys.exit(0)
     build(force="--force" in sys.argv)

@@ -20,10 +20,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float* __restrict__ y, int rows,
                                                         int C, int ldx, int ldy, float eps, int act,
                                                         const float* __restrict__ add, int lda, void* __restrict__ y2,
-                                                        int ldy2, int y2_dt, void* __restrict__ yb, int ldyb, int yb_dt) {
+                                                        int ldy2, int y2_dt, void* __restrict__ yb, int ldyb, int yb_dt,
+                                                        const int* __restrict__ out_rows) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const int orow = out_rows ? out_rows[row] : row;      // row of y2 / yb (far3d_layernorm_rows); requested with the row itself
   const float* xr = x + (long)row * ldx;
   float4 v[MAXV];
   float s = 0.f;
@@ -59,22 +61,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       *reinterpret_cast<float4*>(y + (long)row * ldy + c) = o;
       if (yb) {
-        if (yb_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(yb) + (long)row * ldyb + c) = o;
-        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(yb) + (long)row * ldyb + c) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        if (yb_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(yb) + (long)orow * ldyb + c) = o;
+        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(yb) + (long)orow * ldyb + c) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
       }
       if (y2) {
         const float4 a = *reinterpret_cast<const float4*>(add + (long)row * lda + c);
         const float4 q2 = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
-        if (y2_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(y2) + (long)row * ldy2 + c) = q2;
-        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y2) + (long)row * ldy2 + c) = make_uint2(pack_bf16x2(q2.x, q2.y), pack_bf16x2(q2.z, q2.w));
+        if (y2_dt == FAR3D_DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(y2) + (long)orow * ldy2 + c) = q2;
+        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y2) + (long)orow * ldy2 + c) = make_uint2(pack_bf16x2(q2.x, q2.y), pack_bf16x2(q2.z, q2.w));
       }
     }
   }
 }
 
-extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
-                               int ldx, int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2,
-                               int y2_dt, void* yb, int ldyb, int yb_dt, void* stream) {
+static int layernorm_launch(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
+                            int ldx, int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2,
+                            int y2_dt, void* yb, int ldyb, int yb_dt, const int32_t* out_rows, void* stream) {
   FAR3D_CHECK_ARG(x && y, "far3d_layernorm: null x/y");
   FAR3D_CHECK_ARG(rows >= 0 && C > 0 && (C % 4) == 0 && C <= 1024, "far3d_layernorm: C=%d must be a multiple of 4, <= 1024", C);
   FAR3D_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && (!y2 || (add && lda % 4 == 0 && ldy2 % 4 == 0)) && (!yb || ldyb % 4 == 0),
@@ -83,11 +85,24 @@ extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* 
   dim3 grid((rows + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (C <= 256)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt);
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt, (const int*)out_rows);
   else
-    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt);
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt, (const int*)out_rows);
   FAR3D_CHECK_LAUNCH("far3d_layernorm");
   return FAR3D_OK;
+}
+
+extern "C" int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
+                               int ldx, int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2,
+                               int y2_dt, void* yb, int ldyb, int yb_dt, void* stream) {
+  return layernorm_launch(x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt, nullptr, stream);
+}
+
+extern "C" int far3d_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
+                                    int ldx, int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2,
+                                    int y2_dt, void* yb, int ldyb, int yb_dt, const int32_t* out_rows, void* stream) {
+  FAR3D_CHECK_ARG(out_rows && (y2 || yb), "far3d_layernorm_rows: needs out_rows and at least one of y2 / yb");
+  return layernorm_launch(x, gamma, beta, y, rows, C, ldx, ldy, eps, act, add, lda, y2, ldy2, y2_dt, yb, ldyb, yb_dt, out_rows, stream);
 }
 
 // ---------------------------------------------------------------- per-(image, channel) sums over H*W

@@ -609,7 +609,8 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
                                                          int* __restrict__ perm, int A, int N, float lo0, float lo1, float lo2,
                                                          float sp0, float sp1, float sp2, float pad_h, float pad_w,
                                                          const int* __restrict__ hole_count, int hole_start, int hole_end, int row_base,
-                                                         const float* __restrict__ Vc, float* __restrict__ tables, int J, int split_extra) {
+                                                         const float* __restrict__ Vc, float* __restrict__ tables, int J, int split_extra,
+                                                         int* __restrict__ inv, float4* __restrict__ qbase) {
   __shared__ int hist[AGGO_MAX_BINS];
   __shared__ int wsum[16];
   __shared__ int hsum[16];
@@ -632,13 +633,13 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
     key[k] = -1;
     if (a < A) {
       const float* rp = ref + (long)(row_base + a) * 3;      // rows [row_base, row_base + A) of the caller's reference points
-      const float X = rp[0] * sp0 + lo0, Y = rp[1] * sp1 + lo1, Z = rp[2] * sp2 + lo2;
+      const float X = agg_base_metre(rp[0], sp0, lo0), Y = agg_base_metre(rp[1], sp1, lo1), Z = agg_base_metre(rp[2], sp2, lo2);
       float best = 3.0e9f, bu = 0.f, bv = 0.f;
       int cam = 0, nvis = 0;
       for (int n = 0; n < N; ++n) {
         const float* m = l2i + n * 16;
-        const float x = m[0] * X + m[1] * Y + m[2] * Z + m[3], y = m[4] * X + m[5] * Y + m[6] * Z + m[7],
-                    z = m[8] * X + m[9] * Y + m[10] * Z + m[11];
+        const float x = agg_base_row(m[0], m[1], m[2], m[3], X, Y, Z), y = agg_base_row(m[4], m[5], m[6], m[7], X, Y, Z),
+                    z = agg_base_row(m[8], m[9], m[10], m[11], X, Y, Z);
         const float zc = fmaxf(z, 1e-5f);
         const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
         const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
@@ -698,12 +699,35 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
       const int a = row_base + t + k * 1024;                 // absolute row
       perm[hist[key[k]] + rank[k]] = (a >= hole_lo && a < hole_end) ? ~a : (((splitm >> k) & 1u) ? (a | (1 << 29)) : a);
     }
+  // launch-order operands of far3d_aggregate_forward's sorted mode: inv[i] = the slot (workgroup) of row row_base + i -- the producers
+  // of the per-layer logits / offsets store row i at row inv[i] -- and qbase[slot][n] = lidar2img_n [ref_m, 1] (csrc/agg_tables.hpp),
+  // so that the aggregation kernel's first loads depend on its block index only
+  if (inv || qbase) {
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k)
+      if (key[k] >= 0) {
+        const int i = t + k * 1024, slot = hist[key[k]] + rank[k];
+        if (inv) inv[i] = slot;
+        if (qbase) {
+          const float* rp = ref + (long)(row_base + i) * 3;
+          const float X = agg_base_metre(rp[0], sp0, lo0), Y = agg_base_metre(rp[1], sp1, lo1), Z = agg_base_metre(rp[2], sp2, lo2);
+          for (int n = 0; n < 8; ++n) {
+            const float* m = l2i + min(n, N - 1) * 16;
+            const float x = agg_base_row(m[0], m[1], m[2], m[3], X, Y, Z), y = agg_base_row(m[4], m[5], m[6], m[7], X, Y, Z),
+                        z = agg_base_row(m[8], m[9], m[10], m[11], X, Y, Z);
+            qbase[(long)slot * 8 + n] = n < N ? make_float4(x, y, z, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+  }
 }
 
 extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range,
                                float pad_h, float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
-                               const float* Vc, float* tables, int layers, int J, int split_extra, void* stream) {
+                               const float* Vc, float* tables, int layers, int J, int split_extra, int32_t* inv, float* qbase,
+                               void* stream) {
   FAR3D_CHECK_ARG(ref && lidar2img && perm && pc_range && A >= 0 && N > 0, "far3d_agg_order: bad arguments");
+  FAR3D_CHECK_ARG(!qbase || (N <= 8 && ((uintptr_t)qbase % 16) == 0), "far3d_agg_order: qbase needs N <= 8 (got %d) and 16-byte alignment", N);
   FAR3D_CHECK_ARG(!tables || (Vc && layers > 0 && J > 0), "far3d_agg_order: tables need Vc, layers > 0 and J > 0");
   if (!tables) layers = 0;
   FAR3D_CHECK_ARG(A <= 8192 && N * 64 <= AGGO_MAX_BINS, "far3d_agg_order: A=%d (<= 8192) or N=%d (<= 16) too large", A, N);
@@ -714,7 +738,8 @@ extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t
   if (A == 0 && layers == 0 && split_extra == 0) return FAR3D_OK;
   hipLaunchKernelGGL(agg_order_kernel, dim3(1 + layers), dim3(1024), 0, (hipStream_t)stream, ref, lidar2img, perm, A, N, pc_range[0],
                      pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], pad_h,
-                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base, Vc, tables, J, split_extra);
+                     pad_w, (const int*)hole_count, hole_start, hole_end, row_base, Vc, tables, J, split_extra, (int*)inv,
+                     reinterpret_cast<float4*>(qbase));
   FAR3D_CHECK_LAUNCH("far3d_agg_order");
   return FAR3D_OK;
 }

@@ -171,6 +171,7 @@ struct RowAttnOutParams {
   const uint4* w_wl; const float* b_wl; int n_wl;
   float* x1; int ldx1;                  // (M, E) out: LN0 rows
   float* ul; int ldu;                   // (M, n_wl) out: aggregation logits | key-point offsets
+  const int* ul_rows;                   // optional (M): row i of ul is stored at row ul_rows[i] (far3d_agg_order's inv)
   int M; float eps;
 };
 
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(RC_THREADS) void rowchain_attn_out_kernel(RowAttnOu
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * RC_R;
   rc_load_block(A0, F, P.att, P.ld_att, P.x, P.ldx, row0, P.M, tid);
-  // operands of the later phases, requested now: position codes of this wave's two LayerNorm rows, the affine terms, the biases
+  // operands of the later phases, requested now: position codes of this wave's two LayerNorm rows, the affine terms, the biases,
+  // the destination row of this thread's piece of the logits / offsets
+  const int ulrow_ld = P.ul_rows ? P.ul_rows[min(row0 + (tid >> 5), P.M - 1)] : 0;
   float4 pos[2];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) pos[rr] = rc_ld4(P.qpos + (long)min(row0 + 2 * wave + rr, P.M - 1) * P.ldq + lane * 4);
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(RC_THREADS) void rowchain_attn_out_kernel(RowAttnOu
   {
     const int r = tid >> 5, row = row0 + r;
     if (row < P.M) {
-      float* dst = P.ul + (long)row * P.ldu;
+      float* dst = P.ul + (long)(P.ul_rows ? ulrow_ld : row) * P.ldu;
       for (int c = (tid & 31) * 4; c < P.n_wl; c += 128) {
         const float4 v = *reinterpret_cast<const float4*>(S + r * RC_WL_SLD + c);
         if (c + 3 < P.n_wl) {
@@ -524,7 +527,7 @@ static bool rc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 extern "C" int far3d_rowchain_attn_out(const void* att, int ld_att, const float* x, int ldx, const float* qpos, int ldq,
                                        const void* w_out, const float* b_out, const float* g0, const float* be0,
                                        const void* w_wl, const float* b_wl, int n_wl, float* x1, int ldx1, float* ul, int ldu,
-                                       int M, float eps, void* stream) {
+                                       const int32_t* ul_rows, int M, float eps, void* stream) {
   FAR3D_CHECK_ARG(att && x && qpos && w_out && b_out && g0 && be0 && w_wl && b_wl && x1 && ul, "far3d_rowchain_attn_out: null pointer");
   FAR3D_CHECK_ARG(M >= 0, "far3d_rowchain_attn_out: M=%d", M);
   FAR3D_CHECK_ARG(n_wl > 16 * (RC_WL_TILES - 1) && n_wl <= 16 * RC_WL_TILES && ldu >= n_wl,
@@ -539,7 +542,7 @@ extern "C" int far3d_rowchain_attn_out(const void* att, int ld_att, const float*
   RowAttnOutParams P;
   P.att = (const bf16_t*)att; P.ld_att = ld_att; P.x = x; P.ldx = ldx; P.qpos = qpos; P.ldq = ldq;
   P.w_out = (const uint4*)w_out; P.b_out = b_out; P.g0 = g0; P.be0 = be0;
-  P.w_wl = (const uint4*)w_wl; P.b_wl = b_wl; P.n_wl = n_wl; P.x1 = x1; P.ldx1 = ldx1; P.ul = ul; P.ldu = ldu; P.M = M; P.eps = eps;
+  P.w_wl = (const uint4*)w_wl; P.b_wl = b_wl; P.n_wl = n_wl; P.x1 = x1; P.ldx1 = ldx1; P.ul = ul; P.ldu = ldu; P.ul_rows = (const int*)ul_rows; P.M = M; P.eps = eps;
   static std::atomic<unsigned long long> lds_ok{0};
   if (const int rc_ = far3d_allow_lds(reinterpret_cast<const void*>(&rowchain_attn_out_kernel), RC_LDS, lds_ok, "rowchain_attn_out_kernel")) return rc_;
   hipLaunchKernelGGL(rowchain_attn_out_kernel, dim3((M + RC_R - 1) / RC_R), dim3(RC_THREADS), RC_LDS, (hipStream_t)stream, P);

@@ -517,6 +517,13 @@ AGG_DPP1(agg_max_r8, "v_max_f32_dpp", "row_ror:8")
 AGG_DPP1(agg_add_q2, "v_add_f32_dpp", "quad_perm:[2,3,0,1]")
 AGG_DPP1(agg_add_r4, "v_add_f32_dpp", "row_ror:4")
 AGG_DPP1(agg_add_r8, "v_add_f32_dpp", "row_ror:8")
+// value of lane K of the caller's 16-lane row, in every lane of the row (v_mov_b32_dpp row_newbcast:K)
+template <int K> __device__ __forceinline__ float agg8_row_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
+}
+template <int K> __device__ __forceinline__ float4 agg8_row_bcast4(const float4& v) {
+  return make_float4(agg8_row_bcast<K>(v.x), agg8_row_bcast<K>(v.y), agg8_row_bcast<K>(v.z), agg8_row_bcast<K>(v.w));
+}
 __device__ __forceinline__ float agg8_row_min(float v) { return agg_min_r8(agg_min_r4(agg_min_q2(agg_min_q1(v)))); }     // all 16 lanes of a row
 __device__ __forceinline__ float agg8_row_max(float v) { return agg_max_r8(agg_max_r4(agg_max_q2(agg_max_q1(v)))); }
 __device__ __forceinline__ float agg8_wave_max_parity(float v) {      // over the 32 lanes of a wave with equal (lane & 1)
@@ -1020,11 +1027,16 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
 // shares (same greedy rule), workgroup `part` taking shares 2 part and 2 part + 1; each publishes its unnormalised 256-float sum with
 // device-scope stores and draws a ticket; the one that arrives second adds the two partials in part order (part 0 + part 1 whoever
 // merges: deterministic), applies 1 / S and writes the row.  An unmarked query takes the two-share path, bit-identical to variant 8.
-template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false>
+// SORTED (round 6): U / offs hold the query of perm entry e at ROW e and qbase[e][n] = lidar2img_n [ref_m, 1] comes from
+// far3d_agg_order -- every operand load is issued in the first burst, from the block index alone; perm[e] is read for the hole test
+// and the output row only (before: perm[e] -> ref / offs / U rows, a dependent round trip in front of the first useful instruction,
+// profiles/r5/agg_phase_times.txt).  Same fmaf chains in both forms (csrc/agg_tables.hpp): bit-identical rows.
+template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false, bool SORTED = false>
 __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ tab,
-                                                           const int* __restrict__ perm, void* __restrict__ out, AggParams prm) {
+                                                           const int* __restrict__ perm, void* __restrict__ out, AggParams prm,
+                                                           const float4* __restrict__ qbase) {
   int a0 = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
   bool sibling = false;
   if constexpr (SPLIT) {
@@ -1064,54 +1076,75 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   const bool w0 = wv == 0;                                    // wave-uniform
   const float4* mA = reinterpret_cast<const float4*>(l2i + min(r, N - 1) * 16);
   const float4* mB = reinterpret_cast<const float4*>(l2i + min(r + 4, N - 1) * 16);
-  const float4 ld0 = *(w0 ? mA : T4 + i0), ld1 = *(w0 ? mA + 1 : T4 + i1), ld2 = *(w0 ? mA + 2 : T4 + n4 + i0);
-  const float4 ld3 = *(w0 ? mB : T4 + n4 + i1), ld4 = *(w0 ? mB + 1 : T4), ld5 = *(w0 ? mB + 2 : T4);
-  const float4 mA0 = ld0, mA1 = ld1, mA2 = ld2, mB0 = ld3, mB1 = ld4, mB2 = ld5;        // wave 0's reading of the six slots
-  float4 mv0 = ld0, mv1 = ld1;                                                          // wave 1's
-  const float4 es0 = ld2, es1 = ld3;
-  int a = perm ? perm[a0] : a0;
+  float4 mA0, mA1, mA2, mB0, mB1, mB2;        // wave 0: rows 0..2 of the projection matrices of cameras r and r + 4
+  float4 mv0, mv1, es0, es1;                  // wave 1: table rows mV and EV
+  float4 eu0, eu1, bsA, bsB;                  // wave 1: the query's logits; wave 0: lidar2img [ref_m, 1] of the two cameras
+  float of0, of1, of2;
+  int a;
+  if constexpr (SORTED) {
+    a = perm[a0];                             // needed behind the front end's barrier only (hole test, output row)
+  } else {
+    const float4 ld0 = *(w0 ? mA : T4 + i0), ld1 = *(w0 ? mA + 1 : T4 + i1), ld2 = *(w0 ? mA + 2 : T4 + n4 + i0);
+    const float4 ld3 = *(w0 ? mB : T4 + n4 + i1), ld4 = *(w0 ? mB + 1 : T4), ld5 = *(w0 ? mB + 2 : T4);
+    mA0 = ld0; mA1 = ld1; mA2 = ld2; mB0 = ld3; mB1 = ld4; mB2 = ld5;        // wave 0's reading of the six slots
+    mv0 = ld0; mv1 = ld1;                                                    // wave 1's
+    es0 = ld2; es1 = ld3;
+    a = perm ? perm[a0] : a0;
+  }
   bool split = false;
   if constexpr (SPLIT) {
     if (sibling && a == AGG_NO_SIBLING) return;      // unused sibling slot
   }
-  if (a < 0) {      // ~a: row a holds no query (far3d_agg_order): zero row, no work
+  auto hole_row = [&]() __attribute__((always_inline)) {      // ~a: row a holds no query (far3d_agg_order): zero row, no work
     a = ~a;
     const int c = t * 2;
     if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(0.f, 0.f);
     else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = 0u;
-    return;
+  };
+  // (sorted mode tests for the hole BEHIND the front end's barrier: a test here would make the whole load burst wait for perm[e] --
+  // the compiler sinks the loads below the branch -- and a hole slot's operands are finite rows like any other)
+  if constexpr (!SORTED) {
+    if (a < 0) { hole_row(); return; }
   }
   if constexpr (SPLIT) {
     split = (a & AGG_SPLIT_FLAG) != 0;
     a &= AGG_ROW_MASK;
   }
   const int part = sibling ? 1 : 0;
-  // ---- query-dependent loads, issued together: reference point and this lane's key-point offset (read by wave 0), the query part of
-  // the logits (wave 1; wave 0 receives e^U from wave 1 through LDS below, its two slots read tab[0])
-  const float rf0 = ref[a * 3], rf1 = ref[a * 3 + 1], rf2 = ref[a * 3 + 2];
-  const float* op_ = offs + (long)a * prm.ldO + min(p, P - 1) * 3;
-  const float of0 = op_[0], of1 = op_[1], of2 = op_[2];
-  const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
-  float4 eu0 = *(w0 ? T4 : U4 + i0), eu1 = *(w0 ? T4 : U4 + i1);
-  if (!v0) mv0 = NEG4;         // lanes past the row: logit -inf -> weight 0 (register selects)
-  if (!v1) mv1 = NEG4;
+  if constexpr (!SORTED) {
+    const float rf0 = ref[a * 3], rf1 = ref[a * 3 + 1], rf2 = ref[a * 3 + 2];
+    const float* op_ = offs + (long)a * prm.ldO + min(p, P - 1) * 3;
+    of0 = op_[0]; of1 = op_[1]; of2 = op_[2];
+    const float4* U4 = reinterpret_cast<const float4*>(U + (long)a * prm.ldU);
+    eu0 = *(w0 ? T4 : U4 + i0); eu1 = *(w0 ? T4 : U4 + i1);
+    // the reference point's camera-space images, as far3d_agg_order computes them for the sorted mode (same chain, same bits)
+    const float X = agg_base_metre(rf0, prm.pc_span[0], prm.pc_lo[0]), Y = agg_base_metre(rf1, prm.pc_span[1], prm.pc_lo[1]),
+                Z = agg_base_metre(rf2, prm.pc_span[2], prm.pc_lo[2]);
+    bsA = make_float4(agg_base_row(mA0.x, mA0.y, mA0.z, mA0.w, X, Y, Z), agg_base_row(mA1.x, mA1.y, mA1.z, mA1.w, X, Y, Z),
+                      agg_base_row(mA2.x, mA2.y, mA2.z, mA2.w, X, Y, Z), 0.f);
+    bsB = make_float4(agg_base_row(mB0.x, mB0.y, mB0.z, mB0.w, X, Y, Z), agg_base_row(mB1.x, mB1.y, mB1.z, mB1.w, X, Y, Z),
+                      agg_base_row(mB2.x, mB2.y, mB2.z, mB2.w, X, Y, Z), 0.f);
+  }
+  if constexpr (!SORTED) {
+    if (!v0) mv0 = NEG4;         // lanes past the row: logit -inf -> weight 0 (register selects)
+    if (!v1) mv1 = NEG4;
+  }
   AGG_TS(8);
 
   // ---- projection (detr3d_transformer.py:524-525,547-552) of the P key points into cameras r and r + 4, per-camera bounding box,
   // per (camera, level) item descriptor in lane (r, level)
-  const float k0 = (rf0 * prm.pc_span[0] + prm.pc_lo[0]) + of0, k1 = (rf1 * prm.pc_span[1] + prm.pc_lo[1]) + of1,
-              k2 = (rf2 * prm.pc_span[2] + prm.pc_lo[2]) + of2;
   // level sizes of level (lane & 15), as floats, without indexing the kernel arguments by a VGPR
   float Wf0 = prm.Wf[0], Wf1 = prm.Wf[1], Wf2 = prm.Wf[2], Wf3 = prm.Wf[3], Hf0 = prm.Hf[0], Hf1 = prm.Hf[1], Hf2 = prm.Hf[2], Hf3 = prm.Hf[3];
   asm volatile("" : "+s"(Wf0), "+s"(Wf1), "+s"(Wf2), "+s"(Wf3), "+s"(Hf0), "+s"(Hf1), "+s"(Hf2), "+s"(Hf3));   // in SGPRs here: selects, not branches around loads
   const float Wme = p == 0 ? Wf0 : p == 1 ? Wf1 : p == 2 ? Wf2 : Wf3;
   const float Hme = p == 0 ? Hf0 : p == 1 ? Hf1 : p == 2 ? Hf2 : Hf3;
   const float WfL[AGG_MAX_L] = {Wf0, Wf1, Wf2, Wf3}, HfL[AGG_MAX_L] = {Hf0, Hf1, Hf2, Hf3};
-  auto project = [&](const float4& m0, const float4& m1, const float4& m2, int n, int& d0, int& d1, int& est, bool& is_patch) __attribute__((always_inline)) {
+  auto project = [&](const float4& m0, const float4& m1, const float4& m2, const float4& bs, int n, int& d0, int& d1, int& est, bool& is_patch) __attribute__((always_inline)) {
     const bool act = n < N && p < P;
-    const float x = m0.x * k0 + m0.y * k1 + m0.z * k2 + m0.w;
-    const float y = m1.x * k0 + m1.y * k1 + m1.z * k2 + m1.w;
-    const float z = m2.x * k0 + m2.y * k1 + m2.z * k2 + m2.w;
+    // M [ref_m + off, 1] = bs + M3 off  (bs = M [ref_m, 1]: csrc/agg_tables.hpp)
+    const float x = __builtin_fmaf(m0.x, of0, __builtin_fmaf(m0.y, of1, __builtin_fmaf(m0.z, of2, bs.x)));
+    const float y = __builtin_fmaf(m1.x, of0, __builtin_fmaf(m1.y, of1, __builtin_fmaf(m1.z, of2, bs.y)));
+    const float z = __builtin_fmaf(m2.x, of0, __builtin_fmaf(m2.y, of1, __builtin_fmaf(m2.z, of2, bs.z)));
     const float rz = __builtin_amdgcn_rcpf(fmaxf(z, 1e-5f));
     const float u = (x * rz) * prm.ipw, v = (y * rz) * prm.iph;
     float umin = act ? u : INFINITY, umax = act ? u : -INFINITY, vmin = act ? v : INFINITY, vmax = act ? v : -INFINITY;
@@ -1197,10 +1230,27 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     int4* xd = reinterpret_cast<int4*>(wt_all + CAPT * 8);       // wave 1's list region <- wave 0: descriptors, dealing
     float4* xe = reinterpret_cast<float4*>(wt_all);              // wave 0's list region <- wave 1: eU
     if (wv == 0) {
+      if constexpr (SORTED) {
+        // SORTED front end, wave 0: ONE 16-byte load per lane fetches everything the projection needs that is uniform over a 16-lane
+        // row -- lane (r, k) reads row k of camera r's matrix (k < 3), row k - 3 of camera r + 4's (k < 6), qbase[e][r] (k = 6),
+        // qbase[e][r + 4] (k = 7) -- and 32 row broadcasts (v_mov_dpp row_newbcast) hand every lane of the row its copies; plus the
+        // lane's key-point offset.  2 vector-memory instructions instead of 9: with 12 waves of a CU starting at once, the texture
+        // addresser's 16 cycles per 64 x 16-byte request were what the slowest wave waited for (round 6, s2/phase_8s.txt).
+        const int k = min(p, 7);
+        const float4* Q4 = qbase + (long)a0 * 8 + r;
+        const float4* src = k < 3 ? mA + k : k < 6 ? mB + (k - 3) : Q4 + (k - 6) * 4;
+        const float4 pk = *src;
+        const float* op_ = offs + (long)a0 * prm.ldO + min(p, P - 1) * 3;
+        of0 = op_[0]; of1 = op_[1]; of2 = op_[2];
+        mA0 = agg8_row_bcast4<0>(pk); mA1 = agg8_row_bcast4<1>(pk); mA2 = agg8_row_bcast4<2>(pk);
+        mB0 = agg8_row_bcast4<3>(pk); mB1 = agg8_row_bcast4<4>(pk); mB2 = agg8_row_bcast4<5>(pk);
+        bsA = agg8_row_bcast4<6>(pk); bsB = agg8_row_bcast4<7>(pk);
+      }
       bool patA, patB;
-      const bool visA_ = project(mA0, mA1, mA2, r, dA0, dA1, estA, patA);
-      const bool visB_ = project(mB0, mB1, mB2, r + 4, dB0, dB1, estB, patB);
+      const bool visA_ = project(mA0, mA1, mA2, bsA, r, dA0, dA1, estA, patA);
+      const bool visB_ = project(mB0, mB1, mB2, bsB, r + 4, dB0, dB1, estB, patB);
       visA = __ballot(visA_); visB = __ballot(visB_); patchA = __ballot(patA); patchB = __ballot(patB);
+      AGG_TS(1);
       unsigned long long oA, oB;
       int oload;
       deal2(split ? 4 : 2, 2 * part, 2 * part + 1, mineA, mineB, myload, oA, oB, oload);
@@ -1209,12 +1259,26 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
         unsigned long long* q = reinterpret_cast<unsigned long long*>(xd + 64);
         q[0] = oA; q[1] = oB; q[2] = patchA; q[3] = patchB; q[4] = (unsigned long long)oload;
       }
+      AGG_TS(2);
     } else {
+      if constexpr (SORTED) {
+        // wave 1: the table rows and the query's logits, nothing else (6 requests; before, 3 more that only wave 0 read)
+        const float4* U4 = reinterpret_cast<const float4*>(U + (long)a0 * prm.ldU);
+        mv0 = T4[i0]; mv1 = T4[i1]; es0 = T4[n4 + i0]; es1 = T4[n4 + i1];
+        eu0 = U4[i0]; eu1 = U4[i1];
+        if (!v0) mv0 = NEG4;
+        if (!v1) mv1 = NEG4;
+      }
       softmax_stats();
+      AGG_TS(1);
       xe[lane] = eu0; xe[64 + lane] = eu1;
       if (lane < 2) *reinterpret_cast<float4*>(stat_s + (lane & 1) * 4) = S4;
+      AGG_TS(2);
     }
     __syncthreads();
+    if constexpr (SORTED) {
+      if (a < 0) { hole_row(); return; }      // block-uniform
+    }
     if (wv == 0) {
       eu0 = xe[lane]; eu1 = xe[64 + lane];
     } else {
@@ -1260,8 +1324,6 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   take_batch();
   issue_ev();
 
-  AGG_TS(1);
-  AGG_TS(2);
   AGG_TS(3);
 
   float acc[8];
@@ -1485,7 +1547,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
                                        const float* Vc, const float* cam_tables, const int32_t* perm, void* out, int out_dt, int A, int N,
                                        int S, int C, int G, int P, int L, const int32_t* level_hw, const int32_t* level_start,
                                        const float* pc_range, float pad_h, float pad_w, int ldU, int ldOffs, int variant,
-                                       float* split_partials, int32_t* split_tickets, int split_extra, void* stream) {
+                                       float* split_partials, int32_t* split_tickets, int split_extra, const float* qbase,
+                                       void* stream) {
   FAR3D_CHECK_ARG(feat && ref && offsets && lidar2img && U && (Vc || cam_tables) && out && level_hw && level_start && pc_range,
                   "far3d_aggregate_forward: null pointer argument");
   FAR3D_CHECK_ARG(C == 256 && G == 8, "far3d_aggregate_forward: fused kernel is built for C=256,G=8 (got C=%d G=%d)", C, G);
@@ -1505,6 +1568,8 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(variant != 9 || v8_ok, "far3d_aggregate_forward: variant 9 needs what variant 8 needs (cam_tables, N <= 8, P <= 16)");
   FAR3D_CHECK_ARG(variant != 8 || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
   FAR3D_CHECK_ARG(variant == 8 || variant == 9 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
+  FAR3D_CHECK_ARG(!qbase || (variant == 8 && perm && ((uintptr_t)qbase % 16) == 0),
+                  "far3d_aggregate_forward: qbase (sorted mode) needs kernel 8 (variant %d after defaulting), perm and 16-byte alignment", variant);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -1547,22 +1612,31 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
+  } else if (variant == 8 && qbase) {      // the default kernel in sorted mode: operands in launch order, hoisted projection
+    const float4* qb = reinterpret_cast<const float4*>(qbase);
+    if (feat_dtype == FAR3D_DT_F32) {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, false, true>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0, 1, 4, AGG8_CAPW, false, true>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);
+    } else {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, false, true>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0, 1, 4, AGG8_CAPW, false, true>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);
+    }
   } else if (variant == 8) {      // factored softmax, specialised front ends, work-dealt items (default)
     if (feat_dtype == FAR3D_DT_F32) {
-      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
     } else {
-      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
     }
   } else if (variant == 9) {      // variant 8 + sibling workgroups for the queries far3d_agg_order marked as heavy
     const dim3 grid9(8 * prm.q_per_xcd + split_extra);
     if (feat_dtype == FAR3D_DT_F32) {
-      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
     } else {
-      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
-      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm);
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0, 1, 4, AGG8_CAPW, true>), grid9, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
     }
   } else if (variant == 7) {     // 2 waves per query, levels split by parity, softmax over all 7 cameras
     const int NP = N * P;

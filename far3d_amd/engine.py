@@ -165,6 +165,9 @@ class Far3DEngine:
         self._fidx = 0
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
+        self.agg_sorted = True      # the aggregation kernel's SORTED mode (round 6): far3d_agg_order also emits the launch slot of every
+                                    # row and the hoisted projections; the producers of the per-layer logits / offsets store in launch
+                                    # order, so that no load of the kernel waits for perm[e] (replicated decoder, kernel 8, no split)
         self.agg_split_extra = 0    # > 0: far3d_aggregate_forward variant 9 -- that many sibling workgroups for the queries two cameras see
                                     # (far3d_agg_order marks them; ops.AggSplit holds the partial sums / tickets, one per buffer set)
         self.fused_rows = True      # bf16 decoder: the row-local parts of a decoder layer and the cls / reg branches run as row-resident
@@ -599,11 +602,18 @@ class Far3DEngine:
             if sp is None:
                 sp = self._bufs[sk] = ops.AggSplit(A, self.agg_split_extra, self.dev)
         self.last_agg_split = sp
-        perm, tabs = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A + (sp.extra if sp else 0),), torch.int32),
-                                           hole=hole, Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32), split=sp)
+        srt = None
+        if self.agg_sorted and sp is None and self.agg_variant in (0, 8) and A > 0 and vc_all.shape[1] <= 8 and cfg["num_pts"] <= 16:
+            srt = (self._buf(("agg_inv",), (A,), torch.int32), self._buf(("agg_qbase",), (A, 8, 4), torch.float32))
+        res = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A + (sp.extra if sp else 0),), torch.int32),
+                                    hole=hole, Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32), split=sp,
+                                    sorted_operands=srt)
+        perm, tabs = res[0], res[1]
+        inv, qbase = srt if srt is not None else (None, None)
         x = x0
         if self.fused_rows and fast and all(ly["rc"] is not None for ly in self.layers):
-            return self._decoder_fused(X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs)
+            return self._decoder_fused(X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs,
+                                       inv, qbase)
         for li, ly in enumerate(self.layers):
             c0 = li * 3 * E
             # self-attention: q = x+pos, k = cat[x,mem]+cat[pos,mempos], v = cat[x,mem] (detr3d_transformer.py:378-396)
@@ -611,13 +621,15 @@ class Far3DEngine:
             att = ops.attention_forward(QKV[:A, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
                                         num_heads=cfg["num_heads"], out_dtype=at, hole=hole)
             y = ops.linear(att, ly["out"], res=x)
-            ops.layernorm(y, *ly["norms"][0], out=x1, add=qpos, y2=XW[:, :E], yb=XW[:, E:])
+            # (sorted mode: the GEMM-operand rows [x1 + pos | x1] go to the aggregation kernel's launch slots, so the GEMM below
+            # writes the logits / offsets in launch order)
+            ops.layernorm(y, *ly["norms"][0], out=x1, add=qpos, y2=XW[:, :E], yb=XW[:, E:], out_rows=inv)
             # cross-attention: fused perspective-aware aggregation (detr3d_transformer.py:522-569)
             ops.linear(XW, ly["wl"], out=UL[:, :nJ + nO])
             agg = ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
                                         cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out_dtype=at,
-                                        variant=self.agg_variant, tables=tabs[li], split=sp)
-            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li])
+                                        variant=self.agg_variant, tables=tabs[li], split=sp, qbase=qbase)
+            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li], qbase)
             y = ops.linear(agg, ly["oproj"], res=x1)
             if fast:
                 ops.layernorm(y, *ly["norms"][1], out=x2, yb=x2b)
@@ -630,7 +642,8 @@ class Far3DEngine:
             x = outs[li]
         return outs
 
-    def _decoder_fused(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs):
+    def _decoder_fused(self, X2, x0, qpos, tokens, ref, hw, starts, lidar2img, pad_hw, A, hole, outs, QKV, UL, x1, vc_all, perm, tabs,
+                       inv=None, qbase=None):
         """The decoder layers with their row-local parts as two row-resident chains (csrc/rowchain.hip): per layer the attention
         core, far3d_rowchain_attn_out (out-projection + residual + LN0 + the aggregation's logit / offset linears), the
         aggregation kernel, far3d_rowchain_ffn (output projection + residual + LN1 + FFN + LN2 + the NEXT layer's q / k / v) --
@@ -650,11 +663,11 @@ class Far3DEngine:
             c0 = li * 3 * E
             ops.attention_forward(QKV[:A, c0:c0 + E], QKV[:, c0 + E:c0 + 2 * E], QKV[:, c0 + 2 * E:c0 + 3 * E],
                                   num_heads=cfg["num_heads"], out=att, hole=hole)
-            ops.rowchain_attn_out(att, x, qpos, ly["rc"], x1, UL)
+            ops.rowchain_attn_out(att, x, qpos, ly["rc"], x1, UL, ul_rows=inv)
             ops.aggregate_forward(tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts,
                                   cfg["pc_range"], pad_hw, num_groups=cfg["num_groups"], perm=perm, out=agg,
-                                  variant=self.agg_variant, tables=tabs[li], split=self.last_agg_split)
-            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li])
+                                  variant=self.agg_variant, tables=tabs[li], split=self.last_agg_split, qbase=qbase)
+            self.last_agg = (tokens, ref, UL[:, nJ:nJ + nO], lidar2img, UL[:, :nJ], vc_all[li], hw, starts, pad_hw, perm, tabs[li], qbase)
             last = li + 1 == nL
             ops.rowchain_ffn(agg, x1, qpos, ly["rc"], outs[li], nxt=None if last else self.layers[li + 1]["rc"],
                              qkv=None if last else QKV[:A, c0 + 3 * E:c0 + 6 * E])

@@ -31,15 +31,16 @@ SIGNATURES = {
     "far3d_device_arch": (c_int, [c_int, c_char_p, c_int]),
     "far3d_msda_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p] + [c_int] * 7 + [_p]),
     "far3d_aggregate_forward": (c_int, [_p, c_int, _p, _p, _p, _p, _p, _p, _p, _p, c_int] + [c_int] * 7 +
-                                [_p, _p, _p, c_float, c_float, c_int, c_int, c_int, _p, _p, c_int, _p]),
+                                [_p, _p, _p, c_float, c_float, c_int, c_int, c_int, _p, _p, c_int, _p, _p]),
     "far3d_conv2d_nhwc": (c_int, [_p, c_int, _p, c_int, _p, _p, c_int] + [c_int] * 5 + [c_long] + [c_int] * 4 +
                           [c_long] + [c_int] * 5 + [_p, c_int, c_int, c_long, c_int, c_int] +
                           [_p, c_int, c_int, c_long, _p, _p, _p, c_int, _p]),
     "far3d_attention_forward": (c_int, [_p, _p, _p, c_int, _p, c_int] + [c_int] * 8 + [c_float, _p, c_int, c_int, _p]),
     "far3d_attention_f32_variant": (c_int, [c_int]),
     "far3d_layernorm": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, c_int, _p]),
+    "far3d_layernorm_rows": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_float, c_int, _p, c_int, _p, c_int, c_int, _p, c_int, c_int, _p, _p]),
     "far3d_rowchain_attn_out": (c_int, [_p, c_int, _p, c_int, _p, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_int, _p, c_int,
-                                        c_int, c_float, _p]),
+                                        _p, c_int, c_float, _p]),
     "far3d_rowchain_ffn": (c_int, [_p, c_int, _p, c_int, _p, c_int] + [_p] * 12 + [_p, c_int, _p, c_int, _p, c_int, c_int, c_float, _p]),
     "far3d_rowchain_qkv": (c_int, [_p, c_int, _p, c_int, _p, _p, _p, c_int, c_int, _p]),
     "far3d_rowchain_branches": (c_int, [_p, c_int] + [_p] * 10 + [c_int] + [_p] * 6 + [c_int, _p, c_int, _p, c_int, c_int, c_float, _p]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "far3d_head_finalize": (c_int, [_p] * 5 + [c_int] * 4 + [_p, _p, c_int, c_int, _p]),
     "far3d_memory_post_update": (c_int, [_p] * 10 + [c_int] * 4 + [_p] * 6),
     "far3d_add_cast": (c_int, [_p, _p, _p, c_int, _p, c_int, c_int, c_int, c_long, c_long, _p]),
-    "far3d_agg_order": (c_int, [_p, _p, _p, c_int, c_int, _p, c_float, c_float, _p, c_int, c_int, c_int, _p, _p, c_int, c_int, c_int, _p]),
+    "far3d_agg_order": (c_int, [_p, _p, _p, c_int, c_int, _p, c_float, c_float, _p, c_int, c_int, c_int, _p, _p, c_int, c_int, c_int, _p, _p, _p]),
     "far3d_agg_tables": (c_int, [_p, _p, c_int, c_int, c_int, _p]),
     "far3d_topk": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "far3d_decode_topk": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_long, _p]),

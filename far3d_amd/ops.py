@@ -142,7 +142,7 @@ class AggSplit:
 
 
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None, split=None):
+                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None, split=None, qbase=None):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
@@ -153,6 +153,8 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     only through .contiguous() -- the kernel reads dense rows.  variant: see include/far3d_hip.h (0 = default).
     tables: agg_tables(Vc) (2+N, L*P*G) -- the per-frame softmax factors the default kernel reads instead of Vc; computed here
     (one more launch) when the default kernel runs and the caller did not pass them.
+    qbase: aggregation_order(..., sorted_operands=True)'s (A, 8, 4) table -- SORTED mode of the default kernel: U and offsets hold the
+    query of perm entry e at row e (their producers stored through the order's `inv`), ref is not read; same bits as the unsorted call.
     """
     lib = _lib.require_device()
     _chk(feat, "feat", ndim=3)
@@ -186,6 +188,12 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         variant = 9
     if tables is None and variant in (0, 8, 9) and A > 0 and N <= 8 and P <= 16:
         tables = agg_tables(Vc)
+    if qbase is not None:
+        _chk(qbase, "qbase", torch.float32, 3)
+        if perm is None or split is not None or variant not in (0, 8) or tuple(qbase.shape) != (nperm, 8, 4) or nperm != A:
+            raise ValueError("aggregate_forward: qbase (sorted mode) needs the full perm of aggregation_order(sorted_operands=True), "
+                             "variant 0 / 8, no split and shape (A, 8, 4)")
+        variant = 8
     if tables is not None:
         _chk(tables, "tables", torch.float32, 2)
         if tuple(tables.shape) != (2 + N, L * P * G):
@@ -200,7 +208,8 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
                                            float(pad_hw[0]), float(pad_hw[1]), U.stride(0) if A > 0 else 0,
                                            offsets.stride(0) if A > 0 else 0, int(variant),
                                            _ptr(split.partials) if split is not None else None, _ptr(split.tickets) if split is not None else None,
-                                           split.extra if split is not None else 0, _stream(feat)),
+                                           split.extra if split is not None else 0, _ptr(qbase) if qbase is not None else None,
+                                           _stream(feat)),
                "far3d_aggregate_forward")
     return out
 
@@ -570,9 +579,10 @@ def _rows(t, name, dtype, cols):
     return t
 
 
-def rowchain_attn_out(att, x, qpos, rc, x1, ul, eps=1e-5):
+def rowchain_attn_out(att, x, qpos, rc, x1, ul, eps=1e-5, ul_rows=None):
     """x1 = LN0(att @ W_out^T + b + x); ul[:, :n_wl] = [x1 + qpos | x1] @ W_wl^T + b  -- one launch (far3d_rowchain_attn_out).
-    att (M,E) bf16; x, qpos (M,E) f32; x1 (M,E) f32 out; ul (M, >= n_wl) f32 out.  rc: RowChainLayer."""
+    att (M,E) bf16; x, qpos (M,E) f32; x1 (M,E) f32 out; ul (M, >= n_wl) f32 out.  rc: RowChainLayer.
+    ul_rows (M) int32: row i of ul is stored at row ul_rows[i] (aggregation_order's inv: the aggregation kernel's launch order)."""
     lib = _lib.require_device()
     E = ROWCHAIN_E
     M = att.shape[0]
@@ -582,9 +592,14 @@ def rowchain_attn_out(att, x, qpos, rc, x1, ul, eps=1e-5):
         if t.shape[0] != M:
             raise ValueError("rowchain_attn_out: row counts differ")
     g0, be0 = rc.norms[0]
+    if ul_rows is not None:
+        _chk(ul_rows, "ul_rows", torch.int32, 1)
+        if ul_rows.numel() != M:
+            raise ValueError("rowchain_attn_out: ul_rows needs one entry per row")
     _lib.check(lib.far3d_rowchain_attn_out(_ptr(att), att.stride(0), _ptr(x), x.stride(0), _ptr(qpos), qpos.stride(0),
                                            _ptr(rc.out), _ptr(rc.b_out), _ptr(g0), _ptr(be0), _ptr(rc.wl), _ptr(rc.b_wl), rc.n_wl,
-                                           _ptr(x1), x1.stride(0), _ptr(ul), ul.stride(0), M, float(eps), _stream(att)),
+                                           _ptr(x1), x1.stride(0), _ptr(ul), ul.stride(0), _ptr(ul_rows) if ul_rows is not None else None,
+                                           M, float(eps), _stream(att)),
                "far3d_rowchain_attn_out")
     return x1, ul
 
@@ -676,8 +691,10 @@ def attention_forward(q, k, v, num_heads=8, out=None, out_dtype=torch.float32, h
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=torch.float32, bf16_copy=False, y2=None, yb=None):
+def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=torch.float32, bf16_copy=False, y2=None, yb=None,
+              out_rows=None):
     """Returns LN(x); with `add`: (LN(x), LN(x)+add [add_dtype]); with bf16_copy also a bf16 copy of LN(x) (last).
+    out_rows (rows) int32: row i of y2 / yb is stored at row out_rows[i] (far3d_layernorm_rows; LN(x) itself stays in place).
     y2 / yb: optional preallocated (rows,C) outputs (f32|bf16, unit inner stride, any row stride) for LN(x)+add and the
     copy of LN(x) -- e.g. the two halves of one (rows,2C) [x+pos | x] merged-GEMM operand; they are returned in place of
     freshly allocated ones."""
@@ -695,13 +712,20 @@ def layernorm(x, gamma, beta, eps=1e-5, act=None, add=None, out=None, add_dtype=
     for t in (y, y2, yb):
         if t is not None and (t.stride(1) != 1 or tuple(t.shape) != (rows, C)):
             raise ValueError("layernorm: outputs must be (rows,C) with unit inner stride")
-    _lib.check(lib.far3d_layernorm(_ptr(x), _ptr(gamma) if gamma is not None else None,
-                                   _ptr(beta) if beta is not None else None, _ptr(y), rows, C, x.stride(0), y.stride(0),
-                                   float(eps), 1 if act == "relu" else 0,
-                                   _ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
-                                   _ptr(y2) if y2 is not None else None, y2.stride(0) if y2 is not None else 0,
-                                   _dt(y2) if y2 is not None else 0, _ptr(yb) if yb is not None else None,
-                                   yb.stride(0) if yb is not None else 0, _dt(yb) if yb is not None else 0, _stream(x)), "far3d_layernorm")
+    args = (_ptr(x), _ptr(gamma) if gamma is not None else None,
+            _ptr(beta) if beta is not None else None, _ptr(y), rows, C, x.stride(0), y.stride(0),
+            float(eps), 1 if act == "relu" else 0,
+            _ptr(add) if add is not None else None, add.stride(0) if add is not None else 0,
+            _ptr(y2) if y2 is not None else None, y2.stride(0) if y2 is not None else 0,
+            _dt(y2) if y2 is not None else 0, _ptr(yb) if yb is not None else None,
+            yb.stride(0) if yb is not None else 0, _dt(yb) if yb is not None else 0)
+    if out_rows is not None:
+        _chk(out_rows, "out_rows", torch.int32, 1)
+        if out_rows.numel() != rows:
+            raise ValueError("layernorm: out_rows needs one entry per row")
+        _lib.check(lib.far3d_layernorm_rows(*args, _ptr(out_rows), _stream(x)), "far3d_layernorm_rows")
+    else:
+        _lib.check(lib.far3d_layernorm(*args, _stream(x)), "far3d_layernorm")
     res = (y,) + ((y2,) if y2 is not None else ()) + ((yb,) if yb is not None else ())
     return res if len(res) > 1 else y
 
@@ -1062,12 +1086,15 @@ def add_cast(a, b, sum_dtype, a_dtype=None, out_sum=None, out_a=None):
     return osum, oa
 
 
-def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None, Vc=None, tables_out=None, split=None):
+def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, rows=None, Vc=None, tables_out=None, split=None,
+                      sorted_operands=None):
     """Query order for aggregate_forward's `perm` (camera, then 8x8 image cell), one single-workgroup launch.  Groups the
     same way as camera_sorted_order(spatial=True); the order inside a cell is arbitrary (scheduling only).  hole: rows without a
     query are entered as ~a so that aggregate_forward writes zero rows for them (see _hole).  rows=(a0, a1): order only the rows
     [a0, a1) of ref; the entries are absolute row indices (pass the full-size buffers and this perm to aggregate_forward).
-    Vc (layers, N, J): the same launch also computes agg_tables(Vc) (into tables_out when given); returns (perm, tables) then."""
+    Vc (layers, N, J): the same launch also computes agg_tables(Vc) (into tables_out when given); returns (perm, tables) then.
+    sorted_operands: True, or a preallocated (inv (A) int32, qbase (A, 8, 4) f32) pair -- the same launch also writes the operands of
+    aggregate_forward's sorted mode (include/far3d_hip.h); they are appended to the return value as (inv, qbase)."""
     lib = _lib.require_device()
     _chk(ref, "ref", torch.float32, 2)
     a0, a1 = (0, ref.shape[0]) if rows is None else rows
@@ -1084,10 +1111,25 @@ def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, row
         if Nv != lidar2img.shape[0]:
             raise ValueError("aggregation_order: Vc has %d cameras, lidar2img %d" % (Nv, lidar2img.shape[0]))
         tab = tables_out if tables_out is not None else torch.empty((layers, 2 + Nv, J), dtype=torch.float32, device=ref.device)
+    inv = qbase = None
+    if sorted_operands is not None and sorted_operands is not False:
+        if split is not None:
+            raise ValueError("aggregation_order: sorted operands and sibling workgroups (split) do not combine")
+        if sorted_operands is True:
+            inv = torch.empty((A,), dtype=torch.int32, device=ref.device)
+            qbase = torch.empty((A, 8, 4), dtype=torch.float32, device=ref.device)
+        else:
+            inv, qbase = sorted_operands
+        _chk(inv, "inv", torch.int32, 1)
+        _chk(qbase, "qbase", torch.float32, 3)
+        if inv.numel() != A or tuple(qbase.shape) != (A, 8, 4):
+            raise ValueError("aggregation_order: inv needs A = %d entries and qbase the shape (A, 8, 4)" % A)
     _lib.check(lib.far3d_agg_order(_ptr(ref), _ptr(lidar2img), _ptr(perm), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
                                    *_hole(hole), int(a0), _ptr(Vc) if Vc is not None else None, _ptr(tab) if tab is not None else None,
-                                   layers, J, int(extra), _stream(ref)), "far3d_agg_order")
-    return perm if Vc is None else (perm, tab)
+                                   layers, J, int(extra), _ptr(inv) if inv is not None else None, _ptr(qbase) if qbase is not None else None,
+                                   _stream(ref)), "far3d_agg_order")
+    res = (perm,) + ((tab,) if Vc is not None else ()) + (((inv, qbase),) if inv is not None else ())
+    return res if len(res) > 1 else perm
 
 
 def topk(vals, K, with_values=False):

@@ -98,7 +98,12 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
                             int N, int S, int C, int G, int P, int L, const int32_t* level_hw,
                             const int32_t* level_start, const float* pc_range, float pad_h, float pad_w,
                             int ldU, int ldOffs, int variant, float* split_partials, int32_t* split_tickets, int split_extra,
-                            void* stream);
+                            const float* qbase, void* stream);
+/* qbase != NULL (round 6, kernel 8 only, needs perm): SORTED mode.  U and offsets hold the row of the query of perm entry e AT ROW e
+ * (launch order: their producers stored through far3d_agg_order's inv), qbase is far3d_agg_order's (A, 8, 4) table and `ref` is not
+ * read: every operand load of a workgroup depends on its block index only, perm[e] is needed for the hole test and the output row
+ * alone.  out row a is query a as always, and the result is BIT-IDENTICAL to the unsorted call (same fmaf chains, csrc/agg_tables.hpp).
+ * The unsorted call costs a dependent round trip (perm[e] -> ref / offsets / U rows) before the first useful instruction. */
 /* variant 9 (round 5) = kernel 8 + SIBLING workgroups for heavy queries: the launch ends with its slowest wave, and the slowest waves
  * belong to the queries two cameras see.  far3d_agg_order(split_extra) marks those queries (flag 1 << 29 on their perm entry) and appends
  * one sibling entry per marked query (perm[A + e] = row | 1 << 30 | 1 << 29; unused slots 0x7fffffff); the launch runs split_extra extra
@@ -203,6 +208,13 @@ int far3d_attention_f32_variant(int variant);
 int far3d_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int ldx,
                     int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2, int y2_dt, void* yb, int ldyb,
                     int yb_dt, void* stream);
+/* far3d_layernorm with a ROW MAP for the two GEMM-operand outputs: row i of y2 / yb is stored at row out_rows[i] (y itself stays in
+ * place).  The exact-fp32 decoder uses it to hand the aggregation's logit / offset GEMM its operand rows in the aggregation kernel's
+ * launch order (far3d_agg_order's inv), so that the GEMM's output is in that order with no change to the GEMM.  out_rows (rows) int32
+ * DEVICE, a permutation of [0, rows) (or any injective map into the caller's buffers). */
+int far3d_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int ldx,
+                         int ldy, float eps, int act, const float* add, int lda, void* y2, int ldy2, int y2_dt, void* yb, int ldyb,
+                         int yb_dt, const int32_t* out_rows, void* stream);
 
 /* ROW-RESIDENT CHAINS of a decoder layer (bf16 decoder, embed dims 256, FFN hidden 1024): the row-local work between the
  * attention core and the aggregation kernel, and between the aggregation kernel and the next layer's attention core, in one
@@ -224,7 +236,9 @@ int far3d_layernorm(const float* x, const float* gamma, const float* beta, float
 int far3d_rowchain_attn_out(const void* att, int ld_att, const float* x, int ldx, const float* qpos, int ldq,
                             const void* w_out, const float* b_out, const float* g0, const float* be0,
                             const void* w_wl, const float* b_wl, int n_wl, float* x1, int ldx1, float* ul, int ldu,
-                            int M, float eps, void* stream);
+                            const int32_t* ul_rows, int M, float eps, void* stream);
+/*   ul_rows: optional (M) int32 DEVICE -- row i of the logits / offsets is stored at row ul_rows[i] of `ul` (far3d_agg_order's inv:
+ *   the aggregation kernel's launch order); NULL = row i. */
 
 /* far3d_rowchain_ffn: x2 = LN1(agg W_o^T + b_o + x1);  out = LN2(relu(x2 W_1^T + b_1) W_2^T + b_2 + x2);
  *   with w_qkv: qkv = [out + qpos | out] W_qkv^T + b_qkv (bf16; the NEXT layer's merged q / k / v in-projection).
@@ -395,8 +409,13 @@ int far3d_add_cast(const float* a, const float* b, void* out_sum, int sum_dt, vo
  * per-frame preparations of the aggregation; one launch instead of two). */
 int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int A, int N, const float* pc_range, float pad_h,
                     float pad_w, const int32_t* hole_count, int hole_start, int hole_end, int row_base,
-                    const float* Vc, float* tables, int layers, int J, int split_extra, void* stream);
-/* split_extra > 0 (far3d_aggregate_forward variant 9): perm has A + split_extra entries; the first split_extra queries IN ROW ORDER whose
+                    const float* Vc, float* tables, int layers, int J, int split_extra, int32_t* inv, float* qbase, void* stream);
+/* inv / qbase (both optional, round 6): the operands of far3d_aggregate_forward's SORTED mode.  inv (A) int32: inv[i] = the perm slot
+ * (= workgroup) that handles row row_base + i, i.e. perm[inv[i]] names row row_base + i; the producers of the per-layer logits /
+ * key-point offsets store their row i at row inv[i] (far3d_rowchain_attn_out's ul_rows, far3d_layernorm_rows).  qbase (A, 8, 4) f32,
+ * 16-byte aligned, N <= 8: qbase[slot][n] = (x, y, z, 0) = lidar2img_n [ref_m, 1] of the query in that slot -- the layer-independent
+ * part of the key-point projection (ref models/utils/detr3d_transformer.py:524-525,547-552), evaluated once per frame.
+ * split_extra > 0 (far3d_aggregate_forward variant 9): perm has A + split_extra entries; the first split_extra queries IN ROW ORDER whose
  * reference point projects into two or more cameras are marked and get a sibling entry behind the A main ones (see above). */
 
 /* Descending top-K of n <= 40960 floats (ties -> lower index), one workgroup: idx_out (K) int64, val_out (K) f32 or NULL.

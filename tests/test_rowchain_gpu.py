@@ -200,6 +200,20 @@ def test_in_projection_alone_is_bitwise_the_ffn_chains_tail(hip_lib, M):
     assert torch.equal(alone[:, 3 * E:], tail) and not alone[:, :3 * E].any()
 
 
+@pytest.mark.parametrize("M", [1544, 37])
+def test_attn_out_chain_stores_the_logits_through_a_row_map(hip_lib, M):
+    """ul_rows (round 6: far3d_agg_order's inv): row i of the logits / offsets lands at row ul_rows[i], bit for bit; x1 stays in place."""
+    ly = _layer(4)
+    att, x, qpos = _inputs(M, M + 1)
+    inv = torch.randperm(M, generator=torch.Generator().manual_seed(M)).to(torch.int32).to(DEV)
+    x1a, x1b = torch.empty(M, E, device=DEV), torch.empty(M, E, device=DEV)
+    ula, ulb = torch.zeros(M, 512, device=DEV), torch.zeros(M, 512, device=DEV)
+    ops.rowchain_attn_out(att, x, qpos, ly["rc"], x1a, ula)
+    ops.rowchain_attn_out(att, x, qpos, ly["rc"], x1b, ulb, ul_rows=inv)
+    assert torch.equal(x1a, x1b)
+    assert torch.equal(ulb[inv.long()], ula)
+
+
 def test_bad_arguments_are_refused(hip_lib):
     from far3d_amd.lib import Far3dHipError
     ly = _layer(2)

@@ -192,3 +192,61 @@ def test_aggregate_sibling_workgroups_for_heavy_queries(hip_lib, dtype, extra):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aggregate_sorted_mode_is_bit_identical(hip_lib, dtype):
+    """Round 6: SORTED mode of the default kernel -- far3d_agg_order also emits every row's launch slot (inv) and the layer-independent
+    part of the projection (qbase); U / offsets are handed over in launch order.  Same rows bit for bit as the unsorted call (same
+    fmaf chains), against the oracle, with a hole, launch after launch."""
+    from far3d_amd import ops
+    c = cases.config2_aggregate_case(seed=6)
+    A = c["ref"].shape[0]
+    d = lambda t: t.to(DEV).contiguous()
+    feat = d(c["feat"].to(dtype))
+    ref, offs, l2i, U, Vc = d(c["ref"]), d(c["offsets"]).reshape(A, -1), d(c["lidar2img"]), d(c["U"]), d(c["Vc"])
+    tab = ops.agg_tables(Vc)
+    want = cases.oracle_aggregate(c, dtype)
+    for hole in (None, (torch.tensor([37], dtype=torch.int32, device=DEV), 100, 300)):
+        perm, (inv, qbase) = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"], hole=hole, sorted_operands=True)
+        pm, iv = perm.cpu().long(), inv.cpu().long()
+        rows = torch.where(pm < 0, ~pm, pm)
+        assert torch.equal(rows[iv], torch.arange(A)), "perm[inv[a]] names row a"
+        # qbase = lidar2img [ref_m, 1] per (slot, camera), cameras past N zero
+        pc = torch.tensor(c["pc_range"], dtype=torch.float64)
+        refm = torch.cat([c["ref"].double() * (pc[3:] - pc[:3]) + pc[:3], torch.ones(A, 1, dtype=torch.float64)], 1)
+        qb = torch.einsum("nij,aj->ani", c["lidar2img"].double(), refm)[:, :, :3]
+        got_qb = qbase.cpu().double()[iv]
+        assert (got_qb[:, :7, :3] - qb).abs().max().item() < 1e-4 * qb.abs().max().item()
+        assert got_qb[:, 7:].abs().max().item() == 0.0 and got_qb[:, :, 3].abs().max().item() == 0.0
+        Us, Os = torch.full_like(U, float("nan")), torch.full_like(offs, float("nan"))
+        Us[inv.long()], Os[inv.long()] = U, offs
+        base = ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=8, tables=tab)
+        run = lambda: ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
+                                            qbase=qbase)
+        got = run()
+        assert torch.equal(got, base), "sorted mode differs from the unsorted call"
+        assert torch.equal(run(), got)
+        if hole is None:
+            assert (got.float().cpu() - want).abs().max().item() < 5e-5
+        else:
+            assert got[137:300].abs().max().item() == 0.0 and (got[:137].float().cpu() - want[:137]).abs().max().item() < 5e-5
+    with pytest.raises(ValueError):
+        ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], tables=tab, qbase=qbase)
+
+
+def test_producers_store_in_launch_order(hip_lib):
+    """far3d_layernorm_rows and far3d_rowchain_attn_out(ul_rows): the row map moves the GEMM-operand outputs only."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, C = 203, 256
+    x, add = torch.randn(rows, C, generator=g).to(DEV), torch.randn(rows, C, generator=g).to(DEV)
+    gam, bet = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    inv = torch.randperm(rows, generator=g).to(torch.int32).to(DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        XW0 = torch.zeros(rows, 2 * C, dtype=dt, device=DEV)
+        XW1 = torch.zeros(rows, 2 * C, dtype=dt, device=DEV)
+        y0 = ops.layernorm(x, gam, bet, add=add, y2=XW0[:, :C], yb=XW0[:, C:])[0]
+        y1 = ops.layernorm(x, gam, bet, add=add, y2=XW1[:, :C], yb=XW1[:, C:], out_rows=inv)[0]
+        assert torch.equal(y0, y1)
+        assert torch.equal(XW1[inv.long()], XW0)

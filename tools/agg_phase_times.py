@@ -18,16 +18,16 @@ PROF = os.path.join(ROOT, "far3d_amd", "libfar3d_hip_prof.so")
 
 
 def build_prof():
-    srcs = [os.path.join(fbuild.CSRC, f) for f in fbuild._sources()]
-    cmd = [fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_PROFILING", "-shared", "-o", PROF] + srcs
-    subprocess.run(cmd, check=True)
+    fbuild.build_profiling()
 
 
 def main():
     """argv: [A] [variant] [operands.pt] [layer] [raw_out.npz] -- with an operands file (tools/dump_agg_operands.py) the kernel runs on
     the live operands of that decoder layer of a benchmark frame instead of the seeded test case."""
     A = int(sys.argv[1]) if len(sys.argv) > 1 else 1544
-    variant, nw = (int(sys.argv[2]) if len(sys.argv) > 2 else 7), 2
+    vs = sys.argv[2] if len(sys.argv) > 2 else "7"
+    srt = vs.endswith("s")                     # "8s": kernel 8 in sorted mode (operands in launch order, hoisted projection)
+    variant, nw = int(vs.rstrip("s")), 2
     opfile = sys.argv[3] if len(sys.argv) > 3 else None
     layer = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     raw_out = sys.argv[5] if len(sys.argv) > 5 else None
@@ -52,7 +52,16 @@ def main():
     nblk = 8 * ((A + 7) // 8)
     ts = torch.zeros(nblk * 4 * 16, dtype=torch.int64, device=dev)
     tab = ops.agg_tables(args[4])
-    run = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=variant, tables=tab)
+    qbase = None
+    if srt:
+        perm, (inv, qbase) = ops.aggregation_order(args[0], args[2], c["pc_range"], c["pad_hw"], sorted_operands=True)
+        offs2, U2 = args[1].reshape(A, -1), args[3]
+        Os, Us = torch.empty_like(offs2), torch.empty_like(U2)
+        Os[inv.long()], Us[inv.long()] = offs2, U2
+        args[1], args[3] = Os, Us
+        print("sorted mode: operands in launch order")
+    run = lambda: ops.aggregate_forward(feat, *args, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=variant, tables=tab,
+                                        qbase=qbase)
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -78,16 +87,26 @@ def main():
         np.savez_compressed(raw_out, stamps=t, perm=perm.cpu().numpy(), q_per_xcd=(A + 7) // 8)
     live = t[:, :, 0] != 0
     t = t[live[:, 0]]
-    if variant in (7, 8, 11):
+    if variant in (8, 9):      # v8's specialised front end, per wave (round 6 stamps): wave 0 projects and deals, wave 1 does the softmax statistics
+        for w, names in ((0, ("issue loads", "wait + projection + bbox", "deal + descriptors -> LDS", "barrier + read back", "first eV issue")),
+                         (1, ("issue loads", "wait + softmax statistics", "e^U -> LDS", "barrier + read back", "first eV issue"))):
+            for nm, (i, j) in zip(names, ((0, 8), (8, 1), (1, 2), (2, 9), (9, 3))):
+                dlt = (t[:, w, j] - t[:, w, i]).astype(np.float64)
+                print("  front end wave %d: %-28s median %7.0f  p90 %7.0f  max %7.0f ticks" % (w, nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
+        fe = (t[:, :, 3] - t[:, :, 0]).astype(np.float64)
+        print("  front end (start -> first eV issue), both waves: median %.0f p90 %.0f" % (np.median(fe), np.percentile(fe, 90)))
+    if variant in (7, 11):
         for nm, i, j in (("  issue logit loads", 0, 8), ("  projection+bbox", 8, 9), ("  local max", 9, 1)):
             dlt = (t[:, :, j] - t[:, :, i]).astype(np.float64)
             print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
     t0 = t[:, :, 0].min()
     names = ["loads+proj+localmax", "B1 wait", "exp+sums+B2", "build", "gather", "reduce+B3"]
+    if variant in (8, 9):
+        names = ["loads + projection | softmax", "deal | e^U -> LDS", "barrier + exchange + eV issue", "build", "gather", "reduce + barrier"]
     print("queries %d, workgroups stamped %d; s_memtime ticks (shader-clock cycles, ~2.1 GHz under this kernel: a 23 us launch spans ~48k ticks)" % (A, len(t)))
     for i, nm in enumerate(names):
         dlt = (t[:, :, i + 1] - t[:, :, i]).astype(np.float64)
-        print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
+        print("  %-30s median %8.0f  p90 %8.0f  max %8.0f ticks" % (nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))
     tot = (t[:, :, 6] - t[:, :, 0]).astype(np.float64)
     print("  %-22s median %8.0f  p90 %8.0f  max %8.0f ticks" % ("whole wave", np.median(tot), np.percentile(tot, 90), tot.max()))
     print("  (stamps of different CUs are not mutually synchronised: only differences within one wave are meaningful)")

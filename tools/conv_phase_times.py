@@ -26,17 +26,7 @@ LAYERS = [("s2.c1", 7, 160, 240, 128, 128, 3, (60, 130)), ("s3.c1", 7, 80, 120, 
 
 
 def build_prof():
-    objs = []
-    os.makedirs("/tmp/far3d_prof_obj", exist_ok=True)
-
-    def one(src):
-        o = os.path.join("/tmp/far3d_prof_obj", src[:-4] + ".o")
-        subprocess.run([fbuild.HIPCC] + fbuild.FLAGS + ["-DFAR3D_PROFILING", "-c", os.path.join(fbuild.CSRC, src), "-o", o], check=True)
-        return o
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        objs = list(ex.map(one, fbuild._sources()))
-    subprocess.run([fbuild.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROF] + objs, check=True)
-    print("built", PROF)
+    fbuild.build_profiling()
 
 
 def main():
