@@ -496,6 +496,39 @@ __global__ __launch_bounds__(TOPK_THREADS) void decode_topk_kernel(DecodeParams 
   }
 }
 
+// far3d_decode_topk_mem: the decode and the memory update's top-k (ref farhead.py:488-491) are both single-workgroup rankings of the last
+// layer's outputs and do not depend on each other: workgroup 0 decodes, workgroup 1 ranks the max-class scores -- one launch, the two
+// latency chains side by side on two CUs (in the frame each such launch costs ~8 us of cold start on top of its own time).  Same code
+// paths as the two stand-alone kernels: identical results.
+template <int MAXV>
+__global__ __launch_bounds__(TOPK_THREADS) void decode_topk_mem_kernel(DecodeParams p, int n, const float* __restrict__ vals2, int n2, int K2,
+                                                                       long* __restrict__ idx2) {
+  __shared__ unsigned long long sel[TOPK_MAXK];
+  if (blockIdx.x == 1) {
+    block_topk_sorted<4>(vals2, n2, K2, sel);
+    for (int i = threadIdx.x; i < K2; i += TOPK_THREADS) idx2[i] = (long)(0xffffffffu - (unsigned)(sel[i] & 0xffffffffull));
+    return;
+  }
+  block_topk_sorted<MAXV>(p.cls, n, p.K, sel);
+  for (int i = threadIdx.x; i < p.K; i += TOPK_THREADS) {
+    const unsigned long long e = sel[i];
+    const int idx = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    const float logit = ord_val((unsigned)(e >> 32));
+    const int q = idx / p.ncls;
+    p.labels[i] = (long)(idx - q * p.ncls);
+    p.scores[i] = 1.f / (1.f + expf(-logit));
+    const float* b = p.box + (long)q * p.code;
+    float* o = p.boxes + (long)i * (p.code - 1);
+    const float cx = b[0], cy = b[1], cz = b[2];
+    const float w = expf(b[3]), l = expf(b[4]), h = expf(b[5]);
+    o[0] = cx; o[1] = cy; o[2] = cz - h * 0.5f;
+    o[3] = w; o[4] = l; o[5] = h;
+    o[6] = atan2f(b[6], b[7]);
+    for (int k = 8; k < p.code; ++k) o[k - 1] = b[k];
+    p.keep[i] = (cx >= p.lo[0] && cy >= p.lo[1] && cz >= p.lo[2] && cx <= p.hi[0] && cy <= p.hi[1] && cz <= p.hi[2]) ? 1 : 0;
+  }
+}
+
 // Large inputs (A * ncls > TOPK_THREADS * TOPK_MAXV: the reference's threshold proposal mode on a busy frame): workgroup c
 // ranks chunk c of the logits and leaves its K best (value, original index) in the workspace; decode_topk_kernel then ranks
 // the nchunks * K candidates.  Exact: the global top-K is a subset of the union of the per-chunk top-K.
@@ -554,6 +587,37 @@ extern "C" int far3d_decode_topk(const float* cls_last, const float* box_last, i
       hipLaunchKernelGGL(decode_topk_kernel<TOPK_MAXV>, dim3(1), dim3(TOPK_THREADS), 0, st, p, (int)ncand, (const int*)cand_idx);
   }
   FAR3D_CHECK_LAUNCH("far3d_decode_topk");
+  return FAR3D_OK;
+}
+
+extern "C" int far3d_decode_topk_mem(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
+                                     const float* post_center_range, float* boxes, float* scores, int64_t* labels,
+                                     unsigned char* keep, void* workspace, long workspace_bytes, const float* mem_scores, int mem_n,
+                                     int mem_K, int64_t* mem_idx_out, void* stream) {
+  FAR3D_CHECK_ARG(mem_scores && mem_idx_out, "far3d_decode_topk_mem: null pointer argument");
+  FAR3D_CHECK_ARG(mem_n > 0 && mem_n <= TOPK_THREADS * TOPK_MAXV && mem_K > 0 && mem_K <= mem_n && mem_K <= TOPK_MAXK,
+                  "far3d_decode_topk_mem: need 0 < mem_K <= min(mem_n, %d), mem_n <= %d (got n=%d K=%d)", TOPK_MAXK, TOPK_THREADS * TOPK_MAXV, mem_n, mem_K);
+  const long n = (long)A * num_classes;
+  if (n > DECODE_CHUNK || n <= 0 || mem_n > TOPK_THREADS * 4) {      // shapes outside the fused launch: the two stand-alone calls
+    if (const int rc = far3d_topk(mem_scores, mem_n, mem_K, mem_idx_out, nullptr, stream)) return rc;
+    return far3d_decode_topk(cls_last, box_last, A, num_classes, code_size, K, post_center_range, boxes, scores, labels, keep, workspace,
+                             workspace_bytes, stream);
+  }
+  FAR3D_CHECK_ARG(cls_last && box_last && post_center_range && boxes && scores && labels && keep, "far3d_decode_topk_mem: null pointer argument");
+  FAR3D_CHECK_ARG(A > 0 && num_classes > 0 && code_size >= 8 && K > 0 && K <= TOPK_MAXK && K <= n,
+                  "far3d_decode_topk_mem: bad sizes A=%d ncls=%d code=%d K=%d (K <= %d)", A, num_classes, code_size, K, TOPK_MAXK);
+  DecodeParams p;
+  p.cls = cls_last; p.box = box_last; p.boxes = boxes; p.scores = scores; p.labels = (long*)labels; p.keep = keep;
+  p.A = A; p.ncls = num_classes; p.code = code_size; p.K = K;
+  for (int k = 0; k < 3; ++k) { p.lo[k] = post_center_range[k]; p.hi[k] = post_center_range[3 + k]; }
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= TOPK_THREADS * 4)
+    hipLaunchKernelGGL(decode_topk_mem_kernel<4>, dim3(2), dim3(TOPK_THREADS), 0, st, p, (int)n, mem_scores, mem_n, mem_K, (long*)mem_idx_out);
+  else if (n <= TOPK_THREADS * 16)
+    hipLaunchKernelGGL(decode_topk_mem_kernel<16>, dim3(2), dim3(TOPK_THREADS), 0, st, p, (int)n, mem_scores, mem_n, mem_K, (long*)mem_idx_out);
+  else
+    hipLaunchKernelGGL(decode_topk_mem_kernel<TOPK_MAXV>, dim3(2), dim3(TOPK_THREADS), 0, st, p, (int)n, mem_scores, mem_n, mem_K, (long*)mem_idx_out);
+  FAR3D_CHECK_LAUNCH("far3d_decode_topk_mem");
   return FAR3D_OK;
 }
 

@@ -894,11 +894,12 @@ class Far3DEngine:
         box_flat, sc = ops.head_finalize(rr, ref, all_cls, cfg["pc_range"], nl, cfg["num_classes"], hole=hole)
         all_box = box_flat.view(nl, 1, A, cfg["code_size"])
         # ---- a11: memory post-update (farhead.py:479-508): top-k by max-class score, push, truncate, ego warp -- in place
-        idx = ops.topk(sc, cfg["topk_proposals"])
+        # (the top-k rides in the decode's launch as a second workgroup: far3d_decode_topk_mem -- both rank the last layer's outputs)
+        result, idx = self.decode(all_cls, all_box, mem_scores=sc, mem_K=cfg["topk_proposals"])
         ops.memory_post_update(m, idx, outs_dec[-1], all_box[-1][0], dd["ego_pose"], dd["timestamp"], self.mem)
         outs = dict(all_cls_scores=all_cls, all_bbox_preds=all_box, outs_dec=outs_dec, num_adaptive=M, num_adaptive_dev=m_dev,
                     feat_flatten=tokens, reference_points=ref, memory_topk=idx)
-        outs["result"] = self.decode(all_cls, all_box)
+        outs["result"] = result
         return outs
 
     def _stage_inputs(self, data):
@@ -1062,10 +1063,10 @@ class Far3DEngine:
         return outs
 
     # ------------------------------------------------------------------------------------------ a12: NMS-free decode
-    def decode(self, all_cls, all_box):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245
+    def decode(self, all_cls, all_box, mem_scores=None, mem_K=None):   # core/bbox/coders/nms_free_coder.py:39-112; farhead.py:1224-1245
         cfg = self.cfg
         cls, box = all_cls[-1][0], all_box[-1][0]
         K = min(cfg["max_num"], cls.numel())
         need = ops.decode_ws_bytes(cls.numel(), K)      # > 0 beyond 40960 logits (many adaptive queries): chunked two-launch decode
         ws = self._buf(("decode_ws",), (need,), torch.uint8) if need else None
-        return ops.decode_topk(cls, box, K, cfg.get("post_center_range", cfg["pc_range"]), workspace=ws)
+        return ops.decode_topk(cls, box, K, cfg.get("post_center_range", cfg["pc_range"]), workspace=ws, mem_scores=mem_scores, mem_K=mem_K)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "far3d_agg_tables": (c_int, [_p, _p, c_int, c_int, c_int, _p]),
     "far3d_topk": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "far3d_decode_topk": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_long, _p]),
+    "far3d_decode_topk_mem": (c_int, [_p, _p, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_long, _p, c_int, c_int, _p, _p]),
     "far3d_camera_prep": (c_int, [_p, _p, _p, _p, _p, c_int, _p]),
     "far3d_nan_to_num": (c_int, [_p, _p, c_long, _p]),
     "far3d_image_resample_h": (c_int, [_p, c_long, c_int, c_int, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p]),

@@ -1151,9 +1151,11 @@ def decode_ws_bytes(n, K):
     return 0 if n <= DECODE_CHUNK else -(-n // DECODE_CHUNK) * K * 8
 
 
-def decode_topk(cls_last, box_last, K, post_center_range, workspace=None):
+def decode_topk(cls_last, box_last, K, post_center_range, workspace=None, mem_scores=None, mem_K=None):
     """NMS-free decode of the last layer: returns dict(boxes_3d (K,code-1), scores_3d (K), labels_3d (K) i64, keep (K) bool).
-    workspace: optional uint8 device buffer of decode_ws_bytes(A * ncls, K) bytes (allocated here when needed and not given)."""
+    workspace: optional uint8 device buffer of decode_ws_bytes(A * ncls, K) bytes (allocated here when needed and not given).
+    mem_scores (n) f32 + mem_K: the same launch also ranks them (far3d_decode_topk_mem: topk(mem_scores, mem_K) in a second workgroup);
+    returns (dict, idx (mem_K) int64) then."""
     lib = _lib.require_device()
     _chk(cls_last, "cls_last", torch.float32, 2)
     _chk(box_last, "box_last", torch.float32, 2)
@@ -1168,9 +1170,17 @@ def decode_topk(cls_last, box_last, K, post_center_range, workspace=None):
     need = decode_ws_bytes(A * ncls, int(K))
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    res = dict(boxes_3d=boxes, scores_3d=scores, labels_3d=labels, keep=keep)
+    if mem_scores is not None:
+        _chk(mem_scores, "mem_scores", torch.float32, 1)
+        idx = torch.empty((int(mem_K),), dtype=torch.int64, device=dev)
+        _lib.check(lib.far3d_decode_topk_mem(_ptr(cls_last), _ptr(box_last), A, ncls, code, int(K), rp, _ptr(boxes), _ptr(scores), _ptr(labels),
+                                             _ptr(keep), _ptr(workspace) if need else None, need, _ptr(mem_scores), mem_scores.numel(), int(mem_K),
+                                             _ptr(idx), _stream(cls_last)), "far3d_decode_topk_mem")
+        return res, idx
     _lib.check(lib.far3d_decode_topk(_ptr(cls_last), _ptr(box_last), A, ncls, code, int(K), rp, _ptr(boxes), _ptr(scores), _ptr(labels),
                                      _ptr(keep), _ptr(workspace) if need else None, need, _stream(cls_last)), "far3d_decode_topk")
-    return dict(boxes_3d=boxes, scores_3d=scores, labels_3d=labels, keep=keep)
+    return res
 
 
 def camera_prep(lidar2img, intrinsics=None, extrinsics=None):

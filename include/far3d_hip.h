@@ -436,6 +436,13 @@ int far3d_topk(const float* vals, int n, int K, int64_t* idx_out, float* val_out
 int far3d_decode_topk(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
                       const float* post_center_range, float* boxes, float* scores, int64_t* labels, unsigned char* keep,
                       void* workspace, long workspace_bytes, void* stream);
+/* far3d_decode_topk + far3d_topk(mem_scores, mem_n, mem_K, mem_idx_out) in ONE launch of two workgroups (round 6): the decode and the
+ * memory update's top-k (ref models/dense_heads/farhead.py:488-491) both rank outputs of the last layer and do not depend on each
+ * other.  Same results as the two calls.  Shapes outside the fused launch (A*num_classes > 40960 or mem_n > 4096) run as the two calls. */
+int far3d_decode_topk_mem(const float* cls_last, const float* box_last, int A, int num_classes, int code_size, int K,
+                          const float* post_center_range, float* boxes, float* scores, int64_t* labels, unsigned char* keep,
+                          void* workspace, long workspace_bytes, const float* mem_scores, int mem_n, int mem_K,
+                          int64_t* mem_idx_out, void* stream);
 
 /* Per-frame camera calibration in one launch: img2lidar (N,4,4) = inverse(lidar2img) (ref models/dense_heads/farhead.py:798;
  * Gauss-Jordan with partial pivoting in f64) and c14 (N,14) = [fx/1e3, fy/1e3, extrinsics[:3,:4]] (ref farhead.py:553-556).

@@ -110,6 +110,35 @@ def test_decode_topk_large_query_counts_take_the_chunked_path(hip_lib, A):
     assert ops.decode_ws_bytes(A * ncls, K) == (0 if A * ncls <= 40960 else -(-A * ncls // 40960) * K * 8)
 
 
+@pytest.mark.parametrize("A,ncls,K,mK", [(1544, 26, 300, 256), (1544, 10, 300, 256), (120, 10, 100, 64), (1576, 26, 300, 256), (5000, 26, 300, 256)])
+def test_decode_with_the_memory_topk_in_one_launch(hip_lib, A, ncls, K, mK):
+    """far3d_decode_topk_mem (round 6): workgroup 0 decodes, workgroup 1 ranks the memory update's scores -- bit for bit the two
+    stand-alone calls (ties planted in both inputs; the last two shapes lie outside the fused launch and run as the two calls)."""
+    from far3d_amd import ops
+    g = torch.Generator().manual_seed(A + ncls)
+    cls = torch.randn(A, ncls, generator=g) * 2
+    cls.view(-1)[::977] = 2.5
+    box = torch.randn(A, 8, generator=g)
+    sc = torch.sigmoid(cls.max(-1).values)
+    sc[::7] = sc[3]
+    if A == 5000:
+        sc = torch.cat([sc, sc])                       # more than 4096 scores
+    rng = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+    cd, bd, sd = cls.to(DEV), box.to(DEV), sc.to(DEV)
+    want, widx = ops.decode_topk(cd, bd, K, rng), ops.topk(sd, mK)
+    got, gidx = ops.decode_topk(cd, bd, K, rng, mem_scores=sd, mem_K=mK)
+    assert torch.equal(gidx, widx)
+    for k in want:
+        a, b = got[k], want[k]
+        assert torch.equal(a, b) or (k == "scores_3d" and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))), k
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        r2, i2 = ops.decode_topk(cd, bd, K, rng, mem_scores=sd, mem_K=mK)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(i2, widx) and torch.equal(r2["labels_3d"], want["labels_3d"]) and torch.equal(r2["boxes_3d"], want["boxes_3d"])
+
+
 def test_decode_topk_keeps_velocity_channels(hip_lib):
     """code_size 10 (the reference nuScenes layout): vx, vy are appended like denormalize_bbox does (core/bbox/util.py:45-50)."""
     from far3d_amd import ops
