@@ -689,7 +689,7 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
   for (int i = t; i < AGGO_MAX_BINS; i += 1024) hist[i] = 0;
   __syncthreads();
   constexpr int MAXQ = 8;   // A <= 8192
-  int key[MAXQ], rank[MAXQ];
+  int key[MAXQ], rank[MAXQ], cam2[MAXQ];      // cam2: the camera the reference point projects second closest to (sorted mode's hint)
   unsigned heavy = 0u;      // bit k: query t + 1024 k projects into two or more cameras (twice the items: far3d_aggregate_forward variant 9)
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k) {
@@ -698,8 +698,8 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
     if (a < A) {
       const float* rp = ref + (long)(row_base + a) * 3;      // rows [row_base, row_base + A) of the caller's reference points
       const float X = agg_base_metre(rp[0], sp0, lo0), Y = agg_base_metre(rp[1], sp1, lo1), Z = agg_base_metre(rp[2], sp2, lo2);
-      float best = 3.0e9f, bu = 0.f, bv = 0.f;
-      int cam = 0, nvis = 0;
+      float best = 3.0e9f, best2 = 3.0e9f, bu = 0.f, bv = 0.f;
+      int cam = 0, camb = 0, nvis = 0;
       for (int n = 0; n < N; ++n) {
         const float* m = l2i + n * 16;
         const float x = agg_base_row(m[0], m[1], m[2], m[3], X, Y, Z), y = agg_base_row(m[4], m[5], m[6], m[7], X, Y, Z),
@@ -707,13 +707,15 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
         const float zc = fmaxf(z, 1e-5f);
         const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
         const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
-        if (cost < best) { best = cost; cam = n; bu = u; bv = v; }
+        if (cost < best) { best2 = best; camb = cam; best = cost; cam = n; bu = u; bv = v; }
+        else if (cost < best2) { best2 = cost; camb = n; }
         nvis += (z > 1e-5f && fabsf(u) < 0.55f && fabsf(v) < 0.55f) ? 1 : 0;      // inside the image, 5 % margin for the key-point offsets
       }
       const int arow = row_base + a;
       if (nvis >= 2 && !(arow >= hole_lo && arow < hole_end)) heavy |= 1u << k;
       const int ub = (int)(fminf(fmaxf(bu + 0.5f, 0.f), 0.999f) * 8.f), vb = (int)(fminf(fmaxf(bv + 0.5f, 0.f), 0.999f) * 8.f);
       key[k] = (cam * 8 + vb) * 8 + ub;
+      cam2[k] = camb == cam ? (cam + 1 < N ? cam + 1 : 0) : camb;
       rank[k] = atomicAdd(&hist[key[k]], 1);
     }
   }
@@ -779,7 +781,9 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
             const float* m = l2i + min(n, N - 1) * 16;
             const float x = agg_base_row(m[0], m[1], m[2], m[3], X, Y, Z), y = agg_base_row(m[4], m[5], m[6], m[7], X, Y, Z),
                         z = agg_base_row(m[8], m[9], m[10], m[11], X, Y, Z);
-            qbase[(long)slot * 8 + n] = n < N ? make_float4(x, y, z, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // .w of camera 0's entry: the hint -- the two cameras whose softmax weights the kernel forms ahead of its item loop
+            const float hw = n == 0 ? __int_as_float((key[k] >> 6) | (cam2[k] << 8)) : 0.f;
+            qbase[(long)slot * 8 + n] = n < N ? make_float4(x, y, z, hw) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
       }

@@ -517,6 +517,20 @@ AGG_DPP1(agg_max_r8, "v_max_f32_dpp", "row_ror:8")
 AGG_DPP1(agg_add_q2, "v_add_f32_dpp", "quad_perm:[2,3,0,1]")
 AGG_DPP1(agg_add_r4, "v_add_f32_dpp", "row_ror:4")
 AGG_DPP1(agg_add_r8, "v_add_f32_dpp", "row_ror:8")
+template <int CTRL> __device__ __forceinline__ int agg8_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int agg8_wave_sum_i32(int v) {      // over all 64 lanes, every lane gets it
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  v += agg8_dpp_i32<0xB1>(v);       // quad_perm:[1,0,3,2]
+  v += agg8_dpp_i32<0x4E>(v);       // quad_perm:[2,3,0,1]
+  v += agg8_dpp_i32<0x124>(v);      // row_ror:4
+  v += agg8_dpp_i32<0x128>(v);      // row_ror:8
+  u2_t q = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  unsigned qx = q.x, qy = q.y;
+  v = (int)(qx + qy);
+  q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  qx = q.x; qy = q.y;
+  return (int)(qx + qy);
+}
 // value of lane K of the caller's 16-lane row, in every lane of the row (v_mov_b32_dpp row_newbcast:K)
 template <int K> __device__ __forceinline__ float agg8_row_bcast(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
@@ -940,7 +954,8 @@ __global__ __launch_bounds__(128) void aggregate_v7_kernel(const TV* __restrict_
 #define AGG8_CAPW 128
 #define AGG8_PAD 16
 #define AGG8_WSLOTS 4
-#define AGG8_LDS (8 * 4 * 16 * 8 + 64 + 2 * AGG8_WSLOTS * 32 * 16 + 2 * (AGG8_CAPW + AGG8_PAD) * 36)
+#define AGG8_WCAM 104      // float4 per hinted camera row in sorted mode (L * P * 2 <= 104: P <= 13 at L = 4)
+#define AGG8_LDS (8 * 4 * 16 * 8 + 64 + 2 * AGG8_WSLOTS * 32 * 16 + 256 + 2 * (AGG8_CAPW + AGG8_PAD) * 36)      // + 256: sorted mode's weight layout
 
 template <typename TV, int NB>     // NB loads in flight per buffer, two buffers
 __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const unsigned* off_s, const float* wt_s, int cnt, int lane,
@@ -1031,7 +1046,12 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
 // far3d_agg_order -- every operand load is issued in the first burst, from the block index alone; perm[e] is read for the hole test
 // and the output row only (before: perm[e] -> ref / offs / U rows, a dependent round trip in front of the first useful instruction,
 // profiles/r5/agg_phase_times.txt).  Same fmaf chains in both forms (csrc/agg_tables.hpp): bit-identical rows.
-template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false, bool SORTED = false>
+// DEAL: how the visible (camera, level) items are dealt to the waves: 1 (round 6) = ranked by work estimate and dealt in snake order
+// (deal_snake below); 0 = round 4's greedy rule in arrival order (every item to the least loaded share: a serial scalar chain of ~15
+// instructions per item on the front end's critical path; kept as variant 12 for A/B).  A contiguous split of the items in lane order
+// (lane-parallel, no loop at all) was built first and measured: -2 % on bf16 rows, +8 % on fp32 rows -- the balance of the two waves'
+// gathers is worth more than the dealing's own latency.
+template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false, bool SORTED = false, int DEAL = 1>
 __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ tab,
@@ -1052,7 +1072,9 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   float2* pxy_s = reinterpret_cast<float2*>(smem);                        // [8][4][16] pixel coordinates per (camera, level, point)
   float* stat_s = reinterpret_cast<float*>(pxy_s + 8 * 4 * 16);           // [8] softmax denominators (+ 8 pad)
   float4* w_all = reinterpret_cast<float4*>(stat_s + 16);                 // [2 waves][WSLOTS][16 points x 2] item weights
-  unsigned* off_all = reinterpret_cast<unsigned*>(w_all + 2 * AGG8_WSLOTS * 32);     // [2][CAPT] row byte offsets
+  // sorted mode lays the same 4352 bytes out as [2 hinted cameras][<= 104 float4: the query's weights against that camera, all levels]
+  // + [2 waves][32] for an item of any other camera (AGG8_WCAM float4 per camera row: L * P * 2 <= 104)
+  unsigned* off_all = reinterpret_cast<unsigned*>(w_all + 2 * AGG8_WSLOTS * 32 + 16);     // [2][CAPT] row byte offsets
   float* wt_all = reinterpret_cast<float*>(off_all + 2 * CAPT);           // [2][CAPT][8] merged weights
   float4* w_s = w_all + wv * AGG8_WSLOTS * 32;
   unsigned* off_s = off_all + wv * CAPT;
@@ -1081,8 +1103,11 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   float4 eu0, eu1, bsA, bsB;                  // wave 1: the query's logits; wave 0: lidar2img [ref_m, 1] of the two cameras
   float of0, of1, of2;
   int a;
+  int cam0 = 0, cam1 = 0;                     // sorted mode: the two cameras whose weights wave 1 forms in front of the barrier
   if constexpr (SORTED) {
     a = perm[a0];                             // needed behind the front end's barrier only (hole test, output row)
+    const int hint = reinterpret_cast<const int*>(qbase + (long)a0 * 8)[3];      // qbase[e][0].w: camera hint of far3d_agg_order (scalar load)
+    cam0 = min(hint & 0xff, N - 1); cam1 = min((hint >> 8) & 0xff, N - 1);
   } else {
     const float4 ld0 = *(w0 ? mA : T4 + i0), ld1 = *(w0 ? mA + 1 : T4 + i1), ld2 = *(w0 ? mA + 2 : T4 + n4 + i0);
     const float4 ld3 = *(w0 ? mB : T4 + n4 + i1), ld4 = *(w0 ? mB + 1 : T4), ld5 = *(w0 ? mB + 2 : T4);
@@ -1161,7 +1186,8 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     d0 = x0 | (y0 << 16);
     d1 = spanx | (spany << 16);
     // work estimate in list entries: rows to gather + the build's own cost (a patch build is ~25 rows' worth, the per-corner one ~10)
-    // (a flatter formula -- items cost about the same, profiles/r4 -- was measured and is not faster: agg_live_est_formula_ab.jsonl)
+    // (a flatter formula -- items cost about the same, profiles/r4 -- was measured and is not faster: agg_live_est_formula_ab.jsonl;
+    // round 6: rows weighted 2x for fp32 value rows, priority thresholds scaled: 18.25 against 18.37 us, inside the noise, not kept)
     est = is_patch ? min(spanx * spany, 4 * P) + 25 : 4 * P + 10;
     // pixel coordinates of this lane's point on every level of camera n (read back by the build loops)
     if (act) {
@@ -1224,6 +1250,31 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     l0 = s0 == 0 ? ld0 : s0 == 1 ? ld1 : s0 == 2 ? ld2 : ld3;
     l1 = s1 == 0 ? ld0 : s1 == 1 ? ld1 : s1 == 2 ? ld2 : ld3;
   };
+  // snake deal (DEAL = 1): rank the items by work estimate (descending; ties: cameras 0-3 first, then the lower lane) and deal the
+  // ranks 0 1 1 0 0 1 1 0 ... (four shares: 0 1 2 3 3 2 1 0 ...): the sorted order balances better than arrival order, and the loop
+  // carries no scalar dependency chain -- one v_readlane and two compare-and-count pairs per item.
+  auto deal_snake = [&](bool vA, bool vB, int nsh, int s0, int s1, unsigned long long& a0m, unsigned long long& b0m, int& l0,
+                        unsigned long long& a1m, unsigned long long& b1m, int& l1) __attribute__((always_inline)) {
+    const int eA = vA ? estA : -1, eB = vB ? estB : -1;
+    int rkA = 0, rkB = 0;
+    for (unsigned long long m = visA; m; m &= m - 1ull) {
+      const int b = __builtin_ctzll(m), e = __builtin_amdgcn_readlane(estA, b);
+      rkA += (e > eA || (e == eA && b < lane)) ? 1 : 0;
+      rkB += e >= eB ? 1 : 0;
+    }
+    for (unsigned long long m = visB; m; m &= m - 1ull) {
+      const int b = __builtin_ctzll(m), e = __builtin_amdgcn_readlane(estB, b);
+      rkA += e > eA ? 1 : 0;
+      rkB += (e > eB || (e == eB && b < lane)) ? 1 : 0;
+    }
+    int shA, shB;
+    if (nsh == 2) { shA = ((rkA + 1) >> 1) & 1; shB = ((rkB + 1) >> 1) & 1; }
+    else { const int tA = rkA & 7, tB = rkB & 7; shA = tA < 4 ? tA : 7 - tA; shB = tB < 4 ? tB : 7 - tB; }
+    a0m = __ballot(vA && shA == s0); a1m = __ballot(vA && shA == s1);
+    b0m = __ballot(vB && shB == s0); b1m = __ballot(vB && shB == s1);
+    l0 = __builtin_amdgcn_readfirstlane(agg8_wave_sum_i32((vA && shA == s0 ? estA : 0) + (vB && shB == s0 ? estB : 0)));
+    l1 = __builtin_amdgcn_readfirstlane(agg8_wave_sum_i32((vA && shA == s1 ? estA : 0) + (vB && shB == s1 ? estB : 0)));
+  };
   {
     // SPECIALISED front end: wave 0 projects and deals, wave 1 computes the softmax statistics; they swap results through the
     // (still unused) row-list regions of each other and meet at one barrier
@@ -1253,7 +1304,8 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
       AGG_TS(1);
       unsigned long long oA, oB;
       int oload;
-      deal2(split ? 4 : 2, 2 * part, 2 * part + 1, mineA, mineB, myload, oA, oB, oload);
+      if constexpr (DEAL == 1) deal_snake(visA_, visB_, split ? 4 : 2, 2 * part, 2 * part + 1, mineA, mineB, myload, oA, oB, oload);
+      else deal2(split ? 4 : 2, 2 * part, 2 * part + 1, mineA, mineB, myload, oA, oB, oload);
       xd[lane] = make_int4(dA0, dA1, dB0, dB1);
       if (lane == 0) {
         unsigned long long* q = reinterpret_cast<unsigned long long*>(xd + 64);
@@ -1269,10 +1321,28 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
         if (!v0) mv0 = NEG4;
         if (!v1) mv1 = NEG4;
       }
+      float4 c0a, c0b, c1a, c1b;
+      if constexpr (SORTED) {
+        // the camera factors of the two hinted cameras, for this lane's two pieces of the row: requested behind the hint's scalar load,
+        // in flight under the softmax statistics
+        c0a = T4[(2 + cam0) * n4 + i0]; c0b = T4[(2 + cam0) * n4 + i1];
+        c1a = T4[(2 + cam1) * n4 + i0]; c1b = T4[(2 + cam1) * n4 + i1];
+      }
       softmax_stats();
       AGG_TS(1);
       xe[lane] = eu0; xe[64 + lane] = eu1;
       if (lane < 2) *reinterpret_cast<float4*>(stat_s + (lane & 1) * 4) = S4;
+      if constexpr (SORTED) {
+        // w = e^U * eV[camera] for the whole row of both hinted cameras: the items behind the barrier read their level's slice
+        if (v0) {
+          w_all[lane] = make_float4(eu0.x * c0a.x, eu0.y * c0a.y, eu0.z * c0a.z, eu0.w * c0a.w);
+          w_all[AGG8_WCAM + lane] = make_float4(eu0.x * c1a.x, eu0.y * c1a.y, eu0.z * c1a.z, eu0.w * c1a.w);
+        }
+        if (v1) {
+          w_all[64 + lane] = make_float4(eu1.x * c0b.x, eu1.y * c0b.y, eu1.z * c0b.z, eu1.w * c0b.w);
+          w_all[AGG8_WCAM + 64 + lane] = make_float4(eu1.x * c1b.x, eu1.y * c1b.y, eu1.z * c1b.z, eu1.w * c1b.w);
+        }
+      }
       AGG_TS(2);
     }
     __syncthreads();
@@ -1321,8 +1391,10 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
       }
     }
   };
-  take_batch();
-  issue_ev();
+  if constexpr (!SORTED) {
+    take_batch();
+    issue_ev();
+  }
 
   AGG_TS(3);
 
@@ -1357,6 +1429,124 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   };
   constexpr unsigned ROWB = 256u * (unsigned)sizeof(TV);      // bytes per token row
 
+  // one (camera, level) item: its merged row list appended to the wave's list (gathering first what is listed when the list might overflow)
+  auto build_item = [&](int it, const float4* wrow) __attribute__((always_inline)) {
+#ifdef FAR3D_PROFILING
+    const long long ts_item = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // one item adds at most 64 rows (a patch's tokens; 4 P <= 64 corners): gather what is listed once fewer might fit.  The only
+    // flush site inside the loops (the list is private to the wave: LDS is in order per wave, the test is wave-uniform)
+    if (cnt > CAP - 64) flush();
+    const int b = it & 63, second = it >> 6;
+    const int n = (b >> 4) + (second << 2), l = b & 15;
+    const int Wl = prm.W[l], Hl = prm.H[l];
+    const unsigned rowbase = (unsigned)(n * prm.S + prm.start[l]);
+    const float2* pq = pxy_s + (n * 4 + l) * 16;
+    const bool is_patch = (((second ? patchB : patchA) >> b) & 1ull) != 0ull;
+    if (is_patch) {
+      // merged weights of the patch's tokens as a small matrix product on the (otherwise idle) matrix pipe:
+      //   Wt[g][T] = sum_p w[p][g] * tent(T, p),   tent(T, p) = max(0, 1 - |px_p - tx_T|) * max(0, 1 - |py_p - ty_T|)
+      // (the tent form of the four mmcv corner weights).  v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain: rows = groups (8 of
+      // 16 used), columns = 16 tokens, K = 4 points per step, 4 steps.  Lane (kk = lane >> 4, j = lane & 15) supplies
+      // A = w[4 s + kk][j] and B = tent(token j of the block, point 4 s + kk): ONE tent per lane and step instead of one per
+      // (lane, point), 8 LDS reads per item instead of 39, and a patch of <= 16 tokens costs a quarter of a 64-token one.
+      const int d0 = __builtin_amdgcn_readlane(second ? dB0 : dA0, b), d1 = __builtin_amdgcn_readlane(second ? dB1 : dA1, b);
+      const int x0 = d0 & 0xffff, y0 = d0 >> 16, spanx = d1 & 0xffff, spany = d1 >> 16;
+      const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8) + (spanx > 16) + (spanx > 32);
+      const int nblk = ((spany << lw) + 15) >> 4;                       // 16-token blocks of the pw x spany token grid (<= 4)
+      const int kk = lane >> 4, jt = lane & 15;
+      const float* wf = reinterpret_cast<const float*>(wrow);
+      float aw[4];
+      float2 pp[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int pt = 4 * st + kk, ptc = min(pt, P - 1);
+        pp[st] = pq[ptc];                                               // a valid point for lanes past P (their A is 0; B must stay finite)
+        const float wv_ = wf[ptc * 8 + (jt & 7)];
+        aw[st] = (pt < P && jt < 8) ? wv_ : 0.f;
+      }
+      for (int blk = 0; blk < nblk; ++blk) {
+        const int T = blk * 16 + jt;
+        const int tx = x0 + (T & ((1 << lw) - 1)), ty = y0 + (T >> lw);
+        const float ftx = (float)tx, fty = (float)ty;
+        agg8_f4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          if (4 * st < P) {
+            const float tent = __builtin_amdgcn_fmed3f(1.f - fabsf(pp[st].x - ftx), 0.f, 1.f) *
+                               __builtin_amdgcn_fmed3f(1.f - fabsf(pp[st].y - fty), 0.f, 1.f);
+            acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[st], tent, acc4, 0, 0, 0);
+          }
+        }
+        // lane (kk, jt) now holds groups 4 kk .. 4 kk + 3 of token jt (kk < 2); a token is listed when any of its 8 weights is > 0
+        float hv = fmaxf(fmaxf(acc4[0], acc4[1]), fmaxf(acc4[2], acc4[3])), ha, hb;
+        agg_swap16(hv, ha, hb);
+        hv = fmaxf(ha, hb);
+        const bool hit = lane < 32 && tx < x0 + spanx && ty < y0 + spany && hv > 0.f;
+        const unsigned m16 = (unsigned)__ballot(hit) & 0xffffu;         // rows kk = 0 and kk = 1 carry the same 16-bit pattern
+        const int c = __popc(m16);
+        if (hit) {
+          const int pos = cnt + __popc(m16 & ((1u << jt) - 1u));
+          *reinterpret_cast<float4*>(wt_s + pos * 8 + kk * 4) = make_float4(acc4[0], acc4[1], acc4[2], acc4[3]);
+          if (kk == 0) off_s[pos] = (rowbase + (unsigned)(ty * Wl + tx)) * ROWB;
+        }
+        cnt += c;
+      }
+    } else {
+      // spread wider than 64 tokens: one entry per (point, corner), mmcv's bilinear arithmetic as is (4 P <= 64 lanes)
+      bool hit = false;
+      unsigned off = 0u;
+      float wa[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wa[q] = 0.f;
+      {
+        const int pt = min(lane >> 2, P - 1), tap = lane & 3;
+        const float2 pp = pq[pt];
+        const float4 a0 = wrow[pt * 2], a1 = wrow[pt * 2 + 1];
+        const float h_im = pp.y, w_im = pp.x;
+        const bool inside = lane < P * 4 && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const float lh = h_im - fh, lw_ = w_im - fw;
+        const int ty = (int)fh + (tap >> 1), tx = (int)fw + (tap & 1);
+        const float bw = ((tap >> 1) ? lh : 1.f - lh) * ((tap & 1) ? lw_ : 1.f - lw_);
+        hit = inside && ty >= 0 && ty <= Hl - 1 && tx >= 0 && tx <= Wl - 1 && bw != 0.f;
+        off = hit ? (rowbase + (unsigned)(ty * Wl + tx)) * ROWB : 0u;
+        wa[0] = bw * a0.x; wa[1] = bw * a0.y; wa[2] = bw * a0.z; wa[3] = bw * a0.w;
+        wa[4] = bw * a1.x; wa[5] = bw * a1.y; wa[6] = bw * a1.z; wa[7] = bw * a1.w;
+      }
+      append(hit, off, wa);
+    }
+#ifdef FAR3D_PROFILING
+    if (g_agg_ts && lane == 0) {
+      long long* q = g_agg_ts + ((long)blockIdx.x * 4 + wv) * 16 + (is_patch ? 12 : 14);
+      q[0] += (long long)__builtin_amdgcn_s_memtime() - ts_item; q[1] += 1;
+    }
+#endif
+  };
+  if constexpr (SORTED) {
+    // sorted mode: the weights of the two hinted cameras were formed by wave 1 in front of the barrier (all levels); an item of another
+    // camera (the hint is the two cameras the reference point projects closest to: far3d_agg_order) forms its own here
+    float4* w_fb = w_all + 2 * AGG8_WCAM + wv * 32;
+    unsigned long long qa = mineA, qb = mineB;
+    while (qa | qb) {
+      int it;
+      if (qa) { it = __builtin_ctzll(qa); qa &= qa - 1ull; }
+      else { it = 64 + __builtin_ctzll(qb); qb &= qb - 1ull; }
+      const int n = ((it >> 4) & 3) + ((it >> 6) << 2), l = it & 15, base = l * 2 * P;
+      const float4* wrow;
+      if (n == cam0) wrow = w_all + base;
+      else if (n == cam1) wrow = w_all + AGG8_WCAM + base;
+      else {
+        const bool in0 = (unsigned)(lane - base) < (unsigned)(2 * P), in1 = (unsigned)(lane + 64 - base) < (unsigned)(2 * P);
+        const float4 evv = T4[(2 + n) * n4 + (in0 ? lane : min(lane + 64, n4 - 1))];
+        // (per component: a select of whole vectors goes through scratch)
+        const float ex = in0 ? eu0.x : eu1.x, ey = in0 ? eu0.y : eu1.y, ez = in0 ? eu0.z : eu1.z, ew = in0 ? eu0.w : eu1.w;
+        if (in0 || in1) w_fb[(in0 ? lane : lane + 64) - base] = make_float4(ex * evv.x, ey * evv.y, ez * evv.z, ew * evv.w);
+        wrow = w_fb;
+      }
+      build_item(it, wrow);
+    }
+  } else {
   while (ni > 0) {
     // -- weights of the batch's items: lanes that hold the item's slice of eU multiply it with the camera factor
 #pragma unroll
@@ -1371,102 +1561,10 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     }
     AGG_TS(11);
     // -- build: merged row list of each item
-    for (int k = 0; k < ni; ++k) {
-#ifdef FAR3D_PROFILING
-      const long long ts_item = (long long)__builtin_amdgcn_s_memtime();
-#endif
-      // one item adds at most 64 rows (a patch's tokens; 4 P <= 64 corners): gather what is listed once fewer might fit.  The only
-      // flush site inside the loops (the list is private to the wave: LDS is in order per wave, the test is wave-uniform)
-      if (cnt > CAP - 64) flush();
-      const int it = items[k], b = it & 63, second = it >> 6;
-      const int n = (b >> 4) + (second << 2), l = b & 15;
-      const int Wl = prm.W[l], Hl = prm.H[l];
-      const unsigned rowbase = (unsigned)(n * prm.S + prm.start[l]);
-      const float2* pq = pxy_s + (n * 4 + l) * 16;
-      const float4* wrow = w_s + k * 32;
-      const bool is_patch = (((second ? patchB : patchA) >> b) & 1ull) != 0ull;
-      if (is_patch) {
-        // merged weights of the patch's tokens as a small matrix product on the (otherwise idle) matrix pipe:
-        //   Wt[g][T] = sum_p w[p][g] * tent(T, p),   tent(T, p) = max(0, 1 - |px_p - tx_T|) * max(0, 1 - |py_p - ty_T|)
-        // (the tent form of the four mmcv corner weights).  v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain: rows = groups (8 of
-        // 16 used), columns = 16 tokens, K = 4 points per step, 4 steps.  Lane (kk = lane >> 4, j = lane & 15) supplies
-        // A = w[4 s + kk][j] and B = tent(token j of the block, point 4 s + kk): ONE tent per lane and step instead of one per
-        // (lane, point), 8 LDS reads per item instead of 39, and a patch of <= 16 tokens costs a quarter of a 64-token one.
-        const int d0 = __builtin_amdgcn_readlane(second ? dB0 : dA0, b), d1 = __builtin_amdgcn_readlane(second ? dB1 : dA1, b);
-        const int x0 = d0 & 0xffff, y0 = d0 >> 16, spanx = d1 & 0xffff, spany = d1 >> 16;
-        const int lw = (spanx > 1) + (spanx > 2) + (spanx > 4) + (spanx > 8) + (spanx > 16) + (spanx > 32);
-        const int nblk = ((spany << lw) + 15) >> 4;                       // 16-token blocks of the pw x spany token grid (<= 4)
-        const int kk = lane >> 4, jt = lane & 15;
-        const float* wf = reinterpret_cast<const float*>(wrow);
-        float aw[4];
-        float2 pp[4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const int pt = 4 * st + kk, ptc = min(pt, P - 1);
-          pp[st] = pq[ptc];                                               // a valid point for lanes past P (their A is 0; B must stay finite)
-          const float wv_ = wf[ptc * 8 + (jt & 7)];
-          aw[st] = (pt < P && jt < 8) ? wv_ : 0.f;
-        }
-        for (int blk = 0; blk < nblk; ++blk) {
-          const int T = blk * 16 + jt;
-          const int tx = x0 + (T & ((1 << lw) - 1)), ty = y0 + (T >> lw);
-          const float ftx = (float)tx, fty = (float)ty;
-          agg8_f4 acc4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            if (4 * st < P) {
-              const float tent = __builtin_amdgcn_fmed3f(1.f - fabsf(pp[st].x - ftx), 0.f, 1.f) *
-                                 __builtin_amdgcn_fmed3f(1.f - fabsf(pp[st].y - fty), 0.f, 1.f);
-              acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[st], tent, acc4, 0, 0, 0);
-            }
-          }
-          // lane (kk, jt) now holds groups 4 kk .. 4 kk + 3 of token jt (kk < 2); a token is listed when any of its 8 weights is > 0
-          float hv = fmaxf(fmaxf(acc4[0], acc4[1]), fmaxf(acc4[2], acc4[3])), ha, hb;
-          agg_swap16(hv, ha, hb);
-          hv = fmaxf(ha, hb);
-          const bool hit = lane < 32 && tx < x0 + spanx && ty < y0 + spany && hv > 0.f;
-          const unsigned m16 = (unsigned)__ballot(hit) & 0xffffu;         // rows kk = 0 and kk = 1 carry the same 16-bit pattern
-          const int c = __popc(m16);
-          if (hit) {
-            const int pos = cnt + __popc(m16 & ((1u << jt) - 1u));
-            *reinterpret_cast<float4*>(wt_s + pos * 8 + kk * 4) = make_float4(acc4[0], acc4[1], acc4[2], acc4[3]);
-            if (kk == 0) off_s[pos] = (rowbase + (unsigned)(ty * Wl + tx)) * ROWB;
-          }
-          cnt += c;
-        }
-      } else {
-        // spread wider than 64 tokens: one entry per (point, corner), mmcv's bilinear arithmetic as is (4 P <= 64 lanes)
-        bool hit = false;
-        unsigned off = 0u;
-        float wa[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) wa[q] = 0.f;
-        {
-          const int pt = min(lane >> 2, P - 1), tap = lane & 3;
-          const float2 pp = pq[pt];
-          const float4 a0 = wrow[pt * 2], a1 = wrow[pt * 2 + 1];
-          const float h_im = pp.y, w_im = pp.x;
-          const bool inside = lane < P * 4 && h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
-          const float fh = floorf(h_im), fw = floorf(w_im);
-          const float lh = h_im - fh, lw_ = w_im - fw;
-          const int ty = (int)fh + (tap >> 1), tx = (int)fw + (tap & 1);
-          const float bw = ((tap >> 1) ? lh : 1.f - lh) * ((tap & 1) ? lw_ : 1.f - lw_);
-          hit = inside && ty >= 0 && ty <= Hl - 1 && tx >= 0 && tx <= Wl - 1 && bw != 0.f;
-          off = hit ? (rowbase + (unsigned)(ty * Wl + tx)) * ROWB : 0u;
-          wa[0] = bw * a0.x; wa[1] = bw * a0.y; wa[2] = bw * a0.z; wa[3] = bw * a0.w;
-          wa[4] = bw * a1.x; wa[5] = bw * a1.y; wa[6] = bw * a1.z; wa[7] = bw * a1.w;
-        }
-        append(hit, off, wa);
-      }
-#ifdef FAR3D_PROFILING
-      if (g_agg_ts && lane == 0) {
-        long long* q = g_agg_ts + ((long)blockIdx.x * 4 + wv) * 16 + (is_patch ? 12 : 14);
-        q[0] += (long long)__builtin_amdgcn_s_memtime() - ts_item; q[1] += 1;
-      }
-#endif
-    }
+    for (int k = 0; k < ni; ++k) build_item(items[k], w_s + k * 32);
     take_batch();
     if (ni > 0) issue_ev();
+  }
   }
   AGG_TS(4);
 #ifdef FAR3D_PROFILING
@@ -1558,18 +1656,19 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11,
-                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 9 = 8 + sibling workgroups for heavy queries; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11 || variant == 12,
+                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 9 = 8 + sibling workgroups for heavy queries; 12 = 8 with the greedy dealing of round 4; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
   FAR3D_CHECK_ARG(variant != 9 || (perm && split_partials && split_tickets && split_extra > 0),
                   "far3d_aggregate_forward: variant 9 needs perm (A main + split_extra sibling entries from far3d_agg_order), split_partials, split_tickets and split_extra > 0");
   const size_t esz = feat_dtype == FAR3D_DT_F32 ? 4 : 2;
   const bool v8_ok = cam_tables && N <= 8 && P <= 16 && L <= AGG_MAX_L && (size_t)N * S * C * esz < (1ull << 32);
   if (variant == 0) variant = v8_ok ? 8 : 7;
   FAR3D_CHECK_ARG(variant != 9 || v8_ok, "far3d_aggregate_forward: variant 9 needs what variant 8 needs (cam_tables, N <= 8, P <= 16)");
-  FAR3D_CHECK_ARG(variant != 8 || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
-  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
-  FAR3D_CHECK_ARG(!qbase || (variant == 8 && perm && ((uintptr_t)qbase % 16) == 0),
-                  "far3d_aggregate_forward: qbase (sorted mode) needs kernel 8 (variant %d after defaulting), perm and 16-byte alignment", variant);
+  FAR3D_CHECK_ARG((variant != 8 && variant != 12) || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
+  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || variant == 12 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
+  FAR3D_CHECK_ARG(!qbase || (variant == 8 && perm && ((uintptr_t)qbase % 16) == 0 && L * P * 2 <= AGG8_WCAM),
+                  "far3d_aggregate_forward: qbase (sorted mode) needs kernel 8 (variant %d after defaulting), perm, 16-byte alignment and L * P <= %d",
+                  variant, AGG8_WCAM / 2);
   if (A == 0) return FAR3D_OK;
   AggParams prm;
   prm.A = A; prm.N = N; prm.S = S; prm.P = P; prm.L = L;
@@ -1628,6 +1727,14 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
     } else {
       if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
       else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+    }
+  } else if (variant == 12) {     // kernel 8 with round 4's greedy dealing (A/B of the round-6 contiguous split)
+    if (feat_dtype == FAR3D_DT_F32) {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, false, false, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<float, 0, 1, 4, AGG8_CAPW, false, false, 0>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+    } else {
+      if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, false, false, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
+      else hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 0, 1, 4, AGG8_CAPW, false, false, 0>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, (const float4*)nullptr);
     }
   } else if (variant == 9) {      // variant 8 + sibling workgroups for the queries far3d_agg_order marked as heavy
     const dim3 grid9(8 * prm.q_per_xcd + split_extra);

@@ -603,7 +603,7 @@ class Far3DEngine:
                 sp = self._bufs[sk] = ops.AggSplit(A, self.agg_split_extra, self.dev)
         self.last_agg_split = sp
         srt = None
-        if self.agg_sorted and sp is None and self.agg_variant in (0, 8) and A > 0 and vc_all.shape[1] <= 8 and cfg["num_pts"] <= 16:
+        if self.agg_sorted and sp is None and self.agg_variant in (0, 8) and A > 0 and vc_all.shape[1] <= 8 and cfg["num_pts"] * cfg["num_levels"] <= 52:
             srt = (self._buf(("agg_inv",), (A,), torch.int32), self._buf(("agg_qbase",), (A, 8, 4), torch.float32))
         res = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A + (sp.extra if sp else 0),), torch.int32),
                                     hole=hole, Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32), split=sp,

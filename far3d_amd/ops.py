@@ -186,7 +186,7 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         if perm is None or split.rows < A or variant not in (0, 9):
             raise ValueError("aggregate_forward: split needs the perm of aggregation_order(split=...), a workspace of >= A rows and variant 0 / 9")
         variant = 9
-    if tables is None and variant in (0, 8, 9) and A > 0 and N <= 8 and P <= 16:
+    if tables is None and variant in (0, 8, 9, 12) and A > 0 and N <= 8 and P <= 16:
         tables = agg_tables(Vc)
     if qbase is not None:
         _chk(qbase, "qbase", torch.float32, 3)

@@ -218,7 +218,15 @@ def test_aggregate_sorted_mode_is_bit_identical(hip_lib, dtype):
         qb = torch.einsum("nij,aj->ani", c["lidar2img"].double(), refm)[:, :, :3]
         got_qb = qbase.cpu().double()[iv]
         assert (got_qb[:, :7, :3] - qb).abs().max().item() < 1e-4 * qb.abs().max().item()
-        assert got_qb[:, 7:].abs().max().item() == 0.0 and got_qb[:, :, 3].abs().max().item() == 0.0
+        assert got_qb[:, 7:].abs().max().item() == 0.0 and got_qb[:, 1:, 3].abs().max().item() == 0.0
+        hint = qbase.cpu().view(torch.int32)[:, 0, 3][iv]                 # camera 0's .w: cam0 | cam1 << 8, the two closest cameras
+        cam0, cam1 = (hint & 0xff).long(), ((hint >> 8) & 0xff).long()
+        assert int(cam0.max()) < 7 and int(cam1.max()) < 7 and bool((cam0 != cam1).all())
+        uv = qb[:, :, :2] / qb[:, :, 2:3].clamp(min=1e-5) / torch.tensor([c["pad_hw"][1], c["pad_hw"][0]], dtype=torch.float64) - 0.5
+        cost = torch.where(qb[:, :, 2] > 1e-5, (uv ** 2).sum(-1), torch.full_like(qb[:, :, 2], 1e9))
+        srt = cost.sort(dim=1)
+        clear = (srt.values[:, 1] - srt.values[:, 0]) > 1e-6 * (1 + srt.values[:, 0])           # no near tie for the first place
+        assert torch.equal(cam0[clear], srt.indices[clear, 0])
         Us, Os = torch.full_like(U, float("nan")), torch.full_like(offs, float("nan"))
         Us[inv.long()], Os[inv.long()] = U, offs
         base = ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, variant=8, tables=tab)

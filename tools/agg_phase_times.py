@@ -74,7 +74,8 @@ def main():
     if variant in (8, 9):     # finer account of v8's build phase: weights of the first batch, then per-item times (they include list flushes = gathers)
         w = (t[:, :, 11] - t[:, :, 3]).astype(np.float64)
         w = w[t[:, :, 11] > 0]
-        print("  v8 build: first batch's weights (eV wait + products)  median %6.0f p90 %6.0f" % (np.median(w), np.percentile(w, 90)))
+        if w.size:       # (sorted mode forms the weights in front of the barrier: no such stamp)
+            print("  v8 build: first batch's weights (eV wait + products)  median %6.0f p90 %6.0f" % (np.median(w), np.percentile(w, 90)))
         for nm, i in (("patch item", 12), ("per-corner item", 14)):
             n = t[:, :, i + 1].sum()
             print("  v8 build: %-16s count %6d  mean %7.0f ticks" % (nm, n, t[:, :, i].sum() / max(n, 1)))
@@ -89,7 +90,7 @@ def main():
     t = t[live[:, 0]]
     if variant in (8, 9):      # v8's specialised front end, per wave (round 6 stamps): wave 0 projects and deals, wave 1 does the softmax statistics
         for w, names in ((0, ("issue loads", "wait + projection + bbox", "deal + descriptors -> LDS", "barrier + read back", "first eV issue")),
-                         (1, ("issue loads", "wait + softmax statistics", "e^U -> LDS", "barrier + read back", "first eV issue"))):
+                         (1, ("issue loads", "wait + softmax statistics", "e^U (sorted: + the two hinted cameras' weights) -> LDS", "barrier + read back", "first eV issue"))):
             for nm, (i, j) in zip(names, ((0, 8), (8, 1), (1, 2), (2, 9), (9, 3))):
                 dlt = (t[:, w, j] - t[:, w, i]).astype(np.float64)
                 print("  front end wave %d: %-28s median %7.0f  p90 %7.0f  max %7.0f ticks" % (w, nm, np.median(dlt), np.percentile(dlt, 90), dlt.max()))

@@ -48,14 +48,19 @@ def main():
                                            out=out_a, variant=8)
         fb = lambda: ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
                                            out=out_b, qbase=qbase)
-        ta, tb = [], []
+        out_g = torch.empty(A, 256, device=DEV, dtype=dt)
+        fg = lambda: ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
+                                           out=out_g, variant=12)
+        tg, ta, tb = [], [], []
         for _ in range(4):
+            tg.append(graph_time(fg))
             ta.append(graph_time(fa))
             tb.append(graph_time(fb))
         same = torch.equal(out_a, out_b)
-        print("%-8s rows  unsorted %s us   sorted %s us   min %.2f -> %.2f (%+.1f %%)   bitwise equal: %s" %
-              (str(dt).split(".")[1], " ".join("%.2f" % t for t in ta), " ".join("%.2f" % t for t in tb), min(ta), min(tb),
-               100.0 * (min(tb) / min(ta) - 1.0), same))
+        print("%-8s rows  greedy deal (variant 12) %s us   split deal, unsorted %s us   split deal, sorted %s us   min %.2f -> %.2f -> %.2f (%+.1f %% / %+.1f %%)   "
+              "sorted bitwise == unsorted: %s; |split - greedy| max %.1e" %
+              (str(dt).split(".")[1], " ".join("%.2f" % t for t in tg), " ".join("%.2f" % t for t in ta), " ".join("%.2f" % t for t in tb), min(tg), min(ta), min(tb),
+               100.0 * (min(ta) / min(tg) - 1.0), 100.0 * (min(tb) / min(tg) - 1.0), same, (out_a.float() - out_g.float()).abs().max().item()))
 
 
 if __name__ == "__main__":
