@@ -16,7 +16,13 @@ timeout 600 python bench.py --precision bf16 --steps 50 --no-cpu-baseline --no-p
 timeout 600 python bench.py --proposals threshold --capacity 4096 --steps 30 --no-cpu-baseline --no-pmc 2>$O/bench_thr.err | tail -1 > $O/bench_threshold.json; cut -c1-200 $O/bench_threshold.json
 timeout 300 python tools/stage_times.py bf16 > $O/stage_times_bf16.txt 2>&1; tail -16 $O/stage_times_bf16.txt
 timeout 300 python tools/stage_times.py bf16x3 > $O/stage_times_bf16x3.txt 2>&1
-timeout 300 python tools/agg_phase_times.py 1544 8 > $O/agg_phase_times.txt 2>&1; tail -14 $O/agg_phase_times.txt
+# the aggregation kernel as the engine runs it (sorted mode: "8s") and as a stand-alone caller gets it (unsorted), the A/B of the two with
+# round 4's greedy dealing beside them, the launch time against the number of queries, the dispatch ramp of a one-round launch
+timeout 300 python tools/agg_phase_times.py 1544 8s 2>&1 | grep -v amdgpu.ids > $O/agg_phase_times.txt; tail -14 $O/agg_phase_times.txt
+timeout 300 python tools/agg_phase_times.py 1544 8 2>&1 | grep -v amdgpu.ids > $O/agg_phase_times_unsorted.txt
+timeout 200 python tools/probe/agg_sorted_ab.py 2>&1 | grep -v amdgpu.ids > $O/agg_sorted_ab.txt; cat $O/agg_sorted_ab.txt
+for a in 193 772 1544 3088; do timeout 100 python tools/probe/agg_sorted_ab.py $a 2>&1 | grep -v amdgpu.ids | sed "s/^/A=$a /"; done > $O/agg_launch_vs_queries.txt
+[ -x tools/ubench/_bin/dispatch_ramp ] && timeout 60 tools/ubench/_bin/dispatch_ramp 1544 > $O/dispatch_ramp.txt 2>&1
 python tools/bench_kernels.py --iters 50 --out $O/kernels.jsonl > /dev/null 2>&1; cut -c1-160 $O/kernels.jsonl
 [ -x tools/ubench/_bin/clock_probe ] && timeout 60 tools/ubench/_bin/clock_probe > $O/clock_probe.txt 2>&1
 # the persistent wave-specialised 3x3 kernel: A/B against the shipped tiles (bitwise check included), per-step stamps of consumer wave 0
