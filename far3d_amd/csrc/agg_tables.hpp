@@ -21,12 +21,7 @@ __device__ __forceinline__ void agg_tables_body(const float* __restrict__ v, flo
   }
 }
 
-// Camera-space image of a query's reference point, the part of the key-point projection that does not depend on the decoder layer
-// (ref models/utils/detr3d_transformer.py:524-525,547-552: key point = reference point in metres + learned offset, projected by
-// lidar2img):   M [ref_m + off, 1] = (M [ref_m, 1]) + M3 off.   far3d_agg_order evaluates the first term once per frame for every
-// (query, camera) into `qbase` (launch order); aggregate_v8_kernel evaluates it itself when it is not handed one.  ONE fmaf chain,
-// shared, so that both forms give the same bits.
+// A query's reference point in metres (ref models/utils/detr3d_transformer.py:524-525): far3d_agg_order evaluates it once per frame for
+// every slot of the aggregation kernel's sorted mode (`qbase`), the kernel's unsorted form evaluates it itself -- ONE fma, shared, so
+// that both forms give the same bits.
 __device__ __forceinline__ float agg_base_metre(float r, float span, float lo) { return __builtin_fmaf(r, span, lo); }
-__device__ __forceinline__ float agg_base_row(float m0, float m1, float m2, float m3, float X, float Y, float Z) {
-  return __builtin_fmaf(m0, X, __builtin_fmaf(m1, Y, __builtin_fmaf(m2, Z, m3)));
-}

@@ -702,8 +702,8 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
       int cam = 0, camb = 0, nvis = 0;
       for (int n = 0; n < N; ++n) {
         const float* m = l2i + n * 16;
-        const float x = agg_base_row(m[0], m[1], m[2], m[3], X, Y, Z), y = agg_base_row(m[4], m[5], m[6], m[7], X, Y, Z),
-                    z = agg_base_row(m[8], m[9], m[10], m[11], X, Y, Z);
+        const float x = m[0] * X + m[1] * Y + m[2] * Z + m[3], y = m[4] * X + m[5] * Y + m[6] * Z + m[7],
+                    z = m[8] * X + m[9] * Y + m[10] * Z + m[11];
         const float zc = fmaxf(z, 1e-5f);
         const float u = x / zc / pad_w - 0.5f, v = y / zc / pad_h - 0.5f;
         const float cost = z > 1e-5f ? u * u + v * v : 1.0e9f;
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
       perm[hist[key[k]] + rank[k]] = (a >= hole_lo && a < hole_end) ? ~a : (((splitm >> k) & 1u) ? (a | (1 << 29)) : a);
     }
   // launch-order operands of far3d_aggregate_forward's sorted mode: inv[i] = the slot (workgroup) of row row_base + i -- the producers
-  // of the per-layer logits / offsets store row i at row inv[i] -- and qbase[slot][n] = lidar2img_n [ref_m, 1] (csrc/agg_tables.hpp),
-  // so that the aggregation kernel's first loads depend on its block index only
+  // of the per-layer logits / offsets store row i at row inv[i] -- and qbase[slot] = (the reference point in metres, the camera hint:
+  // cam0 | cam1 << 8, the two cameras it projects closest to), so that the aggregation kernel's first loads depend on its block index only
   if (inv || qbase) {
 #pragma unroll
     for (int k = 0; k < MAXQ; ++k)
@@ -776,15 +776,8 @@ __global__ __launch_bounds__(1024) void agg_order_kernel(const float* __restrict
         if (inv) inv[i] = slot;
         if (qbase) {
           const float* rp = ref + (long)(row_base + i) * 3;
-          const float X = agg_base_metre(rp[0], sp0, lo0), Y = agg_base_metre(rp[1], sp1, lo1), Z = agg_base_metre(rp[2], sp2, lo2);
-          for (int n = 0; n < 8; ++n) {
-            const float* m = l2i + min(n, N - 1) * 16;
-            const float x = agg_base_row(m[0], m[1], m[2], m[3], X, Y, Z), y = agg_base_row(m[4], m[5], m[6], m[7], X, Y, Z),
-                        z = agg_base_row(m[8], m[9], m[10], m[11], X, Y, Z);
-            // .w of camera 0's entry: the hint -- the two cameras whose softmax weights the kernel forms ahead of its item loop
-            const float hw = n == 0 ? __int_as_float((key[k] >> 6) | (cam2[k] << 8)) : 0.f;
-            qbase[(long)slot * 8 + n] = n < N ? make_float4(x, y, z, hw) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          qbase[slot] = make_float4(agg_base_metre(rp[0], sp0, lo0), agg_base_metre(rp[1], sp1, lo1), agg_base_metre(rp[2], sp2, lo2),
+                                    __int_as_float((key[k] >> 6) | (cam2[k] << 8)));
         }
       }
   }
@@ -795,7 +788,7 @@ extern "C" int far3d_agg_order(const float* ref, const float* lidar2img, int32_t
                                const float* Vc, float* tables, int layers, int J, int split_extra, int32_t* inv, float* qbase,
                                void* stream) {
   FAR3D_CHECK_ARG(ref && lidar2img && perm && pc_range && A >= 0 && N > 0, "far3d_agg_order: bad arguments");
-  FAR3D_CHECK_ARG(!qbase || (N <= 8 && ((uintptr_t)qbase % 16) == 0), "far3d_agg_order: qbase needs N <= 8 (got %d) and 16-byte alignment", N);
+  FAR3D_CHECK_ARG(!qbase || ((uintptr_t)qbase % 16) == 0, "far3d_agg_order: qbase needs 16-byte alignment");
   FAR3D_CHECK_ARG(!tables || (Vc && layers > 0 && J > 0), "far3d_agg_order: tables need Vc, layers > 0 and J > 0");
   if (!tables) layers = 0;
   FAR3D_CHECK_ARG(A <= 8192 && N * 64 <= AGGO_MAX_BINS, "far3d_agg_order: A=%d (<= 8192) or N=%d (<= 16) too large", A, N);

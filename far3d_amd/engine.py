@@ -166,7 +166,7 @@ class Far3DEngine:
         self._pipe = None
         self.agg_variant = 0        # far3d_aggregate_forward kernel variant (0 = default; tools/ use 3 for A/B timing)
         self.agg_sorted = True      # the aggregation kernel's SORTED mode (round 6): far3d_agg_order also emits the launch slot of every
-                                    # row and the hoisted projections; the producers of the per-layer logits / offsets store in launch
+                                    # row and the reference points in launch order; the producers of the per-layer logits / offsets store in launch
                                     # order, so that no load of the kernel waits for perm[e] (replicated decoder, kernel 8, no split)
         self.agg_split_extra = 0    # > 0: far3d_aggregate_forward variant 9 -- that many sibling workgroups for the queries two cameras see
                                     # (far3d_agg_order marks them; ops.AggSplit holds the partial sums / tickets, one per buffer set)
@@ -604,7 +604,7 @@ class Far3DEngine:
         self.last_agg_split = sp
         srt = None
         if self.agg_sorted and sp is None and self.agg_variant in (0, 8) and A > 0 and vc_all.shape[1] <= 8 and cfg["num_pts"] * cfg["num_levels"] <= 52:
-            srt = (self._buf(("agg_inv",), (A,), torch.int32), self._buf(("agg_qbase",), (A, 8, 4), torch.float32))
+            srt = (self._buf(("agg_inv",), (A,), torch.int32), self._buf(("agg_qbase",), (A, 4), torch.float32))
         res = ops.aggregation_order(ref, lidar2img, cfg["pc_range"], pad_hw, out=self._buf(("perm",), (A + (sp.extra if sp else 0),), torch.int32),
                                     hole=hole, Vc=vc_all, tables_out=self._buf(("agg_tab",), (nL, 2 + vc_all.shape[1], nJ), torch.float32), split=sp,
                                     sorted_operands=srt)

@@ -153,7 +153,7 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     only through .contiguous() -- the kernel reads dense rows.  variant: see include/far3d_hip.h (0 = default).
     tables: agg_tables(Vc) (2+N, L*P*G) -- the per-frame softmax factors the default kernel reads instead of Vc; computed here
     (one more launch) when the default kernel runs and the caller did not pass them.
-    qbase: aggregation_order(..., sorted_operands=True)'s (A, 8, 4) table -- SORTED mode of the default kernel: U and offsets hold the
+    qbase: aggregation_order(..., sorted_operands=True)'s (A, 4) table -- SORTED mode of the default kernel: U and offsets hold the
     query of perm entry e at row e (their producers stored through the order's `inv`), ref is not read; same bits as the unsorted call.
     """
     lib = _lib.require_device()
@@ -189,10 +189,10 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
     if tables is None and variant in (0, 8, 9, 12) and A > 0 and N <= 8 and P <= 16:
         tables = agg_tables(Vc)
     if qbase is not None:
-        _chk(qbase, "qbase", torch.float32, 3)
-        if perm is None or split is not None or variant not in (0, 8) or tuple(qbase.shape) != (nperm, 8, 4) or nperm != A:
+        _chk(qbase, "qbase", torch.float32, 2)
+        if perm is None or split is not None or variant not in (0, 8) or tuple(qbase.shape) != (nperm, 4) or nperm != A:
             raise ValueError("aggregate_forward: qbase (sorted mode) needs the full perm of aggregation_order(sorted_operands=True), "
-                             "variant 0 / 8, no split and shape (A, 8, 4)")
+                             "variant 0 / 8, no split and shape (A, 4)")
         variant = 8
     if tables is not None:
         _chk(tables, "tables", torch.float32, 2)
@@ -1093,7 +1093,7 @@ def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, row
     query are entered as ~a so that aggregate_forward writes zero rows for them (see _hole).  rows=(a0, a1): order only the rows
     [a0, a1) of ref; the entries are absolute row indices (pass the full-size buffers and this perm to aggregate_forward).
     Vc (layers, N, J): the same launch also computes agg_tables(Vc) (into tables_out when given); returns (perm, tables) then.
-    sorted_operands: True, or a preallocated (inv (A) int32, qbase (A, 8, 4) f32) pair -- the same launch also writes the operands of
+    sorted_operands: True, or a preallocated (inv (A) int32, qbase (A, 4) f32) pair -- the same launch also writes the operands of
     aggregate_forward's sorted mode (include/far3d_hip.h); they are appended to the return value as (inv, qbase)."""
     lib = _lib.require_device()
     _chk(ref, "ref", torch.float32, 2)
@@ -1117,13 +1117,13 @@ def aggregation_order(ref, lidar2img, pc_range, pad_hw, out=None, hole=None, row
             raise ValueError("aggregation_order: sorted operands and sibling workgroups (split) do not combine")
         if sorted_operands is True:
             inv = torch.empty((A,), dtype=torch.int32, device=ref.device)
-            qbase = torch.empty((A, 8, 4), dtype=torch.float32, device=ref.device)
+            qbase = torch.empty((A, 4), dtype=torch.float32, device=ref.device)
         else:
             inv, qbase = sorted_operands
         _chk(inv, "inv", torch.int32, 1)
-        _chk(qbase, "qbase", torch.float32, 3)
-        if inv.numel() != A or tuple(qbase.shape) != (A, 8, 4):
-            raise ValueError("aggregation_order: inv needs A = %d entries and qbase the shape (A, 8, 4)" % A)
+        _chk(qbase, "qbase", torch.float32, 2)
+        if inv.numel() != A or tuple(qbase.shape) != (A, 4):
+            raise ValueError("aggregation_order: inv needs A = %d entries and qbase the shape (A, 4)" % A)
     _lib.check(lib.far3d_agg_order(_ptr(ref), _ptr(lidar2img), _ptr(perm), A, lidar2img.shape[0], pp, float(pad_hw[0]), float(pad_hw[1]),
                                    *_hole(hole), int(a0), _ptr(Vc) if Vc is not None else None, _ptr(tab) if tab is not None else None,
                                    layers, J, int(extra), _ptr(inv) if inv is not None else None, _ptr(qbase) if qbase is not None else None,

@@ -102,9 +102,10 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
                             int ldU, int ldOffs, int variant, float* split_partials, int32_t* split_tickets, int split_extra,
                             const float* qbase, void* stream);
 /* qbase != NULL (round 6, kernel 8 only, needs perm): SORTED mode.  U and offsets hold the row of the query of perm entry e AT ROW e
- * (launch order: their producers stored through far3d_agg_order's inv), qbase is far3d_agg_order's (A, 8, 4) table and `ref` is not
+ * (launch order: their producers stored through far3d_agg_order's inv), qbase is far3d_agg_order's (A, 4) table and `ref` is not
  * read: every operand load of a workgroup depends on its block index only, perm[e] is needed for the hole test and the output row
- * alone.  Needs L * P <= 52 (the two hinted cameras' weight rows live in LDS).  out row a is query a as always, and the result is BIT-IDENTICAL to the unsorted call (same fmaf chains, csrc/agg_tables.hpp).
+ * alone.  out row a is query a as always, and the result is BIT-IDENTICAL to the unsorted call (same arithmetic in the same order).
+ * Needs L * P <= 52 (the two hinted cameras' weight rows live in LDS).
  * The unsorted call costs a dependent round trip (perm[e] -> ref / offsets / U rows) before the first useful instruction. */
 /* variant 9 (round 5) = kernel 8 + SIBLING workgroups for heavy queries: the launch ends with its slowest wave, and the slowest waves
  * belong to the queries two cameras see.  far3d_agg_order(split_extra) marks those queries (flag 1 << 29 on their perm entry) and appends
@@ -414,11 +415,10 @@ int far3d_agg_order(const float* ref, const float* lidar2img, int32_t* perm, int
                     const float* Vc, float* tables, int layers, int J, int split_extra, int32_t* inv, float* qbase, void* stream);
 /* inv / qbase (both optional, round 6): the operands of far3d_aggregate_forward's SORTED mode.  inv (A) int32: inv[i] = the perm slot
  * (= workgroup) that handles row row_base + i, i.e. perm[inv[i]] names row row_base + i; the producers of the per-layer logits /
- * key-point offsets store their row i at row inv[i] (far3d_rowchain_attn_out's ul_rows, far3d_layernorm_rows).  qbase (A, 8, 4) f32,
- * 16-byte aligned, N <= 8: qbase[slot][n] = (x, y, z, *) = lidar2img_n [ref_m, 1] of the query in that slot -- the layer-independent
- * part of the key-point projection (ref models/utils/detr3d_transformer.py:524-525,547-552), evaluated once per frame.  The fourth
- * component is 0 except for n = 0, where it carries an int32 HINT (bit pattern): cam0 | cam1 << 8, the two cameras the reference point
- * projects closest to -- the aggregation kernel forms the softmax weights against those two cameras ahead of its item loop (an item of
+ * key-point offsets store their row i at row inv[i] (far3d_rowchain_attn_out's ul_rows, far3d_layernorm_rows).  qbase (A, 4) f32,
+ * 16-byte aligned: qbase[slot] = (X, Y, Z, hint) -- the reference point of the query in that slot in metres (ref
+ * models/utils/detr3d_transformer.py:524-525) and, as an int32 bit pattern, hint = cam0 | cam1 << 8: the two cameras the reference point
+ * projects closest to.  The aggregation kernel forms the softmax weights against those two cameras ahead of its item loop (an item of
  * any other camera forms its own: the hint never changes a result).
  * split_extra > 0 (far3d_aggregate_forward variant 9): perm has A + split_extra entries; the first split_extra queries IN ROW ORDER whose
  * reference point projects into two or more cameras are marked and get a sibling entry behind the A main ones (see above). */

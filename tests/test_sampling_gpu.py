@@ -197,8 +197,8 @@ def test_aggregate_sibling_workgroups_for_heavy_queries(hip_lib, dtype, extra):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_aggregate_sorted_mode_is_bit_identical(hip_lib, dtype):
     """Round 6: SORTED mode of the default kernel -- far3d_agg_order also emits every row's launch slot (inv) and the layer-independent
-    part of the projection (qbase); U / offsets are handed over in launch order.  Same rows bit for bit as the unsorted call (same
-    fmaf chains), against the oracle, with a hole, launch after launch."""
+    point in metres + a two-camera hint (qbase); U / offsets are handed over in launch order.  Same rows bit for bit as the unsorted call,
+    against the oracle, with a hole, launch after launch."""
     from far3d_amd import ops
     c = cases.config2_aggregate_case(seed=6)
     A = c["ref"].shape[0]
@@ -212,16 +212,16 @@ def test_aggregate_sorted_mode_is_bit_identical(hip_lib, dtype):
         pm, iv = perm.cpu().long(), inv.cpu().long()
         rows = torch.where(pm < 0, ~pm, pm)
         assert torch.equal(rows[iv], torch.arange(A)), "perm[inv[a]] names row a"
-        # qbase = lidar2img [ref_m, 1] per (slot, camera), cameras past N zero
+        # qbase = (the reference point in metres, the camera hint) per slot
         pc = torch.tensor(c["pc_range"], dtype=torch.float64)
-        refm = torch.cat([c["ref"].double() * (pc[3:] - pc[:3]) + pc[:3], torch.ones(A, 1, dtype=torch.float64)], 1)
-        qb = torch.einsum("nij,aj->ani", c["lidar2img"].double(), refm)[:, :, :3]
-        got_qb = qbase.cpu().double()[iv]
-        assert (got_qb[:, :7, :3] - qb).abs().max().item() < 1e-4 * qb.abs().max().item()
-        assert got_qb[:, 7:].abs().max().item() == 0.0 and got_qb[:, 1:, 3].abs().max().item() == 0.0
-        hint = qbase.cpu().view(torch.int32)[:, 0, 3][iv]                 # camera 0's .w: cam0 | cam1 << 8, the two closest cameras
+        refm3 = c["ref"].double() * (pc[3:] - pc[:3]) + pc[:3]
+        got_qb = qbase.cpu()[iv]
+        assert (got_qb[:, :3].double() - refm3).abs().max().item() < 1e-4
+        hint = qbase.cpu().view(torch.int32)[:, 3][iv]                    # cam0 | cam1 << 8, the two closest cameras
         cam0, cam1 = (hint & 0xff).long(), ((hint >> 8) & 0xff).long()
         assert int(cam0.max()) < 7 and int(cam1.max()) < 7 and bool((cam0 != cam1).all())
+        refm = torch.cat([refm3, torch.ones(A, 1, dtype=torch.float64)], 1)
+        qb = torch.einsum("nij,aj->ani", c["lidar2img"].double(), refm)[:, :, :3]
         uv = qb[:, :, :2] / qb[:, :, 2:3].clamp(min=1e-5) / torch.tensor([c["pad_hw"][1], c["pad_hw"][0]], dtype=torch.float64) - 0.5
         cost = torch.where(qb[:, :, 2] > 1e-5, (uv ** 2).sum(-1), torch.full_like(qb[:, :, 2], 1e9))
         srt = cost.sort(dim=1)
