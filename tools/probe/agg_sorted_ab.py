@@ -8,6 +8,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+if "--lib" in sys.argv:      # A/B of two builds in one GPU call: --lib <path to another libfar3d_hip.so>
+    from far3d_amd import lib as _flib
+    _flib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+    del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 from far3d_amd import ops  # noqa: E402
 from tests import cases  # noqa: E402
 
