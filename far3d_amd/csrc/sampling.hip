@@ -1051,7 +1051,11 @@ __device__ __forceinline__ void agg8_gather(const TV* __restrict__ feat, const u
 // instructions per item on the front end's critical path; kept as variant 12 for A/B).  A contiguous split of the items in lane order
 // (lane-parallel, no loop at all) was built first and measured: -2 % on bf16 rows, +8 % on fp32 rows -- the balance of the two waves'
 // gathers is worth more than the dealing's own latency.
-template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false, bool SORTED = false, int DEAL_ = -1>
+// PHASE = 1 (round 6, variant 13, A/B only): the LIST-BUILD half of a two-kernel split -- everything up to the row lists, which go to a
+// global workspace (per wave: AGG_GCAP entries of offset + 8 weights, count; per slot: the 8 softmax denominators) instead of being
+// gathered; aggregate_gather_kernel below is the other half.  VERDICT r5 item 3 (c) asked for the split to be measured.
+#define AGG_GCAP 1024
+template <typename TV, int PT, int PRIO = 1, int LOOPNB = 4, int CAP = AGG8_CAPW, bool SPLIT = false, bool SORTED = false, int DEAL_ = -1, int PHASE = 0>
 __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restrict__ feat, const float* __restrict__ ref,
                                                            const float* __restrict__ offs, const float* __restrict__ l2i,
                                                            const float* __restrict__ U, const float* __restrict__ tab,
@@ -1361,7 +1365,11 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
     }
     __syncthreads();
     if constexpr (SORTED) {
-      if (a < 0) { hole_row(); return; }      // block-uniform
+      if (a < 0) {      // block-uniform
+        if constexpr (PHASE == 1) { if (lane == 0) prm.split_tick[(long)a0 * 2 + wv] = 0; }      // (the gather half writes the zero row)
+        else hole_row();
+        return;
+      }
     }
     if (wv == 0) {
       eu0 = xe[lane]; eu1 = xe[64 + lane];
@@ -1417,16 +1425,35 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
   int cnt = 0;
   // gather the listed rows: NB loads per buffer in flight (4 inside the item loop, 8 -- all of a typical list at once -- for the last one)
+  int gpos = 0;                                  // PHASE 1: entries this wave has written to its global list
   auto flush_nb = [&](auto nbtag) __attribute__((always_inline)) {
     constexpr int NB = decltype(nbtag)::value;
-    constexpr int GRAN = sizeof(TV) == 2 ? 2 * NB : NB;
+    constexpr int GRAN = PHASE == 1 ? 16 : (sizeof(TV) == 2 ? 2 * NB : NB);
     const int padn = (-cnt) & (GRAN - 1);
     if (lane < padn) {
       off_s[cnt + lane] = 0u;
       *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8) = Z4;
       *reinterpret_cast<float4*>(wt_s + (cnt + lane) * 8 + 4) = Z4;
     }
-    agg8_gather<TV, NB>(feat, off_s, wt_s, cnt + padn, lane, acc);
+    if constexpr (PHASE == 1) {
+      // append the (padded) list to the wave's global list; entries past the capacity are dropped and the count says so (negative)
+      const int n = cnt + padn;
+      const long wslot = (long)a0 * 2 + wv;
+      unsigned* goff = reinterpret_cast<unsigned*>(prm.split_part) + wslot * AGG_GCAP;
+      float4* gwt = reinterpret_cast<float4*>(prm.split_part + (long)gridDim.x * 2 * AGG_GCAP) + wslot * AGG_GCAP * 2;
+      if (gpos >= 0 && gpos + n <= AGG_GCAP) {
+        for (int i = lane; i < n; i += 64) {
+          goff[gpos + i] = off_s[i];
+          gwt[(gpos + i) * 2] = *reinterpret_cast<const float4*>(wt_s + i * 8);
+          gwt[(gpos + i) * 2 + 1] = *reinterpret_cast<const float4*>(wt_s + i * 8 + 4);
+        }
+        gpos += n;
+      } else {
+        gpos = -1;
+      }
+    } else {
+      agg8_gather<TV, NB>(feat, off_s, wt_s, cnt + padn, lane, acc);
+    }
     cnt = 0;
   };
   auto flush = [&]() __attribute__((always_inline)) { flush_nb(std::integral_constant<int, LOOPNB>{}); };
@@ -1589,6 +1616,12 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
 #ifdef FAR3D_PROFILING
   if (g_agg_ts && lane == 0) { g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 7] = cnt_last; g_agg_ts[((long)blockIdx.x * 4 + wv) * 16 + 10] = myload; }
 #endif
+  if constexpr (PHASE == 1) {
+    static_assert(SORTED && !SPLIT, "the list-build half exists for the sorted mode only");
+    if (lane == 0) prm.split_tick[(long)a0 * 2 + wv] = gpos;
+    if (wv == 0 && lane < 8) (prm.split_part + (long)gridDim.x * 2 * AGG_GCAP * 9)[(long)a0 * 8 + lane] = stat_s[lane];
+    return;
+  }
 
   // ---- cross-wave sum: partial sums go into the wave's own (now dead) list region; 1/S[g] applied once here
   float* red = wt_s;                       // 256 floats: CAPT * 8 >= 256
@@ -1642,6 +1675,64 @@ __global__ __launch_bounds__(128, 4) void aggregate_v8_kernel(const TV* __restri
   }
 }
 
+// The GATHER half of the two-kernel split (variant 13, A/B only): one workgroup per slot, each wave gathers the list its counterpart of
+// the list-build launch wrote (staged through LDS a chunk at a time, as the fused kernel holds it), then the same cross-wave sum,
+// normalisation and store as the fused kernel -- same entries in the same order (bit-identical on bf16 rows; on fp32 rows the compiler
+// contracts this kernel's accumulate differently: 1 ulp).  Measured: +55 % (bf16 rows) / +115 % (fp32 rows, this kernel spills 21 dwords)
+// against the fused launch (profiles/r6/agg_sorted_ab.txt).
+template <typename TV>
+__global__ __launch_bounds__(128, 4) void aggregate_gather_kernel(const TV* __restrict__ feat, const int* __restrict__ perm, void* __restrict__ out,
+                                                               AggParams prm) {
+  const int a0 = (blockIdx.x & 7) * prm.q_per_xcd + (blockIdx.x >> 3);
+  if (a0 >= prm.A) return;
+  __shared__ __attribute__((aligned(16))) float red_s[2 * 256];
+  __shared__ __attribute__((aligned(16))) unsigned loff_s[2][AGG8_CAPW];      // the wave's list, a chunk at a time (as the fused kernel holds it)
+  __shared__ __attribute__((aligned(16))) float lwt_s[2][AGG8_CAPW * 8];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const long wslot = (long)a0 * 2 + wv;
+  const int n = prm.split_tick[wslot];
+  const unsigned* goff = reinterpret_cast<const unsigned*>(prm.split_part) + wslot * AGG_GCAP;
+  const float* gwt = prm.split_part + (long)gridDim.x * 2 * AGG_GCAP + wslot * AGG_GCAP * 8;
+  const float* gstat = prm.split_part + (long)gridDim.x * 2 * AGG_GCAP * 9 + (long)a0 * 8;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  // (a hole slot's count is 0; the count is a multiple of 16, a chunk holds up to 128 entries)
+  for (int base = 0; base < n; base += AGG8_CAPW) {
+    const int m = min(AGG8_CAPW, n - base);
+    for (int i = lane; i < m; i += 64) loff_s[wv][i] = goff[base + i];
+    for (int i = lane; i < m * 2; i += 64)
+      reinterpret_cast<float4*>(lwt_s[wv])[i] = reinterpret_cast<const float4*>(gwt)[(long)base * 2 + i];
+    agg8_gather<TV, 8>(feat, loff_s[wv], lwt_s[wv], m, lane, acc);      // (LDS is in order per wave: no barrier between the copy and the reads)
+  }
+  int a = perm[a0];
+  const int c = t * 2, g = c >> 5;
+  if (a < 0) {
+    a = ~a;
+    if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(0.f, 0.f);
+    else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = 0u;
+    return;
+  }
+  const float sden = gstat[g];
+  float* red = red_s + wv * 256;
+  if constexpr (sizeof(TV) == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { float x, y; agg_swap32(acc[k], x, y); acc[k] = x + y; }
+    if (lane < 32) {
+      *reinterpret_cast<float4*>(red + lane * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(red + lane * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  } else {
+    *reinterpret_cast<float4*>(red + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  const float inv = 1.f / sden;
+  const float2 p0 = *reinterpret_cast<const float2*>(red_s + c), p1 = *reinterpret_cast<const float2*>(red_s + 256 + c);
+  const float r0 = (p0.x + p1.x) * inv, r1 = (p0.y + p1.y) * inv;
+  if (prm.out_dt == FAR3D_DT_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (long)a * 256 + c) = make_float2(r0, r1);
+  else *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(out) + (long)a * 256 + c) = pack_bf16x2(r0, r1);
+}
+
 // far3d_agg_tables: the softmax factors of csrc/agg_tables.hpp for `layers` decoder layers, block = layer.
 __global__ __launch_bounds__(256) void agg_tables_kernel(const float* __restrict__ Vc, float* __restrict__ tab, int N, int J) {
   agg_tables_body(Vc + (long)blockIdx.x * N * J, tab + (long)blockIdx.x * (2 + N) * J, N, J, threadIdx.x, blockDim.x);
@@ -1670,17 +1761,20 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
   FAR3D_CHECK_ARG(feat_dtype == FAR3D_DT_F32 || feat_dtype == FAR3D_DT_BF16,
                   "far3d_aggregate_forward: unsupported feature dtype %d", feat_dtype);
   FAR3D_CHECK_ARG(A >= 0 && S > 0 && (long)N * S * C < (1L << 31), "far3d_aggregate_forward: bad sizes A=%d S=%d (N*S*C must fit int32)", A, S);
-  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11 || variant == 12,
-                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 9 = 8 + sibling workgroups for heavy queries; 12 = 8 with the greedy dealing of round 4; 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
+  FAR3D_CHECK_ARG(variant == 0 || variant == 3 || variant == 7 || variant == 8 || variant == 9 || variant == 11 || variant == 12 || variant == 13,
+                  "far3d_aggregate_forward: unknown kernel variant %d (0 = default: 8 where it applies, else 7; 9 = 8 + sibling workgroups for heavy queries; 12 = 8 with the greedy dealing of round 4; 13 = 8 as TWO launches (list build, gather: A/B, sorted mode, workspace in split_partials / split_tickets); 3 = round-1 kernel, 11 = 7 + VALU reductions / packed FMAs)", variant);
   FAR3D_CHECK_ARG(variant != 9 || (perm && split_partials && split_tickets && split_extra > 0),
                   "far3d_aggregate_forward: variant 9 needs perm (A main + split_extra sibling entries from far3d_agg_order), split_partials, split_tickets and split_extra > 0");
   const size_t esz = feat_dtype == FAR3D_DT_F32 ? 4 : 2;
   const bool v8_ok = cam_tables && N <= 8 && P <= 16 && L <= AGG_MAX_L && (size_t)N * S * C * esz < (1ull << 32);
   if (variant == 0) variant = v8_ok ? 8 : 7;
   FAR3D_CHECK_ARG(variant != 9 || v8_ok, "far3d_aggregate_forward: variant 9 needs what variant 8 needs (cam_tables, N <= 8, P <= 16)");
-  FAR3D_CHECK_ARG((variant != 8 && variant != 12) || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
-  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || variant == 12 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
-  FAR3D_CHECK_ARG(!qbase || (variant == 8 && perm && ((uintptr_t)qbase % 16) == 0 && L * P * 2 <= AGG8_WCAM),
+  FAR3D_CHECK_ARG((variant != 8 && variant != 12 && variant != 13) || v8_ok, "far3d_aggregate_forward: variant 8 needs cam_tables (far3d_agg_tables), N <= 8, P <= 16 and value maps < 4 GiB (N=%d P=%d)", N, P);
+  FAR3D_CHECK_ARG(variant == 8 || variant == 9 || variant == 12 || variant == 13 || Vc, "far3d_aggregate_forward: variant %d needs Vc", variant);
+  FAR3D_CHECK_ARG(variant != 13 || (qbase && v8_ok && perm && P == 13 && split_partials && split_tickets && ((uintptr_t)split_partials % 16) == 0),
+                  "far3d_aggregate_forward: variant 13 (two-kernel split, A/B) needs the sorted mode's operands (qbase, perm), P = 13 and the workspace "
+                  "FAR3D_AGG_LISTS_FLOATS(A) floats in split_partials + 2 * ceil8(A) int32 in split_tickets");
+  FAR3D_CHECK_ARG(!qbase || ((variant == 8 || variant == 13) && perm && ((uintptr_t)qbase % 16) == 0 && L * P * 2 <= AGG8_WCAM),
                   "far3d_aggregate_forward: qbase (sorted mode) needs kernel 8 (variant %d after defaulting), perm, 16-byte alignment and L * P <= %d",
                   variant, AGG8_WCAM / 2);
   if (A == 0) return FAR3D_OK;
@@ -1725,7 +1819,16 @@ extern "C" int far3d_aggregate_forward(const void* feat, int feat_dtype, const f
       if (P == 13) hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 13, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
       else hipLaunchKernelGGL((aggregate_v7_kernel<bf16_t, 0, 1>), grid, dim3(128), lds7, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, Vc, perm, out, prm);
     }
-  } else if (variant == 8 && qbase) {      // the default kernel in sorted mode: operands in launch order, hoisted projection
+  } else if (variant == 13) {     // A/B: the sorted-mode kernel as two launches -- list build (global lists), then a pure gather
+    const float4* qb = reinterpret_cast<const float4*>(qbase);
+    if (feat_dtype == FAR3D_DT_F32) {
+      hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, false, true, -1, 1>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);
+      hipLaunchKernelGGL((aggregate_gather_kernel<float>), grid, dim3(128), 0, st, (const float*)feat, perm, out, prm);
+    } else {
+      hipLaunchKernelGGL((aggregate_v8_kernel<bf16_t, 13, 1, 4, AGG8_CAPW, false, true, -1, 1>), grid, dim3(128), AGG8_LDS, st, (const bf16_t*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);
+      hipLaunchKernelGGL((aggregate_gather_kernel<bf16_t>), grid, dim3(128), 0, st, (const bf16_t*)feat, perm, out, prm);
+    }
+  } else if (variant == 8 && qbase) {      // the default kernel in sorted mode: operands in launch order
     const float4* qb = reinterpret_cast<const float4*>(qbase);
     if (feat_dtype == FAR3D_DT_F32) {
       if (P == 13) hipLaunchKernelGGL((aggregate_v8_kernel<float, 13, 1, 4, AGG8_CAPW, false, true>), grid, dim3(128), AGG8_LDS, st, (const float*)feat, ref, offsets, lidar2img, U, cam_tables, perm, out, prm, qb);

@@ -141,8 +141,19 @@ class AggSplit:
         self.tickets = torch.zeros((self.rows,), dtype=torch.int32, device=device)
 
 
+class AggLists:
+    """Workspace of far3d_aggregate_forward variant 13 (the two-kernel split, A/B only): FAR3D_AGG_LISTS_FLOATS(A) floats of row lists +
+    softmax denominators, 2 * 8 * ceil(A / 8) int32 of per-wave entry counts."""
+
+    def __init__(self, A, device):
+        slots = -(-A // 8) * 8
+        self.rows = A
+        self.buf = torch.zeros((slots * (2 * 1024 * 9 + 8),), dtype=torch.float32, device=device)
+        self.counts = torch.zeros((slots * 2,), dtype=torch.int32, device=device)
+
+
 def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_start, pc_range, pad_hw,
-                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None, split=None, qbase=None):
+                      num_groups=8, out=None, perm=None, out_dtype=torch.float32, variant=0, tables=None, split=None, qbase=None, lists=None):
     """Fused perspective-aware aggregation for ONE sample (B=1).
 
     feat (N,S,256) f32|bf16 token-major value maps; ref (A,3) f32 normalised reference points;
@@ -186,14 +197,17 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
         if perm is None or split.rows < A or variant not in (0, 9):
             raise ValueError("aggregate_forward: split needs the perm of aggregation_order(split=...), a workspace of >= A rows and variant 0 / 9")
         variant = 9
-    if tables is None and variant in (0, 8, 9, 12) and A > 0 and N <= 8 and P <= 16:
+    if tables is None and variant in (0, 8, 9, 12, 13) and A > 0 and N <= 8 and P <= 16:
         tables = agg_tables(Vc)
     if qbase is not None:
         _chk(qbase, "qbase", torch.float32, 2)
-        if perm is None or split is not None or variant not in (0, 8) or tuple(qbase.shape) != (nperm, 4) or nperm != A:
+        if perm is None or split is not None or variant not in (0, 8, 13) or tuple(qbase.shape) != (nperm, 4) or nperm != A:
             raise ValueError("aggregate_forward: qbase (sorted mode) needs the full perm of aggregation_order(sorted_operands=True), "
-                             "variant 0 / 8, no split and shape (A, 4)")
-        variant = 8
+                             "variant 0 / 8 / 13, no split and shape (A, 4)")
+        variant = 13 if variant == 13 else 8
+    if variant == 13:
+        if qbase is None or lists is None or lists.rows < A:
+            raise ValueError("aggregate_forward: variant 13 (two-kernel split) needs the sorted mode's qbase and an AggLists workspace of >= A rows")
     if tables is not None:
         _chk(tables, "tables", torch.float32, 2)
         if tuple(tables.shape) != (2 + N, L * P * G):
@@ -207,7 +221,8 @@ def aggregate_forward(feat, ref, offsets, lidar2img, U, Vc, level_hw, level_star
                                            A if perm is None else nperm, N, S, C, G, P, L, hw_p, st_p, pc_p,
                                            float(pad_hw[0]), float(pad_hw[1]), U.stride(0) if A > 0 else 0,
                                            offsets.stride(0) if A > 0 else 0, int(variant),
-                                           _ptr(split.partials) if split is not None else None, _ptr(split.tickets) if split is not None else None,
+                                           _ptr(split.partials) if split is not None else (_ptr(lists.buf) if lists is not None else None),
+                                           _ptr(split.tickets) if split is not None else (_ptr(lists.counts) if lists is not None else None),
                                            split.extra if split is not None else 0, _ptr(qbase) if qbase is not None else None,
                                            _stream(feat)),
                "far3d_aggregate_forward")

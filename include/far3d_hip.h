@@ -107,6 +107,11 @@ int far3d_aggregate_forward(const void* feat, int feat_dtype, const float* ref, 
  * alone.  out row a is query a as always, and the result is BIT-IDENTICAL to the unsorted call (same arithmetic in the same order).
  * Needs L * P <= 52 (the two hinted cameras' weight rows live in LDS).
  * The unsorted call costs a dependent round trip (perm[e] -> ref / offsets / U rows) before the first useful instruction. */
+/* variant 13 (round 6, A/B measurement only): the sorted-mode kernel as TWO launches -- a list-build launch that writes every wave's row
+ * list (offset + 8 weights per entry, <= 1024 entries per wave) and the softmax denominators to a global workspace, and a pure gather
+ * launch (one workgroup per query) that reads them: VERDICT r5 item 3 (c).  Same entries in the same order (bit-identical on bf16 rows, 1 ulp on fp32 rows); measured 1.5 - 2.1x SLOWER than the fused launch.  Needs qbase,
+ * perm, P = 13; split_partials = FAR3D_AGG_LISTS_FLOATS(A) floats (16-byte aligned), split_tickets = 2 * 8 * ceil(A / 8) int32. */
+#define FAR3D_AGG_LISTS_FLOATS(A) ((long)(((A) + 7) / 8 * 8) * (2L * 1024 * 9 + 8))
 /* variant 9 (round 5) = kernel 8 + SIBLING workgroups for heavy queries: the launch ends with its slowest wave, and the slowest waves
  * belong to the queries two cameras see.  far3d_agg_order(split_extra) marks those queries (flag 1 << 29 on their perm entry) and appends
  * one sibling entry per marked query (perm[A + e] = row | 1 << 30 | 1 << 29; unused slots 0x7fffffff); the launch runs split_extra extra

@@ -258,3 +258,32 @@ def test_producers_store_in_launch_order(hip_lib):
         y1 = ops.layernorm(x, gam, bet, add=add, y2=XW1[:, :C], yb=XW1[:, C:], out_rows=inv)[0]
         assert torch.equal(y0, y1)
         assert torch.equal(XW1[inv.long()], XW0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aggregate_two_kernel_split_is_bit_identical(hip_lib, dtype):
+    """Variant 13 (round 6, A/B only): the sorted-mode kernel as a list-build launch + a pure gather launch through global lists --
+    the same entries in the same order: the rows of the fused kernel (bit for bit on bf16 rows), with a hole, launch after launch."""
+    from far3d_amd import ops
+    c = cases.config2_aggregate_case(seed=9)
+    A = c["ref"].shape[0]
+    d = lambda t: t.to(DEV).contiguous()
+    feat = d(c["feat"].to(dtype))
+    ref, offs, l2i, U, Vc = d(c["ref"]), d(c["offsets"]).reshape(A, -1), d(c["lidar2img"]), d(c["U"]), d(c["Vc"])
+    tab = ops.agg_tables(Vc)
+    lists = ops.AggLists(A, DEV)
+    for hole in (None, (torch.tensor([11], dtype=torch.int32, device=DEV), 50, 90)):
+        perm, (inv, qbase) = ops.aggregation_order(ref, l2i, c["pc_range"], c["pad_hw"], hole=hole, sorted_operands=True)
+        Us, Os = torch.empty_like(U), torch.empty_like(offs)
+        Us[inv.long()], Os[inv.long()] = U, offs
+        kw = dict(perm=perm, tables=tab, qbase=qbase)
+        fused = ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], **kw)
+        for _ in range(2):
+            split = ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], variant=13, lists=lists, **kw)
+            if dtype == torch.bfloat16:
+                assert torch.equal(split, fused)
+            else:       # fp32 rows: the stand-alone gather kernel's accumulate is contracted differently by the compiler -- 1 ulp
+                assert (split - fused).abs().max().item() <= 2e-7 * fused.abs().max().item()
+        assert 0 < int(lists.counts.max()) <= 1024
+    with pytest.raises(ValueError):
+        ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], variant=13, **kw)

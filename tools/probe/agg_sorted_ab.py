@@ -52,6 +52,18 @@ def main():
                                            out=out_a, variant=8)
         fb = lambda: ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
                                            out=out_b, qbase=qbase)
+        out_s = torch.empty(A, 256, device=DEV, dtype=dt)
+        lists = ops.AggLists(A, DEV)
+        fs = lambda: ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
+                                           out=out_s, qbase=qbase, variant=13, lists=lists)
+        ts = [graph_time(fs) for _ in range(4)]
+        fb_ = lambda: ops.aggregate_forward(feat, ref, Os, l2i, Us, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
+                                            out=out_b, qbase=qbase)
+        tf = [graph_time(fb_) for _ in range(4)]
+        print("%-8s rows  TWO-KERNEL SPLIT (variant 13: list build -> global lists -> gather) %s us   fused, sorted %s us   min %.2f against %.2f (%+.1f %%)   "
+              "bitwise equal: %s; most entries of a wave %d of 1024" %
+              (str(dt).split(".")[1], " ".join("%.2f" % t for t in ts), " ".join("%.2f" % t for t in tf), min(ts), min(tf), 100.0 * (min(ts) / min(tf) - 1.0),
+               torch.equal(out_s, out_b), int(lists.counts.max())))
         out_g = torch.empty(A, 256, device=DEV, dtype=dt)
         fg = lambda: ops.aggregate_forward(feat, ref, offs, l2i, U, Vc, c["level_hw"], c["level_start"], c["pc_range"], c["pad_hw"], perm=perm, tables=tab,
                                            out=out_g, variant=12)
